@@ -1,0 +1,233 @@
+/*
+ * spectralcluster_amd.h -- C ABI of the MI355X (gfx950) implementation of the
+ * dense hot path of SpectralClusterer.predict() (wq2012/SpectralCluster
+ * v0.2.22).  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Every entry point names the reference interface it replaces (paths are
+ * relative to the reference checkout, `spectralcluster/...`).  The reference
+ * is pure Python, so "the binding a maintainer would add" is a ctypes stub;
+ * see INTEGRATION.md.
+ *
+ * Conventions
+ *   - all matrices are float64, C-contiguous row-major, caller-owned;
+ *   - every function returns an sc_status (0 = ok, < 0 = error); the text
+ *     of the last error of a handle is available from sc_last_error();
+ *   - one handle <-> one device <-> one HIP stream.  A handle is NOT
+ *     thread-safe; distinct handles are independent;
+ *   - no host pointer is retained after a call returns.
+ */
+#ifndef SPECTRALCLUSTER_AMD_H_
+#define SPECTRALCLUSTER_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+#define SC_MAX_OPS 16
+#define SC_MAX_BLUR_RADIUS 32
+#define SC_MAX_EIG 128 /* max eigenvalues reported in sc_diag */
+#define SC_MAX_STAGES 16
+
+typedef struct sc_handle_s* sc_handle;
+
+typedef enum sc_status {
+  SC_OK = 0,
+  SC_ERR_INVALID = -1,       /* bad argument (maps to ValueError/TypeError) */
+  SC_ERR_OOM = -2,           /* device allocation failed */
+  SC_ERR_HIP = -3,           /* HIP runtime error */
+  SC_ERR_NOT_CONVERGED = -4, /* eigensolver did not reach tolerance */
+  SC_ERR_UNSUPPORTED = -5    /* configuration outside the device path */
+} sc_status;
+
+/* refinement.py:11-18 RefinementName */
+typedef enum sc_op {
+  SC_OP_CROP_DIAGONAL = 1,
+  SC_OP_GAUSSIAN_BLUR = 2,
+  SC_OP_ROW_WISE_THRESHOLD = 3,
+  SC_OP_SYMMETRIZE = 4,
+  SC_OP_DIFFUSE = 5,
+  SC_OP_ROW_WISE_NORMALIZE = 6
+} sc_op;
+
+/* refinement.py:21-27 ThresholdType, :30-36 SymmetrizeType */
+enum { SC_THRESHOLD_ROW_MAX = 1, SC_THRESHOLD_PERCENTILE = 2 };
+enum { SC_SYMMETRIZE_MAX = 1, SC_SYMMETRIZE_AVERAGE = 2 };
+/* laplacian.py:9-21 LaplacianType (0 = laplacian_type None) */
+enum {
+  SC_LAPLACIAN_NONE = 0,
+  SC_LAPLACIAN_AFFINITY = 1,
+  SC_LAPLACIAN_UNNORMALIZED = 2,
+  SC_LAPLACIAN_RANDOM_WALK = 3,
+  SC_LAPLACIAN_GRAPH_CUT = 4
+};
+/* utils.py:10-17 EigenGapType */
+enum { SC_EIGENGAP_RATIO = 1, SC_EIGENGAP_NORMALIZED_DIFF = 2 };
+
+/* Which eigen path ran (sc_diag.eig_path) */
+enum { SC_EIG_PATH_DENSE_JACOBI = 1, SC_EIG_PATH_BLOCK_LANCZOS = 2 };
+
+/* Stage slots of sc_diag.stage_ms */
+enum {
+  SC_STAGE_AFFINITY = 0,
+  SC_STAGE_REFINE = 1,    /* all refinement ops except Diffuse */
+  SC_STAGE_DIFFUSE = 2,
+  SC_STAGE_SCALING = 3,   /* row stats + Laplacian/normalise scaling vectors */
+  SC_STAGE_EIG = 4,
+  SC_STAGE_KMEANS = 5,
+  SC_STAGE_TOTAL = 6
+};
+
+/*
+ * POD mirror of SpectralClusterer.__init__ (spectral_clusterer.py:29-46) and
+ * RefinementOptions (refinement.py:76-100), restricted to the hot path.
+ * 0 means "None" for min_clusters / max_clusters.
+ */
+typedef struct sc_config {
+  int32_t n_ops;                 /* len(refinement_sequence), 0 = no refinement */
+  int32_t ops[SC_MAX_OPS];       /* sc_op values, applied in order */
+  /* GaussianBlur: the 2*radius+1 symmetric weights as scipy computes them
+   * (sigma -> radius int(4 sigma + .5)); radius 0 = plain copy (sigma == 0).
+   * sc_gaussian_weights() fills these from sigma. */
+  int32_t blur_radius;
+  double blur_weights[2 * SC_MAX_BLUR_RADIUS + 1];
+  double p_percentile;           /* refinement.py:79 */
+  double soft_multiplier;        /* refinement.py:83 */
+  int32_t threshold_type;        /* SC_THRESHOLD_* */
+  int32_t binarize;              /* thresholding_with_binarization */
+  int32_t preserve_diagonal;     /* thresholding_preserve_diagonal */
+  int32_t symmetrize_type;       /* SC_SYMMETRIZE_* */
+  int32_t laplacian_type;        /* SC_LAPLACIAN_* */
+  int32_t min_clusters;          /* 0 = None */
+  int32_t max_clusters;          /* 0 = None */
+  double stop_eigenvalue;        /* spectral_clusterer.py:36 */
+  int32_t eigengap_type;         /* SC_EIGENGAP_* */
+  int32_t row_wise_renorm;       /* spectral_clusterer.py:37 */
+  int32_t max_iter;              /* custom k-means iterations (:39) */
+  /* Eigensolver knobs (no reference equivalent). 0 selects the default. */
+  double eig_value_tol;          /* relative tol on consumed eigenvalues (1e-9) */
+  double eig_vector_tol;         /* residual tol, relative to ||M||, on the
+                                    eigenvectors handed to k-means (1e-10) */
+  int32_t eig_max_cycles;        /* restart cycles before NOT_CONVERGED (40) */
+  int32_t reserved[5];
+} sc_config;
+
+typedef struct sc_diag {
+  int32_t n;                     /* problem size */
+  int32_t n_clusters_raw;        /* eigengap result before max(., min_clusters) */
+  int32_t n_clusters;            /* value handed to k-means */
+  int32_t eig_path;              /* SC_EIG_PATH_* */
+  double max_delta;              /* max eigengap (utils.py:74-130, 2nd result) */
+  int32_t n_eigenvalues;         /* entries valid in eigenvalues[] */
+  int32_t eig_descending;        /* 1: largest first (None/Affinity); 0: smallest first */
+  double eigenvalues[SC_MAX_EIG];/* in the order compute_sorted_eigenvectors returns */
+  int32_t eig_matvec_passes;     /* passes over the n x n operator */
+  int32_t eig_block;             /* vectors per pass */
+  int32_t eig_basis;             /* Krylov basis size at exit */
+  int32_t eig_cycles;            /* restart cycles used */
+  double eig_max_residual;       /* max residual norm over accepted Ritz pairs */
+  int32_t kmeans_iterations;     /* cosine k-means distance passes */
+  int32_t symmetry_state;        /* 1 SYM, 2 DIAG*SYM (after RowWiseNormalize) */
+  float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */
+} sc_diag;
+
+/* ---- library / device ---------------------------------------------------- */
+int sc_abi_version(void);
+/* number of visible HIP devices (0 if none / runtime unavailable) */
+int sc_device_count(void);
+/* copies the device name (e.g. "AMD Instinct MI355X") and gcnArchName */
+int sc_device_info(int device, char* name, int name_len, char* arch, int arch_len,
+                   int* compute_units, int64_t* total_mem_bytes);
+
+/* ---- handle -------------------------------------------------------------- */
+int sc_create(int device, sc_handle* out);
+int sc_destroy(sc_handle h);
+/* pre-size the device arena for problems up to (n_max, d_max); optional */
+int sc_reserve(sc_handle h, int n_max, int d_max);
+const char* sc_last_error(sc_handle h);
+int sc_synchronize(sc_handle h);
+
+/* fills cfg with the reference defaults (refinement.py:76-100,
+ * spectral_clusterer.py:29-46): no ops, sigma 1 weights, p .95, mult .01 ... */
+int sc_config_default(sc_config* cfg);
+/* scipy.ndimage _gaussian_kernel1d(sigma, order 0, radius int(4 sigma + .5)) */
+int sc_gaussian_weights(double sigma, int32_t* radius, double* weights);
+
+/* ---- whole path ---------------------------------------------------------- */
+/*
+ * SpectralClusterer.predict (spectral_clusterer.py:201-314) for the in-scope
+ * branch: affinity -> refinement -> Laplacian -> top-k eigen + eigengap ->
+ * cosine k-means.  X: (n, d).  labels: n int64 (caller-allocated).
+ */
+int sc_predict(sc_handle h, const double* x, int n, int d, const sc_config* cfg,
+               int64_t* labels, sc_diag* diag);
+
+/* Split form, used for device-resident timing and by AutoTune:            */
+/* H2D of the embeddings into the handle's arena. */
+int sc_set_embeddings(sc_handle h, const double* x, int n, int d);
+/* utils.compute_affinity_matrix (utils.py:20-41) on the resident embeddings. */
+int sc_compute_affinity(sc_handle h);
+/* H2D of a caller-supplied (n, n) affinity (custom affinity_function /
+ * _compute_eigenvectors_ncluster(affinity), spectral_clusterer.py:108). */
+int sc_set_affinity(sc_handle h, const double* affinity, int n);
+/*
+ * SpectralClusterer._compute_eigenvectors_ncluster (spectral_clusterer.py:
+ * 108-168) on the resident affinity, which is left untouched (AutoTune calls
+ * this once per p_percentile, spectral_clusterer.py:274-287).  Eigenvectors
+ * stay on the device; diag receives eigenvalues, n_clusters_raw, max_delta.
+ */
+int sc_eig_ncluster(sc_handle h, const sc_config* cfg, sc_diag* diag);
+/* number of eigenvector columns currently resident */
+int sc_num_eigenvectors(sc_handle h);
+/* D2H of the first ncols resident eigenvectors as an (n, ncols) matrix */
+int sc_get_eigenvectors(sc_handle h, double* out, int n, int ncols);
+/*
+ * predict() tail (spectral_clusterer.py:295-313): slice [:, :n_clusters],
+ * optional row re-norm, run_kmeans (custom_distance_kmeans.py:13-52).
+ */
+int sc_cluster(sc_handle h, const sc_config* cfg, int n_clusters,
+               int64_t* labels, sc_diag* diag);
+/* affinity + eig_ncluster + cluster on the resident embeddings (no H2D of X) */
+int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* labels,
+                    sc_diag* diag);
+/* a Python `for` over predict() in the reference: count
+ * independent utterances, xs[i] is (ns[i], d); labels[i] has ns[i] slots. */
+int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,
+                     int count, const sc_config* cfg, int64_t* const* labels,
+                     sc_diag* diags);
+
+/* ---- single stages (ndarray in / ndarray out; parity tests and the
+ *      per-op Python classes use these) ------------------------------------- */
+/* utils.compute_affinity_matrix (utils.py:20-41) */
+int sc_stage_affinity(sc_handle h, const double* x, int n, int d, double* out);
+/* AffinityRefinementOperation.refine (refinement.py:136-245); op = sc_op,
+ * options are read from cfg. */
+int sc_stage_refine(sc_handle h, int op, const sc_config* cfg, const double* in,
+                    int n, double* out);
+/* laplacian.compute_laplacian (laplacian.py:24-60) */
+int sc_stage_laplacian(sc_handle h, int laplacian_type, const double* in, int n,
+                       double* out);
+/*
+ * utils.compute_sorted_eigenvectors (utils.py:44-71) for a SYMMETRIC input:
+ * the `count` largest (descend=1) or smallest (descend=0) eigenpairs.
+ * values: count doubles; vectors: (n, count), unit 2-norm columns.
+ */
+int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, int descend,
+                     double* values, double* vectors, sc_diag* diag);
+/* utils.compute_number_of_clusters (utils.py:74-130) -- host scalar loop */
+int sc_eigengap(const double* eigenvalues, int count, int max_clusters,
+                double stop_eigenvalue, int eigengap_type, int descend,
+                int* n_clusters, double* max_delta);
+/* custom_distance_kmeans.run_kmeans (custom_distance_kmeans.py:13-52),
+ * custom_dist="cosine": sklearn k-means++ (RandomState(0)) + one Lloyd step
+ * for the seeds, then the cosine loop.  e: (n, k).  centroids_out may be
+ * NULL, else (k, k) final centroids. */
+int sc_stage_kmeans(sc_handle h, const double* e, int n, int k, int max_iter,
+                    int64_t* labels, double* centroids_out, int* iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECTRALCLUSTER_AMD_H_ */

@@ -1,0 +1,279 @@
+"""ctypes binding of libspectralcluster_amd.so (include/spectralcluster_amd.h).
+
+The HIP library IS the product path: there is no NumPy fallback.  If the shared
+object is missing, or no MI355X is visible, every compute entry point raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+import typing
+
+import numpy as np
+
+SC_MAX_OPS = 16
+SC_MAX_BLUR_RADIUS = 32
+SC_MAX_EIG = 128
+SC_MAX_STAGES = 16
+
+SC_OK = 0
+SC_ERR_INVALID = -1
+SC_ERR_OOM = -2
+SC_ERR_HIP = -3
+SC_ERR_NOT_CONVERGED = -4
+SC_ERR_UNSUPPORTED = -5
+
+STAGE_NAMES = ("affinity", "refine", "diffuse", "scaling", "eig", "kmeans",
+               "total")
+
+_LIB_NAME = "libspectralcluster_amd.so"
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+
+class DeviceLibraryError(RuntimeError):
+  """The HIP shared library (or a device) is not available."""
+
+
+class UnsupportedOnDeviceError(NotImplementedError):
+  """The requested configuration is outside the device hot path."""
+
+
+class EigenSolverNotConverged(RuntimeError):
+  """The block-Lanczos eigensolver did not reach its tolerance."""
+
+
+class ScConfig(ctypes.Structure):
+  """Mirror of `sc_config`."""
+  _fields_ = [
+      ("n_ops", ctypes.c_int32),
+      ("ops", ctypes.c_int32 * SC_MAX_OPS),
+      ("blur_radius", ctypes.c_int32),
+      ("blur_weights", ctypes.c_double * (2 * SC_MAX_BLUR_RADIUS + 1)),
+      ("p_percentile", ctypes.c_double),
+      ("soft_multiplier", ctypes.c_double),
+      ("threshold_type", ctypes.c_int32),
+      ("binarize", ctypes.c_int32),
+      ("preserve_diagonal", ctypes.c_int32),
+      ("symmetrize_type", ctypes.c_int32),
+      ("laplacian_type", ctypes.c_int32),
+      ("min_clusters", ctypes.c_int32),
+      ("max_clusters", ctypes.c_int32),
+      ("stop_eigenvalue", ctypes.c_double),
+      ("eigengap_type", ctypes.c_int32),
+      ("row_wise_renorm", ctypes.c_int32),
+      ("max_iter", ctypes.c_int32),
+      ("eig_value_tol", ctypes.c_double),
+      ("eig_vector_tol", ctypes.c_double),
+      ("eig_max_cycles", ctypes.c_int32),
+      ("reserved", ctypes.c_int32 * 5),
+  ]
+
+
+class ScDiag(ctypes.Structure):
+  """Mirror of `sc_diag`."""
+  _fields_ = [
+      ("n", ctypes.c_int32),
+      ("n_clusters_raw", ctypes.c_int32),
+      ("n_clusters", ctypes.c_int32),
+      ("eig_path", ctypes.c_int32),
+      ("max_delta", ctypes.c_double),
+      ("n_eigenvalues", ctypes.c_int32),
+      ("eig_descending", ctypes.c_int32),
+      ("eigenvalues", ctypes.c_double * SC_MAX_EIG),
+      ("eig_matvec_passes", ctypes.c_int32),
+      ("eig_block", ctypes.c_int32),
+      ("eig_basis", ctypes.c_int32),
+      ("eig_cycles", ctypes.c_int32),
+      ("eig_max_residual", ctypes.c_double),
+      ("kmeans_iterations", ctypes.c_int32),
+      ("symmetry_state", ctypes.c_int32),
+      ("stage_ms", ctypes.c_float * SC_MAX_STAGES),
+  ]
+
+  def eigenvalue_array(self) -> np.ndarray:
+    return np.array(self.eigenvalues[:self.n_eigenvalues], dtype=np.float64)
+
+  def stage_times_ms(self) -> dict:
+    return {name: float(self.stage_ms[i]) for i, name in enumerate(STAGE_NAMES)}
+
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_handle_t = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/spectralcluster_amd.h declares
+PROTOTYPES = {
+    "sc_abi_version": (ctypes.c_int, []),
+    "sc_device_count": (ctypes.c_int, []),
+    "sc_device_info": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                      ctypes.c_char_p, ctypes.c_int, _c_int_p,
+                                      _c_int64_p]),
+    "sc_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_handle_t)]),
+    "sc_destroy": (ctypes.c_int, [_handle_t]),
+    "sc_reserve": (ctypes.c_int, [_handle_t, ctypes.c_int, ctypes.c_int]),
+    "sc_last_error": (ctypes.c_char_p, [_handle_t]),
+    "sc_synchronize": (ctypes.c_int, [_handle_t]),
+    "sc_config_default": (ctypes.c_int, [ctypes.POINTER(ScConfig)]),
+    "sc_gaussian_weights": (ctypes.c_int, [ctypes.c_double,
+                                           ctypes.POINTER(ctypes.c_int32),
+                                           _c_double_p]),
+    "sc_predict": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(ScConfig), _c_int64_p,
+                                  ctypes.POINTER(ScDiag)]),
+    "sc_set_embeddings": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
+                                         ctypes.c_int]),
+    "sc_compute_affinity": (ctypes.c_int, [_handle_t]),
+    "sc_set_affinity": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int]),
+    "sc_eig_ncluster": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig),
+                                       ctypes.POINTER(ScDiag)]),
+    "sc_num_eigenvectors": (ctypes.c_int, [_handle_t]),
+    "sc_get_eigenvectors": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
+                                           ctypes.c_int]),
+    "sc_cluster": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), ctypes.c_int,
+                                  _c_int64_p, ctypes.POINTER(ScDiag)]),
+    "sc_run_resident": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig),
+                                       _c_int64_p, ctypes.POINTER(ScDiag)]),
+    "sc_predict_batch": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),
+                                        _c_int_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ScConfig),
+                                        ctypes.POINTER(_c_int64_p),
+                                        ctypes.POINTER(ScDiag)]),
+    "sc_stage_affinity": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
+                                         ctypes.c_int, _c_double_p]),
+    "sc_stage_refine": (ctypes.c_int, [_handle_t, ctypes.c_int,
+                                       ctypes.POINTER(ScConfig), _c_double_p,
+                                       ctypes.c_int, _c_double_p]),
+    "sc_stage_laplacian": (ctypes.c_int, [_handle_t, ctypes.c_int, _c_double_p,
+                                          ctypes.c_int, _c_double_p]),
+    "sc_stage_sym_eig": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, _c_double_p,
+                                        _c_double_p, ctypes.POINTER(ScDiag)]),
+    "sc_eigengap": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                   _c_int_p, _c_double_p]),
+    "sc_stage_kmeans": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, _c_int64_p,
+                                       _c_double_p, _c_int_p]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def library_path() -> str:
+  return os.environ.get("SPECTRALCLUSTER_AMD_LIB", os.path.join(_LIB_DIR, _LIB_NAME))
+
+
+def load() -> ctypes.CDLL:
+  """Load the shared library (once) and declare every prototype."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  with _lib_lock:
+    if _lib is not None:
+      return _lib
+    path = library_path()
+    if not os.path.exists(path):
+      raise DeviceLibraryError(
+          "%s not found: build it with `make -C spectralcluster_amd/csrc` "
+          "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is "
+          "no CPU fallback for the hot path." % path)
+    try:
+      lib = ctypes.CDLL(path)
+    except OSError as exc:  # missing libamdhip64 etc.
+      raise DeviceLibraryError("cannot load %s: %s" % (path, exc)) from exc
+    for name, (restype, argtypes) in PROTOTYPES.items():
+      fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+      fn.restype = restype
+      fn.argtypes = argtypes
+    if lib.sc_abi_version() != 1:
+      raise DeviceLibraryError("ABI version mismatch in %s" % path)
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+  return int(load().sc_device_count())
+
+
+def as_double_p(a: np.ndarray):
+  return a.ctypes.data_as(_c_double_p)
+
+
+def as_int64_p(a: np.ndarray):
+  return a.ctypes.data_as(_c_int64_p)
+
+
+class Handle:
+  """Owns one `sc_handle` (one device, one stream).  Not thread-safe."""
+
+  def __init__(self, device: int = 0):
+    self._lib = load()
+    if self._lib.sc_device_count() <= 0:
+      raise DeviceLibraryError(
+          "no HIP device visible: the hot path runs on an MI355X only "
+          "(there is no CPU fallback)")
+    h = _handle_t()
+    rc = self._lib.sc_create(int(device), ctypes.byref(h))
+    if rc != SC_OK:
+      raise DeviceLibraryError("sc_create(device=%d) failed with %d" % (device, rc))
+    self._h = h
+    self.device = int(device)
+
+  def close(self):
+    if getattr(self, "_h", None):
+      self._lib.sc_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # interpreter shutdown
+      pass
+
+  @property
+  def raw(self):
+    return self._h
+
+  @property
+  def lib(self):
+    return self._lib
+
+  def last_error(self) -> str:
+    msg = self._lib.sc_last_error(self._h)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+  def check(self, rc: int, invalid_exc: typing.Type[Exception] = ValueError):
+    """Translate an sc_status into the exception the reference would raise."""
+    if rc == SC_OK:
+      return
+    msg = self.last_error() or "status %d" % rc
+    if rc == SC_ERR_INVALID:
+      raise invalid_exc(msg)
+    if rc == SC_ERR_UNSUPPORTED:
+      raise UnsupportedOnDeviceError(msg)
+    if rc == SC_ERR_NOT_CONVERGED:
+      raise EigenSolverNotConverged(msg)
+    if rc == SC_ERR_OOM:
+      raise MemoryError(msg)
+    raise DeviceLibraryError(msg)
+
+
+_default_handles = {}
+
+
+def default_handle(device: typing.Optional[int] = None) -> Handle:
+  """Process-wide handle per device (device from SPECTRALCLUSTER_AMD_DEVICE,
+  else LOCAL_RANK, else 0)."""
+  if device is None:
+    device = int(os.environ.get("SPECTRALCLUSTER_AMD_DEVICE",
+                                os.environ.get("LOCAL_RANK", "0")))
+    count = device_count()
+    if count > 0:
+      device %= count
+  if device not in _default_handles:
+    _default_handles[device] = Handle(device)
+  return _default_handles[device]

@@ -1,0 +1,1173 @@
+// C ABI (include/spectralcluster_amd.h) and host-side orchestration: device arena,
+// the refinement / Laplacian / eigen / k-means pipeline, the block-Lanczos control
+// loop, the eigengap scalar loop and the MT19937 stream that seeds k-means++.
+// Host code only decides and launches; every O(n) or larger computation runs in
+// the HIP kernels of this library.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "sc_internal.h"
+
+using namespace sc;
+
+// ------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct sc_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // current problem
+  int n = 0, d = 0, ldn = 0, ldx = 0;
+  bool have_x = false, have_affinity = false;
+  int n_vec = 0;          // eigenvector columns resident in E
+  // matrices
+  DevBuf X, Xn, A0, B1, B2;
+  // n-vectors
+  DevBuf rowmax, rowsum, cvec, pvec, tvec, deg;
+  DevBuf blurw;           // device copy of the blur weights
+  // eigen workspace
+  DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
+      flags;
+  DevBuf E, Ek;           // eigenvectors (n x kLdE), renormed copy for k-means
+  // k-means workspace
+  DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo;
+  // pinned host scratch
+  double* h_theta = nullptr;  // 2 * kLdq doubles (theta, resid)
+  int* h_flags = nullptr;
+  hipEvent_t ev[48];
+  int nev = 0;
+};
+
+static constexpr int kLdE = 128;  // row stride of the resident eigenvectors
+
+#define SC_HIP(h, call)                                                         \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);             \
+      return e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP;               \
+    }                                                                           \
+  } while (0)
+
+#define SC_TRY(expr)                \
+  do {                              \
+    int rc_ = (expr);               \
+    if (rc_ != SC_OK) return rc_;   \
+  } while (0)
+
+static int fail(sc_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+static int grow(sc_handle h, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return SC_OK;
+  if (b.p) {
+    SC_HIP(h, hipStreamSynchronize(h->stream));
+    SC_HIP(h, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  SC_HIP(h, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return SC_OK;
+}
+template <typename T>
+static T* ptr(const DevBuf& b) {
+  return reinterpret_cast<T*>(b.p);
+}
+
+static int ensure_matrices(sc_handle h, int n, int d) {
+  const size_t ldn = round_up(n, 16);
+  const size_t nn = (size_t)n * ldn * sizeof(double);
+  SC_TRY(grow(h, h->A0, nn));
+  SC_TRY(grow(h, h->B1, nn));
+  SC_TRY(grow(h, h->B2, nn));
+  if (d > 0) {
+    const size_t ldx = round_up(d, 16);
+    SC_TRY(grow(h, h->X, (size_t)n * ldx * sizeof(double)));
+    SC_TRY(grow(h, h->Xn, (size_t)n * ldx * sizeof(double)));
+  }
+  const size_t nv = (size_t)round_up(n, 16) * sizeof(double);
+  SC_TRY(grow(h, h->rowmax, nv));
+  SC_TRY(grow(h, h->rowsum, nv));
+  SC_TRY(grow(h, h->cvec, nv));
+  SC_TRY(grow(h, h->pvec, nv));
+  SC_TRY(grow(h, h->tvec, nv));
+  SC_TRY(grow(h, h->deg, nv));
+  SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
+  return SC_OK;
+}
+
+static int ensure_eig(sc_handle h, int n) {
+  const size_t nq = (size_t)n * kLdq * sizeof(double);
+  SC_TRY(grow(h, h->Q, nq));
+  SC_TRY(grow(h, h->Q2, nq));
+  SC_TRY(grow(h, h->Vs, (size_t)n * kEigBlock * sizeof(double)));
+  SC_TRY(grow(h, h->W, (size_t)n * kEigBlock * sizeof(double)));
+  SC_TRY(grow(h, h->partial, (size_t)kProjBlocks * kLdq * kEigBlock * sizeof(double)));
+  SC_TRY(grow(h, h->T, (size_t)kLdq * kLdq * sizeof(double)));
+  SC_TRY(grow(h, h->Y, (size_t)kLdq * kLdq * sizeof(double)));
+  SC_TRY(grow(h, h->Yt, (size_t)kLdq * kLdq * sizeof(double)));
+  SC_TRY(grow(h, h->theta, kLdq * sizeof(double)));
+  SC_TRY(grow(h, h->resid, kLdq * sizeof(double)));
+  SC_TRY(grow(h, h->G, 256 * sizeof(double)));
+  SC_TRY(grow(h, h->Rinv, 256 * sizeof(double)));
+  SC_TRY(grow(h, h->Hbuf, (size_t)kLdq * kEigBlock * sizeof(double)));
+  SC_TRY(grow(h, h->hsq, 16 * sizeof(double)));
+  SC_TRY(grow(h, h->colnorm, (size_t)kProjBlocks * kMaxVectors * sizeof(double)));
+  SC_TRY(grow(h, h->flags, 4 * sizeof(int)));
+  SC_TRY(grow(h, h->E, (size_t)n * kLdE * sizeof(double)));
+  return SC_OK;
+}
+
+static int ensure_kmeans(sc_handle h, int n) {
+  SC_TRY(grow(h, h->Ek, (size_t)n * kLdE * sizeof(double)));
+  SC_TRY(grow(h, h->kXc, (size_t)n * kMaxVectors * sizeof(double)));
+  SC_TRY(grow(h, h->kxsq, (size_t)n * sizeof(double)));
+  SC_TRY(grow(h, h->kclosest, (size_t)n * sizeof(double)));
+  SC_TRY(grow(h, h->kcand, (size_t)8 * n * sizeof(double)));
+  SC_TRY(grow(h, h->kenorm, (size_t)n * sizeof(double)));
+  SC_TRY(grow(h, h->krnd, 1024 * sizeof(double)));
+  SC_TRY(grow(h, h->kcent, (size_t)kMaxVectors * kMaxVectors * sizeof(double)));
+  SC_TRY(grow(h, h->klab32, (size_t)n * sizeof(int)));
+  SC_TRY(grow(h, h->klab64, (size_t)n * sizeof(long long)));
+  SC_TRY(grow(h, h->kinfo, 4 * sizeof(int)));
+  return SC_OK;
+}
+
+static int check_last(sc_handle h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    h->err = std::string(what) + ": " + hipGetErrorString(e);
+    return SC_ERR_HIP;
+  }
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// library / device
+// ------------------------------------------------------------------------------
+extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
+
+extern "C" int sc_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+extern "C" int sc_device_info(int device, char* name, int name_len, char* arch,
+                              int arch_len, int* compute_units,
+                              int64_t* total_mem_bytes) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SC_ERR_HIP;
+  if (name && name_len > 0) snprintf(name, name_len, "%s", prop.name);
+  if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (total_mem_bytes) *total_mem_bytes = (int64_t)prop.totalGlobalMem;
+  return SC_OK;
+}
+
+extern "C" int sc_create(int device, sc_handle* out) {
+  if (!out) return SC_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SC_ERR_HIP;
+  if (device < 0 || device >= count) return SC_ERR_INVALID;
+  sc_handle h = new sc_handle_s();
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return SC_ERR_HIP;
+  }
+  for (int i = 0; i < 48; ++i) {
+    if (hipEventCreate(&h->ev[i]) != hipSuccess) {
+      delete h;
+      return SC_ERR_HIP;
+    }
+  }
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->h_theta), 2 * kLdq * sizeof(double)) !=
+          hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->h_flags), 4 * sizeof(int)) !=
+          hipSuccess) {
+    delete h;
+    return SC_ERR_HIP;
+  }
+  *out = h;
+  return SC_OK;
+}
+
+extern "C" int sc_destroy(sc_handle h) {
+  if (!h) return SC_OK;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw,
+                    &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
+                    &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
+                    &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,
+                    &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
+                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo};
+  for (DevBuf* b : bufs)
+    if (b->p) hipFree(b->p);
+  for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);
+  if (h->h_theta) hipHostFree(h->h_theta);
+  if (h->h_flags) hipHostFree(h->h_flags);
+  hipStreamDestroy(h->stream);
+  delete h;
+  return SC_OK;
+}
+
+extern "C" const char* sc_last_error(sc_handle h) { return h ? h->err.c_str() : ""; }
+
+extern "C" int sc_synchronize(sc_handle h) {
+  if (!h) return SC_ERR_INVALID;
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  return SC_OK;
+}
+
+extern "C" int sc_reserve(sc_handle h, int n_max, int d_max) {
+  if (!h || n_max <= 0 || d_max < 0) return SC_ERR_INVALID;
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, n_max, d_max));
+  SC_TRY(ensure_eig(h, n_max));
+  SC_TRY(ensure_kmeans(h, n_max));
+  return SC_OK;
+}
+
+// numpy pairwise sum for short arrays (n < 128): 8 running sums, then the tail
+static double numpy_sum_short(const double* a, int n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+
+extern "C" int sc_gaussian_weights(double sigma, int32_t* radius, double* weights) {
+  if (!radius || !weights || !(sigma >= 0.0)) return SC_ERR_INVALID;
+  if (sigma <= 1e-15) {  // gaussian_filter skips the axis: plain copy
+    *radius = 0;
+    weights[0] = 1.0;
+    return SC_OK;
+  }
+  const int r = (int)(4.0 * sigma + 0.5);  // truncate = 4.0
+  if (r > SC_MAX_BLUR_RADIUS) return SC_ERR_UNSUPPORTED;
+  const double s2 = sigma * sigma;
+  for (int x = -r; x <= r; ++x) weights[x + r] = std::exp(-0.5 / s2 * (double)(x * x));
+  const double sum = numpy_sum_short(weights, 2 * r + 1);
+  for (int i = 0; i < 2 * r + 1; ++i) weights[i] /= sum;
+  *radius = r;
+  return SC_OK;
+}
+
+extern "C" int sc_config_default(sc_config* cfg) {
+  if (!cfg) return SC_ERR_INVALID;
+  memset(cfg, 0, sizeof(*cfg));
+  sc_gaussian_weights(1.0, &cfg->blur_radius, cfg->blur_weights);
+  cfg->p_percentile = 0.95;
+  cfg->soft_multiplier = 0.01;
+  cfg->threshold_type = SC_THRESHOLD_ROW_MAX;
+  cfg->symmetrize_type = SC_SYMMETRIZE_MAX;
+  cfg->laplacian_type = SC_LAPLACIAN_NONE;
+  cfg->stop_eigenvalue = 1e-2;
+  cfg->eigengap_type = SC_EIGENGAP_RATIO;
+  cfg->max_iter = 300;
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// E2: eigengap (reference utils.py:74-130)
+// ------------------------------------------------------------------------------
+static void eigengap_core(const double* w, int count, int max_clusters,
+                          double stop_eigenvalue, int eigengap_type, int descend,
+                          double wmax, int* n_clusters, double* max_delta) {
+  const double eps = 1e-10;  // utils.py:7
+  double best = 0.0;
+  int best_k = 0;
+  int end = count;
+  if (max_clusters > 0 && max_clusters + 1 < end) end = max_clusters + 1;
+  if (descend) {
+    for (int i = 1; i < end; ++i) {
+      if (w[i - 1] < stop_eigenvalue) break;
+      const double d = eigengap_type == SC_EIGENGAP_RATIO ? w[i - 1] / (w[i] + eps)
+                                                          : (w[i - 1] - w[i]) / wmax;
+      if (d > best) { best = d; best_k = i; }
+    }
+  } else {
+    for (int i = 1; i < end - 1; ++i) {
+      const double d = eigengap_type == SC_EIGENGAP_RATIO ? w[i + 1] / (w[i] + eps)
+                                                          : (w[i + 1] - w[i]) / wmax;
+      if (d > best) { best = d; best_k = i + 1; }
+    }
+  }
+  *n_clusters = best_k;
+  *max_delta = best;
+}
+
+extern "C" int sc_eigengap(const double* w, int count, int max_clusters,
+                           double stop_eigenvalue, int eigengap_type, int descend,
+                           int* n_clusters, double* max_delta) {
+  if (!w || count < 0 || !n_clusters || !max_delta) return SC_ERR_INVALID;
+  if (eigengap_type != SC_EIGENGAP_RATIO && eigengap_type != SC_EIGENGAP_NORMALIZED_DIFF)
+    return SC_ERR_INVALID;
+  double wmax = 0.0;
+  if (count > 0) {
+    wmax = w[0];
+    for (int i = 1; i < count; ++i) wmax = w[i] > wmax ? w[i] : wmax;  // np.max(eigenvalues)
+  }
+  eigengap_core(w, count, max_clusters, stop_eigenvalue, eigengap_type, descend, wmax,
+                n_clusters, max_delta);
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// MT19937 as numpy's legacy RandomState(seed) drives it (k-means++ seeding)
+// ------------------------------------------------------------------------------
+namespace {
+struct Mt19937 {
+  uint32_t mt[624];
+  int pos;
+  explicit Mt19937(uint32_t seed) {
+    mt[0] = seed;
+    for (int i = 1; i < 624; ++i)
+      mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    pos = 624;
+  }
+  void twist() {
+    for (int k = 0; k < 624; ++k) {
+      const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+      uint32_t v = mt[(k + 397) % 624] ^ (y >> 1);
+      if (y & 1u) v ^= 0x9908b0dfu;
+      mt[k] = v;
+    }
+    pos = 0;
+  }
+  uint32_t next_u32() {
+    if (pos >= 624) twist();
+    uint32_t y = mt[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+  double next_double() {
+    const uint32_t a = next_u32() >> 5, b = next_u32() >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------
+// data movement helpers
+// ------------------------------------------------------------------------------
+static int h2d_matrix(sc_handle h, const double* src, int rows, int cols, double* dst,
+                      int ld) {
+  SC_HIP(h, hipMemcpy2DAsync(dst, (size_t)ld * sizeof(double), src,
+                             (size_t)cols * sizeof(double), (size_t)cols * sizeof(double),
+                             rows, hipMemcpyHostToDevice, h->stream));
+  return SC_OK;
+}
+static int d2h_matrix(sc_handle h, const double* src, int ld, int rows, int cols,
+                      double* dst) {
+  SC_HIP(h, hipMemcpy2DAsync(dst, (size_t)cols * sizeof(double), src,
+                             (size_t)ld * sizeof(double), (size_t)cols * sizeof(double),
+                             rows, hipMemcpyDeviceToHost, h->stream));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  return SC_OK;
+}
+
+static int validate_config(sc_handle h, const sc_config* cfg) {
+  if (!cfg) return fail(h, SC_ERR_INVALID, "config is NULL");
+  if (cfg->n_ops < 0 || cfg->n_ops > SC_MAX_OPS)
+    return fail(h, SC_ERR_INVALID, "n_ops out of range");
+  for (int i = 0; i < cfg->n_ops; ++i)
+    if (cfg->ops[i] < SC_OP_CROP_DIAGONAL || cfg->ops[i] > SC_OP_ROW_WISE_NORMALIZE)
+      return fail(h, SC_ERR_INVALID, "Unknown refinement operation");
+  if (cfg->blur_radius < 0 || cfg->blur_radius > SC_MAX_BLUR_RADIUS)
+    return fail(h, SC_ERR_UNSUPPORTED, "gaussian blur radius > 32");
+  if (cfg->laplacian_type < SC_LAPLACIAN_NONE || cfg->laplacian_type > SC_LAPLACIAN_GRAPH_CUT)
+    return fail(h, SC_ERR_INVALID, "laplacian_type must be a LaplacianType");
+  if (cfg->eigengap_type != SC_EIGENGAP_RATIO &&
+      cfg->eigengap_type != SC_EIGENGAP_NORMALIZED_DIFF)
+    return fail(h, SC_ERR_INVALID, "eigengap_type must be a EigenGapType");
+  if (cfg->symmetrize_type != SC_SYMMETRIZE_MAX &&
+      cfg->symmetrize_type != SC_SYMMETRIZE_AVERAGE)
+    return fail(h, SC_ERR_INVALID, "Unsupported symmetrize_type.");
+  if (cfg->threshold_type != SC_THRESHOLD_ROW_MAX &&
+      cfg->threshold_type != SC_THRESHOLD_PERCENTILE)
+    return fail(h, SC_ERR_INVALID, "Unsupported thresholding_type");
+  return SC_OK;
+}
+
+// run one refinement op `in` -> `out` (distinct buffers)
+static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double* in,
+                         double* out, int n, int ld) {
+  hipStream_t s = h->stream;
+  switch (op) {
+    case SC_OP_CROP_DIAGONAL:
+      launch_crop_diagonal(s, in, out, n, ld);
+      break;
+    case SC_OP_GAUSSIAN_BLUR:
+      if (cfg->blur_radius > 0)
+        SC_HIP(h, hipMemcpyAsync(h->blurw.p, cfg->blur_weights,
+                                 (2 * cfg->blur_radius + 1) * sizeof(double),
+                                 hipMemcpyHostToDevice, s));
+      launch_gaussian_blur(s, in, out, n, ld, cfg->blur_radius, ptr<double>(h->blurw));
+      break;
+    case SC_OP_ROW_WISE_THRESHOLD:
+      if (cfg->threshold_type == SC_THRESHOLD_PERCENTILE)
+        return fail(h, SC_ERR_UNSUPPORTED,
+                    "ThresholdType.Percentile is not implemented on the device path yet");
+      launch_row_threshold(s, in, out, n, ld, cfg->p_percentile, cfg->soft_multiplier,
+                           cfg->binarize, cfg->preserve_diagonal);
+      break;
+    case SC_OP_SYMMETRIZE:
+      launch_symmetrize(s, in, out, n, ld, cfg->symmetrize_type);
+      break;
+    case SC_OP_DIFFUSE:
+      launch_gemm_nt(s, in, ld, in, ld, out, ld, n, n, n, kEpiNone, true);
+      break;
+    case SC_OP_ROW_WISE_NORMALIZE:
+      launch_row_normalize(s, in, out, n, ld);
+      break;
+    default:
+      return fail(h, SC_ERR_INVALID, "Unknown refinement operation");
+  }
+  return check_last(h, "refinement kernel launch");
+}
+
+// ------------------------------------------------------------------------------
+// embeddings / affinity
+// ------------------------------------------------------------------------------
+extern "C" int sc_set_embeddings(sc_handle h, const double* x, int n, int d) {
+  if (!h) return SC_ERR_INVALID;
+  if (!x || n <= 0 || d <= 0) return fail(h, SC_ERR_INVALID, "embeddings must be (n, d)");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, n, d));
+  h->n = n;
+  h->d = d;
+  h->ldn = round_up(n, 16);
+  h->ldx = round_up(d, 16);
+  h->have_affinity = false;
+  h->n_vec = 0;
+  SC_TRY(h2d_matrix(h, x, n, d, ptr<double>(h->X), h->ldx));
+  SC_HIP(h, hipStreamSynchronize(h->stream));  // caller may reuse x immediately
+  h->have_x = true;
+  return SC_OK;
+}
+
+extern "C" int sc_compute_affinity(sc_handle h) {
+  if (!h) return SC_ERR_INVALID;
+  if (!h->have_x) return fail(h, SC_ERR_INVALID, "no embeddings resident");
+  SC_HIP(h, hipSetDevice(h->device));
+  launch_normalize_rows(h->stream, ptr<double>(h->X), h->ldx, h->n, h->d,
+                        ptr<double>(h->Xn));
+  launch_gemm_nt(h->stream, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx,
+                 ptr<double>(h->A0), h->ldn, h->n, h->n, h->d, kEpiAffinity, true);
+  SC_TRY(check_last(h, "affinity launch"));
+  h->have_affinity = true;
+  h->n_vec = 0;
+  return SC_OK;
+}
+
+extern "C" int sc_set_affinity(sc_handle h, const double* a, int n) {
+  if (!h) return SC_ERR_INVALID;
+  if (!a || n <= 0) return fail(h, SC_ERR_INVALID, "affinity must be (n, n)");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, n, 0));
+  h->n = n;
+  h->ldn = round_up(n, 16);
+  h->have_x = false;
+  h->n_vec = 0;
+  SC_TRY(h2d_matrix(h, a, n, n, ptr<double>(h->A0), h->ldn));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  h->have_affinity = true;
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// symmetric top-k eigensolver driver
+// ------------------------------------------------------------------------------
+struct EigRequest {
+  int descend;          // 1: report largest first (w = theta); 0: w = -theta ascending
+  int max_clusters;     // 0 = None
+  int min_clusters;     // 0 = None
+  double stop_eigenvalue;
+  int eigengap_type;
+  int use_stop;         // stop_eigenvalue only on the descending branch
+  double value_tol, vector_tol;
+  int max_cycles;
+  int fixed_count;      // > 0: plain "count extreme eigenpairs" request (stage API)
+};
+
+struct EigDecision {
+  bool enough = false;     // basis large enough to take a decision
+  bool converged = false;
+  int kw = 0;              // eigenvalues reported
+  int kvec = 0;            // vectors that must be accurate
+  int n_clusters_raw = 0;
+  double max_delta = 0.0;
+  double max_resid = 0.0;
+  bool unsupported = false;
+};
+
+// Inspect Ritz values theta[0..m) (descending) + residual estimates.
+static EigDecision analyze(const EigRequest& rq, const double* theta, const double* resid,
+                           int m, int n, bool exact) {
+  EigDecision dc;
+  std::vector<double> w(m);
+  for (int i = 0; i < m; ++i) w[i] = rq.descend ? theta[i] : -theta[i];
+  const double scale = std::max(std::fabs(theta[0]), std::fabs(theta[m - 1]));
+  int kw;
+  if (rq.fixed_count > 0) {
+    kw = std::min(rq.fixed_count, n);
+  } else if (rq.max_clusters > 0) {
+    kw = std::min(n, rq.max_clusters + 1);
+  } else if (rq.descend) {
+    // max_clusters None: everything >= stop_eigenvalue, plus the first one below
+    int c = 0;
+    while (c < m && !(w[c] < rq.stop_eigenvalue)) ++c;
+    if (c >= m && m < n) return dc;  // have not reached the stop value yet
+    kw = std::min(c + 1, n);
+  } else {
+    kw = n;  // ascending without max_clusters reads every eigenvalue
+  }
+  if (kw > m) {
+    if (kw > kEigBasisCap / 2 && !exact) dc.unsupported = true;
+    return dc;
+  }
+  dc.enough = true;
+  dc.kw = kw;
+  if (rq.fixed_count > 0) {
+    dc.kvec = kw;
+  } else {
+    // np.max(eigenvalues) is taken over the WHOLE spectrum (utils.py:110,123): the
+    // first value when descending, the far end of the Ritz spectrum when ascending.
+    const double wmax = rq.descend ? w[0] : w[m - 1];
+    eigengap_core(w.data(), kw, rq.max_clusters, rq.use_stop ? rq.stop_eigenvalue : 0.0,
+                  rq.eigengap_type, rq.descend, wmax, &dc.n_clusters_raw, &dc.max_delta);
+    dc.kvec = std::max(dc.n_clusters_raw, rq.min_clusters);
+    if (dc.kvec < 1) dc.kvec = 1;
+    if (dc.kvec > m) dc.kvec = m;
+  }
+  if (exact) {
+    dc.converged = true;
+    return dc;
+  }
+  bool ok = true;
+  const double floor_abs = 1e-14 * scale;
+  // values actually read by the eigengap loop
+  int first = rq.descend ? 0 : 1, last = kw - 1;
+  if (rq.fixed_count > 0) first = 0;
+  if (rq.descend && rq.use_stop && rq.fixed_count == 0) {
+    for (int i = 0; i < kw; ++i)
+      if (w[i] < rq.stop_eigenvalue) { last = i; break; }
+  }
+  for (int i = first; i <= last; ++i) {
+    const double tol = std::max(rq.value_tol * std::fabs(w[i]), floor_abs);
+    if (!(resid[i] <= tol)) ok = false;
+    dc.max_resid = std::max(dc.max_resid, resid[i]);
+  }
+  if (!rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF && rq.fixed_count == 0) {
+    const double tol = std::max(rq.value_tol * std::fabs(w[m - 1]), floor_abs);
+    if (!(resid[m - 1] <= tol)) ok = false;
+  }
+  for (int i = 0; i < dc.kvec; ++i) {
+    if (!(resid[i] <= std::max(rq.vector_tol * scale, floor_abs))) ok = false;
+    dc.max_resid = std::max(dc.max_resid, resid[i]);
+  }
+  dc.converged = ok;
+  return dc;
+}
+
+// Orthonormalise W (n x 16) against Q[:, 0:m] and within itself.
+//   record: accumulate the projection coefficients into T columns [col0, col0+16)
+//   store_col: column of Q to receive the result (< 0: do not store)
+static int orthonormalize(sc_handle h, int n, int m, bool record, int col0, int store_col,
+                          bool save_gram) {
+  hipStream_t s = h->stream;
+  double* Q = ptr<double>(h->Q);
+  double* W = ptr<double>(h->W);
+  double* part = ptr<double>(h->partial);
+  double* hsq = ptr<double>(h->hsq);
+  if (m > 0) {
+    for (int pass = 0; pass < 2; ++pass) {
+      launch_proj_partial(s, Q, kLdq, m, W, n, part);
+      launch_reduce_H(s, part, m, ptr<double>(h->Hbuf), record ? ptr<double>(h->T) : nullptr,
+                      kLdq, col0, pass, hsq);
+      launch_update_block(s, Q, kLdq, m, ptr<double>(h->Hbuf), W, n);
+    }
+  } else {
+    SC_HIP(h, hipMemsetAsync(hsq, 0, 16 * sizeof(double), s));
+  }
+  // CholQR2
+  launch_proj_partial(s, W, kEigBlock, kEigBlock, W, n, part);
+  launch_reduce_chol(s, part, ptr<double>(h->Rinv), save_gram ? ptr<double>(h->G) : nullptr,
+                     hsq, ptr<int>(h->flags));
+  launch_apply_rinv(s, W, n, ptr<double>(h->Rinv), nullptr, 0, 0, nullptr, nullptr);
+  launch_proj_partial(s, W, kEigBlock, kEigBlock, W, n, part);
+  launch_reduce_chol(s, part, ptr<double>(h->Rinv), nullptr, nullptr, ptr<int>(h->flags));
+  launch_apply_rinv(s, W, n, ptr<double>(h->Rinv), store_col >= 0 ? Q : nullptr, kLdq,
+                    store_col >= 0 ? store_col : 0, ptr<double>(h->cvec),
+                    ptr<double>(h->Vs));
+  return check_last(h, "orthonormalize launch");
+}
+
+static int read_flags(sc_handle h, int* mask) {
+  SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, sizeof(int), hipMemcpyDeviceToHost,
+                           h->stream));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  *mask = h->h_flags[0];
+  return SC_OK;
+}
+
+// Make sure the block in W is a full-rank orthonormal block; repairs dependent
+// columns with random vectors (bounded retries).
+static int finish_block(sc_handle h, int n, int m, int store_col, uint64_t* seed) {
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    int mask = 0;
+    SC_TRY(read_flags(h, &mask));
+    if (mask == 0) return SC_OK;
+    launch_refill_deficient(h->stream, ptr<double>(h->W), n, ptr<int>(h->flags), ++(*seed));
+    SC_TRY(orthonormalize(h, n, m, false, 0, store_col, false));
+  }
+  return fail(h, SC_ERR_NOT_CONVERGED, "could not build a full-rank Krylov block");
+}
+
+static void back_transform_cols(sc_handle h, int n, int cols) {
+  for (int c0 = 0; c0 < cols; c0 += kMaxVectors) {
+    const int cc = std::min(kMaxVectors, cols - c0);
+    launch_back_transform(h->stream, ptr<double>(h->E) + c0, kLdE, n, cc,
+                          ptr<double>(h->tvec), ptr<double>(h->colnorm));
+  }
+}
+
+// S (n x n, ld) symmetric on the device; cvec/pvec/tvec already set.
+static int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
+                    sc_diag* diag, EigDecision* out_dc, std::vector<double>* out_w) {
+  hipStream_t s = h->stream;
+  SC_TRY(ensure_eig(h, n));
+  double* theta_d = ptr<double>(h->theta);
+  double* resid_d = ptr<double>(h->resid);
+  const double* cvec = ptr<double>(h->cvec);
+  const double* pvec = ptr<double>(h->pvec);
+  EigDecision dc;
+  int m = 0, passes = 0, cycles = 0;
+
+  if (n <= kDenseMax) {
+    // ---- direct dense path: every eigenpair, one Jacobi launch
+    launch_jacobi(s, S, ld, n, 1, cvec, pvec, nullptr, theta_d, ptr<double>(h->Y), kLdq,
+                  nullptr, ptr<double>(h->Yt));
+    SC_TRY(check_last(h, "jacobi launch"));
+    SC_HIP(h, hipMemcpyAsync(h->h_theta, theta_d, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) h->h_theta[kLdq + i] = 0.0;
+    dc = analyze(rq, h->h_theta, h->h_theta + kLdq, n, n, true);
+    if (!dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
+    m = n;
+    const int cols = n;  // all eigenvectors, like np.linalg.eig
+    launch_copy_block(s, ptr<double>(h->Y), kLdq, ptr<double>(h->E), kLdE, n, cols);
+    back_transform_cols(h, n, cols);
+    h->n_vec = cols;
+    if (diag) diag->eig_path = SC_EIG_PATH_DENSE_JACOBI;
+    dc.kw = n;
+  } else {
+    if (rq.fixed_count == 0 && rq.max_clusters == 0 && !rq.descend)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "max_clusters=None with a Laplacian needs every eigenvalue; only "
+                  "supported for n <= 128 on the device path");
+    uint64_t seed = 0x5eed5eedull;
+    // ---- start block
+    launch_random_block(s, ptr<double>(h->W), n, seed);
+    SC_TRY(orthonormalize(h, n, 0, false, 0, 0, false));
+    SC_TRY(finish_block(h, n, 0, 0, &seed));
+    SC_HIP(h, hipMemsetAsync(h->T.p, 0, (size_t)kLdq * kLdq * sizeof(double), s));
+    // basis cap: LDS Jacobi limit, and basis + next block must fit in R^n
+    const int cap = std::min(kEigBasisCap, ((n - kEigBlock) / kEigBlock) * kEigBlock);
+    const int first_check = std::min(4 * kEigBlock, cap);
+    bool done = false;
+    while (!done) {
+      // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
+      launch_block_matvec(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
+                          ptr<double>(h->Vs), ptr<double>(h->W));
+      ++passes;
+      m += kEigBlock;
+      SC_TRY(orthonormalize(h, n, m, true, m - kEigBlock, m, true));
+      const bool check = (m >= first_check);
+      if (check) {
+        launch_jacobi(s, ptr<double>(h->T), kLdq, m, 0, nullptr, nullptr, ptr<double>(h->G),
+                      theta_d, ptr<double>(h->Y), kLdq, resid_d, ptr<double>(h->Yt));
+        SC_TRY(check_last(h, "jacobi launch"));
+        SC_HIP(h, hipMemcpyAsync(h->h_theta, theta_d, m * sizeof(double),
+                                 hipMemcpyDeviceToHost, s));
+        SC_HIP(h, hipMemcpyAsync(h->h_theta + kLdq, resid_d, m * sizeof(double),
+                                 hipMemcpyDeviceToHost, s));
+      }
+      SC_TRY(finish_block(h, n, m, m, &seed));  // syncs the stream
+      if (check) {
+        dc = analyze(rq, h->h_theta, h->h_theta + kLdq, m, n, false);
+        if (dc.unsupported)
+          return fail(h, SC_ERR_UNSUPPORTED,
+                      "more than 64 eigenvalues are needed (max_clusters=None with a "
+                      "slowly decaying spectrum); set max_clusters");
+        if (dc.enough && dc.converged) {
+          done = true;
+          break;
+        }
+      }
+      if (m + kEigBlock > cap) {
+        // ---- thick restart: keep the leading Ritz vectors + the new block
+        if (++cycles > rq.max_cycles)
+          return fail(h, SC_ERR_NOT_CONVERGED, "block Lanczos did not converge");
+        int want = dc.enough ? std::max(dc.kw, dc.kvec) : cap / 4;
+        int keep = round_up(want + kEigBlock, kEigBlock);
+        keep = std::max(kEigBlock, std::min(keep, cap - 2 * kEigBlock));
+        launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, keep,
+                             ptr<double>(h->Q2), kLdq, n);
+        launch_copy_block(s, ptr<double>(h->Q) + m, kLdq, ptr<double>(h->Q2) + keep, kLdq, n,
+                          kEigBlock);
+        std::swap(h->Q, h->Q2);
+        launch_set_diag_T(s, ptr<double>(h->T), kLdq, kLdq, theta_d, keep);
+        SC_TRY(check_last(h, "restart launch"));
+        m = keep;
+      }
+    }
+    const int cols = std::min(std::max(dc.kw, dc.kvec), kMaxVectors);
+    launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, cols,
+                         ptr<double>(h->E), kLdE, n);
+    back_transform_cols(h, n, cols);
+    SC_TRY(check_last(h, "ritz vector launch"));
+    h->n_vec = cols;
+    if (diag) diag->eig_path = SC_EIG_PATH_BLOCK_LANCZOS;
+  }
+  if (out_w) {
+    out_w->resize(dc.kw);
+    for (int i = 0; i < dc.kw; ++i) (*out_w)[i] = rq.descend ? h->h_theta[i] : -h->h_theta[i];
+  }
+  if (diag) {
+    diag->eig_matvec_passes = passes;
+    diag->eig_block = kEigBlock;
+    diag->eig_basis = m;
+    diag->eig_cycles = cycles;
+    diag->eig_max_residual = dc.max_resid;
+  }
+  *out_dc = dc;
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// _compute_eigenvectors_ncluster
+// ------------------------------------------------------------------------------
+static void ev_rec(sc_handle h, int* slot) {
+  if (h->nev < 48) {
+    hipEventRecord(h->ev[h->nev], h->stream);
+    *slot = h->nev++;
+  } else {
+    *slot = -1;
+  }
+}
+static float ev_ms(sc_handle h, int a, int b) {
+  if (a < 0 || b < 0) return 0.f;
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, h->ev[a], h->ev[b]);
+  return ms;
+}
+
+static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
+  const int n = h->n, ld = h->ldn;
+  hipStream_t s = h->stream;
+  const double* cur = ptr<double>(h->A0);
+  double* bufs[2] = {ptr<double>(h->B1), ptr<double>(h->B2)};
+  int which = 0;
+  bool symmetric = true;   // cosine affinity is symmetric
+  bool folded_rownorm = false;
+  int e_begin, e_tmp, e_after_refine;
+  float diffuse_ms_events[SC_MAX_OPS][2];
+  int n_diffuse = 0;
+  ev_rec(h, &e_begin);
+  for (int i = 0; i < cfg->n_ops; ++i) {
+    const int op = cfg->ops[i];
+    if (op == SC_OP_ROW_WISE_NORMALIZE && symmetric && i == cfg->n_ops - 1) {
+      folded_rownorm = true;  // W = diag(1/rowmax) S is never materialised
+      continue;
+    }
+    double* out = bufs[which];
+    which ^= 1;
+    int e0 = -1, e1 = -1;
+    if (op == SC_OP_DIFFUSE) ev_rec(h, &e0);
+    SC_TRY(run_refine_op(h, op, cfg, cur, out, n, ld));
+    if (op == SC_OP_DIFFUSE) {
+      ev_rec(h, &e1);
+      diffuse_ms_events[n_diffuse][0] = (float)e0;
+      diffuse_ms_events[n_diffuse][1] = (float)e1;
+      ++n_diffuse;
+    }
+    cur = out;
+    switch (op) {
+      case SC_OP_CROP_DIAGONAL:
+      case SC_OP_GAUSSIAN_BLUR:
+        break;  // symmetry preserved (blur: up to rounding)
+      case SC_OP_ROW_WISE_THRESHOLD:
+      case SC_OP_ROW_WISE_NORMALIZE:
+        symmetric = false;
+        break;
+      case SC_OP_SYMMETRIZE:
+      case SC_OP_DIFFUSE:
+        symmetric = true;
+        break;
+    }
+  }
+  ev_rec(h, &e_after_refine);
+  if (!symmetric)
+    return fail(h, SC_ERR_UNSUPPORTED,
+                "the refinement sequence ends in a matrix that is not diagonally similar "
+                "to a symmetric one (e.g. RowWiseThreshold without a later Symmetrize/"
+                "Diffuse); the general (dgeev-class) eigenproblem is not on the device path");
+  // ---- scaling vectors (RowWiseNormalize fold + Laplacian)
+  launch_row_stats(s, cur, n, ld, ptr<double>(h->rowmax), ptr<double>(h->rowsum));
+  launch_scaling_vectors(s, ptr<double>(h->rowmax), ptr<double>(h->rowsum), n,
+                         cfg->laplacian_type, folded_rownorm ? 1 : 0, ptr<double>(h->cvec),
+                         ptr<double>(h->pvec), ptr<double>(h->tvec));
+  SC_TRY(check_last(h, "scaling launch"));
+  int e_after_scaling;
+  ev_rec(h, &e_after_scaling);
+  // ---- eigen + eigengap
+  EigRequest rq;
+  rq.descend = (cfg->laplacian_type == SC_LAPLACIAN_NONE ||
+                cfg->laplacian_type == SC_LAPLACIAN_AFFINITY);
+  rq.max_clusters = cfg->max_clusters;
+  rq.min_clusters = cfg->min_clusters;
+  rq.stop_eigenvalue = cfg->stop_eigenvalue;
+  rq.eigengap_type = cfg->eigengap_type;
+  rq.use_stop = rq.descend;  // spectral_clusterer.py:163-167: not passed when ascending
+  rq.value_tol = cfg->eig_value_tol > 0 ? cfg->eig_value_tol : 1e-9;
+  rq.vector_tol = cfg->eig_vector_tol > 0 ? cfg->eig_vector_tol : 1e-10;
+  rq.max_cycles = cfg->eig_max_cycles > 0 ? cfg->eig_max_cycles : 40;
+  rq.fixed_count = 0;
+  EigDecision dc;
+  std::vector<double> w;
+  SC_TRY(sym_topk(h, cur, ld, n, rq, diag, &dc, &w));
+  int e_after_eig;
+  ev_rec(h, &e_after_eig);
+  SC_HIP(h, hipStreamSynchronize(s));
+  if (diag) {
+    diag->n = n;
+    diag->n_clusters_raw = dc.n_clusters_raw;
+    diag->max_delta = dc.max_delta;
+    diag->eig_descending = rq.descend;
+    diag->n_eigenvalues = std::min((int)w.size(), SC_MAX_EIG);
+    for (int i = 0; i < diag->n_eigenvalues; ++i) diag->eigenvalues[i] = w[i];
+    diag->symmetry_state = folded_rownorm ? 2 : 1;
+    float dms = 0.f;
+    for (int i = 0; i < n_diffuse; ++i)
+      dms += ev_ms(h, (int)diffuse_ms_events[i][0], (int)diffuse_ms_events[i][1]);
+    diag->stage_ms[SC_STAGE_DIFFUSE] = dms;
+    diag->stage_ms[SC_STAGE_REFINE] = ev_ms(h, e_begin, e_after_refine) - dms;
+    diag->stage_ms[SC_STAGE_SCALING] = ev_ms(h, e_after_refine, e_after_scaling);
+    diag->stage_ms[SC_STAGE_EIG] = ev_ms(h, e_after_scaling, e_after_eig);
+  }
+  (void)e_tmp;
+  return SC_OK;
+}
+
+extern "C" int sc_eig_ncluster(sc_handle h, const sc_config* cfg, sc_diag* diag) {
+  if (!h) return SC_ERR_INVALID;
+  SC_TRY(validate_config(h, cfg));
+  if (!h->have_affinity) return fail(h, SC_ERR_INVALID, "no affinity resident");
+  SC_HIP(h, hipSetDevice(h->device));
+  h->nev = 0;
+  if (diag) memset(diag, 0, sizeof(*diag));
+  return eig_ncluster_impl(h, cfg, diag);
+}
+
+extern "C" int sc_num_eigenvectors(sc_handle h) { return h ? h->n_vec : 0; }
+
+extern "C" int sc_get_eigenvectors(sc_handle h, double* out, int n, int ncols) {
+  if (!h || !out) return SC_ERR_INVALID;
+  if (n != h->n || ncols <= 0 || ncols > h->n_vec)
+    return fail(h, SC_ERR_INVALID, "eigenvector request out of range");
+  SC_HIP(h, hipSetDevice(h->device));
+  return d2h_matrix(h, ptr<double>(h->E), kLdE, n, ncols, out);
+}
+
+// ------------------------------------------------------------------------------
+// k-means tail
+// ------------------------------------------------------------------------------
+static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k, int max_iter,
+                            int64_t* labels, double* centroids_out, int* iterations) {
+  if (max_iter <= 0)
+    return fail(h, SC_ERR_INVALID, "Number of iterations should be a positive number");
+  if (n < k) return fail(h, SC_ERR_INVALID, "n_samples should be >= n_clusters");
+  if (k < 1 || k > kMaxVectors)
+    return fail(h, SC_ERR_UNSUPPORTED, "n_clusters must be in [1, 64] on the device path");
+  SC_TRY(ensure_kmeans(h, n));
+  // RandomState(0): first centre via choice(n, p=uniform) = cdf.searchsorted(u, 'right')
+  Mt19937 rng(0);
+  const double u = rng.next_double();
+  const double p = 1.0 / (double)n;
+  std::vector<double> cdf(n);
+  double run = 0.0;
+  for (int i = 0; i < n; ++i) {
+    run += p;
+    cdf[i] = run;
+  }
+  const double last = cdf[n - 1];
+  int first = n;  // searchsorted(..., side="right"): first index with cdf > u
+  for (int i = 0; i < n; ++i) {
+    if (cdf[i] / last > u) { first = i; break; }
+  }
+  if (first >= n) first = n - 1;
+  const int trials = 2 + (int)std::log((double)k);
+  std::vector<double> rnd((size_t)std::max(1, (k - 1) * trials));
+  for (size_t i = 0; i < rnd.size(); ++i) rnd[i] = rng.next_double();
+  if (rnd.size() > 1024) return fail(h, SC_ERR_UNSUPPORTED, "too many k-means++ trials");
+  SC_HIP(h, hipMemcpyAsync(h->krnd.p, rnd.data(), rnd.size() * sizeof(double),
+                           hipMemcpyHostToDevice, h->stream));
+  KmeansWorkspace ws;
+  ws.Xc = ptr<double>(h->kXc);
+  ws.xsq = ptr<double>(h->kxsq);
+  ws.closest = ptr<double>(h->kclosest);
+  ws.cand = ptr<double>(h->kcand);
+  ws.enorm = ptr<double>(h->kenorm);
+  ws.rnd = ptr<double>(h->krnd);
+  ws.centroids = ptr<double>(h->kcent);
+  ws.labels32 = ptr<int>(h->klab32);
+  ws.labels64 = ptr<long long>(h->klab64);
+  ws.info = ptr<int>(h->kinfo);
+  launch_kmeans(h->stream, E, lde, n, k, max_iter, first, trials, ws);
+  SC_TRY(check_last(h, "kmeans launch"));
+  SC_HIP(h, hipMemcpyAsync(labels, h->klab64.p, (size_t)n * sizeof(int64_t),
+                           hipMemcpyDeviceToHost, h->stream));
+  int info[4] = {0, 0, 0, 0};
+  SC_HIP(h, hipMemcpyAsync(info, h->kinfo.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (centroids_out)
+    SC_HIP(h, hipMemcpyAsync(centroids_out, h->kcent.p, (size_t)k * k * sizeof(double),
+                             hipMemcpyDeviceToHost, h->stream));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  if (iterations) *iterations = info[0];
+  return SC_OK;
+}
+
+extern "C" int sc_cluster(sc_handle h, const sc_config* cfg, int n_clusters, int64_t* labels,
+                          sc_diag* diag) {
+  if (!h) return SC_ERR_INVALID;
+  if (!cfg || !labels) return fail(h, SC_ERR_INVALID, "NULL argument");
+  if (h->n_vec <= 0) return fail(h, SC_ERR_INVALID, "no eigenvectors resident");
+  if (n_clusters < 1 || n_clusters > h->n_vec)
+    return fail(h, SC_ERR_INVALID, "n_clusters exceeds the resident eigenvectors");
+  SC_HIP(h, hipSetDevice(h->device));
+  const int n = h->n;
+  int e0, e1;
+  ev_rec(h, &e0);
+  const double* E = ptr<double>(h->E);
+  if (cfg->row_wise_renorm) {
+    SC_TRY(ensure_kmeans(h, n));
+    launch_copy_block(h->stream, ptr<double>(h->E), kLdE, ptr<double>(h->Ek), kLdE, n,
+                      n_clusters);
+    launch_row_renorm(h->stream, ptr<double>(h->Ek), kLdE, n, n_clusters);
+    E = ptr<double>(h->Ek);
+  }
+  int iters = 0;
+  SC_TRY(kmeans_on_device(h, E, kLdE, n, n_clusters, cfg->max_iter, labels, nullptr, &iters));
+  ev_rec(h, &e1);
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  if (diag) {
+    diag->n_clusters = n_clusters;
+    diag->kmeans_iterations = iters;
+    diag->stage_ms[SC_STAGE_KMEANS] = ev_ms(h, e0, e1);
+  }
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// whole path
+// ------------------------------------------------------------------------------
+extern "C" int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* labels,
+                               sc_diag* diag) {
+  if (!h) return SC_ERR_INVALID;
+  SC_TRY(validate_config(h, cfg));
+  if (!labels) return fail(h, SC_ERR_INVALID, "labels is NULL");
+  if (!h->have_x) return fail(h, SC_ERR_INVALID, "no embeddings resident");
+  SC_HIP(h, hipSetDevice(h->device));
+  sc_diag local;
+  sc_diag* dg = diag ? diag : &local;
+  memset(dg, 0, sizeof(*dg));
+  h->nev = 0;
+  int e0, e1, e2;
+  ev_rec(h, &e0);
+  SC_TRY(sc_compute_affinity(h));
+  ev_rec(h, &e1);
+  SC_TRY(eig_ncluster_impl(h, cfg, dg));
+  int k = dg->n_clusters_raw;
+  if (cfg->min_clusters > 0 && k < cfg->min_clusters) k = cfg->min_clusters;  // :295-296
+  SC_TRY(sc_cluster(h, cfg, k, labels, dg));
+  ev_rec(h, &e2);
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  dg->stage_ms[SC_STAGE_AFFINITY] = ev_ms(h, e0, e1);
+  dg->stage_ms[SC_STAGE_TOTAL] = ev_ms(h, e0, e2);
+  return SC_OK;
+}
+
+extern "C" int sc_predict(sc_handle h, const double* x, int n, int d, const sc_config* cfg,
+                          int64_t* labels, sc_diag* diag) {
+  if (!h) return SC_ERR_INVALID;
+  SC_TRY(validate_config(h, cfg));
+  SC_TRY(sc_set_embeddings(h, x, n, d));
+  return sc_run_resident(h, cfg, labels, diag);
+}
+
+extern "C" int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,
+                                int count, const sc_config* cfg, int64_t* const* labels,
+                                sc_diag* diags) {
+  if (!h) return SC_ERR_INVALID;
+  if (!xs || !ns || !labels || count < 0) return fail(h, SC_ERR_INVALID, "NULL argument");
+  int nmax = 0;
+  for (int i = 0; i < count; ++i) nmax = std::max(nmax, ns[i]);
+  if (nmax > 0) SC_TRY(sc_reserve(h, nmax, d));  // one arena sized for the largest member
+  for (int i = 0; i < count; ++i)
+    SC_TRY(sc_predict(h, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr));
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// single stages
+// ------------------------------------------------------------------------------
+extern "C" int sc_stage_affinity(sc_handle h, const double* x, int n, int d, double* out) {
+  if (!h) return SC_ERR_INVALID;
+  if (!out) return fail(h, SC_ERR_INVALID, "out is NULL");
+  SC_TRY(sc_set_embeddings(h, x, n, d));
+  SC_TRY(sc_compute_affinity(h));
+  return d2h_matrix(h, ptr<double>(h->A0), h->ldn, n, n, out);
+}
+
+extern "C" int sc_stage_refine(sc_handle h, int op, const sc_config* cfg, const double* in,
+                               int n, double* out) {
+  if (!h) return SC_ERR_INVALID;
+  SC_TRY(validate_config(h, cfg));
+  if (!in || !out || n <= 0) return fail(h, SC_ERR_INVALID, "affinity must be (n, n)");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, n, 0));
+  const int ld = round_up(n, 16);
+  h->have_affinity = false;
+  h->have_x = false;
+  h->n_vec = 0;
+  SC_TRY(h2d_matrix(h, in, n, n, ptr<double>(h->B1), ld));
+  SC_TRY(run_refine_op(h, op, cfg, ptr<double>(h->B1), ptr<double>(h->B2), n, ld));
+  return d2h_matrix(h, ptr<double>(h->B2), ld, n, n, out);
+}
+
+extern "C" int sc_stage_laplacian(sc_handle h, int laplacian_type, const double* in, int n,
+                                  double* out) {
+  if (!h) return SC_ERR_INVALID;
+  if (!in || !out || n <= 0) return fail(h, SC_ERR_INVALID, "affinity must be (n, n)");
+  if (laplacian_type < SC_LAPLACIAN_AFFINITY || laplacian_type > SC_LAPLACIAN_GRAPH_CUT)
+    return fail(h, SC_ERR_INVALID, "laplacian_type must be a LaplacianType");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, n, 0));
+  const int ld = round_up(n, 16);
+  h->have_affinity = false;
+  h->have_x = false;
+  h->n_vec = 0;
+  SC_TRY(h2d_matrix(h, in, n, n, ptr<double>(h->B1), ld));
+  if (laplacian_type == SC_LAPLACIAN_AFFINITY)
+    return d2h_matrix(h, ptr<double>(h->B1), ld, n, n, out);
+  launch_laplacian(h->stream, ptr<double>(h->B1), ptr<double>(h->B2), n, ld, laplacian_type,
+                   ptr<double>(h->deg));
+  SC_TRY(check_last(h, "laplacian launch"));
+  return d2h_matrix(h, ptr<double>(h->B2), ld, n, n, out);
+}
+
+__global__ void k_negate(const double* in, double* out, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x)
+    out[e] = -in[e];
+}
+
+__global__ void k_fill(double* p, int n, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, int descend,
+                                double* values, double* vectors, sc_diag* diag) {
+  if (!h) return SC_ERR_INVALID;
+  if (!m || n <= 0 || count <= 0 || count > n || !values)
+    return fail(h, SC_ERR_INVALID, "bad eigen request");
+  if (n > kDenseMax && count > kMaxVectors)
+    return fail(h, SC_ERR_UNSUPPORTED, "at most 64 eigenpairs for n > 128");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, n, 0));
+  const int ld = round_up(n, 16);
+  h->n = n;
+  h->ldn = ld;
+  h->have_affinity = false;
+  h->have_x = false;
+  SC_TRY(h2d_matrix(h, m, n, n, ptr<double>(h->B1), ld));
+  // Op = +M (descend) or -M (ascend): c = 1, p = 0, t = 1; the sign is folded by
+  // running on sigma * M through c = 1 and a negated copy when ascending.
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, h->stream, ptr<double>(h->cvec), n, 1.0);
+  hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, h->stream, ptr<double>(h->pvec), n, 0.0);
+  hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, h->stream, ptr<double>(h->tvec), n, 1.0);
+  const double* S = ptr<double>(h->B1);
+  if (!descend) {  // smallest eigenpairs of M = largest of -M
+    hipLaunchKernelGGL(k_negate, dim3(2048), dim3(256), 0, h->stream, ptr<double>(h->B1),
+                       ptr<double>(h->B2), (size_t)n * ld);
+    S = ptr<double>(h->B2);
+  }
+  EigRequest rq;
+  rq.descend = descend ? 1 : 0;
+  rq.max_clusters = 0;
+  rq.min_clusters = 0;
+  rq.stop_eigenvalue = 0.0;
+  rq.eigengap_type = SC_EIGENGAP_RATIO;
+  rq.use_stop = 0;
+  rq.value_tol = 1e-10;
+  rq.vector_tol = 1e-11;
+  rq.max_cycles = 60;
+  rq.fixed_count = count;
+  EigDecision dc;
+  std::vector<double> w;
+  sc_diag local;
+  sc_diag* dg = diag ? diag : &local;
+  memset(dg, 0, sizeof(*dg));
+  h->nev = 0;
+  SC_TRY(sym_topk(h, S, ld, n, rq, dg, &dc, &w));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < count; ++i) values[i] = w[i];
+  if (vectors) SC_TRY(d2h_matrix(h, ptr<double>(h->E), kLdE, n, count, vectors));
+  return SC_OK;
+}
+
+extern "C" int sc_stage_kmeans(sc_handle h, const double* e, int n, int k, int max_iter,
+                               int64_t* labels, double* centroids_out, int* iterations) {
+  if (!h) return SC_ERR_INVALID;
+  if (!e || !labels || n <= 0 || k <= 0) return fail(h, SC_ERR_INVALID, "bad k-means input");
+  if (k > kMaxVectors)
+    return fail(h, SC_ERR_UNSUPPORTED, "n_clusters must be <= 64 on the device path");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_kmeans(h, n));
+  SC_TRY(h2d_matrix(h, e, n, k, ptr<double>(h->Ek), kLdE));
+  return kmeans_on_device(h, ptr<double>(h->Ek), kLdE, n, k, max_iter, labels, centroids_out,
+                          iterations);
+}

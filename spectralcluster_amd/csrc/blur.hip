@@ -1,0 +1,92 @@
+// R2: GaussianBlur (reference refinement.py:160-162 -> scipy.ndimage.
+// gaussian_filter, scipy 1.15.3): separable correlation, axis 0 then axis 1,
+// boundary `reflect` (d c b a | a b c d | d c b a), symmetric-kernel summation
+// order of scipy's NI_Correlate1D:
+//     t = x[0] * w[0];  for j = radius .. 1:  t += (x[-j] + x[+j]) * w[j]
+// Both passes are fused in one kernel: a (TH+2R) x (TW+2R) halo tile is staged
+// in LDS, the axis-0 pass writes a TH x (TW+2R) intermediate (full fp64, like
+// scipy's float64 intermediate array), the axis-1 pass writes the output tile.
+// HBM traffic: 1 read (+ halo re-reads served by L2) + 1 write of n^2.
+// Compiled with -ffp-contract=off so mul/add round separately like the C code.
+#include "sc_internal.h"
+
+namespace sc {
+
+constexpr int TH = 32;
+constexpr int TW = 64;
+
+__device__ __forceinline__ int reflect_index(int j, int n) {
+  // scipy "reflect": period 2n, second half mirrored, edge sample repeated
+  const int period = 2 * n;
+  j %= period;
+  if (j < 0) j += period;
+  return j < n ? j : period - 1 - j;
+}
+
+__global__ __launch_bounds__(256) void k_gaussian_blur(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    int radius, const double* __restrict__ weights) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int R = radius;
+  const int HW = TW + 2 * R;          // halo tile width
+  const int HH = TH + 2 * R;          // halo tile height
+  double* tile = smem;                 // HH x HW
+  double* mid = smem + HH * HW;        // TH x HW
+  double* w = mid + TH * HW;           // R + 1 : w[j] = weight at distance j
+
+  const int i0 = blockIdx.y * TH;
+  const int j0 = blockIdx.x * TW;
+  const int tid = threadIdx.x;
+
+  if (tid <= R) w[tid] = weights[R - tid];  // symmetric: left half reversed
+  for (int e = tid; e < HH * HW; e += 256) {
+    const int r = e / HW, c = e - r * HW;
+    const int gi = reflect_index(i0 + r - R, n);
+    const int gj = reflect_index(j0 + c - R, n);
+    tile[e] = in[(size_t)gi * ld + gj];
+  }
+  __syncthreads();
+  // axis 0 (down the rows)
+  for (int e = tid; e < TH * HW; e += 256) {
+    const int r = e / HW, c = e - r * HW;
+    const double* x = tile + (r + R) * HW + c;
+    double t = x[0] * w[0];
+    for (int j = R; j >= 1; --j) t += (x[-j * HW] + x[j * HW]) * w[j];
+    mid[e] = t;
+  }
+  __syncthreads();
+  // axis 1 (along the row)
+  for (int e = tid; e < TH * TW; e += 256) {
+    const int r = e / TW, c = e - r * TW;
+    const int gi = i0 + r, gj = j0 + c;
+    if (gi < n && gj < n) {
+      const double* x = mid + r * HW + c + R;
+      double t = x[0] * w[0];
+      for (int j = R; j >= 1; --j) t += (x[-j] + x[j]) * w[j];
+      out[(size_t)gi * ld + gj] = t;
+    }
+  }
+}
+
+__global__ void k_copy_matrix(const double* __restrict__ in,
+                              double* __restrict__ out, int n, int ld) {
+  const size_t total = (size_t)n * ld;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x)
+    out[e] = in[e];
+}
+
+void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
+                          int ld, int radius, const double* weights_dev) {
+  if (radius <= 0) {  // sigma == 0: gaussian_filter degenerates to a copy
+    hipLaunchKernelGGL(k_copy_matrix, dim3(2048), dim3(256), 0, s, in, out, n, ld);
+    return;
+  }
+  const int HW = TW + 2 * radius, HH = TH + 2 * radius;
+  const size_t lds = sizeof(double) * ((size_t)HH * HW + (size_t)TH * HW + radius + 1);
+  dim3 grid((n + TW - 1) / TW, (n + TH - 1) / TH);
+  hipLaunchKernelGGL(k_gaussian_blur, grid, dim3(256), lds, s, in, out, n, ld,
+                     radius, weights_dev);
+}
+
+}  // namespace sc

@@ -1,0 +1,306 @@
+// Row-parallel fp64 kernels of the refinement chain (reference refinement.py),
+// the Laplacian (laplacian.py) and the scaling vectors of the symmetric
+// eigen-operator.  One 256-thread workgroup per matrix row; 16-byte loads;
+// reductions = wave64 shuffles + one LDS hop.  HBM-bound: 1 read (+ an L2 re-read
+// for two-pass ops) and 1 write of the n x n matrix per op.
+//
+// Compiled with -ffp-contract=off: the elementwise arithmetic keeps the
+// reference's operation order and rounding (no fused multiply-add).
+#include "sc_internal.h"
+
+namespace sc {
+
+constexpr int kRowThreads = 256;
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// block-wide reductions for 256 threads (4 waves); `sm` has >= 4 doubles.
+__device__ __forceinline__ double block_max(double v, double* sm) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// ---- A1: rows of X to unit L2 norm (utils.py:32-33) -------------------------
+__global__ __launch_bounds__(kRowThreads) void k_normalize_rows(
+    const double* __restrict__ X, int ldx, int n, int d, double* __restrict__ Xn) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = X + (size_t)row * ldx;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < d; j += kRowThreads) acc += x[j] * x[j];
+  const double norm = sqrt(block_sum(acc, sm));
+  double* o = Xn + (size_t)row * ldx;
+  for (int j = threadIdx.x; j < ldx; j += kRowThreads)
+    o[j] = j < d ? x[j] / norm : 0.0;
+}
+
+// ---- R1: CropDiagonal (refinement.py:145-151) -------------------------------
+__global__ __launch_bounds__(kRowThreads) void k_crop_diagonal(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = in + (size_t)row * ld;
+  double* o = out + (size_t)row * ld;
+  double m = 0.0;  // the zero-filled diagonal takes part in the max
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    const double2 v = *reinterpret_cast<const double2*>(x + j);
+    if (j != row) m = fmax(m, v.x);
+    if (j + 1 < n && j + 1 != row) m = fmax(m, v.y);
+  }
+  m = block_max(m, sm);
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    double2 v = *reinterpret_cast<const double2*>(x + j);
+    if (j == row) v.x = m;
+    if (j + 1 == row) v.y = m;
+    *reinterpret_cast<double2*>(o + j) = v;
+  }
+}
+
+// ---- R3: RowWiseThreshold, RowMax (refinement.py:182-210) --------------------
+__global__ __launch_bounds__(kRowThreads) void k_row_threshold(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    double p, double mult, int binarize, int preserve_diag) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = in + (size_t)row * ld;
+  double* o = out + (size_t)row * ld;
+  double m = -INFINITY;
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    double2 v = *reinterpret_cast<const double2*>(x + j);
+    if (preserve_diag) {  // diagonal zero-filled before the max (:185-186)
+      if (j == row) v.x = 0.0;
+      if (j + 1 == row) v.y = 0.0;
+    }
+    m = fmax(m, v.x);
+    if (j + 1 < n) m = fmax(m, v.y);
+  }
+  m = block_max(m, sm);
+  const double cut = m * p;  // row_max * p_percentile (:191)
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    double2 v = *reinterpret_cast<const double2*>(x + j);
+    if (preserve_diag) {
+      if (j == row) v.x = 0.0;
+      if (j + 1 == row) v.y = 0.0;
+    }
+    // x*(!small) + x*mult*small == select (exact for finite x)
+    double2 r;
+    r.x = v.x < cut ? v.x * mult : (binarize ? 1.0 : v.x);
+    r.y = v.y < cut ? v.y * mult : (binarize ? 1.0 : v.y);
+    if (preserve_diag) {  // diagonal back to 1 (:208-209)
+      if (j == row) r.x = 1.0;
+      if (j + 1 == row) r.y = 1.0;
+    }
+    *reinterpret_cast<double2*>(o + j) = r;
+  }
+}
+
+// ---- R6: RowWiseNormalize (refinement.py:240-245) ------------------------------
+__global__ __launch_bounds__(kRowThreads) void k_row_normalize(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = in + (size_t)row * ld;
+  double* o = out + (size_t)row * ld;
+  double m = -INFINITY;
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    const double2 v = *reinterpret_cast<const double2*>(x + j);
+    m = fmax(m, v.x);
+    if (j + 1 < n) m = fmax(m, v.y);
+  }
+  m = block_max(m, sm);
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    double2 v = *reinterpret_cast<const double2*>(x + j);
+    v.x = v.x / m;
+    v.y = v.y / m;
+    *reinterpret_cast<double2*>(o + j) = v;
+  }
+}
+
+// ---- row max + row sum of the (symmetric) refined matrix ----------------------
+__global__ __launch_bounds__(kRowThreads) void k_row_stats(
+    const double* __restrict__ in, int n, int ld, double* __restrict__ rowmax,
+    double* __restrict__ rowsum) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = in + (size_t)row * ld;
+  double m = -INFINITY, s = 0.0;
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    const double2 v = *reinterpret_cast<const double2*>(x + j);
+    m = fmax(m, v.x);
+    s += v.x;
+    if (j + 1 < n) {
+      m = fmax(m, v.y);
+      s += v.y;
+    }
+  }
+  m = block_max(m, sm);
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) {
+    rowmax[row] = m;
+    rowsum[row] = s;
+  }
+}
+
+// ---- scaling vectors of Op = diag(p) + diag(c) S diag(c)  ---------------------
+// W = diag(a) S with a = 1/rowmax after RowWiseNormalize (a = 1 otherwise).
+//   None/Affinity : Op = D_c S D_c            c = sqrt(a)            t = sqrt(a)
+//   Unnormalized  : Op = -(D_deg - D_c S D_c) c = sqrt(a)            t = sqrt(a)
+//   RandomWalk    : g = 1/(deg+eps)           c = sqrt(g a), p = -g deg, t = c
+//   GraphCut      : h = 1/(sqrt(deg)+eps)     c = h sqrt(a), p = -h^2 deg, t = sqrt(a)
+// with deg = a * rowsum(S) (laplacian.py:41 on W).  Eigenvector of the
+// reference matrix = normalise(t .* u) for an eigenvector u of Op.
+__global__ void k_scaling_vectors(const double* __restrict__ rowmax,
+                                  const double* __restrict__ rowsum, int n,
+                                  int lap, int rownorm, double* __restrict__ c,
+                                  double* __restrict__ p, double* __restrict__ t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double eps = 1e-10;  // laplacian.py:6
+  const double a = rownorm ? 1.0 / rowmax[i] : 1.0;
+  const double sa = sqrt(a);
+  const double deg = rownorm ? rowsum[i] / rowmax[i] : rowsum[i];
+  double cv = sa, pv = 0.0, tv = sa;
+  if (lap == SC_LAPLACIAN_UNNORMALIZED) {
+    pv = -deg;
+  } else if (lap == SC_LAPLACIAN_RANDOM_WALK) {
+    const double g = 1.0 / (deg + eps);
+    cv = sqrt(g * a);
+    pv = -(g * deg);
+    tv = cv;
+  } else if (lap == SC_LAPLACIAN_GRAPH_CUT) {
+    const double h = 1.0 / (sqrt(deg) + eps);
+    cv = h * sa;
+    pv = -((h * deg) * h);
+  }
+  c[i] = cv;
+  p[i] = pv;
+  t[i] = tv;
+}
+
+// ---- L1: materialised Laplacian for the stage API (laplacian.py:24-60) --------
+__global__ __launch_bounds__(kRowThreads) void k_row_sum(
+    const double* __restrict__ in, int n, int ld, double* __restrict__ rowsum) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = in + (size_t)row * ld;
+  double s = 0.0;
+  for (int j = threadIdx.x; j < n; j += kRowThreads) s += x[j];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) rowsum[row] = s;
+}
+
+__global__ __launch_bounds__(kRowThreads) void k_laplacian(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    int lap, const double* __restrict__ deg) {
+  const int row = blockIdx.x;
+  const double eps = 1e-10;
+  const double* x = in + (size_t)row * ld;
+  double* o = out + (size_t)row * ld;
+  const double di = deg[row];
+  double ri = 1.0;
+  if (lap == SC_LAPLACIAN_RANDOM_WALK) ri = 1.0 / (di + eps);
+  if (lap == SC_LAPLACIAN_GRAPH_CUT) ri = 1.0 / (sqrt(di) + eps);
+  for (int j = threadIdx.x; j < n; j += kRowThreads) {
+    double l = (j == row ? di : 0.0) - x[j];  // degree - affinity (:42)
+    if (lap == SC_LAPLACIAN_RANDOM_WALK) {
+      l = ri * l;
+    } else if (lap == SC_LAPLACIAN_GRAPH_CUT) {
+      const double rj = 1.0 / (sqrt(deg[j]) + eps);
+      l = (ri * l) * rj;  // degree_norm.dot(laplacian).dot(degree_norm) (:57)
+    }
+    o[j] = l;
+  }
+}
+
+// ---- R4: Symmetrize (refinement.py:219-226): 32x32 tiles through LDS ----------
+__global__ __launch_bounds__(256) void k_symmetrize(const double* __restrict__ in,
+                                                    double* __restrict__ out,
+                                                    int n, int ld, int type) {
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.y * 32, bj = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  // transposed tile: rows bj.., cols bi..
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int gi = bj + r, gj = bi + tx;
+    tile[r][tx] = (gi < n && gj < n) ? in[(size_t)gi * ld + gj] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int gi = bi + r, gj = bj + tx;
+    if (gi < n && gj < n) {
+      const double a = in[(size_t)gi * ld + gj];
+      const double b = tile[tx][r];
+      out[(size_t)gi * ld + gj] =
+          type == SC_SYMMETRIZE_MAX ? fmax(a, b) : 0.5 * (a + b);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------
+void launch_normalize_rows(hipStream_t s, const double* X, int ldx, int n, int d,
+                           double* Xn) {
+  hipLaunchKernelGGL(k_normalize_rows, dim3(n), dim3(kRowThreads), 0, s, X, ldx, n,
+                     d, Xn);
+}
+void launch_crop_diagonal(hipStream_t s, const double* in, double* out, int n,
+                          int ld) {
+  hipLaunchKernelGGL(k_crop_diagonal, dim3(n), dim3(kRowThreads), 0, s, in, out, n,
+                     ld);
+}
+void launch_row_threshold(hipStream_t s, const double* in, double* out, int n,
+                          int ld, double p, double mult, int binarize,
+                          int preserve_diag) {
+  hipLaunchKernelGGL(k_row_threshold, dim3(n), dim3(kRowThreads), 0, s, in, out, n,
+                     ld, p, mult, binarize, preserve_diag);
+}
+void launch_row_normalize(hipStream_t s, const double* in, double* out, int n,
+                          int ld) {
+  hipLaunchKernelGGL(k_row_normalize, dim3(n), dim3(kRowThreads), 0, s, in, out, n,
+                     ld);
+}
+void launch_row_stats(hipStream_t s, const double* in, int n, int ld,
+                      double* rowmax, double* rowsum) {
+  hipLaunchKernelGGL(k_row_stats, dim3(n), dim3(kRowThreads), 0, s, in, n, ld,
+                     rowmax, rowsum);
+}
+void launch_scaling_vectors(hipStream_t s, const double* rowmax,
+                            const double* rowsum, int n, int laplacian_type,
+                            int row_normalized, double* c, double* p, double* t) {
+  hipLaunchKernelGGL(k_scaling_vectors, dim3((n + 255) / 256), dim3(256), 0, s,
+                     rowmax, rowsum, n, laplacian_type, row_normalized, c, p, t);
+}
+void launch_laplacian(hipStream_t s, const double* in, double* out, int n, int ld,
+                      int laplacian_type, double* deg_ws) {
+  hipLaunchKernelGGL(k_row_sum, dim3(n), dim3(kRowThreads), 0, s, in, n, ld,
+                     deg_ws);
+  hipLaunchKernelGGL(k_laplacian, dim3(n), dim3(kRowThreads), 0, s, in, out, n, ld,
+                     laplacian_type, deg_ws);
+}
+void launch_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
+                       int type) {
+  const int t = (n + 31) / 32;
+  hipLaunchKernelGGL(k_symmetrize, dim3(t, t), dim3(256), 0, s, in, out, n, ld,
+                     type);
+}
+
+}  // namespace sc

@@ -1,0 +1,136 @@
+// Internal declarations shared by the HIP translation units of
+// libspectralcluster_amd.so.  gfx950 (MI355X) only: wave64, fp64 MFMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/spectralcluster_amd.h"
+
+namespace sc {
+
+constexpr int kWave = 64;
+constexpr int kEigBlock = 16;        // vectors per operator pass (one MFMA tile)
+constexpr int kEigBasisCap = 128;    // Rayleigh-Ritz size limit (LDS Jacobi)
+constexpr int kLdq = kEigBasisCap + kEigBlock;  // row stride of the Krylov basis
+constexpr int kDenseMax = 128;       // n <= this: direct dense Jacobi
+constexpr int kMaxVectors = 64;      // eigenvector columns kept resident
+constexpr int kProjBlocks = 128;     // partial-sum blocks for tall-skinny products
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// GEMM epilogues
+enum { kEpiNone = 0, kEpiAffinity = 1 };
+
+// ---- kernel launchers (each enqueues on `s`, no sync) -----------------------
+// C[M,N] = A[M,K] * B[N,K]^T (row-major, leading dims in elements).  When
+// `symmetric` is set B must alias A and only tile pairs i<=j are computed; the
+// mirror tile is written transposed, so C is exactly symmetric.
+void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
+                    int ldb, double* C, int ldc, int M, int N, int K,
+                    int epilogue, bool symmetric);
+
+void launch_normalize_rows(hipStream_t s, const double* X, int ldx, int n, int d,
+                           double* Xn);
+void launch_crop_diagonal(hipStream_t s, const double* in, double* out, int n,
+                          int ld);
+void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
+                          int ld, int radius, const double* weights_dev);
+void launch_row_threshold(hipStream_t s, const double* in, double* out, int n,
+                          int ld, double p, double mult, int binarize,
+                          int preserve_diag);
+void launch_row_percentile_threshold(hipStream_t s, const double* in, double* out,
+                                     int n, int ld, double p, double mult,
+                                     int binarize, int preserve_diag);
+void launch_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
+                       int type);
+void launch_row_normalize(hipStream_t s, const double* in, double* out, int n,
+                          int ld);
+void launch_row_stats(hipStream_t s, const double* in, int n, int ld,
+                      double* rowmax, double* rowsum);
+// c/p/t vectors of the symmetric operator  Op = diag(p) + diag(c) S diag(c)
+void launch_scaling_vectors(hipStream_t s, const double* rowmax,
+                            const double* rowsum, int n, int laplacian_type,
+                            int row_normalized, double* c, double* p, double* t);
+void launch_laplacian(hipStream_t s, const double* in, double* out, int n, int ld,
+                      int laplacian_type, double* deg_ws);
+
+// ---- eigensolver -------------------------------------------------------------
+struct EigWorkspace {
+  double* Q = nullptr;        // n x kLdq Krylov basis (row-major)
+  double* Q2 = nullptr;       // restart scratch, same shape
+  double* Vs = nullptr;       // n x 16: c .* current block
+  double* W = nullptr;        // n x 16: operator output / next block
+  double* partial = nullptr;  // kProjBlocks x (kLdq*16)
+  double* T = nullptr;        // kLdq x kLdq projected operator
+  double* Y = nullptr;        // kLdq x kLdq Ritz coefficient vectors
+  double* theta = nullptr;    // kLdq Ritz values (descending)
+  double* resid = nullptr;    // kLdq residual estimates
+  double* G = nullptr;        // 16x16 Gram of the residual block
+  double* Rinv = nullptr;     // 16x16
+  double* Hbuf = nullptr;     // kLdq x 16 projection coefficients of one pass
+  double* hsq = nullptr;      // 16 column energies removed by projection
+  double* Yt = nullptr;       // kLdq x kLdq Jacobi vector accumulator (transposed)
+  double* colnorm = nullptr;  // kProjBlocks x kMaxVectors partial column sums
+  int* flags = nullptr;       // [0] rank-deficiency mask of the last block
+};
+
+void launch_random_block(hipStream_t s, double* W, int n, uint64_t seed);
+void launch_block_matvec(hipStream_t s, const double* S, int ld, int n,
+                         const double* cvec, const double* pvec, const double* V,
+                         int ldv, const double* Vs, double* W);
+void launch_proj_partial(hipStream_t s, const double* Q, int ldq, int m,
+                         const double* W, int n, double* partial);
+// H = sum of partials (m x 16) -> Hbuf; if T != nullptr also (accumulated) into
+// T[0:m, col0:col0+16] and mirrored; hsq[j] (+)= sum_i H_ij^2.
+void launch_reduce_H(hipStream_t s, const double* partial, int m, double* Hbuf,
+                     double* T, int ldt, int col0, int accumulate, double* hsq);
+void launch_update_block(hipStream_t s, const double* Q, int ldq, int m,
+                         const double* Hbuf, double* W, int n);
+// Gram reduce + Cholesky: Rinv (16x16 upper), optional copy of G, flags mask.
+void launch_reduce_chol(hipStream_t s, const double* partial, double* Rinv,
+                        double* Gsave, const double* hsq, int* flags);
+// W <- W * Rinv ; optionally also store into Q[:, col0:col0+16] and Vs = c .* W
+void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
+                       double* Qdst, int ldq, int col0, const double* cvec,
+                       double* Vs);
+void launch_refill_deficient(hipStream_t s, double* W, int n, const int* flags,
+                             uint64_t seed);
+// Dense symmetric eigensolver (one workgroup, cyclic Jacobi, matrix in LDS).
+// mode 0: A = T (m x m, ldt).  mode 1: A_ij = c_i c_j S_ij + delta_ij p_i.
+void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
+                   const double* cvec, const double* pvec, const double* G,
+                   double* theta, double* Y, int ldy, double* resid, double* Yt);
+void launch_set_diag_T(hipStream_t s, double* T, int ldt, int mtot,
+                       const double* theta, int keep);
+// dst[:, 0:cols] = Q[:, 0:m] * Y[0:m, 0:cols]
+void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
+                          const double* Y, int ldy, int cols, double* dst,
+                          int lddst, int n);
+void launch_copy_block(hipStream_t s, const double* src, int ldsrc, double* dst,
+                       int lddst, int n, int cols);
+// E[:, j] = t .* U[:, j] / || t .* U[:, j] ||   (LAPACK unit 2-norm columns)
+void launch_back_transform(hipStream_t s, double* E, int lde, int n, int cols,
+                           const double* tvec, double* colnorm_ws);
+
+// ---- k-means -------------------------------------------------------------------
+struct KmeansWorkspace {
+  double* Xc = nullptr;       // n x kMaxVectors centred copy
+  double* xsq = nullptr;      // n
+  double* closest = nullptr;  // n
+  double* cand = nullptr;     // 8 x n candidate distances
+  double* enorm = nullptr;    // n row norms of E
+  double* rnd = nullptr;      // MT19937 doubles (device copy)
+  double* centroids = nullptr;  // kMaxVectors x kMaxVectors
+  int* labels32 = nullptr;    // n
+  long long* labels64 = nullptr;  // n
+  int* info = nullptr;        // [0] iterations
+};
+void launch_row_renorm(hipStream_t s, double* E, int lde, int n, int k);
+void launch_kmeans(hipStream_t s, const double* E, int lde, int n, int k,
+                   int max_iter, int first_center, int trials,
+                   const KmeansWorkspace& ws);
+
+}  // namespace sc

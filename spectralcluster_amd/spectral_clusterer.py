@@ -1,0 +1,260 @@
+"""SpectralClusterer facade: same constructor and predict() surface as the
+reference `spectralcluster/spectral_clusterer.py`, with the dense hot path
+(affinity -> refinement -> Laplacian -> top-k eigen + eigengap -> cosine k-means)
+executed on one MI355X through the C ABI in `include/spectralcluster_amd.h`.
+
+Out of the device scope: FallbackOptions / single-cluster check,
+constraints, max_spectral_size, non-cosine k-means, and refinement sequences whose
+result is not diagonally similar to a symmetric matrix.  Those raise
+`UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import typing
+
+import numpy as np
+
+from spectralcluster_amd import _lib
+from spectralcluster_amd import autotune as autotune_lib
+from spectralcluster_amd import custom_distance_kmeans
+from spectralcluster_amd import laplacian
+from spectralcluster_amd import refinement
+from spectralcluster_amd import utils
+
+AutoTune = autotune_lib.AutoTune
+AutoTuneProxy = autotune_lib.AutoTuneProxy
+LaplacianType = laplacian.LaplacianType
+RefinementName = refinement.RefinementName
+RefinementOptions = refinement.RefinementOptions
+EigenGapType = utils.EigenGapType
+
+
+class SpectralClusterer:
+  """Spectral clustering of speaker embeddings on the GPU.
+
+  Constructor arguments are those of the reference (spectral_clusterer.py:29-46),
+  plus `device` (HIP device ordinal; default: LOCAL_RANK or 0).
+  """
+
+  def __init__(self,
+               min_clusters: typing.Optional[int] = None,
+               max_clusters: typing.Optional[int] = None,
+               refinement_options: typing.Optional[RefinementOptions] = None,
+               autotune: typing.Optional[AutoTune] = None,
+               fallback_options=None,
+               laplacian_type: typing.Optional[LaplacianType] = None,
+               stop_eigenvalue: float = 1e-2,
+               row_wise_renorm: bool = False,
+               custom_dist: typing.Union[str, typing.Callable] = "cosine",
+               max_iter: int = 300,
+               constraint_options=None,
+               eigengap_type: EigenGapType = EigenGapType.Ratio,
+               max_spectral_size: typing.Optional[int] = None,
+               affinity_function: typing.Callable = utils.compute_affinity_matrix,
+               post_eigen_cluster_function: typing.Callable = (
+                   custom_distance_kmeans.run_kmeans),
+               device: typing.Optional[int] = None):
+    self.min_clusters = min_clusters
+    self.max_clusters = max_clusters
+    self.refinement_options = refinement_options or RefinementOptions()
+    self.autotune = autotune
+    self.fallback_options = fallback_options
+    self.laplacian_type = laplacian_type
+    self.row_wise_renorm = row_wise_renorm
+    self.stop_eigenvalue = stop_eigenvalue
+    self.custom_dist = custom_dist
+    self.max_iter = max_iter
+    self.constraint_options = constraint_options
+    self.eigengap_type = eigengap_type
+    self.max_spectral_size = max_spectral_size
+    self.affinity_function = affinity_function
+    self.post_eigen_cluster_function = post_eigen_cluster_function
+    self.device = device
+    self.last_diag: typing.Optional[_lib.ScDiag] = None
+
+  # ----------------------------------------------------------------- plumbing
+  def _handle(self) -> _lib.Handle:
+    return _lib.default_handle(self.device)
+
+  def _scope_check(self, constraint_matrix=None):
+    if self.fallback_options is not None:
+      raise _lib.UnsupportedOnDeviceError(
+          "fallback_options (FallbackClusterer / single-cluster check) is outside "
+          "the device hot path")
+    if self.min_clusters == 1:
+      raise _lib.UnsupportedOnDeviceError(
+          "min_clusters=1 triggers the reference's single-cluster check "
+          "(fallback_clusterer.check_single_cluster), which is out of scope")
+    if self.constraint_options is not None or constraint_matrix is not None:
+      raise _lib.UnsupportedOnDeviceError("constraints are out of scope")
+    if self.max_spectral_size is not None:
+      raise _lib.UnsupportedOnDeviceError(
+          "max_spectral_size (AHC pre-clustering) is out of scope")
+
+  def build_config(self, p_percentile: typing.Optional[float] = None) -> _lib.ScConfig:
+    """Flatten the constructor arguments into an `sc_config`."""
+    cfg = _lib.ScConfig()
+    _lib.load().sc_config_default(cfg)
+    self.refinement_options.to_config(cfg)
+    if p_percentile is not None:
+      cfg.p_percentile = float(p_percentile)
+    if self.laplacian_type is None:
+      cfg.laplacian_type = 0
+    elif isinstance(self.laplacian_type, LaplacianType):
+      cfg.laplacian_type = self.laplacian_type.value
+    else:
+      raise TypeError("laplacian_type must be a LaplacianType")
+    if not isinstance(self.eigengap_type, EigenGapType):
+      raise TypeError("eigengap_type must be a EigenGapType")
+    cfg.eigengap_type = self.eigengap_type.value
+    cfg.min_clusters = int(self.min_clusters or 0)
+    cfg.max_clusters = int(self.max_clusters or 0)
+    cfg.stop_eigenvalue = float(self.stop_eigenvalue)
+    cfg.row_wise_renorm = int(bool(self.row_wise_renorm))
+    cfg.max_iter = int(self.max_iter)
+    return cfg
+
+  def _upload(self, handle: _lib.Handle, embeddings: np.ndarray):
+    """Embeddings -> resident affinity (device GEMM, or the user's function)."""
+    if self.affinity_function is utils.compute_affinity_matrix:
+      x = np.ascontiguousarray(embeddings, dtype=np.float64)
+      handle.check(handle.lib.sc_set_embeddings(
+          handle.raw, _lib.as_double_p(x), x.shape[0], x.shape[1]))
+      handle.check(handle.lib.sc_compute_affinity(handle.raw))
+    else:
+      a = np.ascontiguousarray(self.affinity_function(embeddings), dtype=np.float64)
+      handle.check(handle.lib.sc_set_affinity(handle.raw, _lib.as_double_p(a),
+                                              a.shape[0]))
+
+  def _eig_resident(self, handle: _lib.Handle, p_percentile=None) -> _lib.ScDiag:
+    diag = _lib.ScDiag()
+    cfg = self.build_config(p_percentile)
+    handle.check(handle.lib.sc_eig_ncluster(handle.raw, cfg, diag), TypeError)
+    self.last_diag = diag
+    return diag
+
+  def _download_eigenvectors(self, handle: _lib.Handle, n: int,
+                             cols: typing.Optional[int] = None) -> np.ndarray:
+    have = handle.lib.sc_num_eigenvectors(handle.raw)
+    cols = have if cols is None else cols
+    out = np.empty((n, cols), dtype=np.float64)
+    handle.check(handle.lib.sc_get_eigenvectors(handle.raw, _lib.as_double_p(out), n,
+                                                cols))
+    return out
+
+  # ------------------------------------------------------------- reference API
+  def _compute_eigenvectors_ncluster(
+      self, affinity: np.ndarray, constraint_matrix=None
+  ) -> typing.Tuple[np.ndarray, int, float]:
+    """Refinement + eigen-decomposition + eigengap for a given affinity matrix
+    (reference spectral_clusterer.py:108-168).
+
+    Returns (eigenvectors, n_clusters, max_delta_norm).  For n <= 128 the
+    eigenvector matrix is (n, n) like the reference's; above that it has only the
+    columns the eigengap search can select (max_clusters + 1, at most 64).
+    """
+    self._scope_check(constraint_matrix)
+    a = np.ascontiguousarray(affinity, dtype=np.float64)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+      raise ValueError("affinity must be a square matrix")
+    handle = self._handle()
+    handle.check(handle.lib.sc_set_affinity(handle.raw, _lib.as_double_p(a), a.shape[0]))
+    diag = self._eig_resident(handle)
+    vectors = self._download_eigenvectors(handle, a.shape[0])
+    return vectors, int(diag.n_clusters_raw), float(diag.max_delta)
+
+  def predict(self, embeddings: np.ndarray, constraint_matrix=None) -> np.ndarray:
+    """Cluster `embeddings` (n_samples, n_features); returns int64 labels
+    (reference spectral_clusterer.py:201-314)."""
+    if not isinstance(embeddings, np.ndarray):
+      raise TypeError("embeddings must be a numpy array")
+    if len(embeddings.shape) != 2:
+      raise ValueError("embeddings must be 2-dimensional")
+    self._scope_check(constraint_matrix)
+    n = embeddings.shape[0]
+    handle = self._handle()
+    default_tail = (self.post_eigen_cluster_function is custom_distance_kmeans.run_kmeans)
+    if default_tail and self.custom_dist != "cosine":
+      raise _lib.UnsupportedOnDeviceError(
+          "only custom_dist='cosine' is implemented on the device path")
+
+    if (self.autotune is None and default_tail
+        and self.affinity_function is utils.compute_affinity_matrix):
+      # the whole path in one call: H2D(X), device pipeline, D2H(labels)
+      x = np.ascontiguousarray(embeddings, dtype=np.float64)
+      labels = np.empty(n, dtype=np.int64)
+      diag = _lib.ScDiag()
+      handle.check(handle.lib.sc_predict(
+          handle.raw, _lib.as_double_p(x), n, x.shape[1], self.build_config(),
+          _lib.as_int64_p(labels), diag), TypeError)
+      self.last_diag = diag
+      return labels
+
+    self._upload(handle, embeddings)
+    if self.autotune:
+      sequence = self.refinement_options.refinement_sequence or []
+      if RefinementName.RowWiseThreshold not in sequence:
+        raise ValueError(
+            "AutoTune is only effective when the refinement sequence"
+            "contains RowWiseThreshold")
+      evaluated = []
+
+      def p_percentile_to_ratio(p):
+        diag = self._eig_resident(handle, p)
+        evaluated.append(p)
+        return (self.autotune.ratio(p, diag.max_delta), p, int(diag.n_clusters_raw))
+
+      _, n_clusters, best_p = self.autotune.tune(p_percentile_to_ratio)
+      # reference closure leaves refinement_options.p_percentile at the LAST
+      # evaluated value (spectral_clusterer.py:277); keep that observable state
+      self.refinement_options.p_percentile = evaluated[-1]
+      if evaluated[-1] != best_p:
+        self._eig_resident(handle, best_p)  # bring the winner's vectors back
+      diag = self.last_diag
+    else:
+      diag = self._eig_resident(handle)
+      n_clusters = int(diag.n_clusters_raw)
+
+    if self.min_clusters is not None:
+      n_clusters = max(n_clusters, self.min_clusters)
+
+    if default_tail:
+      labels = np.empty(n, dtype=np.int64)
+      handle.check(handle.lib.sc_cluster(handle.raw, self.build_config(), n_clusters,
+                                         _lib.as_int64_p(labels), diag))
+      return labels
+    # user-supplied post_eigen_cluster_function: hand it the spectral embedding
+    spectral = self._download_eigenvectors(handle, n, n_clusters)
+    if self.row_wise_renorm:
+      spectral = spectral / np.linalg.norm(spectral, axis=1, ord=2)[:, None]
+    return self.post_eigen_cluster_function(
+        spectral_embeddings=spectral, n_clusters=n_clusters,
+        custom_dist=self.custom_dist, max_iter=self.max_iter)
+
+  # -------------------------------------------------------------- batch (new)
+  def predict_batch(self, utterances: typing.Sequence[np.ndarray]) -> typing.List[np.ndarray]:
+    """Independent predict() calls (the reference has no batch API: a batch is a
+    Python loop).  One arena sized for the largest member."""
+    if self.autotune is not None:
+      return [self.predict(u) for u in utterances]
+    self._scope_check()
+    if not utterances:
+      return []
+    xs = [np.ascontiguousarray(u, dtype=np.float64) for u in utterances]
+    d = xs[0].shape[1]
+    for x in xs:
+      if x.ndim != 2 or x.shape[1] != d:
+        raise ValueError("all utterances must be (n_i, d) with the same d")
+    count = len(xs)
+    labels = [np.empty(x.shape[0], dtype=np.int64) for x in xs]
+    xp = (ctypes.POINTER(ctypes.c_double) * count)(*[_lib.as_double_p(x) for x in xs])
+    lp = (ctypes.POINTER(ctypes.c_int64) * count)(*[_lib.as_int64_p(l) for l in labels])
+    ns = (ctypes.c_int * count)(*[x.shape[0] for x in xs])
+    diags = (_lib.ScDiag * count)()
+    handle = self._handle()
+    handle.check(handle.lib.sc_predict_batch(handle.raw, xp, ns, d, count,
+                                             self.build_config(), lp, diags), TypeError)
+    self.last_batch_diags = diags
+    return labels

@@ -107,7 +107,7 @@ typedef struct sc_config {
   int32_t row_wise_renorm;       /* spectral_clusterer.py:37 */
   int32_t max_iter;              /* custom k-means iterations (:39) */
   /* Eigensolver knobs (no reference equivalent). 0 selects the default. */
-  double eig_value_tol;          /* relative tol on consumed eigenvalues (1e-9) */
+  double eig_value_tol;          /* residual bound / |eigenvalue| on consumed values (1e-6) */
   double eig_vector_tol;         /* residual tol, relative to ||M||, on the
                                     eigenvectors handed to k-means (1e-10) */
   int32_t eig_max_cycles;        /* restart cycles before NOT_CONVERGED (40) */

@@ -860,7 +860,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   rq.stop_eigenvalue = cfg->stop_eigenvalue;
   rq.eigengap_type = cfg->eigengap_type;
   rq.use_stop = rq.descend;  // spectral_clusterer.py:163-167: not passed when ascending
-  rq.value_tol = cfg->eig_value_tol > 0 ? cfg->eig_value_tol : 1e-9;
+  rq.value_tol = cfg->eig_value_tol > 0 ? cfg->eig_value_tol : 1e-6;
   rq.vector_tol = cfg->eig_vector_tol > 0 ? cfg->eig_vector_tol : 1e-10;
   rq.max_cycles = cfg->eig_max_cycles > 0 ? cfg->eig_max_cycles : 40;
   rq.fixed_count = 0;

@@ -1,0 +1,300 @@
+"""GPU parity tests for the whole SpectralClusterer.predict() path against golden
+outputs of the real reference (tests/golden, made by oracle/make_golden.py) and
+against the CPU oracle.
+
+Bars (BASELINE.json north_star): labels equal up to permutation (ARI = 1.0);
+eigenvalues the eigengap search consumes within 1e-5 relative (asserted at 1e-7).
+"""
+
+import numpy as np
+import pytest
+
+import spectral_oracle as so
+from conftest import golden
+
+import spectralcluster_amd as sca
+
+pytestmark = pytest.mark.gpu
+
+LAP = {0: None, 1: sca.LaplacianType.Affinity, 2: sca.LaplacianType.Unnormalized,
+       3: sca.LaplacianType.RandomWalk, 4: sca.LaplacianType.GraphCut}
+EIG_RTOL = 1e-7   # north_star allows 1e-5
+
+TOY = np.array([[1.0, 0.0], [1.1, 0.1], [0.0, 1.0], [0.1, 1.0], [0.9, -0.1],
+                [0.0, 1.2]])
+
+
+def icassp_options(sigma=1, p=0.95):
+  return sca.RefinementOptions(
+      gaussian_blur_sigma=sigma, p_percentile=p, thresholding_soft_multiplier=0.01,
+      thresholding_type=sca.ThresholdType.RowMax,
+      refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
+
+
+def rel_err(got, want):
+  return np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-12))
+
+
+# --- the reference's own end-to-end tests ------------------------------------------
+def test_reference_6by2_toy():
+  # reference tests/spectral_clusterer_test.py:33-51
+  clusterer = sca.SpectralClusterer(refinement_options=icassp_options(0, 0.95))
+  labels = sca.utils.enforce_ordered_labels(clusterer.predict(TOY))
+  assert np.array_equal(labels, [0, 0, 1, 1, 0, 1])
+
+
+def test_reference_6by2_normalizeddiff():
+  # reference tests/spectral_clusterer_test.py:91-110
+  clusterer = sca.SpectralClusterer(refinement_options=icassp_options(0, 0.95),
+                                    eigengap_type=sca.EigenGapType.NormalizedDiff)
+  labels = sca.utils.enforce_ordered_labels(clusterer.predict(TOY))
+  assert np.array_equal(labels, [0, 0, 1, 1, 0, 1])
+
+
+def test_reference_6by2_graphcut_renorm():
+  # reference tests/spectral_clusterer_test.py:112-154
+  clusterer = sca.SpectralClusterer(
+      max_clusters=2, refinement_options=icassp_options(0, 0.95),
+      laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  labels = sca.utils.enforce_ordered_labels(clusterer.predict(TOY))
+  assert np.array_equal(labels, [0, 0, 1, 1, 0, 1])
+
+
+def test_reference_1000by6_blocks():
+  # reference tests/spectral_clusterer_test.py:54-69 (noise seeded here)
+  base = np.array([[1.0, 0, 0, 0, 0, 0]] * 400 + [[0, 1.0, 0, 0, 0, 0]] * 300 +
+                  [[0, 0, 2.0, 0, 0, 0]] * 200 + [[0, 0, 0, 1.0, 0, 0]] * 100)
+  noisy = np.random.default_rng(7).random((1000, 6)) * 2 - 1
+  m = base + noisy * 0.1
+  clusterer = sca.SpectralClusterer(refinement_options=icassp_options(0, 0.2),
+                                    stop_eigenvalue=0.01)
+  labels = sca.utils.enforce_ordered_labels(clusterer.predict(m))
+  assert np.array_equal(labels, [0] * 400 + [1] * 300 + [2] * 200 + [3] * 100)
+
+
+def test_reference_icassp2018_preset():
+  # reference tests/configs_test.py:12-22
+  base = np.array([[1.0, 0, 0, 0, 0, 0]] * 400 + [[0, 1.0, 0, 0, 0, 0]] * 300 +
+                  [[0, 0, 2.0, 0, 0, 0]] * 200 + [[0, 0, 0, 1.0, 0, 0]] * 100)
+  m = base + (np.random.default_rng(8).random((1000, 6)) * 2 - 1) * 0.1
+  labels = sca.utils.enforce_ordered_labels(sca.configs.icassp2018_clusterer.predict(m))
+  assert np.array_equal(labels, [0] * 400 + [1] * 300 + [2] * 200 + [3] * 100)
+
+
+# --- golden stage dumps (tiny): every eigenvalue of the dense path --------------------
+@pytest.mark.parametrize("lap", [0, 2, 3, 4])
+def test_toy_all_eigenvalues_vs_reference(lap):
+  g = golden("toy6x2_lap%d.npz" % lap)
+  clusterer = sca.SpectralClusterer(refinement_options=icassp_options(0, 0.95),
+                                    laplacian_type=LAP[lap])
+  vecs, k, delta = clusterer._compute_eigenvectors_ncluster(g["affinity"])
+  assert vecs.shape == (6, 6)  # reference tests/autotune_test.py:79
+  w = clusterer.last_diag.eigenvalue_array()
+  np.testing.assert_allclose(w, g["eigenvalues"], rtol=1e-9, atol=1e-12)
+  assert k == int(g["n_clusters_raw"])
+  np.testing.assert_allclose(delta, float(g["max_delta"]), rtol=1e-7)
+  labels = clusterer.predict(g["x"])
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+
+
+@pytest.mark.parametrize("lap", [0, 4])
+def test_n64_stage_dump_vs_reference(lap):
+  g = golden("stages_n64_lap%d.npz" % lap)
+  clusterer = sca.SpectralClusterer(min_clusters=2, max_clusters=7,
+                                    refinement_options=icassp_options(1, 0.95),
+                                    laplacian_type=LAP[lap])
+  vecs, k, delta = clusterer._compute_eigenvectors_ncluster(g["affinity"])
+  w = clusterer.last_diag.eigenvalue_array()
+  np.testing.assert_allclose(w, g["eigenvalues"], rtol=1e-8,
+                             atol=1e-12 * np.abs(g["eigenvalues"]).max())
+  assert k == int(g["n_clusters_raw"])
+  np.testing.assert_allclose(delta, float(g["max_delta"]), rtol=1e-7)
+  kk = max(k, 2)
+  cos = np.abs(np.einsum("ij,ij->j", vecs[:, :kk], g["eigenvectors"][:, :kk]))
+  np.testing.assert_allclose(cos, 1.0, atol=1e-8)  # unit-norm, sign-free match
+  assert np.array_equal(so.ordered_labels(clusterer.predict(g["x"])),
+                        so.ordered_labels(g["labels"]))
+
+
+# --- golden end-to-end (seeds) -----------------------------------------------------------
+E2E = ["e2e_n200_lap0_max7.npz", "e2e_n200_lap4_max7.npz", "e2e_n1000_lap0_max7.npz",
+       "e2e_n1000_lap4_max20.npz", "e2e_n1000_lap3_max20.npz",
+       "e2e_n1000_lap2_max20.npz", "e2e_n2048_lap0_max7.npz",
+       "e2e_n2048_lap4_max20.npz", "e2e_n8192_lap4_max20.npz",
+       "e2e_n8192_lap0_max7.npz"]
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_predict_vs_reference_golden(name):
+  g = golden(name)
+  n, d, k, seed, lap, max_clusters = [int(v) for v in g["params"]]
+  x = so.blobs(n, d, k, seed)
+  clusterer = sca.SpectralClusterer(min_clusters=2, max_clusters=max_clusters,
+                                    refinement_options=icassp_options(1, 0.95),
+                                    laplacian_type=LAP[lap])
+  labels = clusterer.predict(x)
+  diag = clusterer.last_diag
+  assert labels.dtype == np.int64 and labels.shape == (n,)
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+  assert np.array_equal(so.ordered_labels(labels), so.ordered_labels(g["labels"]))
+  assert diag.n_clusters_raw == int(g["n_clusters_raw"])
+  np.testing.assert_allclose(diag.max_delta, float(g["max_delta"]), rtol=1e-6)
+  w = diag.eigenvalue_array()
+  idx = g["consumed_index"]
+  ref = g["consumed_eigenvalues"]
+  if lap in (0, 1):  # the descending loop stops reading after the first value < 1e-2
+    keep = so.consumed_eigen_indices(n, max_clusters, True, ref, 1e-2)
+    idx, ref = idx[keep], ref[keep]
+  assert rel_err(w[idx], ref) < EIG_RTOL
+
+
+def test_autotune_vs_reference_golden():
+  g = golden("autotune_n512.npz")
+  x = so.blobs(512, 64, 6, 512)
+  tuner = sca.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95,
+                       init_search_step=0.025, search_level=1)
+  np.testing.assert_array_equal(np.array(tuner.get_percentile_range()), g["grid"])
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=20, refinement_options=icassp_options(),
+      autotune=tuner, laplacian_type=sca.LaplacianType.GraphCut)
+  # per-p proxy values through the same device entry point AutoTune uses
+  handle = clusterer._handle()
+  clusterer._upload(handle, x)
+  ratios, ks = [], []
+  for p in g["grid"]:
+    dg = clusterer._eig_resident(handle, p)
+    ratios.append(tuner.ratio(p, dg.max_delta))
+    ks.append(dg.n_clusters_raw)
+  np.testing.assert_allclose(ratios, g["ratios"], rtol=1e-6)
+  assert np.array_equal(ks, g["n_clusters"])
+  labels = clusterer.predict(x)
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+
+
+def test_autotune_requires_threshold():
+  clusterer = sca.SpectralClusterer(
+      refinement_options=sca.RefinementOptions(
+          refinement_sequence=[sca.RefinementName.Symmetrize]),
+      autotune=sca.AutoTune())
+  with pytest.raises(ValueError):
+    clusterer.predict(TOY)
+
+
+# --- oracle comparisons on configurations the goldens do not cover ------------------------
+@pytest.mark.parametrize("n,d,k,lap,gap,renorm", [
+    (300, 32, 3, 0, "Ratio", False), (300, 32, 3, 4, "NormalizedDiff", True),
+    (513, 40, 5, 3, "Ratio", False), (150, 20, 2, 2, "Ratio", False),
+    (129, 16, 3, 4, "Ratio", False), (144, 16, 3, 0, "NormalizedDiff", False),
+    (97, 8, 2, 1, "Ratio", False)])
+def test_predict_vs_oracle(n, d, k, lap, gap, renorm):
+  x = so.blobs(n, d, k, seed=n)
+  cfg = so.icassp2018_config(
+      laplacian_type=lap, max_clusters=9, row_wise_renorm=renorm,
+      eigengap_type=so.EIGENGAP_RATIO if gap == "Ratio" else so.EIGENGAP_NORMALIZED_DIFF)
+  dump = {}
+  want = so.predict(x, cfg, dump)
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=9, refinement_options=icassp_options(),
+      laplacian_type=LAP[lap], row_wise_renorm=renorm,
+      eigengap_type=getattr(sca.EigenGapType, gap))
+  got = clusterer.predict(x)
+  assert so.adjusted_rand_index(got, want) == 1.0
+  idx = so.consumed_eigen_indices(n, 9, lap in (0, 1), dump["eigenvalues"], 1e-2)
+  w = clusterer.last_diag.eigenvalue_array()
+  assert rel_err(w[idx], dump["eigenvalues"][idx]) < EIG_RTOL
+  np.testing.assert_allclose(clusterer.last_diag.max_delta, dump["max_delta"], rtol=1e-6)
+
+
+def test_sequences_without_rownormalize_or_refinement():
+  x = so.blobs(260, 24, 3, seed=5)
+  # no refinement at all: eig of the raw cosine affinity
+  cfg = so.OracleConfig(min_clusters=2, max_clusters=6)
+  want = so.predict(x, cfg)
+  got = sca.SpectralClusterer(min_clusters=2, max_clusters=6).predict(x)
+  assert so.adjusted_rand_index(got, want) == 1.0
+  # sequence ending in Symmetrize (SYM state, nothing folded)
+  seq = [sca.RefinementName.CropDiagonal, sca.RefinementName.RowWiseThreshold,
+         sca.RefinementName.Symmetrize]
+  cfg = so.OracleConfig(min_clusters=2, max_clusters=6, laplacian_type=4,
+                        sequence=(so.OP_CROP_DIAGONAL, so.OP_ROW_WISE_THRESHOLD,
+                                  so.OP_SYMMETRIZE), p_percentile=0.6)
+  want = so.predict(x, cfg)
+  got = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=6, laplacian_type=sca.LaplacianType.GraphCut,
+      refinement_options=sca.RefinementOptions(p_percentile=0.6,
+                                               refinement_sequence=seq)).predict(x)
+  assert so.adjusted_rand_index(got, want) == 1.0
+
+
+# --- size-independent properties at the headline size ---------------------------------------
+def test_properties_n8192():
+  n, d, k = 8192, 256, 8
+  x = so.blobs(n, d, k, seed=0)
+  rng = np.random.default_rng(0)
+  rng.standard_normal((k, d))  # replay blobs() stream to recover its labels
+  truth = np.sort(rng.integers(0, k, n))
+  clusterer = sca.SpectralClusterer(min_clusters=2, max_clusters=20,
+                                    refinement_options=icassp_options(),
+                                    laplacian_type=sca.LaplacianType.GraphCut)
+  a = clusterer.predict(x)
+  assert so.adjusted_rand_index(a, truth) == 1.0        # recovers the blobs
+  b = clusterer.predict(x)
+  assert np.array_equal(a, b)                            # deterministic
+  # (no permutation test: GaussianBlur makes the path depend on temporal order)
+  d2 = clusterer.predict(np.ascontiguousarray(x * 3.7))
+  assert so.adjusted_rand_index(d2, a) == 1.0           # cosine: scale invariant
+
+
+def test_batch_matches_single_calls():
+  rng = np.random.default_rng(3)
+  utts = [so.blobs(int(n), 64, int(k), seed=i)
+          for i, (n, k) in enumerate(zip(rng.integers(130, 900, 6), rng.integers(2, 6, 6)))]
+  clusterer = sca.configs.icassp2018_clusterer
+  batch = clusterer.predict_batch(utts)
+  for u, lab in zip(utts, batch):
+    assert np.array_equal(lab, clusterer.predict(u))
+
+
+# --- error behaviour (reference spectral_clusterer.py:222-227 etc.) ---------------------------
+def test_error_behaviour():
+  clusterer = sca.configs.icassp2018_clusterer
+  with pytest.raises(TypeError):
+    clusterer.predict([[1.0, 2.0]])
+  with pytest.raises(ValueError):
+    clusterer.predict(np.zeros(5))
+  with pytest.raises(sca.UnsupportedOnDeviceError):
+    sca.SpectralClusterer(min_clusters=1).predict(TOY)
+  with pytest.raises(sca.UnsupportedOnDeviceError):
+    sca.SpectralClusterer(max_spectral_size=3).predict(TOY)
+  # RowWiseThreshold alone leaves a genuinely non-symmetric matrix
+  with pytest.raises(sca.UnsupportedOnDeviceError):
+    sca.SpectralClusterer(refinement_options=sca.RefinementOptions(
+        refinement_sequence=[sca.RefinementName.RowWiseThreshold])).predict(TOY)
+  with pytest.raises(sca.UnsupportedOnDeviceError):
+    sca.SpectralClusterer(custom_dist="euclidean").predict(TOY)
+  with pytest.raises(TypeError):
+    sca.SpectralClusterer(laplacian_type="GraphCut").predict(TOY)
+
+
+def test_plugin_points():
+  # reference plug-in points: affinity_function / post_eigen_cluster_function
+  x = so.blobs(200, 16, 3, seed=9)
+  base = sca.SpectralClusterer(min_clusters=2, max_clusters=7,
+                               refinement_options=icassp_options())
+  want = base.predict(x)
+  called = {}
+
+  def my_affinity(e):
+    called["a"] = True
+    return so.affinity(e)
+
+  def my_tail(spectral_embeddings, n_clusters, custom_dist, max_iter):
+    called["t"] = spectral_embeddings.shape
+    return so.run_kmeans(spectral_embeddings, n_clusters, max_iter)
+
+  got = sca.SpectralClusterer(min_clusters=2, max_clusters=7,
+                              refinement_options=icassp_options(),
+                              affinity_function=my_affinity,
+                              post_eigen_cluster_function=my_tail).predict(x)
+  assert called["a"] and called["t"][0] == 200
+  assert so.adjusted_rand_index(got, want) == 1.0

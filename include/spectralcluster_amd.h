@@ -216,6 +216,13 @@ int sc_stage_laplacian(sc_handle h, int laplacian_type, const double* in, int n,
  */
 int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, int descend,
                      double* values, double* vectors, sc_diag* diag);
+/* numpy.random.RandomState(seed).random_sample(count): the MT19937 stream that
+ * sklearn's KMeans(random_state=0) (custom_distance_kmeans.py:39-43) consumes.
+ * Host-only; exported so the stream can be pinned without a GPU. */
+int sc_random_state_doubles(uint32_t seed, int count, double* out);
+/* index RandomState.choice(n, p=uniform) returns for the uniform draw u:
+ * cumsum(1/n) / cdf[-1], searchsorted(u, side="right") (first k-means++ centre) */
+int sc_uniform_choice(int n, double u);
 /* utils.compute_number_of_clusters (utils.py:74-130) -- host scalar loop */
 int sc_eigengap(const double* eigenvalues, int count, int max_clusters,
                 double stop_eigenvalue, int eigengap_type, int descend,

@@ -377,6 +377,28 @@ struct Mt19937 {
 };
 }  // namespace
 
+extern "C" int sc_random_state_doubles(uint32_t seed, int count, double* out) {
+  if (!out || count < 0) return SC_ERR_INVALID;
+  Mt19937 rng(seed);
+  for (int i = 0; i < count; ++i) out[i] = rng.next_double();
+  return SC_OK;
+}
+
+extern "C" int sc_uniform_choice(int n, double u) {
+  if (n <= 0) return SC_ERR_INVALID;
+  const double p = 1.0 / (double)n;
+  std::vector<double> cdf(n);
+  double run = 0.0;
+  for (int i = 0; i < n; ++i) {
+    run += p;
+    cdf[i] = run;
+  }
+  const double last = cdf[n - 1];
+  for (int i = 0; i < n; ++i)
+    if (cdf[i] / last > u) return i;  // searchsorted(..., side="right")
+  return n - 1;
+}
+
 // ------------------------------------------------------------------------------
 // data movement helpers
 // ------------------------------------------------------------------------------
@@ -924,19 +946,7 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   // RandomState(0): first centre via choice(n, p=uniform) = cdf.searchsorted(u, 'right')
   Mt19937 rng(0);
   const double u = rng.next_double();
-  const double p = 1.0 / (double)n;
-  std::vector<double> cdf(n);
-  double run = 0.0;
-  for (int i = 0; i < n; ++i) {
-    run += p;
-    cdf[i] = run;
-  }
-  const double last = cdf[n - 1];
-  int first = n;  // searchsorted(..., side="right"): first index with cdf > u
-  for (int i = 0; i < n; ++i) {
-    if (cdf[i] / last > u) { first = i; break; }
-  }
-  if (first >= n) first = n - 1;
+  const int first = sc_uniform_choice(n, u);
   const int trials = 2 + (int)std::log((double)k);
   std::vector<double> rnd((size_t)std::max(1, (k - 1) * trials));
   for (size_t i = 0; i < rnd.size(); ++i) rnd[i] = rng.next_double();

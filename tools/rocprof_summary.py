@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Turn a rocprofv3 (ROCm 7.2, rocpd sqlite) kernel trace into the text summary we
+commit under profiles/:  python tools/rocprof_summary.py <results.db> > profiles/x.txt"""
+import sqlite3
+import sys
+
+
+def main(path):
+  cur = sqlite3.connect(path).cursor()
+  rows = list(cur.execute(
+      "select name, total_calls, total_duration, average, percentage from top_kernels"))
+  print("# rocprofv3 --kernel-trace --stats summary of %s" % path)
+  print("# durations in microseconds")
+  print("%-70s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+  for name, calls, total, avg, pct in rows:
+    short = name.split("(")[0].replace("void ", "")
+    print("%-70s %8d %14.1f %12.2f %7.2f" % (short[:70], calls, total, avg, pct))
+  extra = list(cur.execute(
+      "select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, grid_x, "
+      "workgroup_x from kernels group by name"))
+  print("\n# per-kernel resources (vgpr, agpr, sgpr, lds bytes, grid_x, wg_x)")
+  for r in extra:
+    short = r[0].split("(")[0].replace("void ", "")
+    print("%-70s %s" % (short[:70], " ".join(str(v) for v in r[1:])))
+
+
+if __name__ == "__main__":
+  main(sys.argv[1])

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,7 +38,7 @@ struct sc_handle_s {
   // eigen workspace
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
       flags;
-  DevBuf E, Ek;           // eigenvectors (n x kLdE), renormed copy for k-means
+  DevBuf E, Ek, Eio;      // eigenvectors (col-major), renormed copy, row-major I/O staging
   // k-means workspace
   DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo;
   // pinned host scratch
@@ -47,7 +48,8 @@ struct sc_handle_s {
   int nev = 0;
 };
 
-static constexpr int kLdE = 128;  // row stride of the resident eigenvectors
+static constexpr int kMaxCols = 128;  // eigenvector columns the arena can hold
+// eigenvectors are column-major on the device: column j at E + j * lde, lde = round_up(n, 16)
 
 #define SC_HIP(h, call)                                                         \
   do {                                                                          \
@@ -126,12 +128,14 @@ static int ensure_eig(sc_handle h, int n) {
   SC_TRY(grow(h, h->hsq, 16 * sizeof(double)));
   SC_TRY(grow(h, h->colnorm, (size_t)kProjBlocks * kMaxVectors * sizeof(double)));
   SC_TRY(grow(h, h->flags, 4 * sizeof(int)));
-  SC_TRY(grow(h, h->E, (size_t)n * kLdE * sizeof(double)));
+  SC_TRY(grow(h, h->E, (size_t)round_up(n, 16) * kMaxCols * sizeof(double)));
+  SC_TRY(grow(h, h->Eio, (size_t)n * kMaxCols * sizeof(double)));
   return SC_OK;
 }
 
 static int ensure_kmeans(sc_handle h, int n) {
-  SC_TRY(grow(h, h->Ek, (size_t)n * kLdE * sizeof(double)));
+  SC_TRY(grow(h, h->Ek, (size_t)round_up(n, 16) * kMaxCols * sizeof(double)));
+  SC_TRY(grow(h, h->Eio, (size_t)n * kMaxCols * sizeof(double)));
   SC_TRY(grow(h, h->kXc, (size_t)n * kMaxVectors * sizeof(double)));
   SC_TRY(grow(h, h->kxsq, (size_t)n * sizeof(double)));
   SC_TRY(grow(h, h->kclosest, (size_t)n * sizeof(double)));
@@ -141,7 +145,7 @@ static int ensure_kmeans(sc_handle h, int n) {
   SC_TRY(grow(h, h->kcent, (size_t)kMaxVectors * kMaxVectors * sizeof(double)));
   SC_TRY(grow(h, h->klab32, (size_t)n * sizeof(int)));
   SC_TRY(grow(h, h->klab64, (size_t)n * sizeof(long long)));
-  SC_TRY(grow(h, h->kinfo, 4 * sizeof(int)));
+  SC_TRY(grow(h, h->kinfo, 16 * sizeof(int)));
   return SC_OK;
 }
 
@@ -215,7 +219,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
-                    &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,
+                    &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
                     &h->kcent, &h->klab32, &h->klab64, &h->kinfo};
   for (DevBuf* b : bufs)
@@ -632,6 +636,7 @@ static int orthonormalize(sc_handle h, int n, int m, bool record, int col0, int 
   double* W = ptr<double>(h->W);
   double* part = ptr<double>(h->partial);
   double* hsq = ptr<double>(h->hsq);
+  SC_HIP(h, hipMemsetAsync(hsq, 0, 16 * sizeof(double), s));
   if (m > 0) {
     for (int pass = 0; pass < 2; ++pass) {
       launch_proj_partial(s, Q, kLdq, m, W, n, part);
@@ -639,8 +644,6 @@ static int orthonormalize(sc_handle h, int n, int m, bool record, int col0, int 
                       kLdq, col0, pass, hsq);
       launch_update_block(s, Q, kLdq, m, ptr<double>(h->Hbuf), W, n);
     }
-  } else {
-    SC_HIP(h, hipMemsetAsync(hsq, 0, 16 * sizeof(double), s));
   }
   // CholQR2
   launch_proj_partial(s, W, kEigBlock, kEigBlock, W, n, part);
@@ -677,11 +680,8 @@ static int finish_block(sc_handle h, int n, int m, int store_col, uint64_t* seed
 }
 
 static void back_transform_cols(sc_handle h, int n, int cols) {
-  for (int c0 = 0; c0 < cols; c0 += kMaxVectors) {
-    const int cc = std::min(kMaxVectors, cols - c0);
-    launch_back_transform(h->stream, ptr<double>(h->E) + c0, kLdE, n, cc,
-                          ptr<double>(h->tvec), ptr<double>(h->colnorm));
-  }
+  launch_back_transform(h->stream, ptr<double>(h->E), round_up(n, 16), n, cols,
+                        ptr<double>(h->tvec));
 }
 
 // S (n x n, ld) symmetric on the device; cvec/pvec/tvec already set.
@@ -708,7 +708,8 @@ static int sym_topk(sc_handle h, const double* S, int ld, int n, const EigReques
     if (!dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
     m = n;
     const int cols = n;  // all eigenvectors, like np.linalg.eig
-    launch_copy_block(s, ptr<double>(h->Y), kLdq, ptr<double>(h->E), kLdE, n, cols);
+    launch_rowmajor_to_colmajor(s, ptr<double>(h->Y), kLdq, n, cols, ptr<double>(h->E),
+                                round_up(n, 16));
     back_transform_cols(h, n, cols);
     h->n_vec = cols;
     if (diag) diag->eig_path = SC_EIG_PATH_DENSE_JACOBI;
@@ -765,7 +766,7 @@ static int sym_topk(sc_handle h, const double* S, int ld, int n, const EigReques
         int keep = round_up(want + kEigBlock, kEigBlock);
         keep = std::max(kEigBlock, std::min(keep, cap - 2 * kEigBlock));
         launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, keep,
-                             ptr<double>(h->Q2), kLdq, n);
+                             ptr<double>(h->Q2), kLdq, n, 0);
         launch_copy_block(s, ptr<double>(h->Q) + m, kLdq, ptr<double>(h->Q2) + keep, kLdq, n,
                           kEigBlock);
         std::swap(h->Q, h->Q2);
@@ -776,7 +777,7 @@ static int sym_topk(sc_handle h, const double* S, int ld, int n, const EigReques
     }
     const int cols = std::min(std::max(dc.kw, dc.kvec), kMaxVectors);
     launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, cols,
-                         ptr<double>(h->E), kLdE, n);
+                         ptr<double>(h->E), round_up(n, 16), n, 1);
     back_transform_cols(h, n, cols);
     SC_TRY(check_last(h, "ritz vector launch"));
     h->n_vec = cols;
@@ -929,7 +930,9 @@ extern "C" int sc_get_eigenvectors(sc_handle h, double* out, int n, int ncols) {
   if (n != h->n || ncols <= 0 || ncols > h->n_vec)
     return fail(h, SC_ERR_INVALID, "eigenvector request out of range");
   SC_HIP(h, hipSetDevice(h->device));
-  return d2h_matrix(h, ptr<double>(h->E), kLdE, n, ncols, out);
+  launch_colmajor_to_rowmajor(h->stream, ptr<double>(h->E), round_up(n, 16), n, ncols,
+                              ptr<double>(h->Eio), ncols);
+  return d2h_matrix(h, ptr<double>(h->Eio), ncols, n, ncols, out);
 }
 
 // ------------------------------------------------------------------------------
@@ -968,13 +971,18 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   SC_TRY(check_last(h, "kmeans launch"));
   SC_HIP(h, hipMemcpyAsync(labels, h->klab64.p, (size_t)n * sizeof(int64_t),
                            hipMemcpyDeviceToHost, h->stream));
-  int info[4] = {0, 0, 0, 0};
-  SC_HIP(h, hipMemcpyAsync(info, h->kinfo.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  SC_HIP(h, hipMemcpyAsync(info, h->kinfo.p, 5 * sizeof(int), hipMemcpyDeviceToHost,
+                           h->stream));
   if (centroids_out)
     SC_HIP(h, hipMemcpyAsync(centroids_out, h->kcent.p, (size_t)k * k * sizeof(double),
                              hipMemcpyDeviceToHost, h->stream));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   if (iterations) *iterations = info[0];
+  if (getenv("SC_KMEANS_TRACE"))
+    fprintf(stderr, "[sc] kmeans n=%d k=%d iters=%d  us: centre %.1f  kmeans++ %.1f  lloyd %.1f"
+            "  cosine-loop %.1f\n", n, k, info[0], info[1] * 0.01, (info[2] - info[1]) * 0.01,
+            (info[3] - info[2]) * 0.01, (info[4] - info[3]) * 0.01);
   return SC_OK;
 }
 
@@ -990,15 +998,16 @@ extern "C" int sc_cluster(sc_handle h, const sc_config* cfg, int n_clusters, int
   int e0, e1;
   ev_rec(h, &e0);
   const double* E = ptr<double>(h->E);
+  const int lde = round_up(n, 16);
   if (cfg->row_wise_renorm) {
     SC_TRY(ensure_kmeans(h, n));
-    launch_copy_block(h->stream, ptr<double>(h->E), kLdE, ptr<double>(h->Ek), kLdE, n,
-                      n_clusters);
-    launch_row_renorm(h->stream, ptr<double>(h->Ek), kLdE, n, n_clusters);
+    SC_HIP(h, hipMemcpyAsync(h->Ek.p, h->E.p, (size_t)lde * n_clusters * sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
+    launch_row_renorm(h->stream, ptr<double>(h->Ek), lde, n, n_clusters);
     E = ptr<double>(h->Ek);
   }
   int iters = 0;
-  SC_TRY(kmeans_on_device(h, E, kLdE, n, n_clusters, cfg->max_iter, labels, nullptr, &iters));
+  SC_TRY(kmeans_on_device(h, E, lde, n, n_clusters, cfg->max_iter, labels, nullptr, &iters));
   ev_rec(h, &e1);
   SC_HIP(h, hipStreamSynchronize(h->stream));
   if (diag) {
@@ -1165,7 +1174,11 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   SC_TRY(sym_topk(h, S, ld, n, rq, dg, &dc, &w));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < count; ++i) values[i] = w[i];
-  if (vectors) SC_TRY(d2h_matrix(h, ptr<double>(h->E), kLdE, n, count, vectors));
+  if (vectors) {
+    launch_colmajor_to_rowmajor(h->stream, ptr<double>(h->E), round_up(n, 16), n, count,
+                                ptr<double>(h->Eio), count);
+    SC_TRY(d2h_matrix(h, ptr<double>(h->Eio), count, n, count, vectors));
+  }
   return SC_OK;
 }
 
@@ -1177,7 +1190,10 @@ extern "C" int sc_stage_kmeans(sc_handle h, const double* e, int n, int k, int m
     return fail(h, SC_ERR_UNSUPPORTED, "n_clusters must be <= 64 on the device path");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_kmeans(h, n));
-  SC_TRY(h2d_matrix(h, e, n, k, ptr<double>(h->Ek), kLdE));
-  return kmeans_on_device(h, ptr<double>(h->Ek), kLdE, n, k, max_iter, labels, centroids_out,
-                          iterations);
+  SC_HIP(h, hipMemcpyAsync(h->Eio.p, e, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
+  launch_to_colmajor(h->stream, ptr<double>(h->Eio), n, k, ptr<double>(h->Ek),
+                     round_up(n, 16));
+  return kmeans_on_device(h, ptr<double>(h->Ek), round_up(n, 16), n, k, max_iter, labels,
+                          centroids_out, iterations);
 }

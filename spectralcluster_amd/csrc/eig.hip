@@ -8,6 +8,8 @@
 //            eigenproblem is a one-workgroup cyclic Jacobi with T in LDS.
 // The only O(n^2) kernel is k_block_matvec (one HBM pass over S per 16 vectors);
 // everything else is tall-skinny (n x <=144) and L2-resident.
+#include <algorithm>
+
 #include "sc_internal.h"
 
 namespace sc {
@@ -41,50 +43,65 @@ __global__ void k_refill_deficient(double* W, int n, const int* flags,
 
 // ---------------------------------------------------------------- block matvec
 // W[r, :] = p[r] * V[r, :] + c[r] * sum_k S[r, k] * Vs[k, :]   (Vs = c .* V)
-// One workgroup = 16 rows of S; its 4 waves split K in interleaved 32-wide
-// chunks.  Lane (i = l & 15, g = l >> 4) loads S[r0 + i][kb + 8 g .. + 7] (64 B
-// contiguous) and feeds it to 8 MFMAs whose k-slot g carries k = kb + 8 g + t.
-__global__ __launch_bounds__(256) void k_block_matvec(
+// One workgroup = 16 rows of S; its 8 waves split K in interleaved 32-wide chunks.
+// Lane (i = l & 15, g = l >> 4) loads S[r0 + i][kb + 8 g .. + 7] (64 B contiguous,
+// next chunk prefetched one iteration ahead) and feeds it to 8 MFMAs whose k-slot g
+// carries k = kb + 8 g + t; two accumulators break the MFMA dependency chain.
+// HBM-bound: one pass over S (n^2 * 8 bytes) per 16 vectors.
+constexpr int kMvWaves = 8;
+__global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
     const double* __restrict__ S, int ld, int n, const double* __restrict__ cvec,
     const double* __restrict__ pvec, const double* __restrict__ V, int ldv,
     const double* __restrict__ Vs, double* __restrict__ W) {
-  __shared__ double red[4][64][4];
+  __shared__ double red[kMvWaves][64][4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int r0 = blockIdx.x * 16;
   int ri = r0 + li;
   ri = ri < n ? ri : n - 1;
-  const double* srow = S + (size_t)ri * ld;
-  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  const double* srow = S + (size_t)ri * ld + 8 * lg;
+  v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   const int nchunks = (n + 31) / 32;
-  for (int ch = wave; ch < nchunks; ch += 4) {
+  double2 cur[4], nxt[4];
+  auto load = [&](double2* dst, int ch) {
     const int kb = ch * 32 + 8 * lg;
-    double a[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      // ld is a multiple of 16 and kb + 7 < ld, so the load stays in the row
-      const double2 v = *reinterpret_cast<const double2*>(srow + kb + 2 * q);
-      a[2 * q] = v.x;
-      a[2 * q + 1] = v.y;
+      // rows are padded to ld (multiple of 16): never read past the row's storage
+      if (kb + 2 * q + 1 < ld)
+        dst[q] = *reinterpret_cast<const double2*>(srow + ch * 32 + 2 * q);
+      else
+        dst[q] = make_double2(0.0, 0.0);
+    }
+  };
+  int ch = wave;
+  if (ch < nchunks) load(cur, ch);
+  for (; ch < nchunks; ch += kMvWaves) {
+    if (ch + kMvWaves < nchunks) load(nxt, ch + kMvWaves);
+    const int kb = ch * 32 + 8 * lg;
+    double b[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b[t] = (kb + t < n) ? Vs[(size_t)(kb + t) * B + li] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double a0 = (kb + 2 * q < n) ? cur[q].x : 0.0;
+      const double a1 = (kb + 2 * q + 1 < n) ? cur[q].y : 0.0;
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[2 * q], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[2 * q + 1], acc1, 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int k = kb + t;
-      const bool ok = k < n;
-      const double av = ok ? a[t] : 0.0;
-      const double bv = ok ? Vs[(size_t)k * B + li] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
+  for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc0[r] + acc1[r];
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double sum = (red[0][lane][r] + red[1][lane][r]) +
-                         (red[2][lane][r] + red[3][lane][r]);
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < kMvWaves; ++w) sum += red[w][lane][r];
       const int row = r0 + lg + 4 * r;  // D[row = (l >> 4) + 4 r][col = l & 15]
       if (row < n)
         W[(size_t)row * B + li] =
@@ -135,19 +152,19 @@ __global__ __launch_bounds__(256) void k_proj_partial(
 
 // H = sum of partials (m x 16), stored to Hbuf; optionally accumulated into
 // T[0:m, col0:col0+16] and mirrored (upper triangle of the diagonal block only);
-// hsq[j] (+)= sum_i H_ij^2.
+// hsq[j] += sum_i H_ij^2 (atomic: only feeds the rank-deficiency threshold; the
+// caller zeroes hsq before the first pass).  One entry per thread, m*16/256 blocks.
 __global__ __launch_bounds__(256) void k_reduce_H(
     const double* __restrict__ partial, int nparts, int m, double* __restrict__ Hbuf,
     double* __restrict__ T, int ldt, int col0, int accumulate,
     double* __restrict__ hsq) {
   __shared__ double sq[256];
   const int tid = threadIdx.x;
-  double mysq = 0.0;
-  for (int e = tid; e < m * B; e += 256) {
-    double h = 0.0;
+  const int e = blockIdx.x * 256 + tid;
+  double h = 0.0;
+  if (e < m * B) {
     for (int g = 0; g < nparts; ++g) h += partial[(size_t)g * (kLdq * B) + e];
     Hbuf[e] = h;
-    mysq = __builtin_fma(h, h, mysq);
     if (T != nullptr) {
       const int i = e >> 4, j = col0 + (e & 15);
       if (i <= j) {
@@ -157,13 +174,12 @@ __global__ __launch_bounds__(256) void k_reduce_H(
       }
     }
   }
-  // per-column sums of squares: thread tid owns column tid & 15 in every stride
-  sq[tid] = mysq;
+  sq[tid] = h * h;
   __syncthreads();
-  if (tid < B) {
+  if (tid < B) {  // thread tid owns column tid & 15 in every stride
     double s = 0.0;
     for (int q = tid; q < 256; q += B) s += sq[q];
-    hsq[tid] = accumulate ? hsq[tid] + s : s;
+    atomicAdd(&hsq[tid], s);
   }
 }
 
@@ -190,48 +206,59 @@ __global__ __launch_bounds__(256) void k_update_block(
   }
 }
 
-// Gram reduce + Cholesky G = R^T R, Rinv = R^-1 (upper).  A column whose pivot is
-// <= 1e-22 * (its own squared norm + what projection removed, hsq) is linearly
-// dependent at working precision: it is zeroed and flagged for a random refill.
+// Gram reduce + Cholesky G = R^T R (right-looking, 256 threads), Rinv = R^-1 (upper).
+// A column whose pivot is <= 1e-22 * (its own squared norm + what projection removed,
+// hsq) is linearly dependent at working precision: it is zeroed and flagged for a
+// random refill.
 __global__ __launch_bounds__(256) void k_reduce_chol(
     const double* __restrict__ partial, int nparts, double* __restrict__ Rinv,
     double* __restrict__ Gsave, const double* __restrict__ hsq,
     int* __restrict__ flags) {
-  __shared__ double G[B][B];
-  __shared__ double R[B][B];
-  __shared__ double Ri[B][B];
+  __shared__ double G[B][B + 1];
+  __shared__ double R[B][B + 1];
+  __shared__ double Ri[B][B + 1];
+  __shared__ double gdiag[B];
+  __shared__ double piv[B];
+  __shared__ int s_mask;
   const int tid = threadIdx.x;
+  const int ra = tid >> 4, cb = tid & 15;
   {
     double g = 0.0;
     for (int q = 0; q < nparts; ++q) g += partial[(size_t)q * (kLdq * B) + tid];
-    G[tid >> 4][tid & 15] = g;
+    G[ra][cb] = g;
     if (Gsave) Gsave[tid] = g;
-    R[tid >> 4][tid & 15] = 0.0;
-    Ri[tid >> 4][tid & 15] = 0.0;
+    R[ra][cb] = 0.0;
+    Ri[ra][cb] = 0.0;
+    if (ra == cb) gdiag[ra] = g;
+    if (tid == 0) s_mask = 0;
   }
   __syncthreads();
-  if (tid == 0) {
-    int mask = 0;
-    for (int j = 0; j < B; ++j) {
-      double d = G[j][j];
-      for (int k = 0; k < j; ++k) d -= R[k][j] * R[k][j];
-      const double total = G[j][j] + (hsq ? hsq[j] : 0.0);
+  for (int j = 0; j < B; ++j) {
+    if (tid == 0) {
+      const double d = G[j][j];
+      const double total = gdiag[j] + (hsq ? hsq[j] : 0.0);
       if (!(d > 1e-22 * total) || !(d > 0.0)) {
-        mask |= 1 << j;
-        R[j][j] = 0.0;  // marks a dropped column
-        continue;
-      }
-      const double rjj = sqrt(d);
-      R[j][j] = rjj;
-      for (int c2 = j + 1; c2 < B; ++c2) {
-        double v = G[j][c2];
-        for (int k = 0; k < j; ++k) v -= R[k][j] * R[k][c2];
-        R[j][c2] = v / rjj;
+        s_mask |= 1 << j;
+        piv[j] = 0.0;  // dropped column
+      } else {
+        piv[j] = sqrt(d);
       }
     }
-    // back substitution for R^-1 (columns of dropped vectors stay zero)
-    for (int j = 0; j < B; ++j) {
-      if (R[j][j] == 0.0) continue;
+    __syncthreads();
+    const double rj = piv[j];
+    if (tid < B) {
+      double v = 0.0;
+      if (rj != 0.0) v = tid == j ? rj : (tid > j ? G[j][tid] / rj : 0.0);
+      R[j][tid] = v;
+    }
+    __syncthreads();
+    if (ra > j && cb > j) G[ra][cb] -= R[j][ra] * R[j][cb];
+    __syncthreads();
+  }
+  // R^-1 by back substitution, one column per thread (dropped columns stay zero)
+  if (tid < B) {
+    const int j = tid;
+    if (R[j][j] != 0.0) {
       Ri[j][j] = 1.0 / R[j][j];
       for (int i = j - 1; i >= 0; --i) {
         if (R[i][i] == 0.0) continue;
@@ -240,10 +267,10 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
         Ri[i][j] = v / R[i][i];
       }
     }
-    flags[0] = mask;
   }
   __syncthreads();
-  Rinv[tid] = Ri[tid >> 4][tid & 15];
+  Rinv[tid] = Ri[ra][cb];
+  if (tid == 0) flags[0] = s_mask;
 }
 
 // W <- W * Rinv; optional copies: Qdst[:, col0 + j] and Vs = c .* W
@@ -283,7 +310,7 @@ __global__ __launch_bounds__(1024) void k_jacobi(
     const double* __restrict__ cvec, const double* __restrict__ pvec,
     const double* __restrict__ G, double* __restrict__ theta,
     double* __restrict__ Y, int ldy, double* __restrict__ resid,
-    double* __restrict__ Yt) {
+    double* __restrict__ Yt_global, int yt_in_lds) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int mp = (m + 1) & ~1;
   const int lda = mp + 1;
@@ -292,6 +319,8 @@ __global__ __launch_bounds__(1024) void k_jacobi(
   double* sn = cs + mp / 2;               // mp/2
   int* pp = reinterpret_cast<int*>(sn + mp / 2);  // mp/2
   int* qq = pp + mp / 2;                  // mp/2
+  // vector accumulator: LDS when it fits beside A (m <= 96), else global (L2)
+  double* Yt = yt_in_lds ? (sn + mp / 2 + mp / 2 + 2) : Yt_global;
   __shared__ int s_rot;
   const int tid = threadIdx.x;
   const int nth = blockDim.x;
@@ -327,27 +356,32 @@ __global__ __launch_bounds__(1024) void k_jacobi(
     if (tid == 0) s_rot = 0;
     __syncthreads();
     for (int round = 0; round < mp - 1; ++round) {
-      // --- rotation parameters
+      // --- rotation parameters of the mp/2 disjoint pairs of this round.  Pair k is
+      //     (p, q) = (round + k, round - k) mod (mp - 1) (k = 0: (mp - 1, round)); p
+      //     and q are NOT sorted so that consecutive lanes touch consecutive columns.
       if (tid < half) {
         int p, q;
         if (tid == 0) {
           p = mp - 1;
           q = round;
         } else {
-          p = (round + tid) % (mp - 1);
-          q = (round - tid + (mp - 1)) % (mp - 1);
+          p = round + tid;
+          p = p >= mp - 1 ? p - (mp - 1) : p;
+          q = round - tid;
+          q = q < 0 ? q + (mp - 1) : q;
         }
-        if (p > q) { const int t2 = p; p = q; q = t2; }
         const double app = A[p * lda + p], aqq = A[q * lda + q];
         const double apq = A[p * lda + q];
         double c = 1.0, s = 0.0;
-        const double thr = 1e-18 * sqrt(fabs(app) * fabs(aqq));
-        if (fabs(apq) > thr && fabs(apq) > 1e-300) {
-          const double th = (aqq - app) / (2.0 * apq);
-          const double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));
-          c = 1.0 / sqrt(t * t + 1.0);
+        const double scale = sqrt(fabs(app) * fabs(aqq));
+        if (fabs(apq) > 1e-18 * scale && fabs(apq) > 1e-300) {
+          // t = tan(angle): smaller root of t^2 + 2 theta t - 1 = 0, theta =
+          // (aqq - app) / (2 apq), written without forming theta
+          const double al = 0.5 * (aqq - app);
+          const double t = apq / (al + copysign(sqrt(al * al + apq * apq), al));
+          c = rsqrt(t * t + 1.0);
           s = t * c;
-          if (s != 0.0) atomicAdd(&s_rot, 1);
+          if (s != 0.0 && fabs(apq) > 1e-9 * scale) atomicAdd(&s_rot, 1);
         }
         cs[tid] = c;
         sn[tid] = s;
@@ -355,38 +389,44 @@ __global__ __launch_bounds__(1024) void k_jacobi(
         qq[tid] = q;
       }
       __syncthreads();
-      // --- columns: A <- A J ; vectors: rows p, q of Yt
+      // --- A <- J^T A J: each thread owns whole 2x2 blocks (pair k1 rows, pair k2
+      //     columns): reads its 4 entries, writes its 4 entries, no other thread
+      //     touches them, so one phase suffices.
+      for (int e = tid; e < half * half; e += nth) {
+        const int k1 = e / half, k2 = e - k1 * half;
+        const double c1 = cs[k1], s1 = sn[k1], c2 = cs[k2], s2 = sn[k2];
+        if (s1 == 0.0 && s2 == 0.0) continue;
+        const int p1 = pp[k1], q1 = qq[k1], p2 = pp[k2], q2 = qq[k2];
+        const double app = A[p1 * lda + p2], apq = A[p1 * lda + q2];
+        const double aqp = A[q1 * lda + p2], aqq = A[q1 * lda + q2];
+        // rows: J1^T
+        const double tpp = c1 * app - s1 * aqp, tpq = c1 * apq - s1 * aqq;
+        const double tqp = s1 * app + c1 * aqp, tqq = s1 * apq + c1 * aqq;
+        // columns: J2
+        double npp = c2 * tpp - s2 * tpq, npq = s2 * tpp + c2 * tpq;
+        double nqp = c2 * tqp - s2 * tqq, nqq = s2 * tqp + c2 * tqq;
+        if (k1 == k2) { npq = 0.0; nqp = 0.0; }  // the annihilated pair, exactly
+        A[p1 * lda + p2] = npp;
+        A[p1 * lda + q2] = npq;
+        A[q1 * lda + p2] = nqp;
+        A[q1 * lda + q2] = nqq;
+      }
+      // --- vectors: rows p, q of Yt
       for (int e = tid; e < mp * half; e += nth) {
         const int k = e / mp, i = e - k * mp;
         const double c = cs[k], s = sn[k];
         if (s != 0.0) {
           const int p = pp[k], q = qq[k];
-          const double aip = A[i * lda + p], aiq = A[i * lda + q];
-          A[i * lda + p] = c * aip - s * aiq;
-          A[i * lda + q] = s * aip + c * aiq;
           const double yp = Yt[(size_t)p * mp + i], yq = Yt[(size_t)q * mp + i];
           Yt[(size_t)p * mp + i] = c * yp - s * yq;
           Yt[(size_t)q * mp + i] = s * yp + c * yq;
         }
       }
       __syncthreads();
-      // --- rows: A <- J^T A
-      for (int e = tid; e < mp * half; e += nth) {
-        const int k = e / mp, j = e - k * mp;
-        const double c = cs[k], s = sn[k];
-        if (s != 0.0) {
-          const int p = pp[k], q = qq[k];
-          const double apj = A[p * lda + j], aqj = A[q * lda + j];
-          double npj = c * apj - s * aqj;
-          double nqj = s * apj + c * aqj;
-          if (j == q) npj = 0.0;
-          if (j == p) nqj = 0.0;
-          A[p * lda + j] = npj;
-          A[q * lda + j] = nqj;
-        }
-      }
-      __syncthreads();
     }
+    // s_rot counts rotations that were still "large" (|apq| > 1e-9 sqrt(app aqq)).
+    // A sweep made only of small rotations leaves off-diagonals ~1e-18 relative
+    // (quadratic convergence): done, without a further all-idle checking sweep.
     if (s_rot == 0) break;
     __syncthreads();
   }
@@ -430,7 +470,7 @@ __global__ void k_set_diag_T(double* T, int ldt, int mtot, const double* theta,
 // dst[r, 0:cols] = Q[r, 0:m] * Y[0:m, 0:cols]
 __global__ __launch_bounds__(256) void k_basis_times_Y(
     const double* __restrict__ Q, int ldq, int m, const double* __restrict__ Y,
-    int ldy, int cols, double* __restrict__ dst, int lddst, int n) {
+    int ldy, int cols, double* __restrict__ dst, int lddst, int n, int colmajor) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Yl = smem;                 // m x cols
   double* Ql = smem + m * cols;      // 16 x (m + 1)
@@ -452,7 +492,10 @@ __global__ __launch_bounds__(256) void k_basis_times_Y(
     double acc = 0.0;
     for (int i = 0; i < m; ++i)
       acc = __builtin_fma(Ql[rr * (m + 1) + i], Yl[i * cols + j], acc);
-    dst[(size_t)r * lddst + j] = acc;
+    if (colmajor)
+      dst[(size_t)j * lddst + r] = acc;  // one vector = one contiguous column
+    else
+      dst[(size_t)r * lddst + j] = acc;
   }
 }
 
@@ -464,49 +507,42 @@ __global__ void k_copy_block(const double* __restrict__ src, int ldsrc,
   dst[(size_t)r * lddst + j] = src[(size_t)r * ldsrc + j];
 }
 
-// E[:, j] <- t .* E[:, j]; partial column sums of squares per block
-__global__ __launch_bounds__(256) void k_scale_colsq(double* __restrict__ E, int lde,
-                                                     int n, int cols,
-                                                     const double* __restrict__ tvec,
-                                                     double* __restrict__ part) {
-  __shared__ double sm[256];
-  const int tid = threadIdx.x;
-  const int rows_per = (n + gridDim.x - 1) / gridDim.x;
-  const int rbeg = blockIdx.x * rows_per, rend = min(n, rbeg + rows_per);
-  // thread -> (row lane = tid / 64 .. , column = tid % 64)
-  const int j = tid & 63, rl = tid >> 6;
+// Column-major eigenvectors: ET[j * ld + r].  One workgroup per column:
+// v = t .* u, then v / ||v||_2  (LAPACK dgeev returns unit 2-norm columns).
+__global__ __launch_bounds__(256) void k_back_transform(double* __restrict__ ET, int ld,
+                                                        int n,
+                                                        const double* __restrict__ tvec) {
+  __shared__ double sm[4];
+  double* col = ET + (size_t)blockIdx.x * ld;
   double acc = 0.0;
-  if (j < cols) {
-    for (int r = rbeg + rl; r < rend; r += 4) {
-      const double v = tvec[r] * E[(size_t)r * lde + j];
-      E[(size_t)r * lde + j] = v;
-      acc = __builtin_fma(v, v, acc);
-    }
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const double v = tvec[r] * col[r];
+    col[r] = v;
+    acc = __builtin_fma(v, v, acc);
   }
-  sm[tid] = acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (tid < 64)
-    part[(size_t)blockIdx.x * kMaxVectors + tid] =
-        (sm[tid] + sm[tid + 64]) + (sm[tid + 128] + sm[tid + 192]);
+  const double inv = 1.0 / sqrt((sm[0] + sm[1]) + (sm[2] + sm[3]));
+  for (int r = threadIdx.x; r < n; r += 256) col[r] *= inv;
 }
-__global__ __launch_bounds__(256) void k_normalize_cols(double* __restrict__ E,
-                                                        int lde, int n, int cols,
-                                                        const double* __restrict__ part,
-                                                        int nparts) {
-  __shared__ double inv[kMaxVectors];
-  const int tid = threadIdx.x;
-  if (tid < cols) {
-    double s = 0.0;
-    for (int g = 0; g < nparts; ++g) s += part[(size_t)g * kMaxVectors + tid];
-    inv[tid] = 1.0 / sqrt(s);
-  }
-  __syncthreads();
-  const size_t total = (size_t)n * cols;
-  for (size_t e = (size_t)blockIdx.x * 256 + tid; e < total;
-       e += (size_t)gridDim.x * 256) {
-    const int r = (int)(e / cols), j = (int)(e - (size_t)r * cols);
-    E[(size_t)r * lde + j] *= inv[j];
-  }
+
+// dst (column-major, ldd) <- src (row-major, lds), n rows x cols
+__global__ void k_rowmajor_to_colmajor(const double* __restrict__ src, int lds, int n,
+                                       int cols, double* __restrict__ dst, int ldd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * cols) return;
+  const int j = e / n, r = e - j * n;
+  dst[(size_t)j * ldd + r] = src[(size_t)r * lds + j];
+}
+// dst (row-major, ldd) <- src (column-major, lds)
+__global__ void k_colmajor_to_rowmajor(const double* __restrict__ src, int lds, int n,
+                                       int cols, double* __restrict__ dst, int ldd) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * cols) return;
+  const int r = e / cols, j = e - r * cols;
+  dst[(size_t)r * ldd + j] = src[(size_t)j * lds + r];
 }
 
 // ---------------------------------------------------------------- launchers
@@ -522,8 +558,8 @@ void launch_refill_deficient(hipStream_t s, double* W, int n, const int* flags,
 void launch_block_matvec(hipStream_t s, const double* S, int ld, int n,
                          const double* cvec, const double* pvec, const double* V,
                          int ldv, const double* Vs, double* W) {
-  hipLaunchKernelGGL(k_block_matvec, dim3((n + 15) / 16), dim3(256), 0, s, S, ld, n,
-                     cvec, pvec, V, ldv, Vs, W);
+  hipLaunchKernelGGL(k_block_matvec, dim3((n + 15) / 16), dim3(64 * kMvWaves), 0, s, S,
+                     ld, n, cvec, pvec, V, ldv, Vs, W);
 }
 void launch_proj_partial(hipStream_t s, const double* Q, int ldq, int m,
                          const double* W, int n, double* partial) {
@@ -532,8 +568,8 @@ void launch_proj_partial(hipStream_t s, const double* Q, int ldq, int m,
 }
 void launch_reduce_H(hipStream_t s, const double* partial, int m, double* Hbuf,
                      double* T, int ldt, int col0, int accumulate, double* hsq) {
-  hipLaunchKernelGGL(k_reduce_H, dim3(1), dim3(256), 0, s, partial, kProjBlocks, m,
-                     Hbuf, T, ldt, col0, accumulate, hsq);
+  hipLaunchKernelGGL(k_reduce_H, dim3((m * B + 255) / 256), dim3(256), 0, s, partial,
+                     kProjBlocks, m, Hbuf, T, ldt, col0, accumulate, hsq);
 }
 void launch_update_block(hipStream_t s, const double* Q, int ldq, int m,
                          const double* Hbuf, double* W, int n) {
@@ -555,16 +591,20 @@ void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
                    const double* cvec, const double* pvec, const double* G,
                    double* theta, double* Y, int ldy, double* resid, double* Yt) {
   const int mp = (m + 1) & ~1;
-  const size_t lds = sizeof(double) * ((size_t)mp * (mp + 1) + mp) +
-                     sizeof(int) * (size_t)mp + 64;
+  const size_t base = sizeof(double) * ((size_t)mp * (mp + 1) + 2 * mp + 2) + 64;
+  const size_t with_yt = base + sizeof(double) * (size_t)mp * mp;
+  const int yt_in_lds = with_yt <= 150 * 1024;
+  const size_t lds = yt_in_lds ? with_yt : base;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(1024), lds, s, src, ldsrc, m, mode, cvec,
-                     pvec, G, theta, Y, ldy, resid, Yt);
+  int threads = ((mp / 2) * (mp / 2) + 63) / 64 * 64;
+  threads = std::max(256, std::min(1024, threads));
+  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(threads), lds, s, src, ldsrc, m, mode, cvec,
+                     pvec, G, theta, Y, ldy, resid, Yt, yt_in_lds);
 }
 void launch_set_diag_T(hipStream_t s, double* T, int ldt, int mtot,
                        const double* theta, int keep) {
@@ -573,7 +613,7 @@ void launch_set_diag_T(hipStream_t s, double* T, int ldt, int mtot,
 }
 void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
                           const double* Y, int ldy, int cols, double* dst,
-                          int lddst, int n) {
+                          int lddst, int n, int colmajor) {
   const size_t lds = sizeof(double) * ((size_t)m * cols + 16 * (size_t)(m + 1));
   static bool attr_set = false;
   if (!attr_set) {
@@ -582,19 +622,26 @@ void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
     attr_set = true;
   }
   hipLaunchKernelGGL(k_basis_times_Y, dim3((n + 15) / 16), dim3(256), lds, s, Q, ldq,
-                     m, Y, ldy, cols, dst, lddst, n);
+                     m, Y, ldy, cols, dst, lddst, n, colmajor);
 }
 void launch_copy_block(hipStream_t s, const double* src, int ldsrc, double* dst,
                        int lddst, int n, int cols) {
   hipLaunchKernelGGL(k_copy_block, dim3((n * cols + 255) / 256), dim3(256), 0, s, src,
                      ldsrc, dst, lddst, n, cols);
 }
-void launch_back_transform(hipStream_t s, double* E, int lde, int n, int cols,
-                           const double* tvec, double* colnorm_ws) {
-  hipLaunchKernelGGL(k_scale_colsq, dim3(kProjBlocks), dim3(256), 0, s, E, lde, n,
-                     cols, tvec, colnorm_ws);
-  hipLaunchKernelGGL(k_normalize_cols, dim3(256), dim3(256), 0, s, E, lde, n, cols,
-                     colnorm_ws, kProjBlocks);
+void launch_back_transform(hipStream_t s, double* ET, int ld, int n, int cols,
+                           const double* tvec) {
+  hipLaunchKernelGGL(k_back_transform, dim3(cols), dim3(256), 0, s, ET, ld, n, tvec);
+}
+void launch_rowmajor_to_colmajor(hipStream_t s, const double* src, int lds, int n, int cols,
+                                 double* dst, int ldd) {
+  hipLaunchKernelGGL(k_rowmajor_to_colmajor, dim3((n * cols + 255) / 256), dim3(256), 0, s,
+                     src, lds, n, cols, dst, ldd);
+}
+void launch_colmajor_to_rowmajor(hipStream_t s, const double* src, int lds, int n, int cols,
+                                 double* dst, int ldd) {
+  hipLaunchKernelGGL(k_colmajor_to_rowmajor, dim3((n * cols + 255) / 256), dim3(256), 0, s,
+                     src, lds, n, cols, dst, ldd);
 }
 
 }  // namespace sc

@@ -8,10 +8,15 @@
 //
 // Tiling: 128x128 block tile, BK = 16, 256 threads = 4 waves, each wave a 64x64
 // sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 acc VGPRs).
-// LDS tiles are [128][16] doubles with the 16-byte chunk index XOR-swizzled by
-// (row >> 1) & 7 so the per-lane ds_read_b64 of an MFMA operand (16 rows x 2 k
-// per 32-lane group) hits 32 distinct bank pairs.
-// Global loads are register-staged one K-tile ahead.
+// LDS tiles are [128][16] doubles; element k of row r sits at position
+// k ^ (r & 15), which makes the MFMA operand reads (16 rows x one k per 16-lane
+// group) conflict-free both as ds_read_b64 (64 banks, 32-lane groups) and as the
+// ds_read2st64_b64 pairs hipcc fuses them into (32 banks, 16-lane groups).
+// Two LDS buffers: tile t+1 is written (from registers loaded one iteration
+// earlier) while tile t feeds the MFMAs, so there is ONE barrier per K-tile and the
+// ds_write / global_load traffic hides under the 64 MFMAs (4096 cycles) of a tile.
+#include <algorithm>
+
 #include "sc_internal.h"
 
 namespace sc {
@@ -22,36 +27,53 @@ constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 16;
 
+// 16-byte chunk kc (k = 2kc, 2kc+1) of row `row`: both elements land in one aligned
+// chunk, in swapped order for odd rows.
 __device__ __forceinline__ int lds_chunk_off(int row, int kc) {
-  return row * BK + (((kc ^ ((row >> 1) & 7))) << 1);
+  return row * BK + ((2 * kc) ^ (row & 14));
 }
 
+// Maps a linear tile id to (ti, tj): row by row over the upper triangle when SYM,
+// plain row-major otherwise.
+template <bool SYM>
+__device__ __forceinline__ void tile_coords(int id, int ntiles_m, int ntiles_n,
+                                            int* ti, int* tj) {
+  if (SYM) {
+    int r = 0, rowlen = ntiles_m;
+    while (id >= rowlen) {
+      id -= rowlen;
+      --rowlen;
+      ++r;
+    }
+    *ti = r;
+    *tj = r + id;
+  } else {
+    *ti = id / ntiles_n;
+    *tj = id - (*ti) * ntiles_n;
+  }
+}
+
+// One workgroup = one 128x128 output tile over the K range of its split:
+//   tile  = tile_offset + blockIdx.x / ksplit,  chunk = blockIdx.x % ksplit.
+// ksplit == 1: full K, epilogue + store to C (and the mirror tile when SYM).
+// ksplit  > 1: raw accumulators go to `partial` (fragment order), to be summed by
+//              k_gemm_reduce -- used for the tiles left over after the last full
+//              wave of workgroups, so the chip does not idle on a ragged tail.
 template <int EPI, bool SYM>
-__global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
+__global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A,
                                                  int lda,
                                                  const double* __restrict__ B,
                                                  int ldb, double* __restrict__ C,
                                                  int ldc, int M, int N, int K,
-                                                 int ntiles) {
-  __shared__ __attribute__((aligned(16))) double As[BM * BK];
-  __shared__ __attribute__((aligned(16))) double Bs[BN * BK];
+                                                 int ntiles_m, int ntiles_n,
+                                                 int tile_offset, int ksplit,
+                                                 double* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) double As[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) double Bs[2][BN * BK];
 
   int ti, tj;
-  if (SYM) {
-    // linear id over the upper triangle (ti <= tj), row by row
-    int id = blockIdx.x;
-    ti = 0;
-    int rowlen = ntiles;
-    while (id >= rowlen) {
-      id -= rowlen;
-      --rowlen;
-      ++ti;
-    }
-    tj = ti + id;
-  } else {
-    ti = blockIdx.y;
-    tj = blockIdx.x;
-  }
+  const int chunk = blockIdx.x % ksplit;
+  tile_coords<SYM>(tile_offset + blockIdx.x / ksplit, ntiles_m, ntiles_n, &ti, &tj);
   const int row0 = ti * BM;
   const int col0 = tj * BN;
 
@@ -68,6 +90,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
   const double* bptr[4];
   int lds_off[4];
   int kcol[4];
+  bool swap[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = tid + 256 * q;
@@ -80,6 +103,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
     aptr[q] = A + (size_t)ga * lda + 2 * kc;
     bptr[q] = B + (size_t)gb * ldb + 2 * kc;
     lds_off[q] = lds_chunk_off(r, kc);
+    swap[q] = r & 1;
     kcol[q] = 2 * kc;
   }
 
@@ -89,7 +113,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-  const int ktiles = (K + BK - 1) / BK;
+  const int ktiles_all = (K + BK - 1) / BK;
+  const int kper = (ktiles_all + ksplit - 1) / ksplit;
+  const int kt_begin = chunk * kper;
+  const int kt_end = min(ktiles_all, kt_begin + kper);
   double2 ra[4], rb[4];
 
   auto gload = [&](int kt) {
@@ -106,32 +133,48 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
     }
   };
 
-  gload(0);
+  auto lds_store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double2 va = ra[q], vb = rb[q];
+      if (swap[q]) {
+        va = make_double2(va.y, va.x);
+        vb = make_double2(vb.y, vb.x);
+      }
+      *reinterpret_cast<double2*>(&As[buf][lds_off[q]]) = va;
+      *reinterpret_cast<double2*>(&Bs[buf][lds_off[q]]) = vb;
+    }
+  };
 
-  // operand read offsets inside a tile (row part); k part added per sub-step
-  const int swz = (li >> 1) & 7;
+  // operand read offsets inside a tile: row part; position k ^ li added per sub-step
   const int arow = (wr * 64 + li) * BK;
   const int brow = (wc * 64 + li) * BK;
 
-  for (int kt = 0; kt < ktiles; ++kt) {
-    __syncthreads();  // previous tile fully consumed
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<double2*>(&As[lds_off[q]]) = ra[q];
-      *reinterpret_cast<double2*>(&Bs[lds_off[q]]) = rb[q];
-    }
-    __syncthreads();
-    if (kt + 1 < ktiles) gload(kt + 1);
+  if (kt_begin < kt_end) {
+    gload(kt_begin);
+    lds_store(0);
+    if (kt_begin + 1 < kt_end) gload(kt_begin + 1);
+  }
+  __syncthreads();
 
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    // stage tile kt+1 into the other buffer, then fetch tile kt+2 into registers;
+    // both overlap the MFMAs below (no barrier until the end of the iteration)
+    if (kt + 1 < kt_end) {
+      lds_store(cur ^ 1);
+      if (kt + 2 < kt_end) gload(kt + 2);
+    }
+    const double* Ac = As[cur];
+    const double* Bc = Bs[cur];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int kc = 2 * s + (lg >> 1);
-      const int koff = ((kc ^ swz) << 1) + (lg & 1);
+      const int koff = (4 * s + lg) ^ li;
       double a[4], b[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) a[m] = As[arow + m * 16 * BK + koff];
+      for (int m = 0; m < 4; ++m) a[m] = Ac[arow + m * 16 * BK + koff];
 #pragma unroll
-      for (int nn = 0; nn < 4; ++nn) b[nn] = Bs[brow + nn * 16 * BK + koff];
+      for (int nn = 0; nn < 4; ++nn) b[nn] = Bc[brow + nn * 16 * BK + koff];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -139,10 +182,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
           acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[nn],
                                                             acc[m][nn], 0, 0, 0);
     }
+    __syncthreads();
   }
 
   // --- epilogue.  D layout of v_mfma_f64_16x16x4_f64: lane l, reg r holds
   //     D[row = (l >> 4) + 4 r][col = l & 15].
+  if (ksplit > 1) {
+    double* out = partial + (size_t)blockIdx.x * (BM * BN);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[((m * 4 + nn) * 4 + r) * 256 + tid] = acc[m][nn][r];
+    return;
+  }
   const bool mirror = SYM && (ti != tj);
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -153,7 +208,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + wr * 64 + m * 16 + lg + 4 * r;
         double v = acc[m][nn][r];
-        if (EPI == kEpiAffinity) v = (v + 1.0) * 0.5;  // == (v + 1) / 2 exactly
+        // (v + 1) / 2: halving is exact, so one fma rounds identically
+        if (EPI == kEpiAffinity) v = __builtin_fma(v, 0.5, 0.5);
         if (row < M && col < N) {
           C[(size_t)row * ldc + col] = v;
           if (mirror) C[(size_t)col * ldc + row] = v;
@@ -163,28 +219,109 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
   }
 }
 
+// Sums the ksplit partial tiles of k_gemm_nt (fixed order: deterministic), applies
+// the epilogue and stores the tile (+ mirror).  Same fragment -> (row, col) map.
+template <int EPI, bool SYM>
+__global__ __launch_bounds__(256) void k_gemm_reduce(const double* __restrict__ partial,
+                                                     double* __restrict__ C, int ldc,
+                                                     int M, int N, int ntiles_m,
+                                                     int ntiles_n, int tile_offset,
+                                                     int ksplit) {
+  int ti, tj;
+  tile_coords<SYM>(tile_offset + blockIdx.x, ntiles_m, ntiles_n, &ti, &tj);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const bool mirror = SYM && (ti != tj);
+  const double* base = partial + (size_t)blockIdx.x * ksplit * (BM * BN);
+  // blockIdx.y picks one of the 16 (m, nn) fragment pairs: 16x more workgroups
+  {
+    const int m = blockIdx.y >> 2;
+    {
+      const int nn = blockIdx.y & 3;
+      const int col = tj * BN + wc * 64 + nn * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * BM + wr * 64 + m * 16 + lg + 4 * r;
+        const int slot = ((m * 4 + nn) * 4 + r) * 256 + tid;
+        double v = 0.0;
+        for (int c = 0; c < ksplit; ++c) v += base[(size_t)c * (BM * BN) + slot];
+        if (EPI == kEpiAffinity) v = __builtin_fma(v, 0.5, 0.5);
+        if (row < M && col < N) {
+          C[(size_t)row * ldc + col] = v;
+          if (mirror) C[(size_t)col * ldc + row] = v;
+        }
+      }
+    }
+  }
+}
+
+constexpr int kMaxDevices = 16;
+static int g_slots_dev[kMaxDevices] = {0};          // co-resident k_gemm_nt workgroups
+static double* g_partial_dev[kMaxDevices] = {nullptr};  // split-K scratch, slots tiles
+
+template <int EPI, bool SYM>
+static void launch_variant(hipStream_t s, const double* A, int lda, const double* B,
+                           int ldb, double* C, int ldc, int M, int N, int K) {
+  const int tm = (M + BM - 1) / BM;
+  const int tn = (N + BN - 1) / BN;
+  const int tiles = SYM ? tm * (tm + 1) / 2 : tm * tn;
+  int dev = 0;
+  hipGetDevice(&dev);
+  dev = dev < kMaxDevices ? dev : 0;
+  if (g_slots_dev[dev] == 0) {
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, dev);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, reinterpret_cast<const void*>(k_gemm_nt<kEpiNone, true>), 256, 0);
+    if (per_cu < 1) per_cu = 1;
+    g_slots_dev[dev] = per_cu * prop.multiProcessorCount;
+    hipMalloc(reinterpret_cast<void**>(&g_partial_dev[dev]),
+              (size_t)g_slots_dev[dev] * BM * BN * sizeof(double));
+  }
+  const int g_slots = g_slots_dev[dev];
+  double* g_partial = g_partial_dev[dev];
+  const int ktiles = (K + BK - 1) / BK;
+  // full waves of workgroups run whole tiles; the ragged remainder is split over K
+  int full = (tiles / g_slots) * g_slots;
+  int rem = tiles - full;
+  int ksplit = 1;
+  if (rem > 0) {
+    ksplit = g_slots / rem;
+    ksplit = std::min(ksplit, std::max(1, ktiles / 8));  // >= 8 k-tiles per chunk
+    if (ksplit < 2) {  // not worth splitting
+      full = tiles;
+      rem = 0;
+      ksplit = 1;
+    }
+  }
+  if (full > 0)
+    hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full), dim3(256), 0, s, A, lda, B,
+                       ldb, C, ldc, M, N, K, tm, tn, 0, 1, nullptr);
+  if (rem > 0) {
+    hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(rem * ksplit), dim3(256), 0, s, A, lda,
+                       B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial);
+    hipLaunchKernelGGL((k_gemm_reduce<EPI, SYM>), dim3(rem, 16), dim3(256), 0, s, g_partial,
+                       C, ldc, M, N, tm, tn, full, ksplit);
+  }
+}
+
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
                     int epilogue, bool symmetric) {
   if (M <= 0 || N <= 0) return;
-  const int tm = (M + BM - 1) / BM;
-  const int tn = (N + BN - 1) / BN;
   if (symmetric) {
-    dim3 grid(tm * (tm + 1) / 2);
     if (epilogue == kEpiAffinity)
-      hipLaunchKernelGGL((k_gemm_nt<kEpiAffinity, true>), grid, dim3(256), 0, s, A,
-                         lda, B, ldb, C, ldc, M, N, K, tm);
+      launch_variant<kEpiAffinity, true>(s, A, lda, B, ldb, C, ldc, M, N, K);
     else
-      hipLaunchKernelGGL((k_gemm_nt<kEpiNone, true>), grid, dim3(256), 0, s, A,
-                         lda, B, ldb, C, ldc, M, N, K, tm);
+      launch_variant<kEpiNone, true>(s, A, lda, B, ldb, C, ldc, M, N, K);
   } else {
-    dim3 grid(tn, tm);
     if (epilogue == kEpiAffinity)
-      hipLaunchKernelGGL((k_gemm_nt<kEpiAffinity, false>), grid, dim3(256), 0, s,
-                         A, lda, B, ldb, C, ldc, M, N, K, tm);
+      launch_variant<kEpiAffinity, false>(s, A, lda, B, ldb, C, ldc, M, N, K);
     else
-      hipLaunchKernelGGL((k_gemm_nt<kEpiNone, false>), grid, dim3(256), 0, s, A,
-                         lda, B, ldb, C, ldc, M, N, K, tm);
+      launch_variant<kEpiNone, false>(s, A, lda, B, ldb, C, ldc, M, N, K);
   }
 }
 

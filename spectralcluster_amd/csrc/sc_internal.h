@@ -108,16 +108,21 @@ void launch_set_diag_T(hipStream_t s, double* T, int ldt, int mtot,
 // dst[:, 0:cols] = Q[:, 0:m] * Y[0:m, 0:cols]
 void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
                           const double* Y, int ldy, int cols, double* dst,
-                          int lddst, int n);
+                          int lddst, int n, int colmajor);
 void launch_copy_block(hipStream_t s, const double* src, int ldsrc, double* dst,
                        int lddst, int n, int cols);
-// E[:, j] = t .* U[:, j] / || t .* U[:, j] ||   (LAPACK unit 2-norm columns)
-void launch_back_transform(hipStream_t s, double* E, int lde, int n, int cols,
-                           const double* tvec, double* colnorm_ws);
+// Eigenvectors live COLUMN-major on the device: ET[j * ld + r].
+// ET[j] = t .* ET[j] / || t .* ET[j] ||   (LAPACK unit 2-norm columns)
+void launch_back_transform(hipStream_t s, double* ET, int ld, int n, int cols,
+                           const double* tvec);
+void launch_rowmajor_to_colmajor(hipStream_t s, const double* src, int lds, int n, int cols,
+                                 double* dst, int ldd);
+void launch_colmajor_to_rowmajor(hipStream_t s, const double* src, int lds, int n, int cols,
+                                 double* dst, int ldd);
 
 // ---- k-means -------------------------------------------------------------------
 struct KmeansWorkspace {
-  double* Xc = nullptr;       // n x kMaxVectors centred copy
+  double* Xc = nullptr;       // kMaxVectors x n centred copy (column-major)
   double* xsq = nullptr;      // n
   double* closest = nullptr;  // n
   double* cand = nullptr;     // 8 x n candidate distances
@@ -128,8 +133,10 @@ struct KmeansWorkspace {
   long long* labels64 = nullptr;  // n
   int* info = nullptr;        // [0] iterations
 };
-void launch_row_renorm(hipStream_t s, double* E, int lde, int n, int k);
-void launch_kmeans(hipStream_t s, const double* E, int lde, int n, int k,
+void launch_row_renorm(hipStream_t s, double* ET, int lde, int n, int k);
+void launch_to_colmajor(hipStream_t s, const double* src, int n, int k, double* dst,
+                        int ldt);
+void launch_kmeans(hipStream_t s, const double* ET, int lde, int n, int k,
                    int max_iter, int first_center, int trials,
                    const KmeansWorkspace& ws);
 

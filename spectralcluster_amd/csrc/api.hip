@@ -33,7 +33,7 @@ struct sc_handle_s {
   // matrices
   DevBuf X, Xn, A0, B1, B2;
   // n-vectors
-  DevBuf rowmax, rowsum, cvec, pvec, tvec, deg;
+  DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart;
   DevBuf blurw;           // device copy of the blur weights
   // eigen workspace
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
@@ -106,6 +106,9 @@ static int ensure_matrices(sc_handle h, int n, int d) {
   SC_TRY(grow(h, h->pvec, nv));
   SC_TRY(grow(h, h->tvec, nv));
   SC_TRY(grow(h, h->deg, nv));
+  SC_TRY(grow(h, h->dvec, nv));
+  SC_TRY(grow(h, h->cut, nv));
+  SC_TRY(grow(h, h->rmpart, (size_t)n * blur_tile_columns(n) * sizeof(double)));
   SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
   return SC_OK;
 }
@@ -216,7 +219,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -828,17 +831,62 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   float diffuse_ms_events[SC_MAX_OPS][2];
   int n_diffuse = 0;
   ev_rec(h, &e_begin);
+  // Fusions (identical arithmetic, fewer passes over the n x n matrix):
+  //   CropDiagonal + GaussianBlur      -> crop value vector + blur with diagonal override
+  //   GaussianBlur -> RowWiseThreshold -> row maxima come out of the blur epilogue
+  //   RowWiseThreshold(RowMax) + Symmetrize -> one tile-pair kernel
+  const bool blur_fast = (cfg->blur_radius == 4 || cfg->blur_radius == 8) && n >= 128;
+  const double* pending_diag = nullptr;
+  bool have_partials = false;
   for (int i = 0; i < cfg->n_ops; ++i) {
     const int op = cfg->ops[i];
+    const int next = i + 1 < cfg->n_ops ? cfg->ops[i + 1] : 0;
+    const int next2 = i + 2 < cfg->n_ops ? cfg->ops[i + 2] : 0;
+    const bool thr_sym_fusable = cfg->threshold_type == SC_THRESHOLD_ROW_MAX &&
+                                 !cfg->preserve_diagonal;
     if (op == SC_OP_ROW_WISE_NORMALIZE && symmetric && i == cfg->n_ops - 1) {
       folded_rownorm = true;  // W = diag(1/rowmax) S is never materialised
       continue;
+    }
+    if (op == SC_OP_CROP_DIAGONAL && next == SC_OP_GAUSSIAN_BLUR && blur_fast) {
+      launch_crop_value(s, cur, n, ld, ptr<double>(h->dvec));
+      pending_diag = ptr<double>(h->dvec);
+      have_partials = false;
+      continue;  // symmetry unchanged; the blur applies the new diagonal on load
     }
     double* out = bufs[which];
     which ^= 1;
     int e0 = -1, e1 = -1;
     if (op == SC_OP_DIFFUSE) ev_rec(h, &e0);
-    SC_TRY(run_refine_op(h, op, cfg, cur, out, n, ld));
+    if (op == SC_OP_GAUSSIAN_BLUR && blur_fast) {
+      const bool want = next == SC_OP_ROW_WISE_THRESHOLD && next2 == SC_OP_SYMMETRIZE &&
+                        thr_sym_fusable;
+      SC_HIP(h, hipMemcpyAsync(h->blurw.p, cfg->blur_weights,
+                               (2 * cfg->blur_radius + 1) * sizeof(double),
+                               hipMemcpyHostToDevice, s));
+      have_partials = launch_gaussian_blur_fused(s, cur, out, n, ld, cfg->blur_radius,
+                                                 ptr<double>(h->blurw), pending_diag,
+                                                 want ? ptr<double>(h->rmpart) : nullptr);
+      pending_diag = nullptr;
+      SC_TRY(check_last(h, "blur launch"));
+    } else if (op == SC_OP_ROW_WISE_THRESHOLD && next == SC_OP_SYMMETRIZE && thr_sym_fusable) {
+      if (have_partials)
+        launch_cut_from_partials(s, ptr<double>(h->rmpart), n, blur_tile_columns(n),
+                                 cfg->p_percentile, ptr<double>(h->cut));
+      else
+        launch_cut_from_rows(s, cur, n, ld, cfg->p_percentile, ptr<double>(h->cut));
+      launch_threshold_symmetrize(s, cur, out, n, ld, ptr<double>(h->cut),
+                                  cfg->soft_multiplier, cfg->binarize, cfg->symmetrize_type);
+      SC_TRY(check_last(h, "threshold+symmetrize launch"));
+      have_partials = false;
+      cur = out;
+      symmetric = true;
+      ++i;  // Symmetrize consumed
+      continue;
+    } else {
+      SC_TRY(run_refine_op(h, op, cfg, cur, out, n, ld));
+      have_partials = false;
+    }
     if (op == SC_OP_DIFFUSE) {
       ev_rec(h, &e1);
       diffuse_ms_events[n_diffuse][0] = (float)e0;

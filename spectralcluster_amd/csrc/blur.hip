@@ -68,6 +68,70 @@ __global__ __launch_bounds__(256) void k_gaussian_blur(
   }
 }
 
+// Fast path: radius known at compile time (index arithmetic by constants), plain
+// conditionals instead of modulo for the reflection (needs n >= R), optional fusions:
+//   diag   != nullptr : element (i, i) of the input is replaced by diag[i] on load
+//                       (CropDiagonal folded in: reference refinement.py:148-150)
+//   rowmax != nullptr : per-tile row maxima of the OUTPUT are written to
+//                       rowmax[row * gridDim.x + blockIdx.x] (feeds RowWiseThreshold)
+template <int R>
+__global__ __launch_bounds__(256) void k_gaussian_blur_r(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    const double* __restrict__ weights, const double* __restrict__ diag,
+    double* __restrict__ rowmax) {
+  constexpr int HW = TW + 2 * R;
+  constexpr int HH = TH + 2 * R;
+  __shared__ double tile[HH * HW];
+  __shared__ double mid[TH * HW];
+  __shared__ double w[R + 1];
+  const int i0 = blockIdx.y * TH;
+  const int j0 = blockIdx.x * TW;
+  const int tid = threadIdx.x;
+  if (tid <= R) w[tid] = weights[R - tid];
+  for (int e = tid; e < HH * HW; e += 256) {
+    const int r = e / HW, c = e - r * HW;
+    int gi = i0 + r - R, gj = j0 + c - R;
+    gi = gi < 0 ? -gi - 1 : gi;
+    gj = gj < 0 ? -gj - 1 : gj;
+    // tiles may hang over the matrix edge: reflect (possibly twice for the overhang)
+    gi = gi >= n ? 2 * n - 1 - gi : gi;
+    gj = gj >= n ? 2 * n - 1 - gj : gj;
+    gi = gi < 0 ? 0 : gi;  // only reachable for overhang cells that are never used
+    gj = gj < 0 ? 0 : gj;
+    double v = in[(size_t)gi * ld + gj];
+    if (diag != nullptr && gi == gj) v = diag[gi];
+    tile[e] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < TH * HW; e += 256) {
+    const int r = e / HW, c = e - r * HW;
+    const double* x = tile + (r + R) * HW + c;
+    double t = x[0] * w[0];
+#pragma unroll
+    for (int j = R; j >= 1; --j) t += (x[-j * HW] + x[j * HW]) * w[j];
+    mid[e] = t;
+  }
+  __syncthreads();
+  // 256 threads = 4 waves; wave `wv` produces rows wv, wv + 4, ...: one row (64
+  // columns) per wave per step, so the row maximum is a single wave reduction
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int r = wv; r < TH; r += 4) {
+    const int gi = i0 + r, gj = j0 + lane;
+    const double* x = mid + r * HW + lane + R;
+    double t = x[0] * w[0];
+#pragma unroll
+    for (int j = R; j >= 1; --j) t += (x[-j] + x[j]) * w[j];
+    const bool ok = gi < n && gj < n;
+    if (ok) out[(size_t)gi * ld + gj] = t;
+    if (rowmax != nullptr) {
+      double m = ok ? t : -INFINITY;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+      if (lane == 0 && gi < n) rowmax[(size_t)gi * gridDim.x + blockIdx.x] = m;
+    }
+  }
+}
+
 __global__ void k_copy_matrix(const double* __restrict__ in,
                               double* __restrict__ out, int n, int ld) {
   const size_t total = (size_t)n * ld;
@@ -78,15 +142,42 @@ __global__ void k_copy_matrix(const double* __restrict__ in,
 
 void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
                           int ld, int radius, const double* weights_dev) {
+  launch_gaussian_blur_fused(s, in, out, n, ld, radius, weights_dev, nullptr, nullptr);
+}
+
+int blur_tile_columns(int n) { return (n + TW - 1) / TW; }
+
+// Returns true if the row-max partials were produced (fast path taken).
+bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, int n, int ld,
+                                int radius, const double* weights_dev, const double* diag,
+                                double* rowmax_partials) {
+  dim3 grid((n + TW - 1) / TW, (n + TH - 1) / TH);
+  if (radius == 4 && n >= 2 * TW) {
+    hipLaunchKernelGGL((k_gaussian_blur_r<4>), grid, dim3(256), 0, s, in, out, n, ld,
+                       weights_dev, diag, rowmax_partials);
+    return rowmax_partials != nullptr;
+  }
+  if (radius == 8 && n >= 2 * TW) {
+    hipLaunchKernelGGL((k_gaussian_blur_r<8>), grid, dim3(256), 0, s, in, out, n, ld,
+                       weights_dev, diag, rowmax_partials);
+    return rowmax_partials != nullptr;
+  }
+  // generic path: no fusion (the caller materialises CropDiagonal itself)
   if (radius <= 0) {  // sigma == 0: gaussian_filter degenerates to a copy
     hipLaunchKernelGGL(k_copy_matrix, dim3(2048), dim3(256), 0, s, in, out, n, ld);
-    return;
+    return false;
   }
   const int HW = TW + 2 * radius, HH = TH + 2 * radius;
   const size_t lds = sizeof(double) * ((size_t)HH * HW + (size_t)TH * HW + radius + 1);
-  dim3 grid((n + TW - 1) / TW, (n + TH - 1) / TH);
-  hipLaunchKernelGGL(k_gaussian_blur, grid, dim3(256), lds, s, in, out, n, ld,
-                     radius, weights_dev);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gaussian_blur),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_gaussian_blur, grid, dim3(256), lds, s, in, out, n, ld, radius,
+                     weights_dev);
+  return false;
 }
 
 }  // namespace sc

@@ -119,24 +119,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   const int kt_end = min(ktiles_all, kt_begin + kper);
   double2 ra[4], rb[4];
 
+  // Raw loads only: nothing here may consume the loaded registers, or hipcc waits
+  // for the loads right away and the one-tile-ahead prefetch is lost.  The K-tail
+  // guard is applied when the tile is written to LDS, one iteration later.
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      double2 va = *reinterpret_cast<const double2*>(aptr[q] + k0);
-      double2 vb = *reinterpret_cast<const double2*>(bptr[q] + k0);
-      const int k = k0 + kcol[q];
-      if (k >= K) { va.x = 0.0; vb.x = 0.0; }
-      if (k + 1 >= K) { va.y = 0.0; vb.y = 0.0; }
-      ra[q] = va;
-      rb[q] = vb;
+      ra[q] = *reinterpret_cast<const double2*>(aptr[q] + k0);
+      rb[q] = *reinterpret_cast<const double2*>(bptr[q] + k0);
     }
   };
 
-  auto lds_store = [&](int buf) {
+  auto lds_store = [&](int buf, int kt) {
+    const int k0 = kt * BK;
+    const bool tail = k0 + BK > K;  // wave-uniform: only the last K-tile can be ragged
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       double2 va = ra[q], vb = rb[q];
+      if (tail) {
+        const int k = k0 + kcol[q];
+        if (k >= K) { va.x = 0.0; vb.x = 0.0; }
+        if (k + 1 >= K) { va.y = 0.0; vb.y = 0.0; }
+      }
       if (swap[q]) {
         va = make_double2(va.y, va.x);
         vb = make_double2(vb.y, vb.x);
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
 
   if (kt_begin < kt_end) {
     gload(kt_begin);
-    lds_store(0);
+    lds_store(0, kt_begin);
     if (kt_begin + 1 < kt_end) gload(kt_begin + 1);
   }
   __syncthreads();
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     // stage tile kt+1 into the other buffer, then fetch tile kt+2 into registers;
     // both overlap the MFMAs below (no barrier until the end of the iteration)
     if (kt + 1 < kt_end) {
-      lds_store(cur ^ 1);
+      lds_store(cur ^ 1, kt + 1);
       if (kt + 2 < kt_end) gload(kt + 2);
     }
     const double* Ac = As[cur];

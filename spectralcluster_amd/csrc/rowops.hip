@@ -74,6 +74,103 @@ __global__ __launch_bounds__(kRowThreads) void k_crop_diagonal(
   }
 }
 
+// ---- R1 (fused form): only the cropped diagonal value max(0, max_{j != i} a_ij) ----
+__global__ __launch_bounds__(kRowThreads) void k_crop_value(
+    const double* __restrict__ in, int n, int ld, double* __restrict__ dvec) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = in + (size_t)row * ld;
+  double m = 0.0;
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    const double2 v = *reinterpret_cast<const double2*>(x + j);
+    if (j != row) m = fmax(m, v.x);
+    if (j + 1 < n && j + 1 != row) m = fmax(m, v.y);
+  }
+  m = block_max(m, sm);
+  if (threadIdx.x == 0) dvec[row] = m;
+}
+
+// cut[i] = (max over the per-tile partial row maxima) * p   (refinement.py:188-191)
+__global__ void k_cut_from_partials(const double* __restrict__ partials, int n, int ntiles,
+                                    double p, double* __restrict__ cut) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double m = -INFINITY;
+  for (int t = 0; t < ntiles; ++t) m = fmax(m, partials[(size_t)i * ntiles + t]);
+  cut[i] = m * p;
+}
+__global__ __launch_bounds__(kRowThreads) void k_cut_from_rows(
+    const double* __restrict__ in, int n, int ld, double p, double* __restrict__ cut) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = in + (size_t)row * ld;
+  double m = -INFINITY;
+  for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
+    const double2 v = *reinterpret_cast<const double2*>(x + j);
+    m = fmax(m, v.x);
+    if (j + 1 < n) m = fmax(m, v.y);
+  }
+  m = block_max(m, sm);
+  if (threadIdx.x == 0) cut[row] = m * p;
+}
+
+// ---- R3 + R4 fused: out = sym(thr(B), thr(B)^T) over tile PAIRS ---------------------
+// thr(x; cut_i) = x < cut_i ? x * mult : (binarize ? 1 : x)   (refinement.py:200-207, no
+// preserve_diagonal); sym = max or average (refinement.py:219-226).  One workgroup
+// handles tiles (I, J) and (J, I), I <= J: both are read once, the symmetric result is
+// computed once and written to both places (the mirror through LDS, so both stores are
+// coalesced): 1 read + 1 write of n^2 for the two ops together.
+__global__ __launch_bounds__(256) void k_threshold_symmetrize(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles) {
+  __shared__ double tA[32][33];  // thr(tile (I, J))
+  __shared__ double tB[32][33];  // thr(tile (J, I))
+  int id = blockIdx.x, ti = 0, rowlen = ntiles;
+  while (id >= rowlen) { id -= rowlen; --rowlen; ++ti; }
+  const int tj = ti + id;
+  const int bi = ti * 32, bj = tj * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    {
+      const int gi = bi + r, gj = bj + tx;
+      double v = 0.0;
+      if (gi < n && gj < n) {
+        v = in[(size_t)gi * ld + gj];
+        v = v < cut[gi] ? v * mult : (binarize ? 1.0 : v);
+      }
+      tA[r][tx] = v;
+    }
+    {
+      const int gi = bj + r, gj = bi + tx;
+      double v = 0.0;
+      if (gi < n && gj < n) {
+        v = in[(size_t)gi * ld + gj];
+        v = v < cut[gi] ? v * mult : (binarize ? 1.0 : v);
+      }
+      tB[r][tx] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    {  // tile (I, J): element (r, tx) pairs with tB[tx][r]
+      const int gi = bi + r, gj = bj + tx;
+      if (gi < n && gj < n) {
+        const double a = tA[r][tx], b = tB[tx][r];
+        out[(size_t)gi * ld + gj] = symtype == SC_SYMMETRIZE_MAX ? fmax(a, b) : 0.5 * (a + b);
+      }
+    }
+    if (ti != tj) {  // tile (J, I): element (r, tx) pairs with tA[tx][r]
+      const int gi = bj + r, gj = bi + tx;
+      if (gi < n && gj < n) {
+        const double a = tB[r][tx], b = tA[tx][r];
+        out[(size_t)gi * ld + gj] = symtype == SC_SYMMETRIZE_MAX ? fmax(a, b) : 0.5 * (a + b);
+      }
+    }
+  }
+}
+
 // ---- R3: RowWiseThreshold, RowMax (refinement.py:182-210) --------------------
 __global__ __launch_bounds__(kRowThreads) void k_row_threshold(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
@@ -272,6 +369,24 @@ void launch_row_threshold(hipStream_t s, const double* in, double* out, int n,
                           int preserve_diag) {
   hipLaunchKernelGGL(k_row_threshold, dim3(n), dim3(kRowThreads), 0, s, in, out, n,
                      ld, p, mult, binarize, preserve_diag);
+}
+void launch_crop_value(hipStream_t s, const double* in, int n, int ld, double* dvec) {
+  hipLaunchKernelGGL(k_crop_value, dim3(n), dim3(kRowThreads), 0, s, in, n, ld, dvec);
+}
+void launch_cut_from_partials(hipStream_t s, const double* partials, int n, int ntiles,
+                              double p, double* cut) {
+  hipLaunchKernelGGL(k_cut_from_partials, dim3((n + 255) / 256), dim3(256), 0, s, partials, n,
+                     ntiles, p, cut);
+}
+void launch_cut_from_rows(hipStream_t s, const double* in, int n, int ld, double p,
+                          double* cut) {
+  hipLaunchKernelGGL(k_cut_from_rows, dim3(n), dim3(kRowThreads), 0, s, in, n, ld, p, cut);
+}
+void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
+                                 const double* cut, double mult, int binarize, int symtype) {
+  const int t = (n + 31) / 32;
+  hipLaunchKernelGGL(k_threshold_symmetrize, dim3(t * (t + 1) / 2), dim3(256), 0, s, in, out,
+                     n, ld, cut, mult, binarize, symtype, t);
 }
 void launch_row_normalize(hipStream_t s, const double* in, double* out, int n,
                           int ld) {

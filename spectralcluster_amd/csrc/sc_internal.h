@@ -38,6 +38,18 @@ void launch_crop_diagonal(hipStream_t s, const double* in, double* out, int n,
                           int ld);
 void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
                           int ld, int radius, const double* weights_dev);
+// fused forms used by the predict() pipeline
+bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, int n, int ld,
+                                int radius, const double* weights_dev, const double* diag,
+                                double* rowmax_partials);
+int blur_tile_columns(int n);
+void launch_crop_value(hipStream_t s, const double* in, int n, int ld, double* dvec);
+void launch_cut_from_partials(hipStream_t s, const double* partials, int n, int ntiles,
+                              double p, double* cut);
+void launch_cut_from_rows(hipStream_t s, const double* in, int n, int ld, double p,
+                          double* cut);
+void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
+                                 const double* cut, double mult, int binarize, int symtype);
 void launch_row_threshold(hipStream_t s, const double* in, double* out, int n,
                           int ld, double p, double mult, int binarize,
                           int preserve_diag);

@@ -15,7 +15,9 @@
 namespace sc {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-constexpr int B = kEigBlock;  // 16
+constexpr int B = kEigBlock;     // vectors per block (8)
+constexpr int RB = 256 / B;       // rows a 256-thread workgroup covers in row-parallel kernels
+static_assert(B == 8 || B == 16, "block width must divide the 16-wide MFMA tile");
 
 // ---------------------------------------------------------------- random block
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -82,7 +84,8 @@ __global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
     const int kb = ch * 32 + 8 * lg;
     double b[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) b[t] = (kb + t < n) ? Vs[(size_t)(kb + t) * B + li] : 0.0;
+    for (int t = 0; t < 8; ++t)  // MFMA tile is 16 wide; columns >= B carry zeros
+      b[t] = (kb + t < n && li < B) ? Vs[(size_t)(kb + t) * B + li] : 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double a0 = (kb + 2 * q < n) ? cur[q].x : 0.0;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
 #pragma unroll
       for (int w = 0; w < kMvWaves; ++w) sum += red[w][lane][r];
       const int row = r0 + lg + 4 * r;  // D[row = (l >> 4) + 4 r][col = l & 15]
-      if (row < n)
+      if (row < n && li < B)
         W[(size_t)row * B + li] =
             __builtin_fma(cvec[row], sum, pvec[row] * V[(size_t)row * ldv + li]);
     }
@@ -111,20 +114,22 @@ __global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
 }
 
 // ---------------------------------------------------------------- projections
-// partial[blk][i * 16 + j] = sum over the block's rows of Q[r][i] * W[r][j]
+// partial[blk][i * B + j] = sum over the block's rows of Q[r][i] * W[r][j]
+constexpr int kProjGroups = 256 / B;                          // i-groups per workgroup
+constexpr int kProjAcc = (kLdq + kProjGroups - 1) / kProjGroups;
 __global__ __launch_bounds__(256) void k_proj_partial(
     const double* __restrict__ Q, int ldq, int m, const double* __restrict__ W,
     int n, double* __restrict__ partial) {
   __shared__ double Ql[8][kLdq];
   __shared__ double Wl[8][B];
   const int tid = threadIdx.x;
-  const int jj = tid & 15, ig = tid >> 4;
+  const int jj = tid % B, ig = tid / B;
   const int rows_per = (n + gridDim.x - 1) / gridDim.x;
   const int rbeg = blockIdx.x * rows_per;
   const int rend = min(n, rbeg + rows_per);
-  double acc[kLdq / 16];
+  double acc[kProjAcc];
 #pragma unroll
-  for (int q = 0; q < kLdq / 16; ++q) acc[q] = 0.0;
+  for (int q = 0; q < kProjAcc; ++q) acc[q] = 0.0;
   for (int r = rbeg; r < rend; r += 8) {
     __syncthreads();
     for (int e = tid; e < 8 * m; e += 256) {
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void k_proj_partial(
       Ql[rr][i] = (r + rr < rend) ? Q[(size_t)(r + rr) * ldq + i] : 0.0;
     }
     if (tid < 8 * B) {
-      const int rr = tid >> 4;
+      const int rr = tid / B;
       Wl[rr][jj] = (r + rr < rend) ? W[(size_t)(r + rr) * B + jj] : 0.0;
     }
     __syncthreads();
@@ -140,14 +145,15 @@ __global__ __launch_bounds__(256) void k_proj_partial(
     for (int rr = 0; rr < 8; ++rr) {
       const double w = Wl[rr][jj];
 #pragma unroll
-      for (int q = 0; q < kLdq / 16; ++q)
-        if (ig + 16 * q < m) acc[q] = __builtin_fma(Ql[rr][ig + 16 * q], w, acc[q]);
+      for (int q = 0; q < kProjAcc; ++q)
+        if (ig + kProjGroups * q < m)
+          acc[q] = __builtin_fma(Ql[rr][ig + kProjGroups * q], w, acc[q]);
     }
   }
   double* out = partial + (size_t)blockIdx.x * (kLdq * B);
 #pragma unroll
-  for (int q = 0; q < kLdq / 16; ++q)
-    if (ig + 16 * q < m) out[(ig + 16 * q) * B + jj] = acc[q];
+  for (int q = 0; q < kProjAcc; ++q)
+    if (ig + kProjGroups * q < m) out[(ig + kProjGroups * q) * B + jj] = acc[q];
 }
 
 // H = sum of partials (m x 16), stored to Hbuf; optionally accumulated into
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void k_reduce_H(
     for (int g = 0; g < nparts; ++g) h += partial[(size_t)g * (kLdq * B) + e];
     Hbuf[e] = h;
     if (T != nullptr) {
-      const int i = e >> 4, j = col0 + (e & 15);
+      const int i = e / B, j = col0 + (e % B);
       if (i <= j) {
         const double v = accumulate ? T[(size_t)i * ldt + j] + h : h;
         T[(size_t)i * ldt + j] = v;
@@ -176,24 +182,24 @@ __global__ __launch_bounds__(256) void k_reduce_H(
   }
   sq[tid] = h * h;
   __syncthreads();
-  if (tid < B) {  // thread tid owns column tid & 15 in every stride
+  if (tid < B) {  // entry e = 256 * block + tid has column e % B == tid % B
     double s = 0.0;
     for (int q = tid; q < 256; q += B) s += sq[q];
     atomicAdd(&hsq[tid], s);
   }
 }
 
-// W[r, :] -= Q[r, 0:m] * H   (H = Hbuf, m x 16)
+// W[r, :] -= Q[r, 0:m] * H   (H = Hbuf, m x B); RB rows per workgroup
 __global__ __launch_bounds__(256) void k_update_block(
     const double* __restrict__ Q, int ldq, int m, const double* __restrict__ Hbuf,
     double* __restrict__ W, int n) {
   __shared__ double Hl[kLdq * B];
-  __shared__ double Ql[16][kLdq + 1];
+  __shared__ double Ql[RB][kLdq + 1];
   const int tid = threadIdx.x;
-  const int jj = tid & 15, rr = tid >> 4;
-  const int r0 = blockIdx.x * 16;
+  const int jj = tid % B, rr = tid / B;
+  const int r0 = blockIdx.x * RB;
   for (int e = tid; e < m * B; e += 256) Hl[e] = Hbuf[e];
-  for (int e = tid; e < 16 * m; e += 256) {
+  for (int e = tid; e < RB * m; e += 256) {
     const int a = e / m, i = e - a * m;
     Ql[a][i] = (r0 + a < n) ? Q[(size_t)(r0 + a) * ldq + i] : 0.0;
   }
@@ -221,8 +227,9 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
   __shared__ double piv[B];
   __shared__ int s_mask;
   const int tid = threadIdx.x;
-  const int ra = tid >> 4, cb = tid & 15;
-  {
+  const bool active = tid < B * B;
+  const int ra = active ? tid / B : 0, cb = active ? tid % B : 0;
+  if (active) {
     double g = 0.0;
     for (int q = 0; q < nparts; ++q) g += partial[(size_t)q * (kLdq * B) + tid];
     G[ra][cb] = g;
@@ -230,8 +237,8 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
     R[ra][cb] = 0.0;
     Ri[ra][cb] = 0.0;
     if (ra == cb) gdiag[ra] = g;
-    if (tid == 0) s_mask = 0;
   }
+  if (tid == 0) s_mask = 0;
   __syncthreads();
   for (int j = 0; j < B; ++j) {
     if (tid == 0) {
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
       R[j][tid] = v;
     }
     __syncthreads();
-    if (ra > j && cb > j) G[ra][cb] -= R[j][ra] * R[j][cb];
+    if (active && ra > j && cb > j) G[ra][cb] -= R[j][ra] * R[j][cb];
     __syncthreads();
   }
   // R^-1 by back substitution, one column per thread (dropped columns stay zero)
@@ -269,21 +276,21 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
     }
   }
   __syncthreads();
-  Rinv[tid] = Ri[ra][cb];
+  if (active) Rinv[tid] = Ri[ra][cb];
   if (tid == 0) flags[0] = s_mask;
 }
 
-// W <- W * Rinv; optional copies: Qdst[:, col0 + j] and Vs = c .* W
+// W <- W * Rinv; optional copies: Qdst[:, col0 + j] and Vs = c .* W; RB rows/workgroup
 __global__ __launch_bounds__(256) void k_apply_rinv(
     double* __restrict__ W, int n, const double* __restrict__ Rinv,
     double* __restrict__ Qdst, int ldq, int col0, const double* __restrict__ cvec,
     double* __restrict__ Vs) {
   __shared__ double Rl[B * B];
   const int tid = threadIdx.x;
-  Rl[tid] = Rinv[tid];
+  if (tid < B * B) Rl[tid] = Rinv[tid];
   __syncthreads();
-  const int jj = tid & 15;
-  const int r = blockIdx.x * 16 + (tid >> 4);
+  const int jj = tid % B;
+  const int r = blockIdx.x * RB + tid / B;
   const double w = r < n ? W[(size_t)r * B + jj] : 0.0;
   double v = 0.0;
 #pragma unroll
@@ -298,20 +305,40 @@ __global__ __launch_bounds__(256) void k_apply_rinv(
   }
 }
 
+// fp64 reciprocal / reciprocal-sqrt from the hardware seeds (v_rcp_f64 / v_rsq_f64)
+// plus two Newton steps each: ~1 ulp, a few dozen cycles instead of the ~250-cycle
+// correctly-rounded sequences -- the rotation parameters are the serial part of
+// every Jacobi round.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = __builtin_fma(y, 0.5 * __builtin_fma(-x * y, y, 1.0), y);
+  y = __builtin_fma(y, 0.5 * __builtin_fma(-x * y, y, 1.0), y);
+  return y;
+}
+
 // ---------------------------------------------------------------- dense Jacobi
 // One workgroup, matrix A (mp x mp, mp = m rounded up to even) in LDS with row
 // stride mp + 1; eigenvector accumulator kept TRANSPOSED in global memory
-// (Yt[p][i] = component i of vector p) so that the rotation of two vectors is
+// (Yt(p)[i] = component i of vector p) so that the rotation of two vectors is
 // two coalesced row updates.  Round-robin ordering: mp/2 disjoint rotations per
 // round, mp - 1 rounds per sweep.
 // mode 0: A = src (m x m).   mode 1: A_ij = c_i c_j src_ij + delta_ij p_i.
+template <bool YT_LDS>
 __global__ __launch_bounds__(1024) void k_jacobi(
     const double* __restrict__ src, int ldsrc, int m, int mode,
     const double* __restrict__ cvec, const double* __restrict__ pvec,
     const double* __restrict__ G, double* __restrict__ theta,
     double* __restrict__ Y, int ldy, double* __restrict__ resid,
-    double* __restrict__ Yt_global, int yt_in_lds) {
+    double* __restrict__ Yt_global, int* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  const long long t_begin = wall_clock64();
+  const long long c_begin = clock64();
   const int mp = (m + 1) & ~1;
   const int lda = mp + 1;
   double* A = smem;                       // mp * lda
@@ -319,8 +346,11 @@ __global__ __launch_bounds__(1024) void k_jacobi(
   double* sn = cs + mp / 2;               // mp/2
   int* pp = reinterpret_cast<int*>(sn + mp / 2);  // mp/2
   int* qq = pp + mp / 2;                  // mp/2
-  // vector accumulator: LDS when it fits beside A (m <= 96), else global (L2)
-  double* Yt = yt_in_lds ? (sn + mp / 2 + mp / 2 + 2) : Yt_global;
+  // vector accumulator: LDS when it fits beside A (m <= 96), else global (L2).  The
+  // choice is a template parameter: a runtime select would make every access a slow
+  // generic (flat) one.
+  double* Yl = sn + mp / 2 + mp / 2 + 2;
+#define Yt(idx) (*(YT_LDS ? &Yl[idx] : &Yt_global[idx]))
   __shared__ int s_rot;
   const int tid = threadIdx.x;
   const int nth = blockDim.x;
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(1024) void k_jacobi(
       }
     }
     A[i * lda + j] = v;
-    Yt[(size_t)i * mp + j] = (i == j) ? 1.0 : 0.0;
+    Yt((size_t)i * mp + j) = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
   if (mode == 1) {  // enforce exact symmetry of the materialised operator
@@ -352,10 +382,14 @@ __global__ __launch_bounds__(1024) void k_jacobi(
   }
 
   const int half = mp / 2;
+  int sweeps_done = 0;
+  long long cyc_param = 0, cyc_bar1 = 0, cyc_upd = 0, cyc_bar2 = 0;
   for (int sweep = 0; sweep < 40; ++sweep) {
+    ++sweeps_done;
     if (tid == 0) s_rot = 0;
     __syncthreads();
     for (int round = 0; round < mp - 1; ++round) {
+      const long long tr0 = clock64();
       // --- rotation parameters of the mp/2 disjoint pairs of this round.  Pair k is
       //     (p, q) = (round + k, round - k) mod (mp - 1) (k = 0: (mp - 1, round)); p
       //     and q are NOT sorted so that consecutive lanes touch consecutive columns.
@@ -373,56 +407,103 @@ __global__ __launch_bounds__(1024) void k_jacobi(
         const double app = A[p * lda + p], aqq = A[q * lda + q];
         const double apq = A[p * lda + q];
         double c = 1.0, s = 0.0;
-        const double scale = sqrt(fabs(app) * fabs(aqq));
-        if (fabs(apq) > 1e-18 * scale && fabs(apq) > 1e-300) {
+        const double apq2 = apq * apq;
+        const double dd = fabs(app) * fabs(aqq);
+        // rotate iff |apq| > 1e-18 sqrt(|app aqq|)   (compared squared: no sqrt)
+        if (apq2 > 1e-36 * dd && fabs(apq) > 1e-300) {
           // t = tan(angle): smaller root of t^2 + 2 theta t - 1 = 0, theta =
           // (aqq - app) / (2 apq), written without forming theta
           const double al = 0.5 * (aqq - app);
-          const double t = apq / (al + copysign(sqrt(al * al + apq * apq), al));
-          c = rsqrt(t * t + 1.0);
+          const double h2 = __builtin_fma(al, al, apq2);
+          double hh = h2 * fast_rsqrt(h2);                       // sqrt(al^2 + apq^2)
+          hh = __builtin_fma(__builtin_fma(-hh, hh, h2), 0.5 * fast_rcp(hh), hh);
+          const double den = al + copysign(hh, al);
+          const double rd = fast_rcp(den);
+          double t = apq * rd;
+          t = __builtin_fma(__builtin_fma(-den, t, apq), rd, t);
+          c = fast_rsqrt(__builtin_fma(t, t, 1.0));
           s = t * c;
-          if (s != 0.0 && fabs(apq) > 1e-9 * scale) atomicAdd(&s_rot, 1);
+          if (s != 0.0 && apq2 > 1e-18 * dd) atomicAdd(&s_rot, 1);  // still "large"
         }
         cs[tid] = c;
         sn[tid] = s;
         pp[tid] = p;
         qq[tid] = q;
       }
+      const long long tr1 = clock64();
       __syncthreads();
+      const long long tr2 = clock64();
       // --- A <- J^T A J: each thread owns whole 2x2 blocks (pair k1 rows, pair k2
       //     columns): reads its 4 entries, writes its 4 entries, no other thread
       //     touches them, so one phase suffices.
-      for (int e = tid; e < half * half; e += nth) {
-        const int k1 = e / half, k2 = e - k1 * half;
-        const double c1 = cs[k1], s1 = sn[k1], c2 = cs[k2], s2 = sn[k2];
-        if (s1 == 0.0 && s2 == 0.0) continue;
-        const int p1 = pp[k1], q1 = qq[k1], p2 = pp[k2], q2 = qq[k2];
-        const double app = A[p1 * lda + p2], apq = A[p1 * lda + q2];
-        const double aqp = A[q1 * lda + p2], aqq = A[q1 * lda + q2];
-        // rows: J1^T
-        const double tpp = c1 * app - s1 * aqp, tpq = c1 * apq - s1 * aqq;
-        const double tqp = s1 * app + c1 * aqp, tqq = s1 * apq + c1 * aqq;
-        // columns: J2
-        double npp = c2 * tpp - s2 * tpq, npq = s2 * tpp + c2 * tpq;
-        double nqp = c2 * tqp - s2 * tqq, nqq = s2 * tqp + c2 * tqq;
-        if (k1 == k2) { npq = 0.0; nqp = 0.0; }  // the annihilated pair, exactly
-        A[p1 * lda + p2] = npp;
-        A[p1 * lda + q2] = npq;
-        A[q1 * lda + p2] = nqp;
-        A[q1 * lda + q2] = nqq;
-      }
-      // --- vectors: rows p, q of Yt
-      for (int e = tid; e < mp * half; e += nth) {
-        const int k = e / mp, i = e - k * mp;
-        const double c = cs[k], s = sn[k];
-        if (s != 0.0) {
-          const int p = pp[k], q = qq[k];
-          const double yp = Yt[(size_t)p * mp + i], yq = Yt[(size_t)q * mp + i];
-          Yt[(size_t)p * mp + i] = c * yp - s * yq;
-          Yt[(size_t)q * mp + i] = s * yp + c * yq;
+      {
+        const int lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
+        // --- vector part first: issue the loads of this thread's Yt items (rows p, q of
+        //     up to kYtMax pairs) so their LDS latency overlaps the A update below
+        // (static unroll 4 pairs x 2 lane steps covers mp <= 128 with the launcher's
+        //  wave count; indices must be compile-time or the arrays land in scratch)
+        double yp[8], yq[8];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = wave + kk * nwaves;
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = lane + 64 * ii;
+            if (k < half && i < mp) {
+              yp[kk * 2 + ii] = Yt((size_t)pp[k] * mp + i);
+              yq[kk * 2 + ii] = Yt((size_t)qq[k] * mp + i);
+            }
+          }
+        }
+        // --- A <- J^T A J over 2x2 blocks; two pair-rows per wave when half <= 32
+        const int rows_per_wave = half <= 32 ? 2 : 1;
+        const int sub = rows_per_wave == 2 ? lane >> 5 : 0;
+        const int l2 = rows_per_wave == 2 ? lane & 31 : lane;
+        const int lstep = rows_per_wave == 2 ? 32 : 64;
+        for (int k1 = wave * rows_per_wave + sub; k1 < half; k1 += nwaves * rows_per_wave) {
+          const double c1 = cs[k1], s1 = sn[k1];
+          const int p1 = pp[k1], q1 = qq[k1];
+          for (int k2 = l2; k2 < half; k2 += lstep) {
+            const double c2 = cs[k2], s2 = sn[k2];
+            if (s1 == 0.0 && s2 == 0.0) continue;
+            const int p2 = pp[k2], q2 = qq[k2];
+            const double app = A[p1 * lda + p2], apq = A[p1 * lda + q2];
+            const double aqp = A[q1 * lda + p2], aqq = A[q1 * lda + q2];
+            // rows: J1^T
+            const double tpp = c1 * app - s1 * aqp, tpq = c1 * apq - s1 * aqq;
+            const double tqp = s1 * app + c1 * aqp, tqq = s1 * apq + c1 * aqq;
+            // columns: J2
+            double npp = c2 * tpp - s2 * tpq, npq = s2 * tpp + c2 * tpq;
+            double nqp = c2 * tqp - s2 * tqq, nqq = s2 * tqp + c2 * tqq;
+            if (k1 == k2) { npq = 0.0; nqp = 0.0; }  // the annihilated pair, exactly
+            A[p1 * lda + p2] = npp;
+            A[p1 * lda + q2] = npq;
+            A[q1 * lda + p2] = nqp;
+            A[q1 * lda + q2] = nqq;
+          }
+        }
+        // --- finish the vectors
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = wave + kk * nwaves;
+          if (k < half) {
+            const double c = cs[k], s = sn[k];
+            const int p = pp[k], q = qq[k];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+              const int i = lane + 64 * ii;
+              if (i < mp && s != 0.0) {
+                const double a = yp[kk * 2 + ii], b = yq[kk * 2 + ii];
+                Yt((size_t)p * mp + i) = c * a - s * b;
+                Yt((size_t)q * mp + i) = s * a + c * b;
+              }
+            }
+          }
         }
       }
+      const long long tr3 = clock64();
       __syncthreads();
+      if (tid == 0) { cyc_param += tr1 - tr0; cyc_bar1 += tr2 - tr1; cyc_upd += tr3 - tr2; cyc_bar2 += clock64() - tr3; }
     }
     // s_rot counts rotations that were still "large" (|apq| > 1e-9 sqrt(app aqq)).
     // A sweep made only of small rotations leaves off-diagonals ~1e-18 relative
@@ -431,6 +512,13 @@ __global__ __launch_bounds__(1024) void k_jacobi(
     __syncthreads();
   }
 
+  if (tid == 0 && dbg != nullptr) {
+    dbg[1] = sweeps_done;
+    dbg[2] = (int)(wall_clock64() - t_begin);  // 10 ns ticks
+    dbg[3] = (int)((clock64() - c_begin) >> 10);  // shader cycles / 1024
+    dbg[4] = (int)(cyc_param >> 10); dbg[5] = (int)(cyc_bar1 >> 10);
+    dbg[6] = (int)(cyc_upd >> 10); dbg[7] = (int)(cyc_bar2 >> 10);
+  }
   // --- sort descending, emit theta, Y (columns) and residual estimates
   for (int i = tid; i < m; i += nth) {
     const double di = A[i * lda + i];
@@ -445,19 +533,21 @@ __global__ __launch_bounds__(1024) void k_jacobi(
       double r2 = 0.0;
       if (G) {
         for (int a = 0; a < B; ++a) {
-          const double ya = Yt[(size_t)i * mp + (m - B + a)];
+          const double ya = Yt((size_t)i * mp + (m - B + a));
           double t = 0.0;
           for (int b2 = 0; b2 < B; ++b2)
-            t = __builtin_fma(G[a * B + b2], Yt[(size_t)i * mp + (m - B + b2)], t);
+            t = __builtin_fma(G[a * B + b2], Yt((size_t)i * mp + (m - B + b2)), t);
           r2 = __builtin_fma(ya, t, r2);
         }
       }
       resid[rank] = sqrt(fmax(r2, 0.0));
     }
     // column `rank` of Y = vector i
-    for (int r = 0; r < m; ++r) Y[(size_t)r * ldy + rank] = Yt[(size_t)i * mp + r];
+    for (int r = 0; r < m; ++r) Y[(size_t)r * ldy + rank] = Yt((size_t)i * mp + r);
   }
 }
+
+#undef Yt
 
 __global__ void k_set_diag_T(double* T, int ldt, int mtot, const double* theta,
                              int keep) {
@@ -496,6 +586,22 @@ __global__ __launch_bounds__(256) void k_basis_times_Y(
       dst[(size_t)j * lddst + r] = acc;  // one vector = one contiguous column
     else
       dst[(size_t)r * lddst + j] = acc;
+  }
+}
+
+// swap Ritz pairs a <-> b (columns of Y, entries of theta): lets a thick restart keep
+// the far end of the spectrum (needed by the NormalizedDiff eigengap when ascending)
+__global__ void k_swap_ritz(double* Y, int ldy, int m, double* theta, int a, int b) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < m) {
+    const double t = Y[(size_t)r * ldy + a];
+    Y[(size_t)r * ldy + a] = Y[(size_t)r * ldy + b];
+    Y[(size_t)r * ldy + b] = t;
+  }
+  if (r == 0) {
+    const double t = theta[a];
+    theta[a] = theta[b];
+    theta[b] = t;
   }
 }
 
@@ -546,6 +652,8 @@ __global__ void k_colmajor_to_rowmajor(const double* __restrict__ src, int lds, 
 }
 
 // ---------------------------------------------------------------- launchers
+// number of partial-sum workgroups for the tall-skinny products: ~64 rows each
+int proj_blocks(int n) { return std::max(1, std::min(kProjBlocks, (n + 63) / 64)); }
 void launch_random_block(hipStream_t s, double* W, int n, uint64_t seed) {
   hipLaunchKernelGGL(k_random_block, dim3((n * B + 255) / 256), dim3(256), 0, s, W, n,
                      seed);
@@ -563,33 +671,33 @@ void launch_block_matvec(hipStream_t s, const double* S, int ld, int n,
 }
 void launch_proj_partial(hipStream_t s, const double* Q, int ldq, int m,
                          const double* W, int n, double* partial) {
-  hipLaunchKernelGGL(k_proj_partial, dim3(kProjBlocks), dim3(256), 0, s, Q, ldq, m, W,
+  hipLaunchKernelGGL(k_proj_partial, dim3(proj_blocks(n)), dim3(256), 0, s, Q, ldq, m, W,
                      n, partial);
 }
-void launch_reduce_H(hipStream_t s, const double* partial, int m, double* Hbuf,
+void launch_reduce_H(hipStream_t s, const double* partial, int nparts, int m, double* Hbuf,
                      double* T, int ldt, int col0, int accumulate, double* hsq) {
   hipLaunchKernelGGL(k_reduce_H, dim3((m * B + 255) / 256), dim3(256), 0, s, partial,
-                     kProjBlocks, m, Hbuf, T, ldt, col0, accumulate, hsq);
+                     nparts, m, Hbuf, T, ldt, col0, accumulate, hsq);
 }
 void launch_update_block(hipStream_t s, const double* Q, int ldq, int m,
                          const double* Hbuf, double* W, int n) {
-  hipLaunchKernelGGL(k_update_block, dim3((n + 15) / 16), dim3(256), 0, s, Q, ldq, m,
+  hipLaunchKernelGGL(k_update_block, dim3((n + RB - 1) / RB), dim3(256), 0, s, Q, ldq, m,
                      Hbuf, W, n);
 }
-void launch_reduce_chol(hipStream_t s, const double* partial, double* Rinv,
+void launch_reduce_chol(hipStream_t s, const double* partial, int nparts, double* Rinv,
                         double* Gsave, const double* hsq, int* flags) {
-  hipLaunchKernelGGL(k_reduce_chol, dim3(1), dim3(256), 0, s, partial, kProjBlocks,
+  hipLaunchKernelGGL(k_reduce_chol, dim3(1), dim3(256), 0, s, partial, nparts,
                      Rinv, Gsave, hsq, flags);
 }
 void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
                        double* Qdst, int ldq, int col0, const double* cvec,
                        double* Vs) {
-  hipLaunchKernelGGL(k_apply_rinv, dim3((n + 15) / 16), dim3(256), 0, s, W, n, Rinv,
+  hipLaunchKernelGGL(k_apply_rinv, dim3((n + RB - 1) / RB), dim3(256), 0, s, W, n, Rinv,
                      Qdst, ldq, col0, cvec, Vs);
 }
 void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
                    const double* cvec, const double* pvec, const double* G,
-                   double* theta, double* Y, int ldy, double* resid, double* Yt) {
+                   double* theta, double* Y, int ldy, double* resid, double* Yt, int* dbg) {
   const int mp = (m + 1) & ~1;
   const size_t base = sizeof(double) * ((size_t)mp * (mp + 1) + 2 * mp + 2) + 64;
   const size_t with_yt = base + sizeof(double) * (size_t)mp * mp;
@@ -597,14 +705,20 @@ void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
   const size_t lds = yt_in_lds ? with_yt : base;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_set = true;
   }
   int threads = ((mp / 2) * (mp / 2) + 63) / 64 * 64;
   threads = std::max(256, std::min(1024, threads));
-  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(threads), lds, s, src, ldsrc, m, mode, cvec,
-                     pvec, G, theta, Y, ldy, resid, Yt, yt_in_lds);
+  if (yt_in_lds)
+    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(threads), lds, s, src, ldsrc, m, mode,
+                       cvec, pvec, G, theta, Y, ldy, resid, Yt, dbg);
+  else
+    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(threads), lds, s, src, ldsrc, m, mode,
+                       cvec, pvec, G, theta, Y, ldy, resid, Yt, dbg);
 }
 void launch_set_diag_T(hipStream_t s, double* T, int ldt, int mtot,
                        const double* theta, int keep) {
@@ -623,6 +737,9 @@ void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
   }
   hipLaunchKernelGGL(k_basis_times_Y, dim3((n + 15) / 16), dim3(256), lds, s, Q, ldq,
                      m, Y, ldy, cols, dst, lddst, n, colmajor);
+}
+void launch_swap_ritz(hipStream_t s, double* Y, int ldy, int m, double* theta, int a, int b) {
+  hipLaunchKernelGGL(k_swap_ritz, dim3((m + 255) / 256), dim3(256), 0, s, Y, ldy, m, theta, a, b);
 }
 void launch_copy_block(hipStream_t s, const double* src, int ldsrc, double* dst,
                        int lddst, int n, int cols) {

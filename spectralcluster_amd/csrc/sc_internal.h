@@ -12,7 +12,7 @@
 namespace sc {
 
 constexpr int kWave = 64;
-constexpr int kEigBlock = 16;        // vectors per operator pass (one MFMA tile)
+constexpr int kEigBlock = 8;         // Lanczos block width (half an MFMA tile column)
 constexpr int kEigBasisCap = 128;    // Rayleigh-Ritz size limit (LDS Jacobi)
 constexpr int kLdq = kEigBasisCap + kEigBlock;  // row stride of the Krylov basis
 constexpr int kDenseMax = 128;       // n <= this: direct dense Jacobi
@@ -97,12 +97,13 @@ void launch_proj_partial(hipStream_t s, const double* Q, int ldq, int m,
                          const double* W, int n, double* partial);
 // H = sum of partials (m x 16) -> Hbuf; if T != nullptr also (accumulated) into
 // T[0:m, col0:col0+16] and mirrored; hsq[j] (+)= sum_i H_ij^2.
-void launch_reduce_H(hipStream_t s, const double* partial, int m, double* Hbuf,
+int proj_blocks(int n);
+void launch_reduce_H(hipStream_t s, const double* partial, int nparts, int m, double* Hbuf,
                      double* T, int ldt, int col0, int accumulate, double* hsq);
 void launch_update_block(hipStream_t s, const double* Q, int ldq, int m,
                          const double* Hbuf, double* W, int n);
 // Gram reduce + Cholesky: Rinv (16x16 upper), optional copy of G, flags mask.
-void launch_reduce_chol(hipStream_t s, const double* partial, double* Rinv,
+void launch_reduce_chol(hipStream_t s, const double* partial, int nparts, double* Rinv,
                         double* Gsave, const double* hsq, int* flags);
 // W <- W * Rinv ; optionally also store into Q[:, col0:col0+16] and Vs = c .* W
 void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
@@ -114,13 +115,15 @@ void launch_refill_deficient(hipStream_t s, double* W, int n, const int* flags,
 // mode 0: A = T (m x m, ldt).  mode 1: A_ij = c_i c_j S_ij + delta_ij p_i.
 void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
                    const double* cvec, const double* pvec, const double* G,
-                   double* theta, double* Y, int ldy, double* resid, double* Yt);
+                   double* theta, double* Y, int ldy, double* resid, double* Yt,
+                   int* dbg);
 void launch_set_diag_T(hipStream_t s, double* T, int ldt, int mtot,
                        const double* theta, int keep);
 // dst[:, 0:cols] = Q[:, 0:m] * Y[0:m, 0:cols]
 void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
                           const double* Y, int ldy, int cols, double* dst,
                           int lddst, int n, int colmajor);
+void launch_swap_ritz(hipStream_t s, double* Y, int ldy, int m, double* theta, int a, int b);
 void launch_copy_block(hipStream_t s, const double* src, int ldsrc, double* dst,
                        int lddst, int n, int cols);
 // Eigenvectors live COLUMN-major on the device: ET[j * ld + r].

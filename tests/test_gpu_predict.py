@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 LAP = {0: None, 1: sca.LaplacianType.Affinity, 2: sca.LaplacianType.Unnormalized,
        3: sca.LaplacianType.RandomWalk, 4: sca.LaplacianType.GraphCut}
-EIG_RTOL = 1e-7   # north_star allows 1e-5
+EIG_RTOL = 1e-6   # north_star allows 1e-5; the solver stops at a residual bound of 1e-6
 
 TOY = np.array([[1.0, 0.0], [1.1, 0.1], [0.0, 1.0], [0.1, 1.0], [0.9, -0.1],
                 [0.0, 1.2]])
@@ -297,4 +297,47 @@ def test_plugin_points():
                               affinity_function=my_affinity,
                               post_eigen_cluster_function=my_tail).predict(x)
   assert called["a"] and called["t"][0] == 200
+  assert so.adjusted_rand_index(got, want) == 1.0
+
+
+# --- randomised sweep: many small problems, every Laplacian / eigengap / option mix ---------
+def _fuzz_cases():
+  rng = np.random.default_rng(2024)
+  cases = []
+  for i in range(36):
+    n = int(rng.integers(129, 700))
+    d = int(rng.integers(4, 48))
+    k = int(rng.integers(2, 7))
+    lap = int(rng.choice([0, 1, 2, 3, 4]))
+    gap = str(rng.choice(["Ratio", "NormalizedDiff"]))
+    noise = float(rng.choice([0.2, 0.4, 0.7]))
+    p = float(rng.choice([0.95, 0.8, 0.5]))
+    sigma = float(rng.choice([1, 1, 2, 0]))
+    maxc = int(rng.choice([7, 12, 20]))
+    cases.append((i, n, d, k, lap, gap, noise, p, sigma, maxc))
+  return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "fuzz%d" % c[0])
+def test_fuzz_predict_vs_oracle(case):
+  i, n, d, k, lap, gap, noise, p, sigma, maxc = case
+  x = so.blobs(n, d, k, seed=1000 + i, noise=noise)
+  cfg = so.icassp2018_config(
+      laplacian_type=lap, max_clusters=maxc, p_percentile=p, gaussian_blur_sigma=sigma,
+      eigengap_type=so.EIGENGAP_RATIO if gap == "Ratio" else so.EIGENGAP_NORMALIZED_DIFF)
+  dump = {}
+  want = so.predict(x, cfg, dump)
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=maxc, refinement_options=icassp_options(sigma, p),
+      laplacian_type=LAP[lap], eigengap_type=getattr(sca.EigenGapType, gap))
+  got = clusterer.predict(x)
+  diag = clusterer.last_diag
+  assert diag.n_clusters_raw == dump["n_clusters"] or dump["n_clusters"] == 2
+  idx = so.consumed_eigen_indices(n, maxc, lap in (0, 1), dump["eigenvalues"], 1e-2)
+  w = diag.eigenvalue_array()
+  assert rel_err(w[idx], dump["eigenvalues"][idx]) < 1e-5   # north-star bar
+  # NormalizedDiff on the ascending branch divides by np.max(eigenvalues), the far edge
+  # of a dense bulk: the solver accepts a 1e-4 residual bound there
+  loose = gap == "NormalizedDiff" and lap not in (0, 1)
+  np.testing.assert_allclose(diag.max_delta, dump["max_delta"], rtol=2e-4 if loose else 1e-5)
   assert so.adjusted_rand_index(got, want) == 1.0

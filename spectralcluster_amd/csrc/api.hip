@@ -464,11 +464,15 @@ static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double
       launch_gaussian_blur(s, in, out, n, ld, cfg->blur_radius, ptr<double>(h->blurw));
       break;
     case SC_OP_ROW_WISE_THRESHOLD:
-      if (cfg->threshold_type == SC_THRESHOLD_PERCENTILE)
-        return fail(h, SC_ERR_UNSUPPORTED,
-                    "ThresholdType.Percentile is not implemented on the device path yet");
-      launch_row_threshold(s, in, out, n, ld, cfg->p_percentile, cfg->soft_multiplier,
-                           cfg->binarize, cfg->preserve_diagonal);
+      if (cfg->threshold_type == SC_THRESHOLD_PERCENTILE) {
+        launch_cut_percentile(s, in, n, ld, cfg->p_percentile, ptr<double>(h->cut),
+                              cfg->preserve_diagonal);
+        launch_row_threshold_cut(s, in, out, n, ld, ptr<double>(h->cut), cfg->soft_multiplier,
+                                 cfg->binarize, cfg->preserve_diagonal);
+      } else {
+        launch_row_threshold(s, in, out, n, ld, cfg->p_percentile, cfg->soft_multiplier,
+                             cfg->binarize, cfg->preserve_diagonal);
+      }
       break;
     case SC_OP_SYMMETRIZE:
       launch_symmetrize(s, in, out, n, ld, cfg->symmetrize_type);
@@ -889,7 +893,8 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
     const int op = cfg->ops[i];
     const int next = i + 1 < cfg->n_ops ? cfg->ops[i + 1] : 0;
     const int next2 = i + 2 < cfg->n_ops ? cfg->ops[i + 2] : 0;
-    const bool thr_sym_fusable = cfg->threshold_type == SC_THRESHOLD_ROW_MAX &&
+    const bool thr_sym_fusable = true;  // RowMax or Percentile, with or without diagonal
+    const bool partials_usable = cfg->threshold_type == SC_THRESHOLD_ROW_MAX &&
                                  !cfg->preserve_diagonal;
     if (op == SC_OP_ROW_WISE_NORMALIZE && symmetric && i == cfg->n_ops - 1) {
       folded_rownorm = true;  // W = diag(1/rowmax) S is never materialised
@@ -907,7 +912,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
     if (op == SC_OP_DIFFUSE) ev_rec(h, &e0);
     if (op == SC_OP_GAUSSIAN_BLUR && blur_fast) {
       const bool want = next == SC_OP_ROW_WISE_THRESHOLD && next2 == SC_OP_SYMMETRIZE &&
-                        thr_sym_fusable;
+                        partials_usable;
       SC_HIP(h, hipMemcpyAsync(h->blurw.p, cfg->blur_weights,
                                (2 * cfg->blur_radius + 1) * sizeof(double),
                                hipMemcpyHostToDevice, s));
@@ -917,13 +922,18 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
       pending_diag = nullptr;
       SC_TRY(check_last(h, "blur launch"));
     } else if (op == SC_OP_ROW_WISE_THRESHOLD && next == SC_OP_SYMMETRIZE && thr_sym_fusable) {
-      if (have_partials)
+      if (cfg->threshold_type == SC_THRESHOLD_PERCENTILE)
+        launch_cut_percentile(s, cur, n, ld, cfg->p_percentile, ptr<double>(h->cut),
+                              cfg->preserve_diagonal);
+      else if (have_partials && partials_usable)
         launch_cut_from_partials(s, ptr<double>(h->rmpart), n, blur_tile_columns(n),
                                  cfg->p_percentile, ptr<double>(h->cut));
       else
-        launch_cut_from_rows(s, cur, n, ld, cfg->p_percentile, ptr<double>(h->cut));
+        launch_cut_from_rows(s, cur, n, ld, cfg->p_percentile, ptr<double>(h->cut),
+                             cfg->preserve_diagonal);
       launch_threshold_symmetrize(s, cur, out, n, ld, ptr<double>(h->cut),
-                                  cfg->soft_multiplier, cfg->binarize, cfg->symmetrize_type);
+                                  cfg->soft_multiplier, cfg->binarize, cfg->symmetrize_type,
+                                  cfg->preserve_diagonal);
       SC_TRY(check_last(h, "threshold+symmetrize launch"));
       have_partials = false;
       cur = out;

@@ -100,18 +100,137 @@ __global__ void k_cut_from_partials(const double* __restrict__ partials, int n, 
   cut[i] = m * p;
 }
 __global__ __launch_bounds__(kRowThreads) void k_cut_from_rows(
-    const double* __restrict__ in, int n, int ld, double p, double* __restrict__ cut) {
+    const double* __restrict__ in, int n, int ld, double p, double* __restrict__ cut,
+    int zero_diag) {
   __shared__ double sm[4];
   const int row = blockIdx.x;
   const double* x = in + (size_t)row * ld;
   double m = -INFINITY;
   for (int j = 2 * threadIdx.x; j < n; j += 2 * kRowThreads) {
-    const double2 v = *reinterpret_cast<const double2*>(x + j);
+    double2 v = *reinterpret_cast<const double2*>(x + j);
+    if (zero_diag) {  // thresholding_preserve_diagonal: diagonal zeroed first (:185-186)
+      if (j == row) v.x = 0.0;
+      if (j + 1 == row) v.y = 0.0;
+    }
     m = fmax(m, v.x);
     if (j + 1 < n) m = fmax(m, v.y);
   }
   m = block_max(m, sm);
   if (threadIdx.x == 0) cut[row] = m * p;
+}
+
+// ---- R3, ThresholdType.Percentile: cut[i] = np.percentile(row_i, 100 p) ------------
+// (refinement.py:192-197; numpy 2.2 `_quantile`, method "linear").  One workgroup per row:
+// the row is turned into order-preserving 64-bit keys in LDS and the element of rank
+// `prev` is found by an 8-pass MSB radix select (256-bin LDS histograms); rank prev+1 is
+// either the same value (duplicates) or the smallest larger key.  Then numpy's `_lerp`:
+//   diff = b - a;  t >= 0.5 ? b - diff * (1 - t) : a + diff * t        (no fma)
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+__global__ __launch_bounds__(256) void k_row_percentile_cut(
+    const double* __restrict__ in, int n, int ld, int zero_diag, int prev, int next,
+    double gamma, double* __restrict__ cut, int keys_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long pkeys[];
+  __shared__ int hist[256];
+  __shared__ unsigned long long s_prefix, s_mask;
+  __shared__ int s_rank;
+  __shared__ unsigned long long s_min[4];
+  __shared__ int s_cnt[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* x = in + (size_t)row * ld;
+  auto key_at = [&](int j) -> unsigned long long {
+    if (keys_in_lds) return pkeys[j];
+    const double v = (zero_diag && j == row) ? 0.0 : x[j];
+    return f64_key(v);
+  };
+  if (keys_in_lds)
+    for (int j = tid; j < n; j += 256)
+      pkeys[j] = f64_key((zero_diag && j == row) ? 0.0 : x[j]);
+  if (tid == 0) { s_prefix = 0; s_mask = 0; s_rank = prev; }
+  __syncthreads();
+  for (int pass = 7; pass >= 0; --pass) {
+    hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix, mask = s_mask;
+    const int shift = 8 * pass;
+    for (int j = tid; j < n; j += 256) {
+      const unsigned long long k = key_at(j);
+      if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {  // bins 4*lane .. 4*lane+3: scan, find the bin holding the rank
+      const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2],
+                h3 = hist[4 * lane + 3];
+      int incl = h0 + h1 + h2 + h3;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+      }
+      const int excl = incl - (h0 + h1 + h2 + h3);
+      const int rank = s_rank;
+      if (rank >= excl && rank < incl) {
+        int r = rank - excl, bin = 4 * lane;
+        if (r >= h0) { r -= h0; ++bin; if (r >= h1) { r -= h1; ++bin; if (r >= h2) { r -= h2; ++bin; } } }
+        s_rank = r;
+        s_prefix = prefix | ((unsigned long long)bin << shift);
+        s_mask = mask | (255ull << shift);
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned long long ka = s_prefix;  // key of rank `prev`
+  // rank prev+1: same key if it has duplicates beyond `prev`, else the next larger key
+  int le = 0;
+  unsigned long long mn = ~0ull;
+  for (int j = tid; j < n; j += 256) {
+    const unsigned long long k = key_at(j);
+    le += k <= ka;
+    if (k > ka && k < mn) mn = k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    le += __shfl_xor(le, o);
+    const unsigned long long u = __shfl_xor(mn, o);
+    mn = u < mn ? u : mn;
+  }
+  if (lane == 0) { s_cnt[wave] = le; s_min[wave] = mn; }
+  __syncthreads();
+  if (tid == 0) {
+    const int total_le = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    unsigned long long m2 = s_min[0];
+    for (int w = 1; w < 4; ++w) m2 = s_min[w] < m2 ? s_min[w] : m2;
+    const double a = key_f64(ka);
+    double b = a;
+    if (next != prev && total_le < prev + 2) b = key_f64(m2);
+    const double diff = b - a;
+    cut[row] = gamma >= 0.5 ? b - diff * (1.0 - gamma) : a + diff * gamma;
+  }
+}
+
+// generic thresholding against a precomputed per-row cut (RowMax with preserved
+// diagonal, Percentile): refinement.py:185-186, 200-209
+__global__ __launch_bounds__(kRowThreads) void k_row_threshold_cut(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    const double* __restrict__ cut, double mult, int binarize, int preserve_diag) {
+  const int row = blockIdx.x;
+  const double* x = in + (size_t)row * ld;
+  double* o = out + (size_t)row * ld;
+  const double c = cut[row];
+  for (int j = threadIdx.x; j < n; j += kRowThreads) {
+    double v = x[j];
+    if (preserve_diag && j == row) v = 0.0;
+    double r = v < c ? v * mult : (binarize ? 1.0 : v);
+    if (preserve_diag && j == row) r = 1.0;
+    o[j] = r;
+  }
 }
 
 // ---- R3 + R4 fused: out = sym(thr(B), thr(B)^T) over tile PAIRS ---------------------
@@ -122,7 +241,8 @@ __global__ __launch_bounds__(kRowThreads) void k_cut_from_rows(
 // coalesced): 1 read + 1 write of n^2 for the two ops together.
 __global__ __launch_bounds__(256) void k_threshold_symmetrize(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
-    const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles) {
+    const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles,
+    int preserve_diag) {
   __shared__ double tA[32][33];  // thr(tile (I, J))
   __shared__ double tB[32][33];  // thr(tile (J, I))
   int id = blockIdx.x, ti = 0, rowlen = ntiles;
@@ -138,6 +258,7 @@ __global__ __launch_bounds__(256) void k_threshold_symmetrize(
       if (gi < n && gj < n) {
         v = in[(size_t)gi * ld + gj];
         v = v < cut[gi] ? v * mult : (binarize ? 1.0 : v);
+        if (preserve_diag && gi == gj) v = 1.0;  // diagonal restored to 1 (:208-209)
       }
       tA[r][tx] = v;
     }
@@ -147,6 +268,7 @@ __global__ __launch_bounds__(256) void k_threshold_symmetrize(
       if (gi < n && gj < n) {
         v = in[(size_t)gi * ld + gj];
         v = v < cut[gi] ? v * mult : (binarize ? 1.0 : v);
+        if (preserve_diag && gi == gj) v = 1.0;
       }
       tB[r][tx] = v;
     }
@@ -379,14 +501,44 @@ void launch_cut_from_partials(hipStream_t s, const double* partials, int n, int 
                      ntiles, p, cut);
 }
 void launch_cut_from_rows(hipStream_t s, const double* in, int n, int ld, double p,
-                          double* cut) {
-  hipLaunchKernelGGL(k_cut_from_rows, dim3(n), dim3(kRowThreads), 0, s, in, n, ld, p, cut);
+                          double* cut, int zero_diag) {
+  hipLaunchKernelGGL(k_cut_from_rows, dim3(n), dim3(kRowThreads), 0, s, in, n, ld, p, cut,
+                     zero_diag);
+}
+// cut[i] = np.percentile(row_i (diagonal zeroed if asked), 100 * p)
+void launch_cut_percentile(hipStream_t s, const double* in, int n, int ld, double p,
+                           double* cut, int zero_diag) {
+  // numpy: q = (p * 100) / 100; virtual index (n - 1) q; floor / +1 / gamma
+  const double q = (p * 100.0) / 100.0;
+  const double vi = (double)(n - 1) * q;
+  int prev = (int)floor(vi);
+  int next = prev + 1;
+  double gamma = vi - (double)prev;
+  if (vi >= (double)(n - 1)) { prev = n - 1; next = n - 1; gamma = 0.0; }
+  if (vi < 0.0) { prev = 0; next = 0; gamma = 0.0; }
+  const size_t bytes = (size_t)n * sizeof(unsigned long long);
+  const int in_lds = bytes <= 128 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_row_percentile_cut),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_row_percentile_cut, dim3(n), dim3(256), in_lds ? bytes : 0, s, in, n,
+                     ld, zero_diag, prev, next, gamma, cut, in_lds);
+}
+void launch_row_threshold_cut(hipStream_t s, const double* in, double* out, int n, int ld,
+                              const double* cut, double mult, int binarize,
+                              int preserve_diag) {
+  hipLaunchKernelGGL(k_row_threshold_cut, dim3(n), dim3(kRowThreads), 0, s, in, out, n, ld,
+                     cut, mult, binarize, preserve_diag);
 }
 void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
-                                 const double* cut, double mult, int binarize, int symtype) {
+                                 const double* cut, double mult, int binarize, int symtype,
+                                 int preserve_diag) {
   const int t = (n + 31) / 32;
   hipLaunchKernelGGL(k_threshold_symmetrize, dim3(t * (t + 1) / 2), dim3(256), 0, s, in, out,
-                     n, ld, cut, mult, binarize, symtype, t);
+                     n, ld, cut, mult, binarize, symtype, t, preserve_diag);
 }
 void launch_row_normalize(hipStream_t s, const double* in, double* out, int n,
                           int ld) {

@@ -47,15 +47,18 @@ void launch_crop_value(hipStream_t s, const double* in, int n, int ld, double* d
 void launch_cut_from_partials(hipStream_t s, const double* partials, int n, int ntiles,
                               double p, double* cut);
 void launch_cut_from_rows(hipStream_t s, const double* in, int n, int ld, double p,
-                          double* cut);
+                          double* cut, int zero_diag);
+void launch_cut_percentile(hipStream_t s, const double* in, int n, int ld, double p,
+                           double* cut, int zero_diag);
+void launch_row_threshold_cut(hipStream_t s, const double* in, double* out, int n, int ld,
+                              const double* cut, double mult, int binarize,
+                              int preserve_diag);
 void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
-                                 const double* cut, double mult, int binarize, int symtype);
+                                 const double* cut, double mult, int binarize, int symtype,
+                                 int preserve_diag);
 void launch_row_threshold(hipStream_t s, const double* in, double* out, int n,
                           int ld, double p, double mult, int binarize,
                           int preserve_diag);
-void launch_row_percentile_threshold(hipStream_t s, const double* in, double* out,
-                                     int n, int ld, double p, double mult,
-                                     int binarize, int preserve_diag);
 void launch_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
                        int type);
 void launch_row_normalize(hipStream_t s, const double* in, double* out, int n,

@@ -341,3 +341,53 @@ def test_fuzz_predict_vs_oracle(case):
   loose = gap == "NormalizedDiff" and lap not in (0, 1)
   np.testing.assert_allclose(diag.max_delta, dump["max_delta"], rtol=2e-4 if loose else 1e-5)
   assert so.adjusted_rand_index(got, want) == 1.0
+
+
+# --- Turn-to-Diarize refinement (reference configs.py:49-59) + AutoTune, without constraints --
+def turntodiarize_options(p=0.95):
+  return sca.RefinementOptions(
+      p_percentile=p, thresholding_soft_multiplier=0.01,
+      thresholding_type=sca.ThresholdType.Percentile, thresholding_with_binarization=True,
+      thresholding_preserve_diagonal=True, symmetrize_type=sca.SymmetrizeType.Average,
+      refinement_sequence=sca.TURNTODIARIZE_REFINEMENT_SEQUENCE)
+
+
+@pytest.mark.parametrize("n,k,seed", [(300, 3, 1), (700, 5, 2), (1500, 4, 3)])
+def test_turntodiarize_sequence_vs_oracle(n, k, seed):
+  x = so.blobs(n, 32, k, seed=seed)
+  for p in (0.95, 0.7):
+    cfg = so.OracleConfig(
+        min_clusters=2, max_clusters=7, laplacian_type=so.LAPLACIAN_GRAPH_CUT,
+        sequence=(so.OP_ROW_WISE_THRESHOLD, so.OP_SYMMETRIZE), p_percentile=p,
+        threshold_type=so.THRESHOLD_PERCENTILE, binarize=True, preserve_diagonal=True,
+        symmetrize_type=so.SYMMETRIZE_AVERAGE, row_wise_renorm=True)
+    dump = {}
+    want = so.predict(x, cfg, dump)
+    clusterer = sca.SpectralClusterer(
+        min_clusters=2, max_clusters=7, refinement_options=turntodiarize_options(p),
+        laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+    got = clusterer.predict(x)
+    assert so.adjusted_rand_index(got, want) == 1.0
+    idx = so.consumed_eigen_indices(n, 7, False)
+    w = clusterer.last_diag.eigenvalue_array()
+    assert rel_err(w[idx], dump["eigenvalues"][idx]) < EIG_RTOL
+
+
+def test_turntodiarize_autotune_vs_oracle():
+  x = so.blobs(400, 32, 4, seed=11)
+  tuner = sca.AutoTune(p_percentile_min=0.40, p_percentile_max=0.95, init_search_step=0.05,
+                       search_level=1)   # reference configs.py:66-70
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=7, refinement_options=turntodiarize_options(),
+      autotune=tuner, laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  got = clusterer.predict(x)
+  cfg = so.OracleConfig(
+      min_clusters=2, max_clusters=7, laplacian_type=so.LAPLACIAN_GRAPH_CUT,
+      sequence=(so.OP_ROW_WISE_THRESHOLD, so.OP_SYMMETRIZE),
+      threshold_type=so.THRESHOLD_PERCENTILE, binarize=True, preserve_diagonal=True,
+      symmetrize_type=so.SYMMETRIZE_AVERAGE, row_wise_renorm=True)
+  vecs, k, best_p, seen = so.autotune_search(so.affinity(x), cfg, 0.40, 0.95, 0.05)
+  k = max(k, 2)
+  emb = vecs[:, :k] / np.linalg.norm(vecs[:, :k], axis=1)[:, None]
+  want = so.run_kmeans(emb, k, 300)
+  assert so.adjusted_rand_index(got, want) == 1.0

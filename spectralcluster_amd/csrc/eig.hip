@@ -381,6 +381,21 @@ __global__ __launch_bounds__(1024) void k_jacobi(
     __syncthreads();
   }
 
+  // scale of the matrix (max |diagonal|): rotations whose off-diagonal entry is below
+  // 1e-17 * scale are rounding noise -- without this floor a near-zero diagonal entry
+  // (the Laplacian's null eigenvalue) keeps the relative test firing sweep after sweep
+  __shared__ double s_scale;
+  if (tid == 0) s_scale = 0.0;
+  __syncthreads();
+  if (tid < 64) {
+    double mx = 0.0;
+    for (int i = tid; i < m; i += 64) mx = fmax(mx, fabs(A[i * lda + i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if (tid == 0) s_scale = mx;
+  }
+  __syncthreads();
+  const double tiny_abs = 1e-17 * s_scale, large_abs = 1e-13 * s_scale;
   const int half = mp / 2;
   int sweeps_done = 0;
   long long cyc_param = 0, cyc_bar1 = 0, cyc_upd = 0, cyc_bar2 = 0;
@@ -410,7 +425,7 @@ __global__ __launch_bounds__(1024) void k_jacobi(
         const double apq2 = apq * apq;
         const double dd = fabs(app) * fabs(aqq);
         // rotate iff |apq| > 1e-18 sqrt(|app aqq|)   (compared squared: no sqrt)
-        if (apq2 > 1e-36 * dd && fabs(apq) > 1e-300) {
+        if (apq2 > 1e-36 * dd && fabs(apq) > tiny_abs && fabs(apq) > 1e-300) {
           // t = tan(angle): smaller root of t^2 + 2 theta t - 1 = 0, theta =
           // (aqq - app) / (2 apq), written without forming theta
           const double al = 0.5 * (aqq - app);
@@ -423,7 +438,8 @@ __global__ __launch_bounds__(1024) void k_jacobi(
           t = __builtin_fma(__builtin_fma(-den, t, apq), rd, t);
           c = fast_rsqrt(__builtin_fma(t, t, 1.0));
           s = t * c;
-          if (s != 0.0 && apq2 > 1e-18 * dd) atomicAdd(&s_rot, 1);  // still "large"
+          if (s != 0.0 && apq2 > 1e-18 * dd && fabs(apq) > large_abs)
+            atomicAdd(&s_rot, 1);  // still "large"
         }
         cs[tid] = c;
         sn[tid] = s;
@@ -711,8 +727,9 @@ void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_set = true;
   }
-  int threads = ((mp / 2) * (mp / 2) + 63) / 64 * 64;
-  threads = std::max(256, std::min(1024, threads));
+  // always 16 waves: each round is a chain of dependent LDS round trips, so the time
+  // per round is set by how many work items a wave handles one after the other
+  const int threads = 1024;
   if (yt_in_lds)
     hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(threads), lds, s, src, ldsrc, m, mode,
                        cvec, pvec, G, theta, Y, ldy, resid, Yt, dbg);

@@ -26,6 +26,14 @@ elif what == "affinity":
   x = rng.standard_normal((n, 256))
   for _ in range(reps):
     sca.utils.compute_affinity_matrix(x)
+elif what == "predict300":
+  sys.path.insert(0, os.path.join(ROOT, "oracle"))
+  import spectral_oracle as so
+  x = so.blobs(n, 256, 4, n)
+  c = sca.configs.icassp2018_clusterer
+  for _ in range(reps):
+    c.predict(x)
+  print(c.last_diag.stage_times_ms())
 else:
   x = rng.standard_normal((n, 256))
   c = sca.SpectralClusterer(min_clusters=2, max_clusters=20,

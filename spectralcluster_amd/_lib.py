@@ -280,3 +280,16 @@ def default_handle(device: typing.Optional[int] = None) -> Handle:
   if device not in _default_handles:
     _default_handles[device] = Handle(device)
   return _default_handles[device]
+
+
+_handle_pools = {}
+
+
+def handle_pool(device: typing.Optional[int], size: int) -> typing.List[Handle]:
+  """`size` independent handles (streams) on one device, created once per process.
+  Handle 0 of the pool is the device's default handle."""
+  first = default_handle(device)
+  pool = _handle_pools.setdefault(first.device, [first])
+  while len(pool) < size:
+    pool.append(Handle(first.device))
+  return pool[:size]

@@ -33,7 +33,7 @@ struct sc_handle_s {
   // matrices
   DevBuf X, Xn, A0, B1, B2;
   // n-vectors
-  DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart;
+  DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart, splitk;
   DevBuf blurw;           // device copy of the blur weights
   // eigen workspace
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
@@ -106,6 +106,7 @@ static int ensure_matrices(sc_handle h, int n, int d) {
   SC_TRY(grow(h, h->pvec, nv));
   SC_TRY(grow(h, h->tvec, nv));
   SC_TRY(grow(h, h->deg, nv));
+  SC_TRY(grow(h, h->splitk, gemm_splitk_workspace_bytes()));
   SC_TRY(grow(h, h->dvec, nv));
   SC_TRY(grow(h, h->cut, nv));
   SC_TRY(grow(h, h->rmpart, (size_t)n * blur_tile_columns(n) * sizeof(double)));
@@ -219,7 +220,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -478,7 +479,7 @@ static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double
       launch_symmetrize(s, in, out, n, ld, cfg->symmetrize_type);
       break;
     case SC_OP_DIFFUSE:
-      launch_gemm_nt(s, in, ld, in, ld, out, ld, n, n, n, kEpiNone, true);
+      launch_gemm_nt(s, in, ld, in, ld, out, ld, n, n, n, kEpiNone, true, ptr<double>(h->splitk));
       break;
     case SC_OP_ROW_WISE_NORMALIZE:
       launch_row_normalize(s, in, out, n, ld);
@@ -516,7 +517,8 @@ extern "C" int sc_compute_affinity(sc_handle h) {
   launch_normalize_rows(h->stream, ptr<double>(h->X), h->ldx, h->n, h->d,
                         ptr<double>(h->Xn));
   launch_gemm_nt(h->stream, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx,
-                 ptr<double>(h->A0), h->ldn, h->n, h->n, h->d, kEpiAffinity, true);
+                 ptr<double>(h->A0), h->ldn, h->n, h->n, h->d, kEpiAffinity, true,
+                 ptr<double>(h->splitk));
   SC_TRY(check_last(h, "affinity launch"));
   h->have_affinity = true;
   h->n_vec = 0;

@@ -262,38 +262,42 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const double* __restrict__ 
   }
 }
 
-constexpr int kMaxDevices = 16;
-static int g_slots_dev[kMaxDevices] = {0};          // co-resident k_gemm_nt workgroups
-static double* g_partial_dev[kMaxDevices] = {nullptr};  // split-K scratch, slots tiles
-
-template <int EPI, bool SYM>
-static void launch_variant(hipStream_t s, const double* A, int lda, const double* B,
-                           int ldb, double* C, int ldc, int M, int N, int K) {
-  const int tm = (M + BM - 1) / BM;
-  const int tn = (N + BN - 1) / BN;
-  const int tiles = SYM ? tm * (tm + 1) / 2 : tm * tn;
+// co-resident k_gemm_nt workgroups on the current device (occupancy x CUs)
+int gemm_resident_slots() {
+  static int slots_dev[16] = {0};
   int dev = 0;
   hipGetDevice(&dev);
-  dev = dev < kMaxDevices ? dev : 0;
-  if (g_slots_dev[dev] == 0) {
+  dev = dev < 16 ? dev : 0;
+  if (slots_dev[dev] == 0) {
     int per_cu = 0;
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, dev);
     hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &per_cu, reinterpret_cast<const void*>(k_gemm_nt<kEpiNone, true>), 256, 0);
     if (per_cu < 1) per_cu = 1;
-    g_slots_dev[dev] = per_cu * prop.multiProcessorCount;
-    hipMalloc(reinterpret_cast<void**>(&g_partial_dev[dev]),
-              (size_t)g_slots_dev[dev] * BM * BN * sizeof(double));
+    slots_dev[dev] = per_cu * prop.multiProcessorCount;
   }
-  const int g_slots = g_slots_dev[dev];
-  double* g_partial = g_partial_dev[dev];
+  return slots_dev[dev];
+}
+size_t gemm_splitk_workspace_bytes() {
+  return (size_t)gemm_resident_slots() * BM * BN * sizeof(double);
+}
+
+template <int EPI, bool SYM>
+static void launch_variant(hipStream_t s, const double* A, int lda, const double* B,
+                           int ldb, double* C, int ldc, int M, int N, int K,
+                           double* splitk_ws) {
+  const int tm = (M + BM - 1) / BM;
+  const int tn = (N + BN - 1) / BN;
+  const int tiles = SYM ? tm * (tm + 1) / 2 : tm * tn;
+  const int g_slots = gemm_resident_slots();
+  double* g_partial = splitk_ws;  // per-handle scratch: handles may run concurrently
   const int ktiles = (K + BK - 1) / BK;
   // full waves of workgroups run whole tiles; the ragged remainder is split over K
   int full = (tiles / g_slots) * g_slots;
   int rem = tiles - full;
   int ksplit = 1;
-  if (rem > 0) {
+  if (rem > 0 && splitk_ws != nullptr) {
     ksplit = g_slots / rem;
     ksplit = std::min(ksplit, std::max(1, ktiles / 8));  // >= 8 k-tiles per chunk
     if (ksplit < 2) {  // not worth splitting
@@ -315,18 +319,18 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
 
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
-                    int epilogue, bool symmetric) {
+                    int epilogue, bool symmetric, double* splitk_ws) {
   if (M <= 0 || N <= 0) return;
   if (symmetric) {
     if (epilogue == kEpiAffinity)
-      launch_variant<kEpiAffinity, true>(s, A, lda, B, ldb, C, ldc, M, N, K);
+      launch_variant<kEpiAffinity, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws);
     else
-      launch_variant<kEpiNone, true>(s, A, lda, B, ldb, C, ldc, M, N, K);
+      launch_variant<kEpiNone, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws);
   } else {
     if (epilogue == kEpiAffinity)
-      launch_variant<kEpiAffinity, false>(s, A, lda, B, ldb, C, ldc, M, N, K);
+      launch_variant<kEpiAffinity, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws);
     else
-      launch_variant<kEpiNone, false>(s, A, lda, B, ldb, C, ldc, M, N, K);
+      launch_variant<kEpiNone, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws);
   }
 }
 

@@ -28,9 +28,12 @@ enum { kEpiNone = 0, kEpiAffinity = 1 };
 // C[M,N] = A[M,K] * B[N,K]^T (row-major, leading dims in elements).  When
 // `symmetric` is set B must alias A and only tile pairs i<=j are computed; the
 // mirror tile is written transposed, so C is exactly symmetric.
+// `splitk_ws`: gemm_splitk_workspace_bytes() of scratch owned by the caller (per handle).
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
-                    int epilogue, bool symmetric);
+                    int epilogue, bool symmetric, double* splitk_ws);
+int gemm_resident_slots();
+size_t gemm_splitk_workspace_bytes();
 
 void launch_normalize_rows(hipStream_t s, const double* X, int ldx, int n, int d,
                            double* Xn);

@@ -234,27 +234,59 @@ class SpectralClusterer:
         custom_dist=self.custom_dist, max_iter=self.max_iter)
 
   # -------------------------------------------------------------- batch (new)
-  def predict_batch(self, utterances: typing.Sequence[np.ndarray]) -> typing.List[np.ndarray]:
+  def _predict_batch_on(self, handle, xs, labels, diags_out, indices):
+    """Run utterances `indices` back to back on one handle (one HIP stream)."""
+    count = len(indices)
+    if count == 0:
+      return
+    xp = (ctypes.POINTER(ctypes.c_double) * count)(
+        *[_lib.as_double_p(xs[i]) for i in indices])
+    lp = (ctypes.POINTER(ctypes.c_int64) * count)(
+        *[_lib.as_int64_p(labels[i]) for i in indices])
+    ns = (ctypes.c_int * count)(*[xs[i].shape[0] for i in indices])
+    diags = (_lib.ScDiag * count)()
+    handle.check(handle.lib.sc_predict_batch(handle.raw, xp, ns, xs[0].shape[1], count,
+                                             self.build_config(), lp, diags), TypeError)
+    for slot, i in enumerate(indices):
+      diags_out[i] = diags[slot]
+
+  def predict_batch(self, utterances: typing.Sequence[np.ndarray],
+                    streams: int = 4) -> typing.List[np.ndarray]:
     """Independent predict() calls (the reference has no batch API: a batch is a
-    Python loop).  One arena sized for the largest member."""
+    Python loop).
+
+    Small utterances cannot fill 256 CUs, and their eigen stage is a chain of short
+    launches, so the batch is spread (longest-processing-time first) over `streams`
+    independent handles -- one HIP stream and one arena each -- driven by one host
+    thread per handle (ctypes releases the GIL during the calls).
+    """
     if self.autotune is not None:
       return [self.predict(u) for u in utterances]
     self._scope_check()
     if not utterances:
       return []
+    for u in utterances:
+      if not isinstance(u, np.ndarray):
+        raise TypeError("embeddings must be a numpy array")
     xs = [np.ascontiguousarray(u, dtype=np.float64) for u in utterances]
-    d = xs[0].shape[1]
+    d = xs[0].shape[1] if xs[0].ndim == 2 else -1
     for x in xs:
       if x.ndim != 2 or x.shape[1] != d:
         raise ValueError("all utterances must be (n_i, d) with the same d")
-    count = len(xs)
     labels = [np.empty(x.shape[0], dtype=np.int64) for x in xs]
-    xp = (ctypes.POINTER(ctypes.c_double) * count)(*[_lib.as_double_p(x) for x in xs])
-    lp = (ctypes.POINTER(ctypes.c_int64) * count)(*[_lib.as_int64_p(l) for l in labels])
-    ns = (ctypes.c_int * count)(*[x.shape[0] for x in xs])
-    diags = (_lib.ScDiag * count)()
-    handle = self._handle()
-    handle.check(handle.lib.sc_predict_batch(handle.raw, xp, ns, d, count,
-                                             self.build_config(), lp, diags), TypeError)
+    diags = [None] * len(xs)
+    streams = max(1, min(int(streams), len(xs)))
+    if streams == 1:
+      self._predict_batch_on(self._handle(), xs, labels, diags, list(range(len(xs))))
+    else:
+      from spectralcluster_amd import multigpu
+      import concurrent.futures
+      shares = multigpu.lpt_assignment([x.shape[0] for x in xs], streams)
+      pool = _lib.handle_pool(self.device, streams)
+      with concurrent.futures.ThreadPoolExecutor(max_workers=streams) as ex:
+        futures = [ex.submit(self._predict_batch_on, h, xs, labels, diags, share)
+                   for h, share in zip(pool, shares)]
+        for f in futures:
+          f.result()
     self.last_batch_diags = diags
     return labels

@@ -52,12 +52,13 @@ ns = rng.integers(300, 3001, 512)
 ks = rng.integers(2, 8, 512)
 utts = [so.blobs(int(n), 256, int(k), seed=i) for i, (n, k) in enumerate(zip(ns, ks))]
 c = sca.configs.icassp2018_clusterer
-c.predict_batch(utts[:8])
-t = time.perf_counter()
-labs = c.predict_batch(utts)
-dt = time.perf_counter() - t
-out["cfg5_batch512_s"] = dt
-out["cfg5_utterances_per_s"] = 512 / dt
+for streams in (1, 2, 4, 8):
+  c.predict_batch(utts[:16], streams=streams)
+  t = time.perf_counter()
+  labs = c.predict_batch(utts, streams=streams)
+  dt = time.perf_counter() - t
+  out["cfg5_batch512_s_streams%d" % streams] = dt
+  out["cfg5_utterances_per_s_streams%d" % streams] = 512 / dt
 truth_ok = 0
 for i, (n, k) in enumerate(zip(ns, ks)):
   r = np.random.default_rng(i)

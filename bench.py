@@ -85,6 +85,44 @@ def cpu_baseline_leg(gpu_clusterer):
   }
 
 
+def concurrent_leg(sca, _lib, cfg, x, steps, streams=2):
+  """Throughput of independent predict() calls issued from `streams` host threads on
+  `streams` handles (HIP streams) of the same GPU: the single-workgroup phases of one
+  call (Rayleigh-Ritz, k-means) overlap the GEMM of the other.  Extra information only;
+  the headline `value` stays the single-stream number."""
+  import threading
+  pool = _lib.handle_pool(None, streams)
+  n, d = x.shape
+  per = max(1, steps // streams)
+
+  def worker(h, out):
+    lab = np.empty(n, dtype=np.int64)
+    diag = _lib.ScDiag()
+    h.check(h.lib.sc_set_embeddings(h.raw, _lib.as_double_p(x), n, d))
+    h.check(h.lib.sc_run_resident(h.raw, cfg, _lib.as_int64_p(lab), diag))  # warm-up
+    out.append((h, lab, diag))
+
+  ready = []
+  for h in pool:
+    worker(h, ready)
+
+  def run(h, lab, diag):
+    for _ in range(per):
+      h.check(h.lib.sc_run_resident(h.raw, cfg, _lib.as_int64_p(lab), diag))
+
+  for h, _, _ in ready:
+    h.check(h.lib.sc_synchronize(h.raw))
+  t0 = time.perf_counter()
+  threads = [threading.Thread(target=run, args=r) for r in ready]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  dt = time.perf_counter() - t0
+  return {"streams": streams, "calls": per * streams, "value": per * streams / dt,
+          "unit": "calls/s"}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +226,13 @@ def main():
           np.abs(w - g["consumed_eigenvalues"]) /
           np.maximum(np.abs(g["consumed_eigenvalues"]), 1e-12)))
       out["parity"]["reference_seconds_per_call_8vcpu"] = float(g["ref_seconds"])
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_diffuse.json")
+    if os.path.exists(tpath):  # HBM bytes per Diffuse launch from a separate --pmc run
+      t = json.load(open(tpath))
+      out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+      out["roofline"]["traffic_source"] = t["source"]
+    if world == 1:
+      out["concurrent_streams"] = concurrent_leg(sca, _lib, cfg, x, args.steps)
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline_leg(clusterer)
     print(json.dumps(out), flush=True)

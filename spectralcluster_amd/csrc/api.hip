@@ -33,7 +33,8 @@ struct sc_handle_s {
   // matrices
   DevBuf X, Xn, A0, B1, B2;
   // n-vectors
-  DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart, splitk;
+  DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart, splitk, tilemap;
+  int tilemap_nt = 0;     // tile-grid size the resident tilemap was built for
   DevBuf blurw;           // device copy of the blur weights
   // eigen workspace
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
@@ -111,6 +112,20 @@ static int ensure_matrices(sc_handle h, int n, int d) {
   SC_TRY(grow(h, h->cut, nv));
   SC_TRY(grow(h, h->rmpart, (size_t)n * blur_tile_columns(n) * sizeof(double)));
   SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
+  return SC_OK;
+}
+
+// (ti, tj) order of the symmetric GEMM tiles for problems of n rows (cached per handle)
+static int ensure_tilemap(sc_handle h, int n) {
+  const int nt = gemm_tile_dim(n);
+  if (h->tilemap_nt == nt) return SC_OK;
+  std::vector<int2> map;
+  gemm_build_sym_tilemap(nt, &map);
+  SC_TRY(grow(h, h->tilemap, map.size() * sizeof(int2)));
+  SC_HIP(h, hipMemcpyAsync(h->tilemap.p, map.data(), map.size() * sizeof(int2),
+                           hipMemcpyHostToDevice, h->stream));
+  SC_HIP(h, hipStreamSynchronize(h->stream));  // `map` is a local
+  h->tilemap_nt = nt;
   return SC_OK;
 }
 
@@ -220,7 +235,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -479,7 +494,9 @@ static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double
       launch_symmetrize(s, in, out, n, ld, cfg->symmetrize_type);
       break;
     case SC_OP_DIFFUSE:
-      launch_gemm_nt(s, in, ld, in, ld, out, ld, n, n, n, kEpiNone, true, ptr<double>(h->splitk));
+      SC_TRY(ensure_tilemap(h, n));
+      launch_gemm_nt(s, in, ld, in, ld, out, ld, n, n, n, kEpiNone, true, ptr<double>(h->splitk),
+                     ptr<int2>(h->tilemap));
       break;
     case SC_OP_ROW_WISE_NORMALIZE:
       launch_row_normalize(s, in, out, n, ld);
@@ -514,11 +531,12 @@ extern "C" int sc_compute_affinity(sc_handle h) {
   if (!h) return SC_ERR_INVALID;
   if (!h->have_x) return fail(h, SC_ERR_INVALID, "no embeddings resident");
   SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_tilemap(h, h->n));
   launch_normalize_rows(h->stream, ptr<double>(h->X), h->ldx, h->n, h->d,
                         ptr<double>(h->Xn));
   launch_gemm_nt(h->stream, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx,
                  ptr<double>(h->A0), h->ldn, h->n, h->n, h->d, kEpiAffinity, true,
-                 ptr<double>(h->splitk));
+                 ptr<double>(h->splitk), ptr<int2>(h->tilemap));
   SC_TRY(check_last(h, "affinity launch"));
   h->have_affinity = true;
   h->n_vec = 0;

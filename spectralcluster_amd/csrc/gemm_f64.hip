@@ -16,6 +16,7 @@
 // earlier) while tile t feeds the MFMAs, so there is ONE barrier per K-tile and the
 // ds_write / global_load traffic hides under the 64 MFMAs (4096 cycles) of a tile.
 #include <algorithm>
+#include <vector>
 
 #include "sc_internal.h"
 
@@ -67,13 +68,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  int ldc, int M, int N, int K,
                                                  int ntiles_m, int ntiles_n,
                                                  int tile_offset, int ksplit,
-                                                 double* __restrict__ partial) {
+                                                 double* __restrict__ partial,
+                                                 const int2* __restrict__ tilemap,
+                                                 int xcd_chunk) {
   __shared__ __attribute__((aligned(16))) double As[2][BM * BK];
   __shared__ __attribute__((aligned(16))) double Bs[2][BN * BK];
 
   int ti, tj;
   const int chunk = blockIdx.x % ksplit;
-  tile_coords<SYM>(tile_offset + blockIdx.x / ksplit, ntiles_m, ntiles_n, &ti, &tj);
+  int tile = blockIdx.x / ksplit;
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own
+  // L2), so XCD x walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the
+  // patch-ordered tile list: the ~64 tiles it has in flight share 8 + 8 operand panels.
+  if (xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
+  tile += tile_offset;
+  if (tilemap != nullptr) {
+    const int2 t = tilemap[tile];
+    ti = t.x;
+    tj = t.y;
+  } else {
+    tile_coords<SYM>(tile, ntiles_m, ntiles_n, &ti, &tj);
+  }
   const int row0 = ti * BM;
   const int col0 = tj * BN;
 
@@ -172,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     }
     const double* Ac = As[cur];
     const double* Bc = Bs[cur];
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int koff = (4 * s + lg) ^ li;
@@ -187,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
           acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[nn],
                                                             acc[m][nn], 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
 
@@ -231,9 +248,16 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const double* __restrict__ 
                                                      double* __restrict__ C, int ldc,
                                                      int M, int N, int ntiles_m,
                                                      int ntiles_n, int tile_offset,
-                                                     int ksplit) {
+                                                     int ksplit,
+                                                     const int2* __restrict__ tilemap) {
   int ti, tj;
-  tile_coords<SYM>(tile_offset + blockIdx.x, ntiles_m, ntiles_n, &ti, &tj);
+  if (tilemap != nullptr) {
+    const int2 t = tilemap[tile_offset + blockIdx.x];
+    ti = t.x;
+    tj = t.y;
+  } else {
+    tile_coords<SYM>(tile_offset + blockIdx.x, ntiles_m, ntiles_n, &ti, &tj);
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -286,7 +310,7 @@ size_t gemm_splitk_workspace_bytes() {
 template <int EPI, bool SYM>
 static void launch_variant(hipStream_t s, const double* A, int lda, const double* B,
                            int ldb, double* C, int ldc, int M, int N, int K,
-                           double* splitk_ws) {
+                           double* splitk_ws, const int2* tilemap) {
   const int tm = (M + BM - 1) / BM;
   const int tn = (N + BN - 1) / BN;
   const int tiles = SYM ? tm * (tm + 1) / 2 : tm * tn;
@@ -306,31 +330,47 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
       ksplit = 1;
     }
   }
-  if (full > 0)
+  if (full > 0) {
+    const int xcd_chunk = (tilemap != nullptr && full % 8 == 0 && full >= 512) ? full / 8 : 0;
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full), dim3(256), 0, s, A, lda, B,
-                       ldb, C, ldc, M, N, K, tm, tn, 0, 1, nullptr);
+                       ldb, C, ldc, M, N, K, tm, tn, 0, 1, nullptr, tilemap, xcd_chunk);
+  }
   if (rem > 0) {
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(rem * ksplit), dim3(256), 0, s, A, lda,
-                       B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial);
+                       B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, tilemap, 0);
     hipLaunchKernelGGL((k_gemm_reduce<EPI, SYM>), dim3(rem, 16), dim3(256), 0, s, g_partial,
-                       C, ldc, M, N, tm, tn, full, ksplit);
+                       C, ldc, M, N, tm, tn, full, ksplit, tilemap);
   }
 }
 
+// Upper-triangle tiles (ti <= tj) of an nt x nt tile grid in patch order: 8 x 8-tile
+// patches row by row, tiles row by row inside a patch.  Returns nt (nt + 1) / 2 pairs.
+void gemm_build_sym_tilemap(int nt, std::vector<int2>* out) {
+  out->clear();
+  const int np = (nt + 7) / 8;
+  for (int pi = 0; pi < np; ++pi)
+    for (int pj = pi; pj < np; ++pj)
+      for (int ti = pi * 8; ti < std::min(nt, pi * 8 + 8); ++ti)
+        for (int tj = std::max(ti, pj * 8); tj < std::min(nt, pj * 8 + 8); ++tj)
+          out->push_back(make_int2(ti, tj));
+}
+int gemm_tile_dim(int n) { return (n + BM - 1) / BM; }
+
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
-                    int epilogue, bool symmetric, double* splitk_ws) {
+                    int epilogue, bool symmetric, double* splitk_ws,
+                    const int2* tilemap) {
   if (M <= 0 || N <= 0) return;
   if (symmetric) {
     if (epilogue == kEpiAffinity)
-      launch_variant<kEpiAffinity, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws);
+      launch_variant<kEpiAffinity, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap);
     else
-      launch_variant<kEpiNone, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws);
+      launch_variant<kEpiNone, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap);
   } else {
     if (epilogue == kEpiAffinity)
-      launch_variant<kEpiAffinity, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws);
+      launch_variant<kEpiAffinity, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap);
     else
-      launch_variant<kEpiNone, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws);
+      launch_variant<kEpiNone, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap);
   }
 }
 

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/spectralcluster_amd.h"
 
@@ -31,7 +32,11 @@ enum { kEpiNone = 0, kEpiAffinity = 1 };
 // `splitk_ws`: gemm_splitk_workspace_bytes() of scratch owned by the caller (per handle).
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
-                    int epilogue, bool symmetric, double* splitk_ws);
+                    int epilogue, bool symmetric, double* splitk_ws,
+                    const int2* tilemap);
+// patch-ordered (ti, tj) list of the upper triangle, for `tilemap` (symmetric launches)
+void gemm_build_sym_tilemap(int nt, std::vector<int2>* out);
+int gemm_tile_dim(int n);
 int gemm_resident_slots();
 size_t gemm_splitk_workspace_bytes();
 

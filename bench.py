@@ -129,6 +129,7 @@ def main():
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-concurrent", action="store_true")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,7 +232,7 @@ def main():
       t = json.load(open(tpath))
       out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
       out["roofline"]["traffic_source"] = t["source"]
-    if world == 1:
+    if world == 1 and not args.no_concurrent:
       out["concurrent_streams"] = concurrent_leg(sca, _lib, cfg, x, args.steps)
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline_leg(clusterer)

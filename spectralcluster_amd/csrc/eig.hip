@@ -164,27 +164,37 @@ __global__ __launch_bounds__(256) void k_reduce_H(
     const double* __restrict__ partial, int nparts, int m, double* __restrict__ Hbuf,
     double* __restrict__ T, int ldt, int col0, int accumulate,
     double* __restrict__ hsq) {
-  __shared__ double sq[256];
+  // 8 lanes per entry: each sums every 8th partial, then a fixed-order butterfly
+  __shared__ double sq[32];
   const int tid = threadIdx.x;
-  const int e = blockIdx.x * 256 + tid;
+  const int sub = tid & 7;
+  const int e = blockIdx.x * 32 + (tid >> 3);
   double h = 0.0;
-  if (e < m * B) {
-    for (int g = 0; g < nparts; ++g) h += partial[(size_t)g * (kLdq * B) + e];
-    Hbuf[e] = h;
-    if (T != nullptr) {
-      const int i = e / B, j = col0 + (e % B);
-      if (i <= j) {
-        const double v = accumulate ? T[(size_t)i * ldt + j] + h : h;
-        T[(size_t)i * ldt + j] = v;
-        T[(size_t)j * ldt + i] = v;
+  if (e < m * B)
+    for (int g = sub; g < nparts; g += 8) h += partial[(size_t)g * (kLdq * B) + e];
+  h += __shfl_xor(h, 1);
+  h += __shfl_xor(h, 2);
+  h += __shfl_xor(h, 4);
+  if (sub == 0) {
+    if (e < m * B) {
+      Hbuf[e] = h;
+      if (T != nullptr) {
+        const int i = e / B, j = col0 + (e % B);
+        if (i <= j) {
+          const double v = accumulate ? T[(size_t)i * ldt + j] + h : h;
+          T[(size_t)i * ldt + j] = v;
+          T[(size_t)j * ldt + i] = v;
+        }
       }
+    } else {
+      h = 0.0;
     }
+    sq[tid >> 3] = h * h;
   }
-  sq[tid] = h * h;
   __syncthreads();
-  if (tid < B) {  // entry e = 256 * block + tid has column e % B == tid % B
+  if (tid < B) {  // entry e = 32 * block + q has column e % B == q % B (32 % B == 0)
     double s = 0.0;
-    for (int q = tid; q < 256; q += B) s += sq[q];
+    for (int q = tid; q < 32; q += B) s += sq[q];
     atomicAdd(&hsq[tid], s);
   }
 }
@@ -229,14 +239,21 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
   const int tid = threadIdx.x;
   const bool active = tid < B * B;
   const int ra = active ? tid / B : 0, cb = active ? tid % B : 0;
-  if (active) {
+  {
+    // Gram entry e summed by (256 / (B*B)) lanes, fixed-order butterfly
+    constexpr int kLanes = 256 / (B * B);
+    const int e = tid / kLanes, sub = tid % kLanes;
     double g = 0.0;
-    for (int q = 0; q < nparts; ++q) g += partial[(size_t)q * (kLdq * B) + tid];
-    G[ra][cb] = g;
-    if (Gsave) Gsave[tid] = g;
-    R[ra][cb] = 0.0;
-    Ri[ra][cb] = 0.0;
-    if (ra == cb) gdiag[ra] = g;
+    for (int q = sub; q < nparts; q += kLanes) g += partial[(size_t)q * (kLdq * B) + e];
+#pragma unroll
+    for (int o = 1; o < kLanes; o <<= 1) g += __shfl_xor(g, o);
+    if (sub == 0) {
+      G[e / B][e % B] = g;
+      if (Gsave) Gsave[e] = g;
+      R[e / B][e % B] = 0.0;
+      Ri[e / B][e % B] = 0.0;
+      if (e / B == e % B) gdiag[e / B] = g;
+    }
   }
   if (tid == 0) s_mask = 0;
   __syncthreads();
@@ -692,7 +709,7 @@ void launch_proj_partial(hipStream_t s, const double* Q, int ldq, int m,
 }
 void launch_reduce_H(hipStream_t s, const double* partial, int nparts, int m, double* Hbuf,
                      double* T, int ldt, int col0, int accumulate, double* hsq) {
-  hipLaunchKernelGGL(k_reduce_H, dim3((m * B + 255) / 256), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL(k_reduce_H, dim3((m * B + 31) / 32), dim3(256), 0, s, partial,
                      nparts, m, Hbuf, T, ldt, col0, accumulate, hsq);
 }
 void launch_update_block(hipStream_t s, const double* Q, int ldq, int m,

@@ -82,6 +82,7 @@ __device__ __forceinline__ void cluster_means(const double* __restrict__ data, i
       double acc[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+#pragma unroll 4
       for (int r = tid; r < n; r += KT) {
         if (lab[r] == c) {
           if (j0 == 0) { ++cnt; nz += r > 0; }
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     double part[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) part[t] = 0.0;
+#pragma unroll 4
     for (int r = tid; r < n; r += KT) {
       double dot[8];
 #pragma unroll
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     for (int t = 1; t < trials; ++t)
       if (pots[t] < pots[best]) best = t;  // np.argmin: first minimum
     pot = pots[best];
+#pragma unroll 4
     for (int r = tid; r < n; r += KT) closest[r] = cand_d[(size_t)best * n + r];
     if (tid == 0) seeds[c] = cand[best];
     __syncthreads();
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     cnorm[tid] = s;  // squared norms here
   }
   __syncthreads();
+#pragma unroll 2
   for (int r = tid; r < n; r += KT) {
     int best = 0;
     double bd = INFINITY;
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     }
     __syncthreads();
     double part = 0.0;
+#pragma unroll 2
     for (int r = tid; r < n; r += KT) {
       int best = 0;
       double bd = INFINITY;

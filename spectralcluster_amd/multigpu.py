@@ -80,11 +80,14 @@ def broadcast_array(arr: typing.Optional[np.ndarray], src: int = 0) -> np.ndarra
 
 
 def predict_batch_sharded(
-    predict_fn: typing.Callable[[np.ndarray], np.ndarray],
-    utterances: typing.Sequence[np.ndarray]) -> typing.List[np.ndarray]:
+    predict_fn: typing.Optional[typing.Callable[[np.ndarray], np.ndarray]],
+    utterances: typing.Sequence[np.ndarray],
+    predict_many_fn: typing.Optional[typing.Callable] = None) -> typing.List[np.ndarray]:
   """Every rank holds (or has been broadcast) the same utterance list; rank r runs
-  `predict_fn` on its LPT share and the int64 labels are all-gathered (padded to the
-  longest utterance).  Every rank returns the complete, input-ordered result."""
+  `predict_fn` on its LPT share (or `predict_many_fn(list_of_arrays) -> list_of_labels`
+  on the whole share at once, e.g. a multi-stream batch) and the int64 labels are
+  all-gathered (padded to the longest utterance).  Every rank returns the complete,
+  input-ordered result."""
   import torch
   dist = _dist()
   world, rank = dist.get_world_size(), dist.get_rank()
@@ -94,8 +97,12 @@ def predict_batch_sharded(
   slots = max((len(o) for o in owned), default=0)
   longest = max(sizes, default=0)
   mine = torch.full((slots, longest), -1, dtype=torch.int64, device=dev)
-  for s, idx in enumerate(owned[rank]):
-    lab = np.asarray(predict_fn(utterances[idx]), dtype=np.int64)
+  if predict_many_fn is not None:
+    local = predict_many_fn([utterances[idx] for idx in owned[rank]])
+  else:
+    local = [predict_fn(utterances[idx]) for idx in owned[rank]]
+  for s, lab in enumerate(local):
+    lab = np.asarray(lab, dtype=np.int64)
     mine[s, :lab.shape[0]] = torch.from_numpy(lab).to(dev)
   gathered = [torch.empty_like(mine) for _ in range(world)]
   dist.all_gather(gathered, mine)
@@ -143,3 +150,49 @@ def first_strict_minimum(ratios: np.ndarray) -> int:
     if r < best:
       best, best_i = r, i
   return best_i
+
+
+# --------------------------------------------------------------------------------
+# thin wrappers around a SpectralClusterer (device compute on this rank's GPU)
+# --------------------------------------------------------------------------------
+def predict_batch_distributed(clusterer, utterances: typing.Sequence[np.ndarray],
+                              streams: int = 4) -> typing.List[np.ndarray]:
+  """BASELINE config 5: utterances partitioned over the ranks (LPT), each rank runs its
+  share as a multi-stream batch on its own GPU, labels all-gathered."""
+  return predict_batch_sharded(
+      None, utterances,
+      predict_many_fn=lambda share: clusterer.predict_batch(share, streams=streams))
+
+
+def predict_autotune_distributed(clusterer, embeddings: np.ndarray) -> np.ndarray:
+  """BASELINE config 4: every rank holds the embeddings (broadcast them first if only
+  rank 0 has them), recomputes the affinity locally (cheaper than shipping n^2 doubles),
+  evaluates its share of each AutoTune search level, all-gathers (ratio, n_clusters),
+  and every rank finishes with the winner's eigenvectors + k-means: identical labels
+  everywhere, no n x n or n x k matrix ever crosses xGMI."""
+  import ctypes
+  from spectralcluster_amd import _lib
+  tuner = clusterer.autotune
+  if tuner is None:
+    raise ValueError("clusterer.autotune is not set")
+  handle = clusterer._handle()
+  clusterer._scope_check()
+  clusterer._upload(handle, embeddings)
+
+  def evaluate(p):
+    diag = clusterer._eig_resident(handle, p)
+    return tuner.ratio(p, diag.max_delta), int(diag.n_clusters_raw)
+
+  def evaluate_many(ps):
+    ratios, ks = autotune_sharded(evaluate, ps)
+    return [(float(r), p, int(k)) for r, p, k in zip(ratios, ps, ks)]
+
+  _, n_clusters, best_p = tuner.tune(None, evaluate_many=evaluate_many)
+  diag = clusterer._eig_resident(handle, best_p)
+  if clusterer.min_clusters is not None:
+    n_clusters = max(n_clusters, clusterer.min_clusters)
+  n = embeddings.shape[0]
+  labels = np.empty(n, dtype=np.int64)
+  handle.check(handle.lib.sc_cluster(handle.raw, clusterer.build_config(best_p), n_clusters,
+                                     _lib.as_int64_p(labels), diag))
+  return labels

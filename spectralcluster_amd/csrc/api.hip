@@ -110,7 +110,7 @@ static int ensure_matrices(sc_handle h, int n, int d) {
   SC_TRY(grow(h, h->splitk, gemm_splitk_workspace_bytes()));
   SC_TRY(grow(h, h->dvec, nv));
   SC_TRY(grow(h, h->cut, nv));
-  SC_TRY(grow(h, h->rmpart, (size_t)n * blur_tile_columns(n) * sizeof(double)));
+  SC_TRY(grow(h, h->rmpart, (size_t)n * blur_tile_columns(n, 8) * sizeof(double)));
   SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
   return SC_OK;
 }
@@ -946,7 +946,8 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
         launch_cut_percentile(s, cur, n, ld, cfg->p_percentile, ptr<double>(h->cut),
                               cfg->preserve_diagonal);
       else if (have_partials && partials_usable)
-        launch_cut_from_partials(s, ptr<double>(h->rmpart), n, blur_tile_columns(n),
+        launch_cut_from_partials(s, ptr<double>(h->rmpart), n,
+                                 blur_tile_columns(n, cfg->blur_radius),
                                  cfg->p_percentile, ptr<double>(h->cut));
       else
         launch_cut_from_rows(s, cur, n, ld, cfg->p_percentile, ptr<double>(h->cut),

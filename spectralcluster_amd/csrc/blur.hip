@@ -68,65 +68,77 @@ __global__ __launch_bounds__(256) void k_gaussian_blur(
   }
 }
 
-// Fast path: radius known at compile time (index arithmetic by constants), plain
-// conditionals instead of modulo for the reflection (needs n >= R), optional fusions:
+// Fast path (radius R known at compile time, n >= 128).  One workgroup = 4 waves
+// produces a 64-row x (64 - 2R)-column output tile:
+//   * the (64 + 2R) x 64 halo tile is loaded once, one 512-byte row per wave
+//     instruction, into LDS (the only LDS traffic);
+//   * axis 0: lane = column, each wave owns 16 output rows and reads its 16 + 2R halo
+//     rows from LDS ONCE into registers (2.5 LDS reads per output instead of 2R + 1);
+//   * axis 1: the 64 halo columns of a row sit in the 64 lanes of the wave, so the
+//     horizontal taps are wave shuffles -- no second LDS buffer;
+//   * lanes R .. 63-R hold valid outputs: one coalesced store per row, and the row
+//     maximum (for RowWiseThreshold) is a wave reduction.
+// scipy's summation order is kept in both passes:  t = x0 w0; t += (x[-j] + x[+j]) w[j],
+// j = R .. 1.  Optional fusions:
 //   diag   != nullptr : element (i, i) of the input is replaced by diag[i] on load
 //                       (CropDiagonal folded in: reference refinement.py:148-150)
 //   rowmax != nullptr : per-tile row maxima of the OUTPUT are written to
-//                       rowmax[row * gridDim.x + blockIdx.x] (feeds RowWiseThreshold)
+//                       rowmax[row * gridDim.x + blockIdx.x]
+constexpr int kBlurRows = 64;
 template <int R>
 __global__ __launch_bounds__(256) void k_gaussian_blur_r(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ weights, const double* __restrict__ diag,
     double* __restrict__ rowmax) {
-  constexpr int HW = TW + 2 * R;
-  constexpr int HH = TH + 2 * R;
-  __shared__ double tile[HH * HW];
-  __shared__ double mid[TH * HW];
-  __shared__ double w[R + 1];
-  const int i0 = blockIdx.y * TH;
-  const int j0 = blockIdx.x * TW;
-  const int tid = threadIdx.x;
-  if (tid <= R) w[tid] = weights[R - tid];
-  for (int e = tid; e < HH * HW; e += 256) {
-    const int r = e / HW, c = e - r * HW;
-    int gi = i0 + r - R, gj = j0 + c - R;
+  constexpr int HH = kBlurRows + 2 * R;
+  constexpr int OW = 64 - 2 * R;      // output columns per tile
+  constexpr int WR = kBlurRows / 4;   // output rows per wave
+  __shared__ double tile[HH * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * kBlurRows;
+  const int j0 = blockIdx.x * OW;
+  double w[R + 1];
+#pragma unroll
+  for (int j = 0; j <= R; ++j) w[j] = weights[R - j];  // symmetric: w[j] = weight at +-j
+
+  // reflected global column of this lane (scipy "reflect": edge sample repeated)
+  int gj = j0 - R + lane;
+  gj = gj < 0 ? -gj - 1 : gj;
+  gj = gj >= n ? 2 * n - 1 - gj : gj;
+  gj = gj < 0 ? 0 : gj;  // overhang lanes of the last tile column (never stored)
+  for (int r = wv; r < HH; r += 4) {
+    int gi = i0 - R + r;
     gi = gi < 0 ? -gi - 1 : gi;
-    gj = gj < 0 ? -gj - 1 : gj;
-    // tiles may hang over the matrix edge: reflect (possibly twice for the overhang)
     gi = gi >= n ? 2 * n - 1 - gi : gi;
-    gj = gj >= n ? 2 * n - 1 - gj : gj;
-    gi = gi < 0 ? 0 : gi;  // only reachable for overhang cells that are never used
-    gj = gj < 0 ? 0 : gj;
+    gi = gi < 0 ? 0 : gi;
     double v = in[(size_t)gi * ld + gj];
     if (diag != nullptr && gi == gj) v = diag[gi];
-    tile[e] = v;
+    tile[r * 64 + lane] = v;
   }
   __syncthreads();
-  for (int e = tid; e < TH * HW; e += 256) {
-    const int r = e / HW, c = e - r * HW;
-    const double* x = tile + (r + R) * HW + c;
-    double t = x[0] * w[0];
+
+  // axis 0: rows wv*WR .. wv*WR + WR - 1 of the tile's output, column = lane
+  double x[WR + 2 * R];
 #pragma unroll
-    for (int j = R; j >= 1; --j) t += (x[-j * HW] + x[j * HW]) * w[j];
-    mid[e] = t;
-  }
-  __syncthreads();
-  // 256 threads = 4 waves; wave `wv` produces rows wv, wv + 4, ...: one row (64
-  // columns) per wave per step, so the row maximum is a single wave reduction
-  const int lane = tid & 63, wv = tid >> 6;
-  for (int r = wv; r < TH; r += 4) {
-    const int gi = i0 + r, gj = j0 + lane;
-    const double* x = mid + r * HW + lane + R;
-    double t = x[0] * w[0];
+  for (int q = 0; q < WR + 2 * R; ++q) x[q] = tile[(wv * WR + q) * 64 + lane];
+  const int gjo = j0 + lane - R;                 // global column of this lane's output
+  const bool col_ok = lane >= R && lane < 64 - R && gjo < n;
 #pragma unroll
-    for (int j = R; j >= 1; --j) t += (x[-j] + x[j]) * w[j];
-    const bool ok = gi < n && gj < n;
-    if (ok) out[(size_t)gi * ld + gj] = t;
+  for (int o = 0; o < WR; ++o) {
+    double t = x[o + R] * w[0];
+#pragma unroll
+    for (int j = R; j >= 1; --j) t += (x[o + R - j] + x[o + R + j]) * w[j];
+    // axis 1 on this row: neighbours live in the neighbouring lanes
+    double u = t * w[0];
+#pragma unroll
+    for (int j = R; j >= 1; --j) u += (__shfl_up(t, j) + __shfl_down(t, j)) * w[j];
+    const int gi = i0 + wv * WR + o;
+    const bool ok = col_ok && gi < n;
+    if (ok) out[(size_t)gi * ld + gjo] = u;
     if (rowmax != nullptr) {
-      double m = ok ? t : -INFINITY;
+      double m = ok ? u : -INFINITY;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+      for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
       if (lane == 0 && gi < n) rowmax[(size_t)gi * gridDim.x + blockIdx.x] = m;
     }
   }
@@ -145,21 +157,25 @@ void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
   launch_gaussian_blur_fused(s, in, out, n, ld, radius, weights_dev, nullptr, nullptr);
 }
 
-int blur_tile_columns(int n) { return (n + TW - 1) / TW; }
+// tile columns of the fast path for `radius` (row-max partials per row)
+int blur_tile_columns(int n, int radius) {
+  const int ow = 64 - 2 * radius;
+  return (n + ow - 1) / ow;
+}
 
 // Returns true if the row-max partials were produced (fast path taken).
 bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, int n, int ld,
                                 int radius, const double* weights_dev, const double* diag,
                                 double* rowmax_partials) {
   dim3 grid((n + TW - 1) / TW, (n + TH - 1) / TH);
-  if (radius == 4 && n >= 2 * TW) {
-    hipLaunchKernelGGL((k_gaussian_blur_r<4>), grid, dim3(256), 0, s, in, out, n, ld,
-                       weights_dev, diag, rowmax_partials);
-    return rowmax_partials != nullptr;
-  }
-  if (radius == 8 && n >= 2 * TW) {
-    hipLaunchKernelGGL((k_gaussian_blur_r<8>), grid, dim3(256), 0, s, in, out, n, ld,
-                       weights_dev, diag, rowmax_partials);
+  if ((radius == 4 || radius == 8) && n >= 128) {
+    dim3 fgrid(blur_tile_columns(n, radius), (n + kBlurRows - 1) / kBlurRows);
+    if (radius == 4)
+      hipLaunchKernelGGL((k_gaussian_blur_r<4>), fgrid, dim3(256), 0, s, in, out, n, ld,
+                         weights_dev, diag, rowmax_partials);
+    else
+      hipLaunchKernelGGL((k_gaussian_blur_r<8>), fgrid, dim3(256), 0, s, in, out, n, ld,
+                         weights_dev, diag, rowmax_partials);
     return rowmax_partials != nullptr;
   }
   // generic path: no fusion (the caller materialises CropDiagonal itself)

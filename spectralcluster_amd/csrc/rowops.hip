@@ -91,13 +91,17 @@ __global__ __launch_bounds__(kRowThreads) void k_crop_value(
 }
 
 // cut[i] = (max over the per-tile partial row maxima) * p   (refinement.py:188-191)
-__global__ void k_cut_from_partials(const double* __restrict__ partials, int n, int ntiles,
-                                    double p, double* __restrict__ cut) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per row: lanes stride the row's partials (coalesced), wave max
+__global__ __launch_bounds__(256) void k_cut_from_partials(const double* __restrict__ partials,
+                                                           int n, int ntiles, double p,
+                                                           double* __restrict__ cut) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= n) return;
   double m = -INFINITY;
-  for (int t = 0; t < ntiles; ++t) m = fmax(m, partials[(size_t)i * ntiles + t]);
-  cut[i] = m * p;
+  for (int t = lane; t < ntiles; t += 64) m = fmax(m, partials[(size_t)i * ntiles + t]);
+  m = wave_max(m);
+  if (lane == 0) cut[i] = m * p;
 }
 __global__ __launch_bounds__(kRowThreads) void k_cut_from_rows(
     const double* __restrict__ in, int n, int ld, double p, double* __restrict__ cut,
@@ -497,7 +501,7 @@ void launch_crop_value(hipStream_t s, const double* in, int n, int ld, double* d
 }
 void launch_cut_from_partials(hipStream_t s, const double* partials, int n, int ntiles,
                               double p, double* cut) {
-  hipLaunchKernelGGL(k_cut_from_partials, dim3((n + 255) / 256), dim3(256), 0, s, partials, n,
+  hipLaunchKernelGGL(k_cut_from_partials, dim3((n + 3) / 4), dim3(256), 0, s, partials, n,
                      ntiles, p, cut);
 }
 void launch_cut_from_rows(hipStream_t s, const double* in, int n, int ld, double p,

@@ -50,7 +50,7 @@ void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
 bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, int n, int ld,
                                 int radius, const double* weights_dev, const double* diag,
                                 double* rowmax_partials);
-int blur_tile_columns(int n);
+int blur_tile_columns(int n, int radius);
 void launch_crop_value(hipStream_t s, const double* in, int n, int ld, double* dvec);
 void launch_cut_from_partials(hipStream_t s, const double* partials, int n, int ntiles,
                               double p, double* cut);

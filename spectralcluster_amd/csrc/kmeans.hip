@@ -12,6 +12,8 @@
 // The whole stage is ONE single-workgroup kernel (1024 threads): the data is at
 // most n*k*8 = 1.3 MB at n = 8192, k = 20 and L2-resident; a grid would spend its
 // time in launch gaps, not arithmetic.  Compiled with -ffp-contract=off.
+#include <cstdlib>
+
 #include "sc_internal.h"
 
 namespace sc {
@@ -386,6 +388,439 @@ __global__ __launch_bounds__(KT) void k_kmeans(
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Register-resident variant for n <= 1024 * NR (NR = 8 or 16) and k <= 8.
+// Thread t owns the NR CONTIGUOUS rows NR*t .. NR*t+NR-1, so
+//   * every column access is one 64-byte (NR = 8) vector load per lane, a wave reading
+//     4 KiB contiguous: each pass over the data streams from L2 at full line efficiency;
+//   * per-row state (closest distance, |x|^2, |e|, label) lives in registers for the
+//     whole kernel -- no global round trips between the phases;
+//   * the cumulative sum k-means++ samples from is a per-thread running sum in row
+//     order plus one block scan of the thread totals;
+//   * all k-means++ trials of a round, and all cluster sums of an update, share one pass.
+// Same arithmetic as k_kmeans (and as the reference); only the association of the long
+// sums differs.
+// ------------------------------------------------------------------------------------
+template <int NR>
+__device__ __forceinline__ void load_rows(const double* __restrict__ col, int r0, int n,
+                                          bool full, double (&v)[NR]) {
+  if (full) {
+#pragma unroll
+    for (int q = 0; q < NR / 2; ++q) {
+      const double2 d = *reinterpret_cast<const double2*>(col + r0 + 2 * q);
+      v[2 * q] = d.x;
+      v[2 * q + 1] = d.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) v[i] = (r0 + i < n) ? col[r0 + i] : 0.0;
+  }
+}
+
+template <int NR, int NT>
+__global__ __launch_bounds__(NT) void k_kmeans_fast(
+    const double* __restrict__ ET, int lde, int n, int k, int max_iter,
+    int first_center, int trials, const double* __restrict__ rnd,
+    double* __restrict__ cent_out, long long* __restrict__ labels64,
+    int* __restrict__ info) {
+  constexpr int KC = 8;  // k <= 8 on this path
+  constexpr int NW = NT / 64;  // waves
+  __shared__ double sm[NW * 8];
+  __shared__ double mean[KC];
+  __shared__ double cent[KC * KC];      // k x k, stride k
+  __shared__ double cnorm[KC];
+  __shared__ double candrow[8 * KC];    // candidate rows, stride k
+  __shared__ double candsq[8];
+  __shared__ double scan[NT];
+  __shared__ double pots[8];
+  __shared__ double rvals[8];
+  __shared__ int cand[8];
+  __shared__ int seeds[KC];
+  __shared__ double wsumv[NW * KC * KC];  // per-wave partial cluster sums
+  __shared__ int wcnt[NW * KC], wnz[NW * KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long t_start = wall_clock64();
+  const int r0 = NR * tid;
+  const bool full = r0 + NR <= n;
+  int nvalid = n - r0;
+  nvalid = nvalid < 0 ? 0 : (nvalid > NR ? NR : nvalid);
+
+  // block reduction of `cnt` doubles held by every thread (cnt <= 8): result in sm[0..cnt)
+  auto block_sum = [&](double* vals, int cnt) {
+    for (int q = 0; q < cnt; ++q) {
+      const double v = wsum(vals[q]);
+      if (lane == 0) sm[wave * 8 + q] = v;
+    }
+    __syncthreads();
+    if (tid < cnt) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += sm[w * 8 + tid];
+      pots[tid] = t;  // reuse `pots` as the broadcast slot
+    }
+    __syncthreads();
+  };
+
+  // ---- column means ---------------------------------------------------------------
+  {
+    double part[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      part[j] = 0.0;
+      if (j < k) {
+        double v[NR];
+        load_rows<NR>(ET + (size_t)j * lde, r0, n, full, v);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) part[j] += v[i];
+      }
+    }
+    block_sum(part, k);
+    if (tid < k) mean[tid] = pots[tid] / (double)n;
+    __syncthreads();
+  }
+  // ---- |x - mean|^2 and |e| per row -------------------------------------------------
+  double xsq[NR], closest[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) xsq[i] = 0.0;
+  for (int j = 0; j < k; ++j) {
+    double v[NR];
+    load_rows<NR>(ET + (size_t)j * lde, r0, n, full, v);
+    const double mj = mean[j];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const double x = v[i] - mj;
+      xsq[i] += x * x;
+    }
+  }
+  if (tid == 0) info[1] = (int)(wall_clock64() - t_start);
+
+  // ---- k-means++ ----------------------------------------------------------------------
+  if (tid == 0) seeds[0] = first_center;
+  if (tid < k) candrow[tid] = ET[(size_t)tid * lde + first_center] - mean[tid];
+  if (tid == 0) {
+    // |x_first - mean|^2 in the same association as the owner's xsq
+    double s2 = 0.0;
+    for (int j = 0; j < k; ++j) {
+      const double x = ET[(size_t)j * lde + first_center] - mean[j];
+      s2 += x * x;
+    }
+    candsq[0] = s2;
+  }
+  __syncthreads();
+  double pot;
+  {
+    double dot[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) dot[i] = 0.0;
+    for (int j = 0; j < k; ++j) {
+      double v[NR];
+      load_rows<NR>(ET + (size_t)j * lde, r0, n, full, v);
+      const double mj = mean[j], cj = candrow[j];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) dot[i] += cj * (v[i] - mj);
+    }
+    double part = 0.0;
+    const double csq = candsq[0];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      double d = -2.0 * dot[i];
+      d += csq;
+      d += xsq[i];
+      d = fmax(d, 0.0);
+      closest[i] = i < nvalid ? d : 0.0;
+      part += closest[i];
+    }
+    block_sum(&part, 1);
+    pot = pots[0];
+    __syncthreads();
+  }
+  int rpos = 0;
+  for (int c = 1; c < k; ++c) {
+    if (tid < trials) {
+      rvals[tid] = rnd[rpos + tid] * pot;
+      cand[tid] = n - 1;  // np.clip(candidate_ids, None, n - 1)
+    }
+    rpos += trials;
+    // cumulative sum in row order: running sum inside the thread + scan of thread totals
+    double mysum = 0.0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) mysum += closest[i];
+    {
+      double v = mysum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+      }
+      if (lane == 63) sm[wave] = v;
+      __syncthreads();
+      double off = 0.0;
+      for (int w = 0; w < wave; ++w) off += sm[w];
+      scan[tid] = v + off;
+    }
+    __syncthreads();
+    {
+      const double excl = tid == 0 ? 0.0 : scan[tid - 1];
+      const double incl = scan[tid];
+      for (int t = 0; t < trials; ++t) {
+        const double rv = rvals[t];
+        // searchsorted(cumsum, rv, 'left'): first index with cumsum >= rv
+        if (nvalid > 0 && (rv > excl || tid == 0) && rv <= incl) {
+          double run = excl;
+          int hit = r0 + nvalid - 1;
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            run += closest[i];
+            if (i < nvalid - 1 && run >= rv && hit == r0 + nvalid - 1) hit = r0 + i;
+          }
+          atomicMin(&cand[t], hit);
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < trials * k; e += NT) {
+      const int t = e / k, j = e - t * k;
+      candrow[t * k + j] = ET[(size_t)j * lde + cand[t]] - mean[j];
+    }
+    __syncthreads();
+    if (tid < trials) {
+      double s2 = 0.0;
+      for (int j = 0; j < k; ++j) s2 += candrow[tid * k + j] * candrow[tid * k + j];
+      candsq[tid] = s2;
+    }
+    __syncthreads();
+    // trials two at a time (register budget: 1024 threads -> 128 VGPRs each)
+    double best_pot = INFINITY;
+    int best_t = 0;
+    for (int t0 = 0; t0 < trials; t0 += 2) {
+      double dot[2][NR];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) dot[t][i] = 0.0;
+      for (int j = 0; j < k; ++j) {
+        double v[NR];
+        load_rows<NR>(ET + (size_t)j * lde, r0, n, full, v);
+        const double mj = mean[j];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const double cj = (t0 + t < trials) ? candrow[(t0 + t) * k + j] : 0.0;
+#pragma unroll
+          for (int i = 0; i < NR; ++i) dot[t][i] += cj * (v[i] - mj);
+        }
+      }
+      double part[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        part[t] = 0.0;
+        const double csq = (t0 + t < trials) ? candsq[t0 + t] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          double d = -2.0 * dot[t][i];
+          d += csq;
+          d += xsq[i];
+          d = fmax(d, 0.0);
+          d = fmin(closest[i], d);
+          part[t] += i < nvalid ? d : 0.0;
+        }
+      }
+      block_sum(part, 2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t0 + t < trials && pots[t] < best_pot) {  // np.argmin: first minimum
+          best_pot = pots[t];
+          best_t = t0 + t;
+        }
+      }
+      __syncthreads();
+    }
+    // closest <- min(closest, distance to the winning candidate): recomputed (one more
+    // pass) instead of keeping every trial's distances alive in registers
+    {
+      double dot[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) dot[i] = 0.0;
+      for (int j = 0; j < k; ++j) {
+        double v[NR];
+        load_rows<NR>(ET + (size_t)j * lde, r0, n, full, v);
+        const double mj = mean[j], cj = candrow[best_t * k + j];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) dot[i] += cj * (v[i] - mj);
+      }
+      const double csq = candsq[best_t];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        double d = -2.0 * dot[i];
+        d += csq;
+        d += xsq[i];
+        d = fmax(d, 0.0);
+        closest[i] = i < nvalid ? fmin(closest[i], d) : 0.0;
+      }
+    }
+    pot = best_pot;
+    if (tid == 0) seeds[c] = cand[best_t];
+    __syncthreads();
+  }
+  if (tid == 0) info[2] = (int)(wall_clock64() - t_start);
+
+  // shared: assignment of this thread's rows against `cent` (k x k).
+  //   euclid = true : argmin |c|^2 - 2 x.c on centred data (cnorm = |c|^2)
+  //   euclid = false: argmin 1 - clip(e.c / (|e| |c|))     (cnorm = |c|)
+  int label[NR];
+  double enorm[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) enorm[i] = 0.0;
+  auto assign = [&](bool euclid) -> double {
+    double dsum = 0.0;
+#pragma unroll
+    for (int h = 0; h < NR; h += 4) {
+      double dot[KC][4];
+#pragma unroll
+      for (int c2 = 0; c2 < KC; ++c2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dot[c2][i] = 0.0;
+      for (int j = 0; j < k; ++j) {
+        double v[NR];
+        load_rows<NR>(ET + (size_t)j * lde, r0, n, full, v);
+        const double mj = euclid ? mean[j] : 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < KC; ++c2) {
+          const double cj = c2 < k ? cent[c2 * k + j] : 0.0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dot[c2][i] += (v[h + i] - mj) * cj;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int best = 0;
+        double bd = INFINITY;
+#pragma unroll
+        for (int c2 = 0; c2 < KC; ++c2) {
+          if (c2 < k) {
+            double d;
+            if (euclid) {
+              d = cnorm[c2] - 2.0 * dot[c2][i];
+            } else {
+              double cosine = dot[c2][i] / (enorm[h + i] * cnorm[c2]);
+              if (fabs(cosine) > 1.0) cosine = copysign(1.0, cosine);
+              d = 1.0 - cosine;
+            }
+            if (d < bd) { bd = d; best = c2; }
+          }
+        }
+        label[h + i] = best;
+        if (h + i < nvalid) dsum += bd;
+      }
+    }
+    return dsum;
+  };
+  // shared: per-cluster means of the member rows, all clusters in ONE pass over the data
+  //   centred = true : Lloyd (mean of x - mean, + mean; empty cluster keeps its seed)
+  //   centred = false: cosine loop (`.any()` on the member indices)
+  auto update = [&](bool centred) {
+    int cnt[KC], nz[KC];
+#pragma unroll
+    for (int c2 = 0; c2 < KC; ++c2) {
+      cnt[c2] = 0;
+      nz[c2] = 0;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int hit = (i < nvalid) && (label[i] == c2);
+        cnt[c2] += hit;
+        nz[c2] += hit && (r0 + i > 0);
+      }
+      cnt[c2] = wsumi(cnt[c2]);
+      nz[c2] = wsumi(nz[c2]);
+      if (lane == 0) { wcnt[wave * KC + c2] = cnt[c2]; wnz[wave * KC + c2] = nz[c2]; }
+    }
+    for (int j = 0; j < k; ++j) {
+      double v[NR];
+      load_rows<NR>(ET + (size_t)j * lde, r0, n, full, v);
+      const double mj = centred ? mean[j] : 0.0;
+#pragma unroll
+      for (int c2 = 0; c2 < KC; ++c2) {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+          if (i < nvalid && label[i] == c2) a += v[i] - mj;
+        a = wsum(a);
+        if (lane == 0) wsumv[(wave * KC + c2) * KC + j] = a;
+      }
+    }
+    __syncthreads();
+    if (tid < k * k) {
+      const int c2 = tid / k, j = tid - c2 * k;
+      double tot = 0.0;
+      int count = 0, nzc = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        tot += wsumv[(w * KC + c2) * KC + j];
+        count += wcnt[w * KC + c2];
+        nzc += wnz[w * KC + c2];
+      }
+      if (centred) {
+        const double vv = count > 0 ? tot / (double)count : cent[c2 * k + j];
+        cent[c2 * k + j] = vv + mean[j];
+      } else if (nzc > 0) {
+        cent[c2 * k + j] = tot / (double)count;
+      }
+    }
+    __syncthreads();
+  };
+
+  // ---- one Euclidean Lloyd step on the centred data (max_iter = 1) -----------------------
+  for (int e = tid; e < k * k; e += NT) {
+    const int c2 = e / k, j = e - c2 * k;
+    cent[e] = ET[(size_t)j * lde + seeds[c2]] - mean[j];
+  }
+  __syncthreads();
+  if (tid < k) {
+    double s2 = 0.0;
+    for (int j = 0; j < k; ++j) s2 += cent[tid * k + j] * cent[tid * k + j];
+    cnorm[tid] = s2;
+  }
+  __syncthreads();
+  assign(true);
+  __syncthreads();  // every thread is done reading `cent` before update rewrites it
+  update(true);
+  if (tid == 0) info[3] = (int)(wall_clock64() - t_start);
+
+  // ---- CustomKMeans.predict, cosine (custom_distance_kmeans.py:118-141) ------------------
+  for (int j = 0; j < k; ++j) {
+    double v[NR];
+    load_rows<NR>(ET + (size_t)j * lde, r0, n, full, v);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) enorm[i] += v[i] * v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) enorm[i] = sqrt(enorm[i]);
+  double prev = 0.0;
+  int it = 0;
+  for (;; ++it) {
+    if (tid < k) {
+      double s2 = 0.0;
+      for (int j = 0; j < k; ++j) s2 += cent[tid * k + j] * cent[tid * k + j];
+      cnorm[tid] = sqrt(s2);
+    }
+    __syncthreads();
+    double part = assign(false);
+    block_sum(&part, 1);
+    const double mean_d = pots[0] / (double)n;
+    __syncthreads();
+    if ((mean_d <= prev && mean_d >= (1.0 - 0.001) * prev) || it == max_iter) break;
+    prev = mean_d;
+    update(false);
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (i < nvalid) labels64[r0 + i] = label[i];
+  for (int e = tid; e < k * k; e += NT) cent_out[e] = cent[e];
+  if (tid == 0) {
+    info[0] = it + 1;
+    info[4] = (int)(wall_clock64() - t_start);
+  }
+}
+
 void launch_row_renorm(hipStream_t s, double* ET, int lde, int n, int k) {
   hipLaunchKernelGGL(k_row_renorm, dim3((n + 255) / 256), dim3(256), 0, s, ET, lde, n,
                      k);
@@ -400,6 +835,18 @@ void launch_to_colmajor(hipStream_t s, const double* src, int n, int k, double* 
 void launch_kmeans(hipStream_t s, const double* ET, int lde, int n, int k,
                    int max_iter, int first_center, int trials,
                    const KmeansWorkspace& ws) {
+  if (k <= 8 && n <= 16 * 512 && trials <= 8 && !getenv("SC_KMEANS_GENERIC")) {
+    // register-resident fast path: 512 threads (256 VGPRs each), contiguous rows per thread
+    if (n <= 8 * 512)
+      hipLaunchKernelGGL((k_kmeans_fast<8, 512>), dim3(1), dim3(512), 0, s, ET, lde, n, k,
+                         max_iter, first_center, trials, ws.rnd, ws.centroids, ws.labels64,
+                         ws.info);
+    else
+      hipLaunchKernelGGL((k_kmeans_fast<16, 512>), dim3(1), dim3(512), 0, s, ET, lde, n, k,
+                         max_iter, first_center, trials, ws.rnd, ws.centroids, ws.labels64,
+                         ws.info);
+    return;
+  }
   hipLaunchKernelGGL(k_kmeans, dim3(1), dim3(KT), 0, s, ET, lde, n, k, max_iter,
                      first_center, trials, ws.Xc, ws.xsq, ws.closest, ws.cand,
                      ws.enorm, ws.rnd, ws.centroids, ws.labels32, ws.labels64,

@@ -29,11 +29,13 @@ struct sc_handle_s {
   // current problem
   int n = 0, d = 0, ldn = 0, ldx = 0;
   bool have_x = false, have_affinity = false;
+  bool have_cropval = false;  // cropval = CropDiagonal fill values of A0 (affinity GEMM epilogue)
   int n_vec = 0;          // eigenvector columns resident in E
   // matrices
   DevBuf X, Xn, A0, B1, B2;
   // n-vectors
   DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart, splitk, tilemap;
+  DevBuf cropval, statp;  // fused GEMM row statistics: result + per-tile partials
   int tilemap_nt = 0;     // tile-grid size the resident tilemap was built for
   DevBuf blurw;           // device copy of the blur weights
   // eigen workspace
@@ -110,6 +112,8 @@ static int ensure_matrices(sc_handle h, int n, int d) {
   SC_TRY(grow(h, h->splitk, gemm_splitk_workspace_bytes()));
   SC_TRY(grow(h, h->dvec, nv));
   SC_TRY(grow(h, h->cut, nv));
+  SC_TRY(grow(h, h->cropval, nv));
+  SC_TRY(grow(h, h->statp, (size_t)2 * n * gemm_tile_dim(n) * sizeof(double)));
   SC_TRY(grow(h, h->rmpart, (size_t)n * blur_tile_columns(n, 8) * sizeof(double)));
   SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
   return SC_OK;
@@ -235,7 +239,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -519,7 +523,7 @@ extern "C" int sc_set_embeddings(sc_handle h, const double* x, int n, int d) {
   h->d = d;
   h->ldn = round_up(n, 16);
   h->ldx = round_up(d, 16);
-  h->have_affinity = false;
+  h->have_affinity = h->have_cropval = false;
   h->n_vec = 0;
   SC_TRY(h2d_matrix(h, x, n, d, ptr<double>(h->X), h->ldx));
   SC_HIP(h, hipStreamSynchronize(h->stream));  // caller may reuse x immediately
@@ -534,11 +538,14 @@ extern "C" int sc_compute_affinity(sc_handle h) {
   SC_TRY(ensure_tilemap(h, h->n));
   launch_normalize_rows(h->stream, ptr<double>(h->X), h->ldx, h->n, h->d,
                         ptr<double>(h->Xn));
+  // CropDiagonal's fill value (max_{j != i} A_ij, >= 0) comes out of the GEMM epilogue
+  GemmRowStats rs{2, ptr<double>(h->statp), nullptr, ptr<double>(h->cropval), nullptr};
   launch_gemm_nt(h->stream, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx,
                  ptr<double>(h->A0), h->ldn, h->n, h->n, h->d, kEpiAffinity, true,
-                 ptr<double>(h->splitk), ptr<int2>(h->tilemap));
+                 ptr<double>(h->splitk), ptr<int2>(h->tilemap), &rs);
   SC_TRY(check_last(h, "affinity launch"));
   h->have_affinity = true;
+  h->have_cropval = true;
   h->n_vec = 0;
   return SC_OK;
 }
@@ -555,6 +562,7 @@ extern "C" int sc_set_affinity(sc_handle h, const double* a, int n) {
   SC_TRY(h2d_matrix(h, a, n, n, ptr<double>(h->A0), h->ldn));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   h->have_affinity = true;
+  h->have_cropval = false;
   return SC_OK;
 }
 
@@ -909,6 +917,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   const bool blur_fast = (cfg->blur_radius == 4 || cfg->blur_radius == 8) && n >= 128;
   const double* pending_diag = nullptr;
   bool have_partials = false;
+  bool have_row_stats = false;
   for (int i = 0; i < cfg->n_ops; ++i) {
     const int op = cfg->ops[i];
     const int next = i + 1 < cfg->n_ops ? cfg->ops[i + 1] : 0;
@@ -921,8 +930,12 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
       continue;
     }
     if (op == SC_OP_CROP_DIAGONAL && next == SC_OP_GAUSSIAN_BLUR && blur_fast) {
-      launch_crop_value(s, cur, n, ld, ptr<double>(h->dvec));
-      pending_diag = ptr<double>(h->dvec);
+      if (cur == ptr<double>(h->A0) && h->have_cropval) {
+        pending_diag = ptr<double>(h->cropval);
+      } else {
+        launch_crop_value(s, cur, n, ld, ptr<double>(h->dvec));
+        pending_diag = ptr<double>(h->dvec);
+      }
       have_partials = false;
       continue;  // symmetry unchanged; the blur applies the new diagonal on load
     }
@@ -961,6 +974,19 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
       symmetric = true;
       ++i;  // Symmetrize consumed
       continue;
+    } else if (op == SC_OP_DIFFUSE) {
+      // when Diffuse is the last materialised matrix its row max / row sum (for the
+      // RowWiseNormalize fold and the Laplacian scaling) come out of the GEMM epilogue
+      const bool last = i == cfg->n_ops - 1 ||
+                        (i == cfg->n_ops - 2 && next == SC_OP_ROW_WISE_NORMALIZE);
+      GemmRowStats rs{1, ptr<double>(h->statp), ptr<double>(h->statp) + (size_t)n * gemm_tile_dim(n),
+                      ptr<double>(h->rowmax), ptr<double>(h->rowsum)};
+      SC_TRY(ensure_tilemap(h, n));
+      launch_gemm_nt(s, cur, ld, cur, ld, out, ld, n, n, n, kEpiNone, true,
+                     ptr<double>(h->splitk), ptr<int2>(h->tilemap), last ? &rs : nullptr);
+      SC_TRY(check_last(h, "diffuse launch"));
+      have_row_stats = last;
+      have_partials = false;
     } else {
       SC_TRY(run_refine_op(h, op, cfg, cur, out, n, ld));
       have_partials = false;
@@ -993,7 +1019,8 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
                 "to a symmetric one (e.g. RowWiseThreshold without a later Symmetrize/"
                 "Diffuse); the general (dgeev-class) eigenproblem is not on the device path");
   // ---- scaling vectors (RowWiseNormalize fold + Laplacian)
-  launch_row_stats(s, cur, n, ld, ptr<double>(h->rowmax), ptr<double>(h->rowsum));
+  if (!have_row_stats)
+    launch_row_stats(s, cur, n, ld, ptr<double>(h->rowmax), ptr<double>(h->rowsum));
   launch_scaling_vectors(s, ptr<double>(h->rowmax), ptr<double>(h->rowsum), n,
                          cfg->laplacian_type, folded_rownorm ? 1 : 0, ptr<double>(h->cvec),
                          ptr<double>(h->pvec), ptr<double>(h->tvec));
@@ -1213,7 +1240,7 @@ extern "C" int sc_stage_refine(sc_handle h, int op, const sc_config* cfg, const 
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
   const int ld = round_up(n, 16);
-  h->have_affinity = false;
+  h->have_affinity = h->have_cropval = false;
   h->have_x = false;
   h->n_vec = 0;
   SC_TRY(h2d_matrix(h, in, n, n, ptr<double>(h->B1), ld));
@@ -1230,7 +1257,7 @@ extern "C" int sc_stage_laplacian(sc_handle h, int laplacian_type, const double*
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
   const int ld = round_up(n, 16);
-  h->have_affinity = false;
+  h->have_affinity = h->have_cropval = false;
   h->have_x = false;
   h->n_vec = 0;
   SC_TRY(h2d_matrix(h, in, n, n, ptr<double>(h->B1), ld));
@@ -1265,7 +1292,7 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   const int ld = round_up(n, 16);
   h->n = n;
   h->ldn = ld;
-  h->have_affinity = false;
+  h->have_affinity = h->have_cropval = false;
   h->have_x = false;
   SC_TRY(h2d_matrix(h, m, n, n, ptr<double>(h->B1), ld));
   // Op = +M (descend) or -M (ascend): c = 1, p = 0, t = 1; the sign is folded by

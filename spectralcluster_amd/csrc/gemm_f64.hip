@@ -54,6 +54,125 @@ __device__ __forceinline__ void tile_coords(int id, int ntiles_m, int ntiles_n,
   }
 }
 
+// Optional fused row statistics of the (symmetric) result, so the next stage does not
+// have to re-read the n x n matrix:
+//   mode 1 (Diffuse)  : per row  max_j C_ij  and  sum_j C_ij
+//   mode 2 (affinity) : per row  max_{j != i} C_ij      (CropDiagonal's value, pre-clamp)
+// A tile (ti, tj) contributes, for each of its 128 rows, the max / sum over its 128 columns
+// into slot tj of that row, and -- being the mirror of tile (tj, ti) -- for each of its
+// columns the max / sum over its rows into slot ti of row `col`.  Every (row, slot) of the
+// n x ntiles partial arrays is written exactly once; k_gemm_stats_reduce finishes in a fixed
+// order (deterministic).  `scratch` is >= 1024 doubles of LDS (the operand tiles are dead).
+struct GemmStats {
+  double* pmax;   // n x ntiles
+  double* psum;   // n x ntiles (mode 1 only)
+  int mode;       // 0 = off
+};
+
+template <int EPI, bool SYM>
+__device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti, int tj,
+                                               int ntiles, int M, int N, int tid,
+                                               const GemmStats& st, double* scratch) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  double* rmax = scratch;            // [2][128]  (wc, row)
+  double* rsum = scratch + 256;      // [2][128]
+  double* cmax = scratch + 512;      // [2][128]  (wr, col)
+  double* csum = scratch + 768;      // [2][128]
+  const bool diag_tile = ti == tj;
+  // --- per-row partials over this wave's 64 columns
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = wr * 64 + m * 16 + lg + 4 * r;
+      double mx = -INFINITY, sm = 0.0;
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) {
+        const int lcol = wc * 64 + nn * 16 + li;
+        const bool inside = tj * BN + lcol < N;
+        const bool skip = st.mode == 2 && diag_tile && lrow == lcol;
+        double x = acc[m][nn][r];
+        if (EPI == kEpiAffinity) x = __builtin_fma(x, 0.5, 0.5);
+        if (inside && !skip) mx = fmax(mx, x);
+        if (inside) sm += x;
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        mx = fmax(mx, __shfl_xor(mx, o));
+        sm += __shfl_xor(sm, o);
+      }
+      if (li == 0) {
+        rmax[wc * 128 + lrow] = mx;
+        rsum[wc * 128 + lrow] = sm;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the live range of each reduction short
+    }
+  }
+  // --- per-column partials over this wave's 64 rows (the mirror tile's rows)
+  if (SYM && !diag_tile) {
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+      const int lcol = wc * 64 + nn * 16 + li;
+      double mx = -INFINITY, sm = 0.0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lrow = wr * 64 + m * 16 + lg + 4 * r;
+          double x = acc[m][nn][r];
+          if (EPI == kEpiAffinity) x = __builtin_fma(x, 0.5, 0.5);
+          if (ti * BM + lrow < M) {
+            mx = fmax(mx, x);
+            sm += x;
+          }
+        }
+      mx = fmax(mx, __shfl_xor(mx, 16));
+      sm += __shfl_xor(sm, 16);
+      mx = fmax(mx, __shfl_xor(mx, 32));
+      sm += __shfl_xor(sm, 32);
+      if (lg == 0) {
+        cmax[wr * 128 + lcol] = mx;
+        csum[wr * 128 + lcol] = sm;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int row = ti * BM + tid;
+    if (row < M) {
+      st.pmax[(size_t)row * ntiles + tj] = fmax(rmax[tid], rmax[128 + tid]);
+      if (st.mode == 1) st.psum[(size_t)row * ntiles + tj] = rsum[tid] + rsum[128 + tid];
+    }
+  } else if (SYM && !diag_tile) {
+    const int c = tid - 128;
+    const int row = tj * BN + c;
+    if (row < N) {
+      st.pmax[(size_t)row * ntiles + ti] = fmax(cmax[c], cmax[128 + c]);
+      if (st.mode == 1) st.psum[(size_t)row * ntiles + ti] = csum[c] + csum[128 + c];
+    }
+  }
+}
+
+// rowmax[i] / rowsum[i] from the per-tile partials (fixed slot order)
+__global__ void k_gemm_stats_reduce(const double* __restrict__ pmax,
+                                    const double* __restrict__ psum, int n, int ntiles,
+                                    int mode, double* __restrict__ rowmax,
+                                    double* __restrict__ rowsum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double mx = -INFINITY, sm = 0.0;
+  for (int t = 0; t < ntiles; ++t) {
+    mx = fmax(mx, pmax[(size_t)i * ntiles + t]);
+    if (mode == 1) sm += psum[(size_t)i * ntiles + t];
+  }
+  if (mode == 2) mx = fmax(mx, 0.0);  // CropDiagonal: the zero-filled diagonal takes part
+  rowmax[i] = mx;
+  if (mode == 1) rowsum[i] = sm;
+}
+
 // One workgroup = one 128x128 output tile over the K range of its split:
 //   tile  = tile_offset + blockIdx.x / ksplit,  chunk = blockIdx.x % ksplit.
 // ksplit == 1: full K, epilogue + store to C (and the mirror tile when SYM).
@@ -70,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  int tile_offset, int ksplit,
                                                  double* __restrict__ partial,
                                                  const int2* __restrict__ tilemap,
-                                                 int xcd_chunk) {
+                                                 int xcd_chunk, GemmStats stats) {
   __shared__ __attribute__((aligned(16))) double As[2][BM * BK];
   __shared__ __attribute__((aligned(16))) double Bs[2][BN * BK];
 
@@ -221,6 +340,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     return;
   }
   const bool mirror = SYM && (ti != tj);
+  if (stats.mode != 0) {
+    __syncthreads();  // operand tiles are dead: their LDS serves the reductions
+    tile_row_stats<EPI, SYM>(acc, ti, tj, ntiles_n, M, N, tid, stats, &As[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -286,6 +410,55 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const double* __restrict__ 
   }
 }
 
+// Row statistics for the split-K tail tiles, read back from C once k_gemm_reduce has
+// written them (they are L2-hot).  blockIdx.y = 0: rows of tile (ti, tj) -> slot tj;
+// blockIdx.y = 1 (SYM): rows of the mirror tile (tj, ti) -> slot ti.
+template <bool SYM>
+__global__ __launch_bounds__(256) void k_gemm_tail_stats(const double* __restrict__ C, int ldc,
+                                                         int M, int N, int ntiles_m,
+                                                         int ntiles_n, int tile_base,
+                                                         const int2* __restrict__ tilemap,
+                                                         GemmStats st) {
+  int ti, tj;
+  if (tilemap != nullptr) {
+    const int2 t = tilemap[tile_base + blockIdx.x];
+    ti = t.x;
+    tj = t.y;
+  } else {
+    tile_coords<SYM>(tile_base + blockIdx.x, ntiles_m, ntiles_n, &ti, &tj);
+  }
+  if (blockIdx.y == 1) {
+    if (!SYM || ti == tj) return;
+    const int t = ti;
+    ti = tj;
+    tj = t;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int lr = wave; lr < BM; lr += 4) {
+    const int row = ti * BM + lr;
+    if (row >= M) break;
+    double mx = -INFINITY, sm = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = tj * BN + lane + 64 * h;
+      if (col < N) {
+        const double x = C[(size_t)row * ldc + col];
+        if (!(st.mode == 2 && row == col)) mx = fmax(mx, x);
+        sm += x;
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      mx = fmax(mx, __shfl_xor(mx, o));
+      sm += __shfl_xor(sm, o);
+    }
+    if (lane == 0) {
+      st.pmax[(size_t)row * ntiles_n + tj] = mx;
+      if (st.mode == 1) st.psum[(size_t)row * ntiles_n + tj] = sm;
+    }
+  }
+}
+
 // co-resident k_gemm_nt workgroups on the current device (occupancy x CUs)
 int gemm_resident_slots() {
   static int slots_dev[16] = {0};
@@ -310,7 +483,14 @@ size_t gemm_splitk_workspace_bytes() {
 template <int EPI, bool SYM>
 static void launch_variant(hipStream_t s, const double* A, int lda, const double* B,
                            int ldb, double* C, int ldc, int M, int N, int K,
-                           double* splitk_ws, const int2* tilemap) {
+                           double* splitk_ws, const int2* tilemap, const GemmRowStats* rs) {
+  GemmStats stats{nullptr, nullptr, 0};
+  if (rs != nullptr && rs->mode != 0) {
+    stats.pmax = rs->partial_max;
+    stats.psum = rs->partial_sum;
+    stats.mode = rs->mode;
+  }
+  const GemmStats no_stats{nullptr, nullptr, 0};
   const int tm = (M + BM - 1) / BM;
   const int tn = (N + BN - 1) / BN;
   const int tiles = SYM ? tm * (tm + 1) / 2 : tm * tn;
@@ -333,14 +513,22 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
   if (full > 0) {
     const int xcd_chunk = (tilemap != nullptr && full % 8 == 0 && full >= 512) ? full / 8 : 0;
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full), dim3(256), 0, s, A, lda, B,
-                       ldb, C, ldc, M, N, K, tm, tn, 0, 1, nullptr, tilemap, xcd_chunk);
+                       ldb, C, ldc, M, N, K, tm, tn, 0, 1, nullptr, tilemap, xcd_chunk,
+                       stats);
   }
   if (rem > 0) {
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(rem * ksplit), dim3(256), 0, s, A, lda,
-                       B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, tilemap, 0);
+                       B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, tilemap, 0,
+                       no_stats);
     hipLaunchKernelGGL((k_gemm_reduce<EPI, SYM>), dim3(rem, 16), dim3(256), 0, s, g_partial,
                        C, ldc, M, N, tm, tn, full, ksplit, tilemap);
+    if (stats.mode != 0)
+      hipLaunchKernelGGL((k_gemm_tail_stats<SYM>), dim3(rem, SYM ? 2 : 1), dim3(256), 0, s, C,
+                         ldc, M, N, tm, tn, full, tilemap, stats);
   }
+  if (stats.mode != 0)
+    hipLaunchKernelGGL(k_gemm_stats_reduce, dim3((M + 255) / 256), dim3(256), 0, s, stats.pmax,
+                       stats.psum, M, tn, stats.mode, rs->rowmax, rs->rowsum);
 }
 
 // Upper-triangle tiles (ti <= tj) of an nt x nt tile grid in patch order: 8 x 8-tile
@@ -359,18 +547,18 @@ int gemm_tile_dim(int n) { return (n + BM - 1) / BM; }
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
                     int epilogue, bool symmetric, double* splitk_ws,
-                    const int2* tilemap) {
+                    const int2* tilemap, const GemmRowStats* rs) {
   if (M <= 0 || N <= 0) return;
   if (symmetric) {
     if (epilogue == kEpiAffinity)
-      launch_variant<kEpiAffinity, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap);
+      launch_variant<kEpiAffinity, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap, rs);
     else
-      launch_variant<kEpiNone, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap);
+      launch_variant<kEpiNone, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap, rs);
   } else {
     if (epilogue == kEpiAffinity)
-      launch_variant<kEpiAffinity, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap);
+      launch_variant<kEpiAffinity, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap, rs);
     else
-      launch_variant<kEpiNone, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap);
+      launch_variant<kEpiNone, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap, rs);
   }
 }
 

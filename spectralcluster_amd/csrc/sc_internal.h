@@ -30,10 +30,20 @@ enum { kEpiNone = 0, kEpiAffinity = 1 };
 // `symmetric` is set B must alias A and only tile pairs i<=j are computed; the
 // mirror tile is written transposed, so C is exactly symmetric.
 // `splitk_ws`: gemm_splitk_workspace_bytes() of scratch owned by the caller (per handle).
+// `rs` (optional): row statistics of C fused into the epilogue -- mode 1: rowmax / rowsum,
+// mode 2: max over j != i clamped at 0 (CropDiagonal's fill value) in rowmax.  The partial
+// arrays hold M x gemm_tile_dim(N) doubles each.
+struct GemmRowStats {
+  int mode;
+  double* partial_max;
+  double* partial_sum;
+  double* rowmax;
+  double* rowsum;
+};
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
                     int epilogue, bool symmetric, double* splitk_ws,
-                    const int2* tilemap);
+                    const int2* tilemap, const GemmRowStats* rs = nullptr);
 // patch-ordered (ti, tj) list of the upper triangle, for `tilemap` (symmetric launches)
 void gemm_build_sym_tilemap(int nt, std::vector<int2>* out);
 int gemm_tile_dim(int n);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 1
+#define SC_ABI_VERSION 2
 #define SC_MAX_OPS 16
 #define SC_MAX_BLUR_RADIUS 32
 #define SC_MAX_EIG 128 /* max eigenvalues reported in sc_diag */
@@ -63,6 +63,13 @@ enum {
   SC_LAPLACIAN_RANDOM_WALK = 3,
   SC_LAPLACIAN_GRAPH_CUT = 4
 };
+/* constraint.py:10-16 ConstraintName (0 = constraint_options None), :19-22 IntegrationType */
+enum {
+  SC_CONSTRAINT_NONE = 0,
+  SC_CONSTRAINT_AFFINITY_INTEGRATION = 1,
+  SC_CONSTRAINT_PROPAGATION = 2
+};
+enum { SC_INTEGRATION_MAX = 1, SC_INTEGRATION_AVERAGE = 2 };
 /* utils.py:10-17 EigenGapType */
 enum { SC_EIGENGAP_RATIO = 1, SC_EIGENGAP_NORMALIZED_DIFF = 2 };
 
@@ -111,7 +118,13 @@ typedef struct sc_config {
   double eig_vector_tol;         /* residual tol, relative to ||M||, on the
                                     eigenvectors handed to k-means (1e-10) */
   int32_t eig_max_cycles;        /* restart cycles before NOT_CONVERGED (40) */
-  int32_t reserved[5];
+  /* ConstraintOptions (constraint.py:26-48); used only while a constraint matrix
+   * is resident (sc_set_constraint), like constraint_matrix=None in the reference */
+  int32_t constraint_name;       /* SC_CONSTRAINT_* */
+  int32_t constraint_before_refinement; /* apply_before_refinement */
+  int32_t integration_type;      /* SC_INTEGRATION_* */
+  double constraint_alpha;       /* constraint_propagation_alpha (0.6) */
+  int32_t reserved[6];
 } sc_config;
 
 typedef struct sc_diag {
@@ -135,6 +148,8 @@ typedef struct sc_diag {
 
 /* ---- library / device ---------------------------------------------------- */
 int sc_abi_version(void);
+/* sizeof(sc_config) / sizeof(sc_diag) as compiled, so a binding can verify its mirror */
+int sc_struct_sizes(int* config_bytes, int* diag_bytes);
 /* number of visible HIP devices (0 if none / runtime unavailable) */
 int sc_device_count(void);
 /* copies the device name (e.g. "AMD Instinct MI355X") and gcnArchName */
@@ -189,6 +204,23 @@ int sc_get_eigenvectors(sc_handle h, double* out, int n, int ncols);
  */
 int sc_cluster(sc_handle h, const sc_config* cfg, int n_clusters,
                int64_t* labels, sc_diag* diag);
+/*
+ * Constraints (constraint.py:95-164; spectral_clusterer.py:137-142, 259-264).
+ * sc_set_constraint uploads the (n, n) constraint matrix (it stays resident until
+ * sc_clear_constraint; exact symmetry is detected on the device).  While one is
+ * resident and cfg->constraint_name != 0:
+ *   - apply_before_refinement: sc_predict / sc_run_resident adjust the affinity right
+ *     after computing it; on the split path call sc_apply_constraint once after
+ *     sc_compute_affinity / sc_set_affinity (it rewrites the resident affinity);
+ *   - otherwise sc_eig_ncluster adjusts the refined matrix (each call).
+ * ConstraintPropagation's (I - alpha A_norm)^-1 is evaluated as the Neumann product
+ * prod_j (I + (alpha A_norm)^(2^j)) with fp64 MFMA GEMMs, which needs |alpha| < 1 and
+ * a non-negative affinity (spectral radius of A_norm <= 1) -- both hold for the
+ * reference's cosine affinity and its 0.4 / 0.6 presets.
+ */
+int sc_set_constraint(sc_handle h, const double* constraint_matrix, int n);
+int sc_clear_constraint(sc_handle h);
+int sc_apply_constraint(sc_handle h, const sc_config* cfg);
 /* affinity + eig_ncluster + cluster on the resident embeddings (no H2D of X) */
 int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* labels,
                     sc_diag* diag);
@@ -206,6 +238,10 @@ int sc_stage_affinity(sc_handle h, const double* x, int n, int d, double* out);
  * options are read from cfg. */
 int sc_stage_refine(sc_handle h, int op, const sc_config* cfg, const double* in,
                     int n, double* out);
+/* ConstraintOperation.adjust_affinity (constraint.py:106-118, 138-164); the operator
+ * and its options are read from cfg.  Any square affinity / constraint matrix. */
+int sc_stage_constraint(sc_handle h, const sc_config* cfg, const double* affinity,
+                        const double* constraint_matrix, int n, double* out);
 /* laplacian.compute_laplacian (laplacian.py:24-60) */
 int sc_stage_laplacian(sc_handle h, int laplacian_type, const double* in, int n,
                        double* out);

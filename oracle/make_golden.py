@@ -3,7 +3,7 @@
 Run in the build container only (needs /root/reference, which does not exist
 on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints]
 
 `--large` additionally runs the two n=8192 configurations (about 150-160 s of
 CPU each).  Inputs are regenerated from seeds by `spectral_oracle.blobs`; only
@@ -11,6 +11,7 @@ small outputs are stored (consumed eigenvalues, cluster counts, labels), plus
 full per-stage matrices for the tiny cases.
 """
 
+import copy
 import os
 import sys
 import time
@@ -25,6 +26,7 @@ sys.path.insert(0, HERE)
 import spectral_oracle as so  # noqa: E402
 from spectralcluster import autotune as ref_autotune  # noqa: E402
 from spectralcluster import configs as ref_configs  # noqa: E402
+from spectralcluster import constraint as ref_constraint  # noqa: E402
 from spectralcluster import custom_distance_kmeans as ref_kmeans  # noqa: E402
 from spectralcluster import laplacian as ref_laplacian  # noqa: E402
 from spectralcluster import refinement as ref_refinement  # noqa: E402
@@ -127,9 +129,92 @@ def save(name, **arrays):
   print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 
 
+def constraint_goldens():
+  """7. Constraint operators (N3): per-op known answers + constrained predict()."""
+  rng = np.random.default_rng(41)
+  x40 = so.blobs(40, 8, 3, 41)
+  a_sym = ref_utils.compute_affinity_matrix(x40)
+  a_gen = rng.random((40, 40))                     # non-symmetric "affinity"
+  q_sym = np.zeros((40, 40))
+  for i, j, v in zip(rng.integers(0, 40, 60), rng.integers(0, 40, 60),
+                     rng.choice([-1.0, 1.0], 60)):
+    q_sym[i, j] = q_sym[j, i] = v
+  q_gen = rng.choice([-1.0, 0.0, 0.0, 1.0], size=(40, 40))
+  ops = {"x40": x40, "a_sym": a_sym, "a_gen": a_gen, "q_sym": q_sym, "q_gen": q_gen}
+  for aname, a in (("sym", a_sym), ("gen", a_gen)):
+    for qname, q in (("sym", q_sym), ("gen", q_gen)):
+      tag = "a%s_q%s" % (aname, qname)
+      ops["integ_max_" + tag] = ref_constraint.AffinityIntegration(
+          ref_constraint.IntegrationType.Max).adjust_affinity(a, q)
+      ops["integ_avg_" + tag] = ref_constraint.AffinityIntegration(
+          ref_constraint.IntegrationType.Average).adjust_affinity(a, q)
+      for alpha in (0.4, 0.6, 0.9):
+        ops["cp_%02d_%s" % (round(alpha * 10), tag)] = (
+            ref_constraint.ConstraintPropagation(alpha).adjust_affinity(a, q))
+  scores = [0, 0, 14.308253288269043, 0.12095779925584793, 0, 3.5, 0.0, 1.0, 1.0001]
+  ops["turn_scores"] = np.array(scores)
+  ops["turn_matrix"] = ref_constraint.ConstraintMatrix(scores, 1).compute_diagonals()
+  ops["turn_matrix_t3"] = ref_constraint.ConstraintMatrix(scores, 3).compute_diagonals()
+  save("constraint_ops_n40.npz", **ops)
+
+  # Turn-to-Diarize preset end to end (constraint propagation before refinement +
+  # AutoTune), on synthetic conversations with speaker-turn scores.
+  for n, d, k, seed in ((120, 16, 3, 7), (300, 32, 4, 11), (700, 64, 5, 13)):
+    x, truth, sc = so.turn_blobs(n, d, k, seed)
+    q = ref_constraint.ConstraintMatrix(list(sc), threshold=1).compute_diagonals()
+    # the preset singleton narrows its own AutoTune range on every call
+    # (autotune.py:126-131), so every run below starts from a pristine copy
+    pristine = copy.deepcopy(ref_configs.turntodiarize_clusterer)
+    clusterer = copy.deepcopy(pristine)
+    a = ref_utils.compute_affinity_matrix(x)
+    adj = clusterer.constraint_options.constraint_operator.adjust_affinity(a, q)
+    grid = np.array(clusterer.autotune.get_percentile_range())
+    ratios, ks = [], []
+    for p in grid:
+      clusterer.refinement_options.p_percentile = p
+      _, kk, delta = clusterer._compute_eigenvectors_ncluster(adj, q)
+      ratios.append(np.sqrt(1 - p) / delta)
+      ks.append(kk)
+    labels = copy.deepcopy(pristine).predict(x, q)
+    unconstrained = copy.deepcopy(pristine).predict(x)
+    save("turntodiarize_n%d.npz" % n, n=n, d=d, k=k, seed=seed, truth=truth, scores=sc,
+         grid=grid, ratios=np.array(ratios), n_clusters=np.array(ks), labels=labels,
+         labels_unconstrained=unconstrained,
+         adjusted_checksum=np.array([adj.sum(), np.abs(adj).max(), adj[0, 1], adj[n // 2, n // 3]]))
+
+  # AffinityIntegration after refinement (the reference's own 6x2 test shape,
+  # tests/spectral_clusterer_test.py:243-286) on a larger conversation.
+  x, truth, sc = so.turn_blobs(200, 16, 3, 17)
+  q = ref_constraint.ConstraintMatrix(list(sc), threshold=1).compute_diagonals()
+  q = np.maximum(q, 0) + np.eye(200)  # must-links only, ones on the diagonal
+  out = {}
+  for tag, kind in (("max", ref_constraint.IntegrationType.Max),
+                    ("avg", ref_constraint.IntegrationType.Average)):
+    opts = ref_refinement.RefinementOptions(
+        p_percentile=0.9, thresholding_type=ref_refinement.ThresholdType.Percentile,
+        thresholding_with_binarization=True, thresholding_preserve_diagonal=True,
+        symmetrize_type=ref_refinement.SymmetrizeType.Average,
+        refinement_sequence=ref_configs.TURNTODIARIZE_REFINEMENT_SEQUENCE)
+    clusterer = ref_sc.SpectralClusterer(
+        max_clusters=6, refinement_options=opts,
+        constraint_options=ref_constraint.ConstraintOptions(
+            constraint_name=ref_constraint.ConstraintName.AffinityIntegration,
+            apply_before_refinement=False, integration_type=kind),
+        laplacian_type=LAP[4], row_wise_renorm=True)
+    out["labels_" + tag] = clusterer.predict(x, q)
+    v, kk, delta = clusterer._compute_eigenvectors_ncluster(
+        ref_utils.compute_affinity_matrix(x), q)
+    out["n_clusters_" + tag] = np.int64(kk)
+    out["max_delta_" + tag] = np.float64(delta)
+  save("integration_n200.npz", truth=truth, scores=sc, q=q, **out)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
+  if "--constraints" in sys.argv:  # only section 7
+    constraint_goldens()
+    return
 
   # 1. The 6x2 toy of the reference tests, sigma=0, full stage dump, all
   #    Laplacian types (max_clusters None: every eigenvalue is consumed).
@@ -209,6 +294,8 @@ def main():
   save("autotune_n512.npz", grid=grid, ratios=np.array(ratios),
        n_clusters=np.array(ks), labels=labels,
        best_p=np.float64(grid[int(np.argmin(ratios))]))
+
+  constraint_goldens()
 
   if large:
     for c in [(8192, 256, 8, 0, 4, 20), (8192, 256, 4, 1, 0, 7)]:

@@ -7,6 +7,7 @@ for everything that touches the hot path.
 from spectralcluster_amd import _lib
 from spectralcluster_amd import autotune
 from spectralcluster_amd import configs
+from spectralcluster_amd import constraint
 from spectralcluster_amd import custom_distance_kmeans
 from spectralcluster_amd import laplacian
 from spectralcluster_amd import refinement
@@ -15,6 +16,10 @@ from spectralcluster_amd import utils
 
 AutoTune = autotune.AutoTune
 AutoTuneProxy = autotune.AutoTuneProxy
+ConstraintOptions = constraint.ConstraintOptions
+ConstraintName = constraint.ConstraintName
+IntegrationType = constraint.IntegrationType
+ConstraintMatrix = constraint.ConstraintMatrix
 LaplacianType = laplacian.LaplacianType
 RefinementName = refinement.RefinementName
 RefinementOptions = refinement.RefinementOptions

@@ -44,6 +44,9 @@ class EigenSolverNotConverged(RuntimeError):
   """The block-Lanczos eigensolver did not reach its tolerance."""
 
 
+SC_ABI_VERSION = 2
+
+
 class ScConfig(ctypes.Structure):
   """Mirror of `sc_config`."""
   _fields_ = [
@@ -67,7 +70,11 @@ class ScConfig(ctypes.Structure):
       ("eig_value_tol", ctypes.c_double),
       ("eig_vector_tol", ctypes.c_double),
       ("eig_max_cycles", ctypes.c_int32),
-      ("reserved", ctypes.c_int32 * 5),
+      ("constraint_name", ctypes.c_int32),
+      ("constraint_before_refinement", ctypes.c_int32),
+      ("integration_type", ctypes.c_int32),
+      ("constraint_alpha", ctypes.c_double),
+      ("reserved", ctypes.c_int32 * 6),
   ]
 
 
@@ -107,6 +114,8 @@ _handle_t = ctypes.c_void_p
 # name -> (restype, argtypes); every symbol include/spectralcluster_amd.h declares
 PROTOTYPES = {
     "sc_abi_version": (ctypes.c_int, []),
+    "sc_struct_sizes": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int),
+                                       ctypes.POINTER(ctypes.c_int)]),
     "sc_device_count": (ctypes.c_int, []),
     "sc_device_info": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                       ctypes.c_char_p, ctypes.c_int, _c_int_p,
@@ -134,6 +143,11 @@ PROTOTYPES = {
                                            ctypes.c_int]),
     "sc_cluster": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), ctypes.c_int,
                                   _c_int64_p, ctypes.POINTER(ScDiag)]),
+    "sc_set_constraint": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int]),
+    "sc_clear_constraint": (ctypes.c_int, [_handle_t]),
+    "sc_apply_constraint": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig)]),
+    "sc_stage_constraint": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), _c_double_p,
+                                           _c_double_p, ctypes.c_int, _c_double_p]),
     "sc_run_resident": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig),
                                        _c_int64_p, ctypes.POINTER(ScDiag)]),
     "sc_predict_batch": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),
@@ -192,8 +206,13 @@ def load() -> ctypes.CDLL:
       fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
       fn.restype = restype
       fn.argtypes = argtypes
-    if lib.sc_abi_version() != 1:
-      raise DeviceLibraryError("ABI version mismatch in %s" % path)
+    if lib.sc_abi_version() != SC_ABI_VERSION:
+      raise DeviceLibraryError("ABI version mismatch in %s (rebuild it)" % path)
+    cfg_bytes, diag_bytes = ctypes.c_int(0), ctypes.c_int(0)
+    lib.sc_struct_sizes(ctypes.byref(cfg_bytes), ctypes.byref(diag_bytes))
+    if (cfg_bytes.value != ctypes.sizeof(ScConfig) or
+        diag_bytes.value != ctypes.sizeof(ScDiag)):
+      raise DeviceLibraryError("sc_config / sc_diag layout mismatch in %s" % path)
     _lib = lib
     return lib
 

@@ -36,6 +36,11 @@ struct sc_handle_s {
   // n-vectors
   DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart, splitk, tilemap;
   DevBuf cropval, statp;  // fused GEMM row statistics: result + per-tile partials
+  // constraints: Cq (resident constraint matrix), Neumann-product work matrices, flag word
+  DevBuf Cq, cp[5], symflag;
+  bool have_constraint = false, constraint_symmetric = false, constraint_applied = false;
+  bool affinity_symmetric = true;
+  int qn = 0;
   int tilemap_nt = 0;     // tile-grid size the resident tilemap was built for
   DevBuf blurw;           // device copy of the blur weights
   // eigen workspace
@@ -185,6 +190,11 @@ static int check_last(sc_handle h, const char* what) {
 // library / device
 // ------------------------------------------------------------------------------
 extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
+extern "C" int sc_struct_sizes(int* config_bytes, int* diag_bytes) {
+  if (config_bytes) *config_bytes = (int)sizeof(sc_config);
+  if (diag_bytes) *diag_bytes = (int)sizeof(sc_diag);
+  return SC_OK;
+}
 
 extern "C" int sc_device_count(void) {
   int c = 0;
@@ -239,7 +249,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -318,6 +328,9 @@ extern "C" int sc_config_default(sc_config* cfg) {
   cfg->stop_eigenvalue = 1e-2;
   cfg->eigengap_type = SC_EIGENGAP_RATIO;
   cfg->max_iter = 300;
+  cfg->constraint_name = SC_CONSTRAINT_NONE;
+  cfg->integration_type = SC_INTEGRATION_MAX;
+  cfg->constraint_alpha = 0.6;  // constraint.py:41
   return SC_OK;
 }
 
@@ -512,6 +525,169 @@ static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double
 }
 
 // ------------------------------------------------------------------------------
+// N3: constraints (reference constraint.py:95-164)
+// ------------------------------------------------------------------------------
+// exact symmetry of a resident (n, ld) matrix; one 4-byte D2H + stream sync
+static int device_is_symmetric(sc_handle h, const double* m, int n, int ld, bool* out) {
+  SC_TRY(grow(h, h->symflag, 16));
+  const int one = 1;
+  int result = 0;
+  SC_HIP(h, hipMemcpyAsync(h->symflag.p, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  launch_symmetry_flag(h->stream, m, n, ld, ptr<int>(h->symflag));
+  SC_HIP(h, hipMemcpyAsync(&result, h->symflag.p, sizeof(int), hipMemcpyDeviceToHost,
+                           h->stream));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  *out = result != 0;
+  return SC_OK;
+}
+
+// ConstraintPropagation.adjust_affinity (constraint.py:138-164):  out may alias a.
+//   P = alpha D^-1/2 A D^-1/2,  T = (I - P)^-1 = prod_{j>=0} (I + P^(2^j))  (rho(P) <= |alpha|),
+//   F = (1 - alpha)^2 T Q T,  out = F > 0 ? 1 - (1 - F)(1 - A) : (1 + F) A.
+// Every product runs on the fp64 MFMA GEMM (C = X Y^T).  For a symmetric A all factors
+// are symmetric and commute, so squarings and T updates compute the upper tile triangle
+// only; a general A carries explicit transposes instead.
+static int constraint_propagation(sc_handle h, const double* a, bool sym_a, const double* q,
+                                  bool sym_q, double alpha, double* out, int n, int ld) {
+  hipStream_t s = h->stream;
+  const double mag = fabs(alpha);
+  if (!(mag < 1.0))
+    return fail(h, SC_ERR_UNSUPPORTED,
+                "ConstraintPropagation on the device needs |constraint_propagation_alpha| < 1");
+  // factors (I + P^(2^j)), j = 0 .. steps-1, leave a remainder of P^(2^steps)
+  int steps = 0;
+  if (mag > 0.0) {
+    double rem = mag;
+    while (rem > 1e-18 && steps < 18) {
+      rem *= rem;
+      ++steps;
+    }
+    if (rem > 1e-18)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "constraint_propagation_alpha too close to 1 for the Neumann product");
+  }
+  const size_t bytes = (size_t)n * ld * sizeof(double);
+  for (int i = 0; i < 5; ++i) SC_TRY(grow(h, h->cp[i], bytes));
+  SC_TRY(ensure_tilemap(h, n));
+  double* P = ptr<double>(h->cp[0]);
+  double* T = ptr<double>(h->cp[1]);
+  double* Pn = ptr<double>(h->cp[2]);
+  double* Tn = ptr<double>(h->cp[3]);
+  double* X = ptr<double>(h->cp[4]);  // transposes (general A), then T Q^T
+  double* ws = ptr<double>(h->splitk);
+  const int2* tm = ptr<int2>(h->tilemap);
+  launch_row_stats(s, a, n, ld, ptr<double>(h->cut), ptr<double>(h->deg));  // deg = rowsum
+  launch_cp_prepare(s, a, ptr<double>(h->deg), alpha, P, T, n, ld);          // T = I + P
+  for (int j = 1; j < steps; ++j) {
+    // Pn = P P
+    if (sym_a) {
+      launch_gemm_nt(s, P, ld, P, ld, Pn, ld, n, n, n, kEpiNone, true, ws, tm);
+    } else {
+      launch_transpose(s, P, X, n, ld);
+      launch_gemm_nt(s, P, ld, X, ld, Pn, ld, n, n, n, kEpiNone, false, ws, nullptr);
+    }
+    std::swap(P, Pn);
+    // Tn = T + T P
+    if (sym_a) {
+      launch_gemm_nt(s, T, ld, P, ld, Tn, ld, n, n, n, kEpiAdd, true, ws, tm, nullptr, T);
+    } else {
+      launch_transpose(s, P, X, n, ld);
+      launch_gemm_nt(s, T, ld, X, ld, Tn, ld, n, n, n, kEpiAdd, false, ws, nullptr, nullptr, T);
+    }
+    std::swap(T, Tn);
+  }
+  // G^T = T^T Q^T  (X),  T Q T = T (G^T)^T  (Pn)
+  const double* Tt = T;
+  if (!sym_a) {
+    launch_transpose(s, T, Tn, n, ld);
+    Tt = Tn;
+  }
+  launch_gemm_nt(s, Tt, ld, q, ld, X, ld, n, n, n, kEpiNone, false, ws, nullptr);
+  const bool sym_f = sym_a && sym_q;
+  launch_gemm_nt(s, T, ld, X, ld, Pn, ld, n, n, n, kEpiNone, sym_f, ws, sym_f ? tm : nullptr);
+  launch_cp_adjust(s, Pn, a, (1.0 - alpha) * (1.0 - alpha), out, n, ld);
+  return check_last(h, "constraint propagation launch");
+}
+
+// cfg's constraint operator on `a` with the resident constraint matrix; out may alias a
+static int adjust_affinity(sc_handle h, const sc_config* cfg, const double* a, bool sym_a,
+                           double* out, int n, int ld) {
+  if (cfg->constraint_name == SC_CONSTRAINT_AFFINITY_INTEGRATION) {
+    if (cfg->integration_type != SC_INTEGRATION_MAX &&
+        cfg->integration_type != SC_INTEGRATION_AVERAGE)
+      return fail(h, SC_ERR_INVALID, "Unsupported integration type");
+    launch_affinity_integration(h->stream, a, ptr<double>(h->Cq), out, n, ld,
+                                cfg->integration_type);
+    return check_last(h, "affinity integration launch");
+  }
+  if (cfg->constraint_name == SC_CONSTRAINT_PROPAGATION)
+    return constraint_propagation(h, a, sym_a, ptr<double>(h->Cq), h->constraint_symmetric,
+                                  cfg->constraint_alpha, out, n, ld);
+  return fail(h, SC_ERR_INVALID, "constraint_name must be a ConstraintName");
+}
+
+extern "C" int sc_set_constraint(sc_handle h, const double* q, int n) {
+  if (!h) return SC_ERR_INVALID;
+  if (!q || n <= 0) return fail(h, SC_ERR_INVALID, "constraint matrix must be (n, n)");
+  SC_HIP(h, hipSetDevice(h->device));
+  const int ld = round_up(n, 16);
+  SC_TRY(grow(h, h->Cq, (size_t)n * ld * sizeof(double)));
+  SC_TRY(h2d_matrix(h, q, n, n, ptr<double>(h->Cq), ld));
+  SC_TRY(device_is_symmetric(h, ptr<double>(h->Cq), n, ld, &h->constraint_symmetric));
+  h->have_constraint = true;
+  h->qn = n;
+  return SC_OK;
+}
+
+extern "C" int sc_clear_constraint(sc_handle h) {
+  if (!h) return SC_ERR_INVALID;
+  h->have_constraint = false;
+  h->qn = 0;
+  return SC_OK;
+}
+
+static bool constraint_active(sc_handle h, const sc_config* cfg, bool before) {
+  return cfg->constraint_name != SC_CONSTRAINT_NONE && h->have_constraint &&
+         (cfg->constraint_before_refinement != 0) == before;
+}
+
+extern "C" int sc_apply_constraint(sc_handle h, const sc_config* cfg) {
+  if (!h) return SC_ERR_INVALID;
+  SC_TRY(validate_config(h, cfg));
+  if (!h->have_affinity) return fail(h, SC_ERR_INVALID, "no affinity resident");
+  if (!h->have_constraint) return fail(h, SC_ERR_INVALID, "no constraint matrix resident");
+  if (cfg->constraint_name == SC_CONSTRAINT_NONE)
+    return fail(h, SC_ERR_INVALID, "no constraint operation configured");
+  if (h->qn != h->n)
+    return fail(h, SC_ERR_INVALID, "affinity and constraint matrix must have the same shape");
+  if (h->constraint_applied)
+    return fail(h, SC_ERR_INVALID, "the resident affinity is already constraint-adjusted");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, h->n, 0));
+  SC_TRY(adjust_affinity(h, cfg, ptr<double>(h->A0), h->affinity_symmetric, ptr<double>(h->A0),
+                         h->n, h->ldn));
+  h->affinity_symmetric = h->affinity_symmetric && h->constraint_symmetric;
+  h->have_cropval = false;
+  h->constraint_applied = true;
+  h->n_vec = 0;
+  return SC_OK;
+}
+
+extern "C" int sc_stage_constraint(sc_handle h, const sc_config* cfg, const double* affinity,
+                                   const double* q, int n, double* out) {
+  if (!h) return SC_ERR_INVALID;
+  SC_TRY(validate_config(h, cfg));
+  if (!affinity || !q || !out || n <= 0)
+    return fail(h, SC_ERR_INVALID, "affinity and constraint matrix must be (n, n)");
+  SC_TRY(sc_set_affinity(h, affinity, n));
+  SC_TRY(sc_set_constraint(h, q, n));
+  const int rc = sc_apply_constraint(h, cfg);
+  sc_clear_constraint(h);
+  SC_TRY(rc);
+  return d2h_matrix(h, ptr<double>(h->A0), h->ldn, n, n, out);
+}
+
+// ------------------------------------------------------------------------------
 // embeddings / affinity
 // ------------------------------------------------------------------------------
 extern "C" int sc_set_embeddings(sc_handle h, const double* x, int n, int d) {
@@ -546,6 +722,8 @@ extern "C" int sc_compute_affinity(sc_handle h) {
   SC_TRY(check_last(h, "affinity launch"));
   h->have_affinity = true;
   h->have_cropval = true;
+  h->affinity_symmetric = true;
+  h->constraint_applied = false;
   h->n_vec = 0;
   return SC_OK;
 }
@@ -560,9 +738,10 @@ extern "C" int sc_set_affinity(sc_handle h, const double* a, int n) {
   h->have_x = false;
   h->n_vec = 0;
   SC_TRY(h2d_matrix(h, a, n, n, ptr<double>(h->A0), h->ldn));
-  SC_HIP(h, hipStreamSynchronize(h->stream));
+  SC_TRY(device_is_symmetric(h, ptr<double>(h->A0), n, h->ldn, &h->affinity_symmetric));
   h->have_affinity = true;
   h->have_cropval = false;
+  h->constraint_applied = false;
   return SC_OK;
 }
 
@@ -904,7 +1083,8 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   const double* cur = ptr<double>(h->A0);
   double* bufs[2] = {ptr<double>(h->B1), ptr<double>(h->B2)};
   int which = 0;
-  bool symmetric = true;   // cosine affinity is symmetric
+  bool symmetric = h->affinity_symmetric;  // cosine affinity: always
+  const bool constrain_after = constraint_active(h, cfg, false);
   bool folded_rownorm = false;
   int e_begin, e_tmp, e_after_refine;
   float diffuse_ms_events[SC_MAX_OPS][2];
@@ -925,7 +1105,8 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
     const bool thr_sym_fusable = true;  // RowMax or Percentile, with or without diagonal
     const bool partials_usable = cfg->threshold_type == SC_THRESHOLD_ROW_MAX &&
                                  !cfg->preserve_diagonal;
-    if (op == SC_OP_ROW_WISE_NORMALIZE && symmetric && i == cfg->n_ops - 1) {
+    if (op == SC_OP_ROW_WISE_NORMALIZE && symmetric && i == cfg->n_ops - 1 &&
+        !constrain_after) {
       folded_rownorm = true;  // W = diag(1/rowmax) S is never materialised
       continue;
     }
@@ -1011,6 +1192,17 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
         symmetric = true;
         break;
     }
+  }
+  if (constrain_after) {  // spectral_clusterer.py:137-142
+    if (h->qn != n)
+      return fail(h, SC_ERR_INVALID,
+                  "affinity and constraint matrix must have the same shape");
+    double* out = bufs[which];
+    which ^= 1;
+    SC_TRY(adjust_affinity(h, cfg, cur, symmetric, out, n, ld));
+    cur = out;
+    symmetric = symmetric && h->constraint_symmetric;
+    have_row_stats = false;
   }
   ev_rec(h, &e_after_refine);
   if (!symmetric)
@@ -1188,6 +1380,7 @@ extern "C" int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* label
   int e0, e1, e2;
   ev_rec(h, &e0);
   SC_TRY(sc_compute_affinity(h));
+  if (constraint_active(h, cfg, true)) SC_TRY(sc_apply_constraint(h, cfg));  // :259-264
   ev_rec(h, &e1);
   SC_TRY(eig_ncluster_impl(h, cfg, dg));
   int k = dg->n_clusters_raw;

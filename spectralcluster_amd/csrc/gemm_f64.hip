@@ -67,6 +67,7 @@ struct GemmStats {
   double* pmax;   // n x ntiles
   double* psum;   // n x ntiles (mode 1 only)
   int mode;       // 0 = off
+  const double* addend;  // kEpiAdd: C = A B^T + addend (same ld as C; may not alias C)
 };
 
 template <int EPI, bool SYM>
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
         // (v + 1) / 2: halving is exact, so one fma rounds identically
         if (EPI == kEpiAffinity) v = __builtin_fma(v, 0.5, 0.5);
         if (row < M && col < N) {
+          if (EPI == kEpiAdd) v += stats.addend[(size_t)row * ldc + col];
           C[(size_t)row * ldc + col] = v;
           if (mirror) C[(size_t)col * ldc + row] = v;
         }
@@ -373,7 +375,8 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const double* __restrict__ 
                                                      int M, int N, int ntiles_m,
                                                      int ntiles_n, int tile_offset,
                                                      int ksplit,
-                                                     const int2* __restrict__ tilemap) {
+                                                     const int2* __restrict__ tilemap,
+                                                     const double* __restrict__ addend) {
   int ti, tj;
   if (tilemap != nullptr) {
     const int2 t = tilemap[tile_offset + blockIdx.x];
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const double* __restrict__ 
         for (int c = 0; c < ksplit; ++c) v += base[(size_t)c * (BM * BN) + slot];
         if (EPI == kEpiAffinity) v = __builtin_fma(v, 0.5, 0.5);
         if (row < M && col < N) {
+          if (EPI == kEpiAdd) v += addend[(size_t)row * ldc + col];
           C[(size_t)row * ldc + col] = v;
           if (mirror) C[(size_t)col * ldc + row] = v;
         }
@@ -483,14 +487,15 @@ size_t gemm_splitk_workspace_bytes() {
 template <int EPI, bool SYM>
 static void launch_variant(hipStream_t s, const double* A, int lda, const double* B,
                            int ldb, double* C, int ldc, int M, int N, int K,
-                           double* splitk_ws, const int2* tilemap, const GemmRowStats* rs) {
-  GemmStats stats{nullptr, nullptr, 0};
+                           double* splitk_ws, const int2* tilemap, const GemmRowStats* rs,
+                           const double* addend) {
+  GemmStats stats{nullptr, nullptr, 0, addend};
   if (rs != nullptr && rs->mode != 0) {
     stats.pmax = rs->partial_max;
     stats.psum = rs->partial_sum;
     stats.mode = rs->mode;
   }
-  const GemmStats no_stats{nullptr, nullptr, 0};
+  const GemmStats no_stats{nullptr, nullptr, 0, addend};
   const int tm = (M + BM - 1) / BM;
   const int tn = (N + BN - 1) / BN;
   const int tiles = SYM ? tm * (tm + 1) / 2 : tm * tn;
@@ -521,7 +526,7 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
                        B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, tilemap, 0,
                        no_stats);
     hipLaunchKernelGGL((k_gemm_reduce<EPI, SYM>), dim3(rem, 16), dim3(256), 0, s, g_partial,
-                       C, ldc, M, N, tm, tn, full, ksplit, tilemap);
+                       C, ldc, M, N, tm, tn, full, ksplit, tilemap, addend);
     if (stats.mode != 0)
       hipLaunchKernelGGL((k_gemm_tail_stats<SYM>), dim3(rem, SYM ? 2 : 1), dim3(256), 0, s, C,
                          ldc, M, N, tm, tn, full, tilemap, stats);
@@ -547,19 +552,21 @@ int gemm_tile_dim(int n) { return (n + BM - 1) / BM; }
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
                     int epilogue, bool symmetric, double* splitk_ws,
-                    const int2* tilemap, const GemmRowStats* rs) {
+                    const int2* tilemap, const GemmRowStats* rs, const double* addend) {
   if (M <= 0 || N <= 0) return;
+#define SC_GEMM_CASE(E, S)                                                                \
+  launch_variant<E, S>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, S ? tilemap : nullptr, \
+                       rs, addend)
   if (symmetric) {
-    if (epilogue == kEpiAffinity)
-      launch_variant<kEpiAffinity, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap, rs);
-    else
-      launch_variant<kEpiNone, true>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap, rs);
+    if (epilogue == kEpiAffinity) SC_GEMM_CASE(kEpiAffinity, true);
+    else if (epilogue == kEpiAdd) SC_GEMM_CASE(kEpiAdd, true);
+    else SC_GEMM_CASE(kEpiNone, true);
   } else {
-    if (epilogue == kEpiAffinity)
-      launch_variant<kEpiAffinity, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap, rs);
-    else
-      launch_variant<kEpiNone, false>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, tilemap, rs);
+    if (epilogue == kEpiAffinity) SC_GEMM_CASE(kEpiAffinity, false);
+    else if (epilogue == kEpiAdd) SC_GEMM_CASE(kEpiAdd, false);
+    else SC_GEMM_CASE(kEpiNone, false);
   }
+#undef SC_GEMM_CASE
 }
 
 }  // namespace sc

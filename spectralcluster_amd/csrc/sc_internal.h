@@ -23,12 +23,14 @@ constexpr int kProjBlocks = 128;     // partial-sum blocks for tall-skinny produ
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // GEMM epilogues
-enum { kEpiNone = 0, kEpiAffinity = 1 };
+enum { kEpiNone = 0, kEpiAffinity = 1, kEpiAdd = 2 };
 
 // ---- kernel launchers (each enqueues on `s`, no sync) -----------------------
 // C[M,N] = A[M,K] * B[N,K]^T (row-major, leading dims in elements).  When
-// `symmetric` is set B must alias A and only tile pairs i<=j are computed; the
-// mirror tile is written transposed, so C is exactly symmetric.
+// `symmetric` is set the caller asserts that the product is symmetric (B aliasing A, or
+// commuting symmetric operands): only tile pairs i<=j are computed and the mirror tile
+// is written transposed, so C is exactly symmetric.  kEpiAdd adds `addend` (ld = ldc,
+// symmetric when `symmetric`; must not alias C).
 // `splitk_ws`: gemm_splitk_workspace_bytes() of scratch owned by the caller (per handle).
 // `rs` (optional): row statistics of C fused into the epilogue -- mode 1: rowmax / rowsum,
 // mode 2: max over j != i clamped at 0 (CropDiagonal's fill value) in rowmax.  The partial
@@ -43,7 +45,8 @@ struct GemmRowStats {
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
                     int epilogue, bool symmetric, double* splitk_ws,
-                    const int2* tilemap, const GemmRowStats* rs = nullptr);
+                    const int2* tilemap, const GemmRowStats* rs = nullptr,
+                    const double* addend = nullptr);
 // patch-ordered (ti, tj) list of the upper triangle, for `tilemap` (symmetric launches)
 void gemm_build_sym_tilemap(int nt, std::vector<int2>* out);
 int gemm_tile_dim(int n);
@@ -79,6 +82,16 @@ void launch_row_threshold(hipStream_t s, const double* in, double* out, int n,
                           int preserve_diag);
 void launch_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
                        int type);
+
+// constraint.hip (reference constraint.py:95-164)
+void launch_affinity_integration(hipStream_t s, const double* a, const double* q, double* out,
+                                 int n, int ld, int type);
+void launch_cp_prepare(hipStream_t s, const double* a, const double* deg, double alpha,
+                       double* p, double* t0, int n, int ld);
+void launch_cp_adjust(hipStream_t s, const double* tqt, const double* a, double scale,
+                      double* out, int n, int ld);
+void launch_transpose(hipStream_t s, const double* in, double* out, int n, int ld);
+void launch_symmetry_flag(hipStream_t s, const double* in, int n, int ld, int* flag);
 void launch_row_normalize(hipStream_t s, const double* in, double* out, int n,
                           int ld);
 void launch_row_stats(hipStream_t s, const double* in, int n, int ld,

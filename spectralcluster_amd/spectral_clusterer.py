@@ -3,9 +3,10 @@ reference `spectralcluster/spectral_clusterer.py`, with the dense hot path
 (affinity -> refinement -> Laplacian -> top-k eigen + eigengap -> cosine k-means)
 executed on one MI355X through the C ABI in `include/spectralcluster_amd.h`.
 
-Out of the device scope: FallbackOptions / single-cluster check,
-constraints, max_spectral_size, non-cosine k-means, and refinement sequences whose
-result is not diagonally similar to a symmetric matrix.  Those raise
+Constraints (`constraint_options` + `predict(embeddings, constraint_matrix)`) run on the
+device too.  Out of the device scope: FallbackOptions /
+single-cluster check, max_spectral_size, non-cosine k-means, and refinement sequences
+whose result is not diagonally similar to a symmetric matrix.  Those raise
 `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
 """
 
@@ -18,6 +19,7 @@ import numpy as np
 
 from spectralcluster_amd import _lib
 from spectralcluster_amd import autotune as autotune_lib
+from spectralcluster_amd import constraint as constraint_lib
 from spectralcluster_amd import custom_distance_kmeans
 from spectralcluster_amd import laplacian
 from spectralcluster_amd import refinement
@@ -87,9 +89,10 @@ class SpectralClusterer:
       raise _lib.UnsupportedOnDeviceError(
           "min_clusters=1 triggers the reference's single-cluster check "
           "(fallback_clusterer.check_single_cluster), which is out of scope")
-    if self.constraint_options is not None or constraint_matrix is not None:
-      raise _lib.UnsupportedOnDeviceError("constraints are out of scope")
     if self.max_spectral_size is not None:
+      if constraint_matrix is not None:  # reference spectral_clusterer.py:240-242
+        raise RuntimeError(
+            "Cannot handle constraint_matrix when max_spectral_size is set")
       raise _lib.UnsupportedOnDeviceError(
           "max_spectral_size (AHC pre-clustering) is out of scope")
 
@@ -114,7 +117,24 @@ class SpectralClusterer:
     cfg.stop_eigenvalue = float(self.stop_eigenvalue)
     cfg.row_wise_renorm = int(bool(self.row_wise_renorm))
     cfg.max_iter = int(self.max_iter)
+    if self.constraint_options is not None:
+      self.constraint_options.to_config(cfg)
     return cfg
+
+  def _set_constraint(self, handle: _lib.Handle, n: int, constraint_matrix) -> bool:
+    """Make `constraint_matrix` resident (or clear a stale one).  Like the reference
+    (spectral_clusterer.py:137-142, 259-264) it is used only when both
+    `constraint_options` and the matrix are given."""
+    if self.constraint_options is None or constraint_matrix is None:
+      handle.check(handle.lib.sc_clear_constraint(handle.raw))
+      return False
+    con = np.asarray(constraint_matrix)
+    # ConstraintOperation.check_input against the (n, n) affinity
+    self.constraint_options.constraint_operator.check_input(np.empty((n, n), dtype=bool),
+                                                            con)
+    con = np.ascontiguousarray(con, dtype=np.float64)
+    handle.check(handle.lib.sc_set_constraint(handle.raw, _lib.as_double_p(con), n))
+    return True
 
   def _upload(self, handle: _lib.Handle, embeddings: np.ndarray):
     """Embeddings -> resident affinity (device GEMM, or the user's function)."""
@@ -161,6 +181,8 @@ class SpectralClusterer:
       raise ValueError("affinity must be a square matrix")
     handle = self._handle()
     handle.check(handle.lib.sc_set_affinity(handle.raw, _lib.as_double_p(a), a.shape[0]))
+    # only the after-refinement branch lives in this method (reference :137-142)
+    self._set_constraint(handle, a.shape[0], constraint_matrix)
     diag = self._eig_resident(handle)
     vectors = self._download_eigenvectors(handle, a.shape[0])
     return vectors, int(diag.n_clusters_raw), float(diag.max_delta)
@@ -179,6 +201,7 @@ class SpectralClusterer:
     if default_tail and self.custom_dist != "cosine":
       raise _lib.UnsupportedOnDeviceError(
           "only custom_dist='cosine' is implemented on the device path")
+    constrained = self._set_constraint(handle, n, constraint_matrix)
 
     if (self.autotune is None and default_tail
         and self.affinity_function is utils.compute_affinity_matrix):
@@ -193,6 +216,9 @@ class SpectralClusterer:
       return labels
 
     self._upload(handle, embeddings)
+    if constrained and self.constraint_options.apply_before_refinement:
+      # reference :259-264 -- once, before the AutoTune sweep re-reads the affinity
+      handle.check(handle.lib.sc_apply_constraint(handle.raw, self.build_config()))
     if self.autotune:
       sequence = self.refinement_options.refinement_sequence or []
       if RefinementName.RowWiseThreshold not in sequence:
@@ -239,6 +265,7 @@ class SpectralClusterer:
     count = len(indices)
     if count == 0:
       return
+    handle.check(handle.lib.sc_clear_constraint(handle.raw))  # a batch carries none
     xp = (ctypes.POINTER(ctypes.c_double) * count)(
         *[_lib.as_double_p(xs[i]) for i in indices])
     lp = (ctypes.POINTER(ctypes.c_int64) * count)(

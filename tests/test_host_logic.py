@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), name
   assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-  assert lib.sc_abi_version() == 1
+  assert lib.sc_abi_version() == 2
 
 
 def test_struct_layout_matches_header():
@@ -149,6 +149,48 @@ def test_public_surface_mirrors_reference():
   opts = sca.RefinementOptions()
   assert (opts.gaussian_blur_sigma, opts.p_percentile, opts.thresholding_soft_multiplier,
           opts.refinement_sequence) == (1, 0.95, 0.01, None)
+
+
+def test_constraint_host_side():
+  from conftest import golden
+  g = golden("constraint_ops_n40.npz")
+  scores = list(g["turn_scores"])
+  np.testing.assert_array_equal(sca.ConstraintMatrix(scores, 1).compute_diagonals(),
+                                g["turn_matrix"])
+  np.testing.assert_array_equal(sca.ConstraintMatrix(scores, 3).compute_diagonals(),
+                                g["turn_matrix_t3"])
+  assert sca.ConstraintMatrix([], 1).compute_diagonals().shape == (0, 0)
+  assert sca.ConstraintMatrix([0.0], 1).compute_diagonals().shape == (1, 1)
+  with pytest.raises(ValueError):
+    sca.ConstraintMatrix([0, -0.5])
+  # names / members of the reference enums (constraint.py:10-22)
+  assert [m.name for m in sca.ConstraintName] == ["AffinityIntegration",
+                                                  "ConstraintPropagation"]
+  assert [m.name for m in sca.IntegrationType] == ["Max", "Average"]
+  # flattening into sc_config
+  c = sca.configs.turntodiarize_clusterer
+  cfg = c.build_config()
+  assert (cfg.constraint_name, cfg.constraint_before_refinement, cfg.constraint_alpha) == (
+      2, 1, 0.4)
+  assert (c.min_clusters, c.max_clusters, c.laplacian_type, c.row_wise_renorm) == (
+      2, 7, sca.LaplacianType.GraphCut, True)
+  opts = sca.ConstraintOptions(sca.ConstraintName.AffinityIntegration, False,
+                               sca.IntegrationType.Average)
+  cfg = sca.SpectralClusterer(constraint_options=opts).build_config()
+  assert (cfg.constraint_name, cfg.constraint_before_refinement, cfg.integration_type) == (
+      1, 0, 2)
+  # integration_type=None only fails when the operator is used (reference :117-118)
+  broken = sca.ConstraintOptions(sca.ConstraintName.AffinityIntegration, False)
+  with pytest.raises(ValueError):
+    sca.SpectralClusterer(constraint_options=broken).build_config()
+  # check_input messages (constraint.py:54-76) fire before any device work
+  op = sca.constraint.ConstraintPropagation()
+  with pytest.raises(ValueError, match="same shape"):
+    op.adjust_affinity(np.zeros((3, 3)), np.zeros((2, 2)))
+  with pytest.raises(ValueError, match="constraint matrix must be a square"):
+    op.adjust_affinity(np.zeros((3, 3)), np.zeros((3, 2)))
+  with pytest.raises(ValueError, match="affinity must be 2-dimensional"):
+    op.adjust_affinity(np.zeros(3), np.zeros((3, 3)))
 
 
 def test_enforce_ordered_labels():

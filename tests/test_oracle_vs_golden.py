@@ -151,6 +151,86 @@ def test_autotune_small():
   assert best_p == float(g["best_p"])
 
 
+def test_constraint_ops_vs_reference():
+  g = golden("constraint_ops_n40.npz")
+  for aname in ("sym", "gen"):
+    for qname in ("sym", "gen"):
+      a, q = g["a_" + aname], g["q_" + qname]
+      tag = "a%s_q%s" % (aname, qname)
+      assert np.array_equal(so.affinity_integration(a, q, so.INTEGRATION_MAX),
+                            g["integ_max_" + tag])
+      assert np.array_equal(so.affinity_integration(a, q, so.INTEGRATION_AVERAGE),
+                            g["integ_avg_" + tag])
+      for alpha in (0.4, 0.6, 0.9):
+        got = so.constraint_propagation(a, q, alpha)
+        # same LAPACK inverse and matmuls; the diag-matrix products of the reference
+        # are elementwise scalings here, identical up to the order of two roundings
+        np.testing.assert_allclose(got, g["cp_%02d_%s" % (round(alpha * 10), tag)],
+                                   rtol=1e-12, atol=1e-14)
+  scores = list(g["turn_scores"])
+  np.testing.assert_array_equal(so.constraint_matrix_diagonals(scores, 1), g["turn_matrix"])
+  np.testing.assert_array_equal(so.constraint_matrix_diagonals(scores, 3),
+                                g["turn_matrix_t3"])
+
+
+def test_constraint_known_answers():
+  # reference tests/constraint_test.py
+  a = np.array([[1, 0.25, 0], [0.31, 1, 0], [0, 0, 1]])
+  q = np.array([[1, 1, 0], [1, 1, 0], [0, 0, 0]], dtype=np.float64)
+  np.testing.assert_allclose(so.affinity_integration(a, q),
+                             [[1, 1, 0], [1, 1, 0], [0, 0, 1]], atol=0.01)
+  np.testing.assert_allclose(so.constraint_propagation(a, q, 0.6),
+                             [[1, 0.97, 0], [1.03, 1, 0], [0, 0, 1]], atol=0.01)
+  np.testing.assert_equal(so.constraint_matrix_diagonals([0, 0, 14.308253288269043], 1),
+                          [[0, 1, 0], [1, 0, -1], [0, -1, 0]])
+  np.testing.assert_equal(so.constraint_matrix_diagonals([0, 0, 0.12095779925584793], 1),
+                          [[0, 1, 0], [1, 0, 0], [0, 0, 0]])
+  with pytest.raises(ValueError):
+    so.constraint_matrix_diagonals([0, -1.0], 1)
+  with pytest.raises(ValueError):
+    so.affinity_integration(a, q[:2, :2])
+
+
+@pytest.mark.parametrize("n", [120, 300])
+def test_turntodiarize_constrained_predict(n):
+  g = golden("turntodiarize_n%d.npz" % n)
+  x, truth, scores = so.turn_blobs(n, int(g["d"]), int(g["k"]), int(g["seed"]))
+  np.testing.assert_array_equal(truth, g["truth"])
+  np.testing.assert_array_equal(scores, g["scores"])
+  q = so.constraint_matrix_diagonals(list(scores), 1)
+  cfg = so.turntodiarize_config()
+  adj = so.constraint_propagation(so.affinity(x), q, 0.4)
+  np.testing.assert_allclose(
+      [adj.sum(), np.abs(adj).max(), adj[0, 1], adj[n // 2, n // 3]],
+      g["adjusted_checksum"], rtol=1e-11)
+  grid = so.autotune_range(*so.TURNTODIARIZE_AUTOTUNE[:3])
+  np.testing.assert_array_equal(grid, g["grid"])
+  _, _, _, seen = so.autotune_search(adj, cfg, *so.TURNTODIARIZE_AUTOTUNE,
+                                     constraint_matrix=q)
+  np.testing.assert_allclose([seen[p] for p in grid], g["ratios"], rtol=1e-7)
+  labels = so.predict(x, cfg, constraint_matrix=q, autotune=so.TURNTODIARIZE_AUTOTUNE)
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+  free = so.predict(x, cfg, autotune=so.TURNTODIARIZE_AUTOTUNE)
+  assert so.adjusted_rand_index(free, g["labels_unconstrained"]) == 1.0
+
+
+def test_integration_after_refinement_predict():
+  g = golden("integration_n200.npz")
+  x, truth, _ = so.turn_blobs(200, 16, 3, 17)
+  np.testing.assert_array_equal(truth, g["truth"])
+  for tag, kind in (("max", so.INTEGRATION_MAX), ("avg", so.INTEGRATION_AVERAGE)):
+    cfg = so.turntodiarize_config(
+        min_clusters=None, max_clusters=6, p_percentile=0.9,
+        constraint_name=so.CONSTRAINT_AFFINITY_INTEGRATION,
+        apply_before_refinement=False, integration_type=kind)
+    dump = {}
+    labels = so.predict(x, cfg, dump, constraint_matrix=g["q"])
+    assert so.adjusted_rand_index(labels, g["labels_" + tag]) == 1.0
+    _, k, delta = so.eig_ncluster(so.affinity(x), cfg, constraint_matrix=g["q"])
+    assert k == int(g["n_clusters_" + tag])
+    np.testing.assert_allclose(delta, float(g["max_delta_" + tag]), rtol=1e-8)
+
+
 def test_adjusted_rand_index():
   from sklearn.metrics import adjusted_rand_score
   rng = np.random.default_rng(0)

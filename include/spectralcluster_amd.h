@@ -74,7 +74,12 @@ enum { SC_INTEGRATION_MAX = 1, SC_INTEGRATION_AVERAGE = 2 };
 enum { SC_EIGENGAP_RATIO = 1, SC_EIGENGAP_NORMALIZED_DIFF = 2 };
 
 /* Which eigen path ran (sc_diag.eig_path) */
-enum { SC_EIG_PATH_DENSE_JACOBI = 1, SC_EIG_PATH_BLOCK_LANCZOS = 2 };
+enum {
+  SC_EIG_PATH_DENSE_JACOBI = 1,   /* symmetric, n <= 128 */
+  SC_EIG_PATH_BLOCK_LANCZOS = 2,  /* symmetric, larger n */
+  SC_EIG_PATH_DENSE_GENERAL = 3,  /* non-symmetric, n <= 64: Hessenberg + complex QR */
+  SC_EIG_PATH_BLOCK_ARNOLDI = 4   /* non-symmetric, larger n */
+};
 
 /* Stage slots of sc_diag.stage_ms */
 enum {
@@ -142,7 +147,7 @@ typedef struct sc_diag {
   int32_t eig_cycles;            /* restart cycles used */
   double eig_max_residual;       /* max residual norm over accepted Ritz pairs */
   int32_t kmeans_iterations;     /* cosine k-means distance passes */
-  int32_t symmetry_state;        /* 1 SYM, 2 DIAG*SYM (after RowWiseNormalize) */
+  int32_t symmetry_state;        /* 1 SYM, 2 DIAG*SYM (after RowWiseNormalize), 3 GENERAL */
   float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */
 } sc_diag;
 
@@ -252,6 +257,16 @@ int sc_stage_laplacian(sc_handle h, int laplacian_type, const double* in, int n,
  */
 int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, int descend,
                      double* values, double* vectors, sc_diag* diag);
+/*
+ * utils.compute_sorted_eigenvectors (utils.py:44-71) for ANY square input: what
+ * np.linalg.eig + .real + argsort give -- real parts of the `count` eigenvalues of
+ * largest (descend=1) / smallest (descend=0) real part and the real parts of their
+ * eigenvectors, normalised like LAPACK dgeev (unit 2-norm, largest component of a
+ * complex vector real).  n <= 64: Hessenberg + complex QR in one wavefront (all pairs
+ * available); larger n: block Arnoldi, count <= 32.
+ */
+int sc_stage_eig(sc_handle h, const double* m, int n, int count, int descend,
+                 double* values, double* vectors, sc_diag* diag);
 /* numpy.random.RandomState(seed).random_sample(count): the MT19937 stream that
  * sklearn's KMeans(random_state=0) (custom_distance_kmeans.py:39-43) consumes.
  * Host-only; exported so the stream can be pinned without a GPU. */

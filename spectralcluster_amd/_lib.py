@@ -165,6 +165,9 @@ PROTOTYPES = {
     "sc_stage_sym_eig": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, _c_double_p,
                                         _c_double_p, ctypes.POINTER(ScDiag)]),
+    "sc_stage_eig": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, _c_double_p,
+                                        _c_double_p, ctypes.POINTER(ScDiag)]),
     "sc_random_state_doubles": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_int,
                                                _c_double_p]),
     "sc_uniform_choice": (ctypes.c_int, [ctypes.c_int, ctypes.c_double]),

@@ -47,10 +47,14 @@ struct sc_handle_s {
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
       flags;
   DevBuf E, Ek, Eio;      // eigenvectors (col-major), renormed copy, row-major I/O staging
+  // general (non-symmetric) eigen path: right scaling, Im(theta), complex Ritz vectors
+  // (column-major), residual partials, restart codes, dense Laplacian scratch
+  DevBuf crvec, thetai, Vre, Vim, gpart, gsrc, genL;
+  const double* vs_scale = nullptr;  // Vs = vs_scale .* V in orthonormalize (default cvec)
   // k-means workspace
   DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo;
   // pinned host scratch
-  double* h_theta = nullptr;  // 2 * kLdq doubles (theta, resid)
+  double* h_theta = nullptr;  // 3 * kLdq doubles (theta, resid, Im theta)
   int* h_flags = nullptr;
   hipEvent_t ev[48];
   int nev = 0;
@@ -161,6 +165,19 @@ static int ensure_eig(sc_handle h, int n) {
   return SC_OK;
 }
 
+static int ensure_gen(sc_handle h, int n) {
+  const size_t ldv = round_up(n, 16);
+  const size_t nv = ldv * sizeof(double);
+  SC_TRY(grow(h, h->crvec, nv));
+  SC_TRY(grow(h, h->thetai, kLdq * sizeof(double)));
+  SC_TRY(grow(h, h->Vre, ldv * kGenMax * sizeof(double)));
+  SC_TRY(grow(h, h->Vim, ldv * kGenMax * sizeof(double)));
+  SC_TRY(grow(h, h->gpart, (size_t)gen_residual_blocks(n) * 32 * sizeof(double)));
+  SC_TRY(grow(h, h->gsrc, 16 * sizeof(int)));
+  SC_TRY(grow(h, h->genL, (size_t)kGenMax * kGenMax * sizeof(double)));
+  return SC_OK;
+}
+
 static int ensure_kmeans(sc_handle h, int n) {
   SC_TRY(grow(h, h->Ek, (size_t)round_up(n, 16) * kMaxCols * sizeof(double)));
   SC_TRY(grow(h, h->Eio, (size_t)n * kMaxCols * sizeof(double)));
@@ -233,7 +250,7 @@ extern "C" int sc_create(int device, sc_handle* out) {
       return SC_ERR_HIP;
     }
   }
-  if (hipHostMalloc(reinterpret_cast<void**>(&h->h_theta), 2 * kLdq * sizeof(double)) !=
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->h_theta), 3 * kLdq * sizeof(double)) !=
           hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&h->h_flags), 16 * sizeof(int)) !=
           hipSuccess) {
@@ -249,7 +266,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -758,6 +775,12 @@ struct EigRequest {
   double value_tol, vector_tol;
   int max_cycles;
   int fixed_count;      // > 0: plain "count extreme eigenpairs" request (stage API)
+  // General path only.  Consumed eigenvalues deep in a dense bulk converge arbitrarily
+  // slowly in a small Krylov basis, yet cannot influence the result: only the two values
+  // that form the maximum gap (and the normaliser of NormalizedDiff) are held to value_tol;
+  // the others must be accurate enough that, with their residual intervals, no other gap
+  // can reach the maximum and no comparison with stop_eigenvalue can flip.
+  int decision_aware = 0;
 };
 
 struct EigDecision {
@@ -825,13 +848,70 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
     for (int i = 0; i < kw; ++i)
       if (w[i] < rq.stop_eigenvalue) { last = i; break; }
   }
+  const bool aware = rq.decision_aware && rq.fixed_count == 0;
+  const int kb = dc.n_clusters_raw;  // the maximum gap sits between w[kb - 1] and w[kb]
   for (int i = first; i <= last; ++i) {
-    const double tol = std::max(rq.value_tol * std::fabs(w[i]), floor_abs);
+    const bool decisive = !aware || i == kb - 1 || i == kb ||
+                          (rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF && rq.descend && i == 0);
+    const double rel = decisive ? rq.value_tol : std::max(rq.value_tol, 1e-3);
+    const double tol = std::max(rel * std::fabs(w[i]), floor_abs);
     if (!(resid[i] <= tol)) {
       if (ok) { dc.fail_kind = 1; dc.fail_index = i; }
       ok = false;
     }
     dc.max_resid = std::max(dc.max_resid, resid[i]);
+  }
+  if (aware && ok) {
+    // interval check: eigenvalue i lies within err(i) of w[i] (10 x residual: a safety
+    // factor for the departure from normality)
+    auto err = [&](int i) { return 10.0 * resid[i]; };
+    const double eps = 1e-10;
+    const double wmax = rq.descend ? w[0] : w[m - 1];
+    auto gap_bounds = [&](int lo_i, int hi_i, double* lower, double* upper) {
+      // Ratio: w[hi_i] / (w[lo_i] + eps); NormalizedDiff: (w[hi_i] - w[lo_i]) / wmax,
+      // where hi_i is the numerator index
+      const double a = w[hi_i], b = w[lo_i], ea = err(hi_i), eb = err(lo_i);
+      if (rq.eigengap_type == SC_EIGENGAP_RATIO) {
+        const double den_lo = b - eb + eps, den_hi = b + eb + eps;
+        *upper = den_lo > 0.0 ? (a + ea) / den_lo : 1e300;
+        *lower = den_hi > 0.0 ? (a - ea) / den_hi : -1e300;
+      } else {
+        *upper = (a - b + ea + eb) / wmax;
+        *lower = (a - b - ea - eb) / wmax;
+      }
+    };
+    double best_lo = 0.0, dummy;
+    if (kb >= 1) {
+      if (rq.descend) gap_bounds(kb, kb - 1, &best_lo, &dummy);
+      else gap_bounds(kb - 1, kb, &best_lo, &dummy);
+    }
+    const int end = kw;
+    if (rq.descend) {
+      for (int i = 1; i < end && ok; ++i) {
+        if (rq.use_stop) {
+          if (std::fabs(w[i - 1] - rq.stop_eigenvalue) <= err(i - 1)) {
+            ok = false; dc.fail_kind = 4; dc.fail_index = i - 1;
+            break;
+          }
+          if (w[i - 1] < rq.stop_eigenvalue) break;
+        }
+        if (i == kb) continue;
+        double lo, up;
+        gap_bounds(i, i - 1, &lo, &up);
+        if (!(up < best_lo) && !(kb == 0 && up <= 0.0)) {
+          ok = false; dc.fail_kind = 4; dc.fail_index = i;
+        }
+      }
+    } else {
+      for (int i = 1; i < end - 1 && ok; ++i) {
+        if (i + 1 == kb) continue;
+        double lo, up;
+        gap_bounds(i, i + 1, &lo, &up);
+        if (!(up < best_lo) && !(kb == 0 && up <= 0.0)) {
+          ok = false; dc.fail_kind = 4; dc.fail_index = i;
+        }
+      }
+    }
   }
   if (!rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF && rq.fixed_count == 0) {
     // np.max(eigenvalues): the far end of the spectrum only normalises the gaps (it
@@ -882,8 +962,8 @@ static int orthonormalize(sc_handle h, int n, int m, bool record, int col0, int 
   launch_reduce_chol(s, part, proj_blocks(n), ptr<double>(h->Rinv), nullptr, nullptr,
                      ptr<int>(h->flags));
   launch_apply_rinv(s, W, n, ptr<double>(h->Rinv), store_col >= 0 ? Q : nullptr, kLdq,
-                    store_col >= 0 ? store_col : 0, ptr<double>(h->cvec),
-                    ptr<double>(h->Vs));
+                    store_col >= 0 ? store_col : 0,
+                    h->vs_scale ? h->vs_scale : ptr<double>(h->cvec), ptr<double>(h->Vs));
   return check_last(h, "orthonormalize launch");
 }
 
@@ -1060,6 +1140,242 @@ static int sym_topk(sc_handle h, const double* S, int ld, int n, const EigReques
 }
 
 // ------------------------------------------------------------------------------
+// general (non-symmetric) top-k eigensolver driver
+// ------------------------------------------------------------------------------
+// M (n x n, ld): the refined matrix, NOT diagonally similar to a symmetric one.
+// Operator  Op x = p .* x + cl .* (M (cr .* x))  (= M, or minus the Laplacian), whose
+// eigenvalues of largest real part are wanted; eigenvectors are those of the reference's
+// matrix itself (no similarity transform).  n <= 64: the dense solver on the materialised
+// matrix (every eigenpair, like np.linalg.eig).  Larger n: block Arnoldi with full
+// re-orthogonalisation, explicit Rayleigh-Ritz H = Q^T Op Q (basis <= 64), explicit
+// residuals ||Op v - theta v||, explicit restart from the wanted Ritz vectors (real and
+// imaginary parts of complex pairs).
+static int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
+                    const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
+                    std::vector<double>* out_w) {
+  hipStream_t s = h->stream;
+  SC_TRY(ensure_eig(h, n));
+  SC_TRY(ensure_gen(h, n));
+  double* theta_d = ptr<double>(h->theta);
+  double* thetai_d = ptr<double>(h->thetai);
+  double* resid_d = ptr<double>(h->resid);
+  double* Yre = ptr<double>(h->Y);
+  double* Yim = ptr<double>(h->Yt);
+  double* Vre = ptr<double>(h->Vre);
+  double* Vim = ptr<double>(h->Vim);
+  int* info_d = ptr<int>(h->flags) + 8;
+  const int ldv = round_up(n, 16);
+  double* th = h->h_theta;             // [0, kLdq): Re theta, [kLdq, 2 kLdq): resid
+  double* thi = h->h_theta + 2 * kLdq;  // Im theta
+  EigDecision dc;
+  int m = 0, passes = 0, cycles = 0;
+  const bool is_lap = laplacian_type >= SC_LAPLACIAN_UNNORMALIZED;
+  const bool far_end = !rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF &&
+                       rq.fixed_count == 0;
+
+  auto fetch_ritz = [&](int count) -> int {
+    SC_HIP(h, hipMemcpyAsync(th, theta_d, count * sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipMemcpyAsync(thi, thetai_d, count * sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipMemcpyAsync(h->h_flags + 8, info_d, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipStreamSynchronize(s));
+    if (h->h_flags[8] != 0)
+      return fail(h, SC_ERR_NOT_CONVERGED, "QR iteration of the projected eigenproblem failed");
+    return SC_OK;
+  };
+
+  if (n <= kGenMax) {
+    // ---- dense: eigen-decomposition of the reference's own matrix
+    const double* src = M;
+    if (is_lap) {
+      launch_laplacian(s, M, ptr<double>(h->genL), n, ld, laplacian_type, ptr<double>(h->deg));
+      src = ptr<double>(h->genL);
+    }
+    launch_gen_eig(s, src, ld, n, is_lap ? -1.0 : 1.0, n, theta_d, thetai_d, Yre, Yim, kLdq,
+                   info_d);
+    SC_TRY(check_last(h, "dense general eigensolver launch"));
+    SC_TRY(fetch_ritz(n));
+    for (int i = 0; i < n; ++i) th[kLdq + i] = 0.0;
+    dc = analyze(rq, th, th + kLdq, n, n, true);
+    if (!dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
+    launch_gen_ritz(s, nullptr, 0, n, n, Yre, Yim, kLdq, n, Vre, Vim, ldv);
+    launch_gen_phase(s, Vre, Vim, ldv, n, n, ptr<double>(h->E), ldv);
+    SC_TRY(check_last(h, "eigenvector normalisation launch"));
+    h->n_vec = n;
+    m = n;
+    dc.kw = n;
+    if (diag) diag->eig_path = SC_EIG_PATH_DENSE_GENERAL;
+  } else {
+    if (rq.fixed_count == 0 && rq.max_clusters == 0 && !rq.descend)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "max_clusters=None with a Laplacian needs every eigenvalue; only "
+                  "supported for n <= 64 on the general eigen path");
+    const double* cl = ptr<double>(h->cvec);
+    const double* cr = ptr<double>(h->crvec);
+    const double* pv = ptr<double>(h->pvec);
+    double* Q = ptr<double>(h->Q);
+    double* OpQ = ptr<double>(h->Q2);
+    double* W = ptr<double>(h->W);
+    h->vs_scale = cr;
+    struct Restore {
+      sc_handle h;
+      ~Restore() { h->vs_scale = nullptr; }
+    } restore{h};
+    const int cap = std::min(kGenMax, ((n - kEigBlock) / kEigBlock) * kEigBlock);
+    const int first_check = std::min(3 * kEigBlock, cap);
+    uint64_t seed = 0x9e3779b97f4a7c15ull;
+    std::vector<std::vector<int>> start_blocks;  // restart: codes 2*col+part, -1 = noise
+    size_t next_start = 0;
+    const int kMaxCheck = 32;  // Ritz pairs whose residual is evaluated
+    while (true) {
+      // ---- next block into W
+      if (next_start < start_blocks.size()) {
+        SC_HIP(h, hipMemcpyAsync(h->gsrc.p, start_blocks[next_start].data(),
+                                 kEigBlock * sizeof(int), hipMemcpyHostToDevice, s));
+        launch_gen_gather(s, Vre, Vim, ldv, n, ptr<int>(h->gsrc), ++seed, W);
+        SC_HIP(h, hipStreamSynchronize(s));  // the code vector is host memory
+        ++next_start;
+      } else if (m == 0) {
+        launch_random_block(s, W, n, seed);
+      } else {
+        launch_copy_block(s, OpQ + (m - kEigBlock), kLdq, W, kEigBlock, n, kEigBlock);
+      }
+      SC_TRY(orthonormalize(h, n, m, false, 0, m, false));
+      SC_TRY(finish_block(h, n, m, m, &seed));
+      launch_block_matvec(s, M, ld, n, cl, pv, Q + m, kLdq, ptr<double>(h->Vs), W);
+      launch_copy_block(s, W, kEigBlock, OpQ + m, kLdq, n, kEigBlock);
+      ++passes;
+      m += kEigBlock;
+      const bool check = next_start >= start_blocks.size() && m >= first_check;
+      if (check) {
+        // H = Q^T (Op Q), one 8-column block at a time
+        for (int jb = 0; jb < m; jb += kEigBlock) {
+          launch_copy_block(s, OpQ + jb, kLdq, W, kEigBlock, n, kEigBlock);
+          launch_proj_partial(s, Q, kLdq, m, W, n, ptr<double>(h->partial));
+          launch_reduce_H(s, ptr<double>(h->partial), proj_blocks(n), m, ptr<double>(h->Hbuf),
+                          nullptr, 0, 0, 0, ptr<double>(h->hsq));
+          launch_copy_block(s, ptr<double>(h->Hbuf), kEigBlock, ptr<double>(h->T) + jb, kLdq,
+                            m, kEigBlock);
+        }
+        launch_gen_eig(s, ptr<double>(h->T), kLdq, m, 1.0, m, theta_d, thetai_d, Yre, Yim, kLdq,
+                       info_d);
+        const int c1 = std::min(m, kMaxCheck);
+        launch_gen_residual(s, Q, OpQ, kLdq, m, n, Yre, Yim, kLdq, theta_d, thetai_d, c1,
+                            ptr<double>(h->gpart), resid_d);
+        if (far_end && m - 1 >= c1)
+          launch_gen_residual(s, Q, OpQ, kLdq, m, n, Yre + (m - 1), Yim + (m - 1), kLdq,
+                              theta_d + (m - 1), thetai_d + (m - 1), 1, ptr<double>(h->gpart),
+                              resid_d + (m - 1));
+        SC_TRY(check_last(h, "Rayleigh-Ritz launch"));
+        for (int i = 0; i < m; ++i) th[kLdq + i] = 1e300;  // not evaluated = not converged
+        SC_HIP(h, hipMemcpyAsync(th + kLdq, resid_d, c1 * sizeof(double), hipMemcpyDeviceToHost,
+                                 s));
+        if (far_end && m - 1 >= c1)
+          SC_HIP(h, hipMemcpyAsync(th + kLdq + m - 1, resid_d + (m - 1), sizeof(double),
+                                   hipMemcpyDeviceToHost, s));
+        SC_TRY(fetch_ritz(m));
+        dc = analyze(rq, th, th + kLdq, m, n, false);
+        if (getenv("SC_EIG_TRACE"))
+          fprintf(stderr, "[sc] arnoldi pass %d m=%d cycle %d sweeps %d: enough=%d conv=%d kw=%d "
+                  "kvec=%d fail kind %d at %d (resid %.2e)\n", passes, m, cycles, h->h_flags[9],
+                  dc.enough, dc.converged, dc.kw, dc.kvec, dc.fail_kind, dc.fail_index,
+                  dc.fail_index >= 0 ? th[kLdq + dc.fail_index] : 0.0);
+        if (getenv("SC_EIG_TRACE") && atoi(getenv("SC_EIG_TRACE")) > 1) {
+          for (int i = 0; i < std::min(m, 12); ++i)
+            fprintf(stderr, "[sc]    ritz %2d  re %.12g  im %.3e  resid %.3e\n", i, th[i], thi[i],
+                    th[kLdq + i]);
+        }
+        if (dc.unsupported || (dc.enough && std::max(dc.kw, dc.kvec) > kMaxCheck))
+          return fail(h, SC_ERR_UNSUPPORTED,
+                      "the general eigen path reports at most 32 eigenpairs for n > 64; set "
+                      "max_clusters <= 31");
+        if (dc.enough && dc.converged) break;
+      }
+      if (m + kEigBlock > cap) {
+        // ---- explicit restart from the wanted Ritz vectors
+        if (++cycles > rq.max_cycles)
+          return fail(h, SC_ERR_NOT_CONVERGED, "block Arnoldi did not converge");
+        // (thick restart: the new basis is [wanted Ritz vectors | residual block], after
+        // which the Arnoldi recurrence continues from the residual block)
+        constexpr int kStash = 48;  // Vre columns [48, 56) hold the residual block
+        launch_copy_block(s, OpQ + (m - kEigBlock), kLdq, W, kEigBlock, n, kEigBlock);
+        SC_TRY(orthonormalize(h, n, m, false, 0, -1, false));
+        SC_TRY(finish_block(h, n, m, -1, &seed));
+        launch_rowmajor_to_colmajor(s, W, kEigBlock, n, kEigBlock, Vre + (size_t)kStash * ldv,
+                                    ldv);
+        const int want = dc.enough ? std::max(dc.kw, dc.kvec) : cap / 4;
+        const int avail = std::min(m, 40);  // Ritz vectors materialised: columns [0, avail)
+        launch_gen_ritz(s, Q, kLdq, m, n, Yre, Yim, kLdq, avail, Vre, Vim, ldv);
+        int vcols = avail;
+        const bool far_kept = far_end && m - 1 >= avail;
+        if (far_kept) {  // Ritz vector m-1 -> column `avail`
+          launch_gen_ritz(s, Q, kLdq, m, n, Yre + (m - 1), Yim + (m - 1), kLdq, 1,
+                          Vre + (size_t)avail * ldv, Vim + (size_t)avail * ldv, ldv);
+          vcols = avail + 1;
+        }
+        launch_gen_phase(s, Vre, Vim, ldv, n, vcols, nullptr, 0);
+        SC_TRY(check_last(h, "restart launch"));
+        const double scale = std::max(std::fabs(th[0]), std::fabs(th[m - 1]));
+        auto is_complex = [&](int i) { return std::fabs(thi[i]) > 1e-12 * std::max(scale, 1e-300); };
+        std::vector<int> codes;
+        if (far_kept) {
+          codes.push_back(2 * avail);
+          if (is_complex(m - 1)) codes.push_back(2 * avail + 1);
+        }
+        // Kept vectors must fill whole blocks: a random pad column r would break the
+        // relation Op [kept] in span(kept, residual block) -- (I - Q Q^T) Op r is not in the
+        // basis -- and the Ritz pairs then stall at the size of their component along r.
+        // So the kept set is extended, never padded.
+        const int max_cols = (std::max(1, cap / kEigBlock - 3)) * kEigBlock;
+        const int target = std::min(round_up(want + kEigBlock / 2, kEigBlock), max_cols);
+        for (int i = 0; i < avail; ++i) {
+          if ((int)codes.size() >= target && codes.size() % kEigBlock == 0) break;
+          if (!is_complex(i)) {
+            codes.push_back(2 * i);
+            continue;
+          }
+          bool partner_kept = false;  // its conjugate, earlier in the list
+          for (int j = 0; j < i; ++j)
+            if (is_complex(j) && std::fabs(th[j] - th[i]) <= 1e-9 * scale &&
+                std::fabs(thi[j] + thi[i]) <= 1e-9 * scale)
+              partner_kept = true;
+          if (partner_kept) continue;
+          codes.push_back(2 * i);
+          codes.push_back(2 * i + 1);
+        }
+        if ((int)codes.size() > max_cols) codes.resize(max_cols);
+        while (codes.size() % kEigBlock) codes.push_back(-1);  // last resort (tiny bases)
+        for (int j = 0; j < kEigBlock; ++j) codes.push_back(2 * (kStash + j));
+        start_blocks.clear();
+        for (size_t b = 0; b * kEigBlock < codes.size(); ++b)
+          start_blocks.emplace_back(codes.begin() + b * kEigBlock,
+                                    codes.begin() + (b + 1) * kEigBlock);
+        next_start = 0;
+        m = 0;
+      }
+    }
+    const int cols = std::min(std::max(dc.kw, dc.kvec), kMaxCheck);
+    launch_gen_ritz(s, Q, kLdq, m, n, Yre, Yim, kLdq, cols, Vre, Vim, ldv);
+    launch_gen_phase(s, Vre, Vim, ldv, n, cols, ptr<double>(h->E), ldv);
+    SC_TRY(check_last(h, "ritz vector launch"));
+    h->n_vec = cols;
+    if (diag) diag->eig_path = SC_EIG_PATH_BLOCK_ARNOLDI;
+  }
+  if (out_w) {
+    out_w->resize(dc.kw);
+    for (int i = 0; i < dc.kw; ++i) (*out_w)[i] = rq.descend ? th[i] : -th[i];
+  }
+  if (diag) {
+    diag->eig_matvec_passes = passes;
+    diag->eig_block = kEigBlock;
+    diag->eig_basis = m;
+    diag->eig_cycles = cycles;
+    diag->eig_max_residual = dc.max_resid;
+  }
+  *out_dc = dc;
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
 // _compute_eigenvectors_ncluster
 // ------------------------------------------------------------------------------
 static void ev_rec(sc_handle h, int* slot) {
@@ -1205,17 +1521,21 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
     have_row_stats = false;
   }
   ev_rec(h, &e_after_refine);
-  if (!symmetric)
-    return fail(h, SC_ERR_UNSUPPORTED,
-                "the refinement sequence ends in a matrix that is not diagonally similar "
-                "to a symmetric one (e.g. RowWiseThreshold without a later Symmetrize/"
-                "Diffuse); the general (dgeev-class) eigenproblem is not on the device path");
   // ---- scaling vectors (RowWiseNormalize fold + Laplacian)
-  if (!have_row_stats)
-    launch_row_stats(s, cur, n, ld, ptr<double>(h->rowmax), ptr<double>(h->rowsum));
-  launch_scaling_vectors(s, ptr<double>(h->rowmax), ptr<double>(h->rowsum), n,
-                         cfg->laplacian_type, folded_rownorm ? 1 : 0, ptr<double>(h->cvec),
-                         ptr<double>(h->pvec), ptr<double>(h->tvec));
+  if (!symmetric) {
+    // general matrix (e.g. RowWiseThreshold without a later Symmetrize / Diffuse):
+    // Op x = p .* x + cl .* (M (cr .* x)), no similarity transform
+    SC_TRY(ensure_gen(h, n));
+    launch_row_stats(s, cur, n, ld, ptr<double>(h->rowmax), ptr<double>(h->deg));
+    launch_scaling_general(s, ptr<double>(h->deg), n, cfg->laplacian_type,
+                           ptr<double>(h->cvec), ptr<double>(h->crvec), ptr<double>(h->pvec));
+  } else {
+    if (!have_row_stats)
+      launch_row_stats(s, cur, n, ld, ptr<double>(h->rowmax), ptr<double>(h->rowsum));
+    launch_scaling_vectors(s, ptr<double>(h->rowmax), ptr<double>(h->rowsum), n,
+                           cfg->laplacian_type, folded_rownorm ? 1 : 0, ptr<double>(h->cvec),
+                           ptr<double>(h->pvec), ptr<double>(h->tvec));
+  }
   SC_TRY(check_last(h, "scaling launch"));
   int e_after_scaling;
   ev_rec(h, &e_after_scaling);
@@ -1234,7 +1554,12 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   rq.fixed_count = 0;
   EigDecision dc;
   std::vector<double> w;
-  SC_TRY(sym_topk(h, cur, ld, n, rq, diag, &dc, &w));
+  if (symmetric) {
+    SC_TRY(sym_topk(h, cur, ld, n, rq, diag, &dc, &w));
+  } else {
+    rq.decision_aware = 1;
+    SC_TRY(gen_topk(h, cur, ld, n, cfg->laplacian_type, rq, diag, &dc, &w));
+  }
   int e_after_eig;
   ev_rec(h, &e_after_eig);
   SC_HIP(h, hipStreamSynchronize(s));
@@ -1245,7 +1570,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
     diag->eig_descending = rq.descend;
     diag->n_eigenvalues = std::min((int)w.size(), SC_MAX_EIG);
     for (int i = 0; i < diag->n_eigenvalues; ++i) diag->eigenvalues[i] = w[i];
-    diag->symmetry_state = folded_rownorm ? 2 : 1;
+    diag->symmetry_state = !symmetric ? 3 : (folded_rownorm ? 2 : 1);
     float dms = 0.f;
     for (int i = 0; i < n_diffuse; ++i)
       dms += ev_ms(h, (int)diffuse_ms_events[i][0], (int)diffuse_ms_events[i][1]);
@@ -1518,6 +1843,60 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   memset(dg, 0, sizeof(*dg));
   h->nev = 0;
   SC_TRY(sym_topk(h, S, ld, n, rq, dg, &dc, &w));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < count; ++i) values[i] = w[i];
+  if (vectors) {
+    launch_colmajor_to_rowmajor(h->stream, ptr<double>(h->E), round_up(n, 16), n, count,
+                                ptr<double>(h->Eio), count);
+    SC_TRY(d2h_matrix(h, ptr<double>(h->Eio), count, n, count, vectors));
+  }
+  return SC_OK;
+}
+
+extern "C" int sc_stage_eig(sc_handle h, const double* m, int n, int count, int descend,
+                            double* values, double* vectors, sc_diag* diag) {
+  if (!h) return SC_ERR_INVALID;
+  if (!m || n <= 0 || count <= 0 || count > n || !values)
+    return fail(h, SC_ERR_INVALID, "bad eigen request");
+  if (n > kGenMax && count > 32)
+    return fail(h, SC_ERR_UNSUPPORTED, "at most 32 eigenpairs for n > 64 on the general path");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, n, 0));
+  SC_TRY(ensure_gen(h, n));
+  const int ld = round_up(n, 16);
+  h->n = n;
+  h->ldn = ld;
+  h->have_affinity = h->have_cropval = false;
+  h->have_x = false;
+  SC_TRY(h2d_matrix(h, m, n, n, ptr<double>(h->B1), ld));
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, h->stream, ptr<double>(h->cvec), n, 1.0);
+  hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, h->stream, ptr<double>(h->crvec), n, 1.0);
+  hipLaunchKernelGGL(k_fill, dim3(nb), dim3(256), 0, h->stream, ptr<double>(h->pvec), n, 0.0);
+  const double* S = ptr<double>(h->B1);
+  if (!descend) {  // smallest real parts of M = largest of -M
+    hipLaunchKernelGGL(k_negate, dim3(2048), dim3(256), 0, h->stream, ptr<double>(h->B1),
+                       ptr<double>(h->B2), (size_t)n * ld);
+    S = ptr<double>(h->B2);
+  }
+  EigRequest rq;
+  rq.descend = descend ? 1 : 0;
+  rq.max_clusters = 0;
+  rq.min_clusters = 0;
+  rq.stop_eigenvalue = 0.0;
+  rq.eigengap_type = SC_EIGENGAP_RATIO;
+  rq.use_stop = 0;
+  rq.value_tol = 1e-10;
+  rq.vector_tol = 1e-11;
+  rq.max_cycles = 100;
+  rq.fixed_count = count;
+  EigDecision dc;
+  std::vector<double> w;
+  sc_diag local;
+  sc_diag* dg = diag ? diag : &local;
+  memset(dg, 0, sizeof(*dg));
+  h->nev = 0;
+  SC_TRY(gen_topk(h, S, ld, n, SC_LAPLACIAN_NONE, rq, dg, &dc, &w));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < count; ++i) values[i] = w[i];
   if (vectors) {

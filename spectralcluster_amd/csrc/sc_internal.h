@@ -17,6 +17,7 @@ constexpr int kEigBlock = 8;         // Lanczos block width (half an MFMA tile c
 constexpr int kEigBasisCap = 128;    // Rayleigh-Ritz size limit (LDS Jacobi)
 constexpr int kLdq = kEigBasisCap + kEigBlock;  // row stride of the Krylov basis
 constexpr int kDenseMax = 128;       // n <= this: direct dense Jacobi
+constexpr int kGenMax = 64;          // general eigen path: dense limit and Arnoldi basis cap
 constexpr int kMaxVectors = 64;      // eigenvector columns kept resident
 constexpr int kProjBlocks = 128;     // partial-sum blocks for tall-skinny products
 
@@ -168,6 +169,32 @@ void launch_rowmajor_to_colmajor(hipStream_t s, const double* src, int lds, int 
                                  double* dst, int ldd);
 void launch_colmajor_to_rowmajor(hipStream_t s, const double* src, int lds, int n, int cols,
                                  double* dst, int ldd);
+
+// ---- general (non-symmetric) eigen path, eig_general.hip ---------------------------
+// Dense complex-Schur eigensolver, one wavefront, order m <= kGenMax: eigenvalues of
+// sign * A sorted by real part (descending) into theta_re / theta_im, the first `nvec`
+// unit-norm eigenvectors into Y[:, q] = Yre + i Yim (row-major, ldy).  info[0] != 0: the QR
+// iteration failed; info[1] = sweeps.
+void launch_gen_eig(hipStream_t s, const double* A, int lda, int m, double sign, int nvec,
+                    double* theta_re, double* theta_im, double* Yre, double* Yim, int ldy,
+                    int* info);
+int gen_residual_blocks(int n);
+// resid[c] = || OpQ y_c - theta_c Q y_c ||_2 for c < cols (<= 32); partial: blocks x 32
+void launch_gen_residual(hipStream_t s, const double* Q, const double* OpQ, int ldq, int m,
+                         int n, const double* Yre, const double* Yim, int ldy,
+                         const double* theta_re, const double* theta_im, int cols,
+                         double* partial, double* resid);
+// V[:, c] = Q y_c (complex, column-major ldv); Q == nullptr: V = Y
+void launch_gen_ritz(hipStream_t s, const double* Q, int ldq, int m, int n, const double* Yre,
+                     const double* Yim, int ldy, int cols, double* Vre, double* Vim, int ldv);
+// dgeev's normalisation per column (unit norm, largest component real); E (may be null)
+// receives the real parts, column-major lde
+void launch_gen_phase(hipStream_t s, double* Vre, double* Vim, int ldv, int n, int cols,
+                      double* E, int lde);
+void launch_gen_gather(hipStream_t s, const double* Vre, const double* Vim, int ldv, int n,
+                       const int* src, uint64_t seed, double* W);
+void launch_scaling_general(hipStream_t s, const double* deg, int n, int laplacian_type,
+                            double* cl, double* cr, double* p);
 
 // ---- k-means -------------------------------------------------------------------
 struct KmeansWorkspace {

@@ -36,27 +36,31 @@ def compute_affinity_matrix(embeddings: np.ndarray) -> np.ndarray:
 def compute_sorted_eigenvectors(
     input_matrix: np.ndarray, descend: bool = True,
     count: typing.Optional[int] = None) -> typing.Tuple[np.ndarray, np.ndarray]:
-  """Sorted eigenpairs of a SYMMETRIC matrix (reference utils.py:44-71).
+  """Sorted eigenpairs (reference utils.py:44-71): `np.linalg.eig`, real parts,
+  argsort by eigenvalue.
 
-  The reference calls LAPACK dgeev on whatever it is given; the device solver is
-  symmetric, so `input_matrix` must equal its transpose.  For
-  n <= 128 every eigenpair is returned, as the reference does; above that only
-  the `count` (default 64, max 64) extreme ones.
+  A symmetric input runs on the symmetric solver (dense Jacobi for n <= 128 -- every
+  eigenpair, as the reference returns -- else block Lanczos for the `count` (default
+  and max 64) extreme ones).  Anything else runs on the general solver (Hessenberg +
+  complex QR for n <= 64, else block Arnoldi for `count` <= 32 extreme ones, default
+  32); eigenvectors of complex pairs carry LAPACK's normalisation before `.real`.
   """
   m = np.ascontiguousarray(input_matrix, dtype=np.float64)
   if m.ndim != 2 or m.shape[0] != m.shape[1]:
     raise ValueError("input_matrix must be square")
   n = m.shape[0]
   scale = float(np.max(np.abs(m))) if m.size else 0.0
-  if not np.allclose(m, m.T, rtol=0.0, atol=1e-12 * max(scale, 1e-300)):
-    raise _lib.UnsupportedOnDeviceError(
-        "compute_sorted_eigenvectors on the device path needs a symmetric matrix")
+  symmetric = np.allclose(m, m.T, rtol=0.0, atol=1e-12 * max(scale, 1e-300))
   if count is None:
-    count = n if n <= 128 else 64
+    if symmetric:
+      count = n if n <= 128 else 64
+    else:
+      count = n if n <= 64 else 32
   values = np.empty(count, dtype=np.float64)
   vectors = np.empty((n, count), dtype=np.float64)
   handle = _lib.default_handle()
-  handle.check(handle.lib.sc_stage_sym_eig(
+  entry = handle.lib.sc_stage_sym_eig if symmetric else handle.lib.sc_stage_eig
+  handle.check(entry(
       handle.raw, _lib.as_double_p(m), n, count, int(bool(descend)),
       _lib.as_double_p(values), _lib.as_double_p(vectors), None))
   return values, vectors

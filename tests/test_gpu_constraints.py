@@ -232,7 +232,7 @@ def test_constraint_errors():
   with pytest.raises(ValueError, match="square"):
     clusterer.predict(x, np.zeros((50, 49)))
   # a non-symmetric constraint matrix after a symmetric refinement leaves a general
-  # matrix: outside the device eigen path, and said so
+  # matrix: the general eigen path takes it
   q = np.zeros((50, 50))
   q[3, 7] = 1.0
   after = sca.SpectralClusterer(
@@ -240,9 +240,15 @@ def test_constraint_errors():
       constraint_options=sca.ConstraintOptions(
           constraint_name=sca.ConstraintName.AffinityIntegration,
           apply_before_refinement=False, integration_type=sca.IntegrationType.Max))
-  with pytest.raises(sca.UnsupportedOnDeviceError):
-    after.predict(x, q)
-  # ... but before a symmetrising refinement it is fine, and matches the oracle
+  got = after.predict(x, q)
+  assert after.last_diag.symmetry_state == 3
+  cfg = so.turntodiarize_config(min_clusters=None, max_clusters=4, p_percentile=0.95,
+                                row_wise_renorm=False, laplacian_type=so.LAPLACIAN_NONE,
+                                constraint_name=so.CONSTRAINT_AFFINITY_INTEGRATION,
+                                apply_before_refinement=False,
+                                integration_type=so.INTEGRATION_MAX)
+  assert so.adjusted_rand_index(got, so.predict(x, cfg, constraint_matrix=q)) == 1.0
+  # ... and before a symmetrising refinement the symmetric path still runs
   before = sca.SpectralClusterer(
       max_clusters=4, refinement_options=toy_refinement(),
       constraint_options=sca.ConstraintOptions(

@@ -1,0 +1,189 @@
+"""GPU parity tests for the general (non-symmetric) eigen path:
+what `np.linalg.eig(...)` + `.real` + argsort give in reference utils.py:44-71 when the
+refined matrix is NOT diagonally similar to a symmetric one (e.g. a refinement sequence
+that ends in RowWiseThreshold -- the reference's own AutoTune tests,
+tests/spectral_clusterer_test.py:156-241).
+
+Tolerances: eigenvalues 1e-10 (dense) / 1e-7 (Arnoldi, whose stop rule is a 1e-10 residual
+for the stage API and the 1e-6 bound of the pipeline); eigenvectors are compared up to the
+sign of each column, like every other test (LAPACK fixes a complex vector's phase -- largest
+component real -- and so does the device; a sign is not fixed by either).
+"""
+
+import numpy as np
+import pytest
+
+import spectral_oracle as so
+
+import spectralcluster_amd as sca
+
+pytestmark = pytest.mark.gpu
+
+TOY = np.array([[1.0, 0.0], [1.1, 0.1], [0.0, 1.0], [0.1, 1.0], [0.9, -0.1], [0.0, 1.2]])
+
+
+def reference_sorted(m, descend=True):
+  w, v = np.linalg.eig(m)          # utils.py:59
+  w, v = w.real, v.real            # :60-61
+  idx = np.argsort(-w if descend else w, kind="stable")
+  return w[idx], v[:, idx]
+
+
+def column_error(got, want):
+  """max over columns of min(|g - w|, |g + w|) (sign-insensitive)."""
+  worst = 0.0
+  for j in range(want.shape[1]):
+    worst = max(worst, min(np.abs(got[:, j] - want[:, j]).max(),
+                           np.abs(got[:, j] + want[:, j]).max()))
+  return worst
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 6, 17, 33, 64])
+@pytest.mark.parametrize("descend", [True, False])
+def test_dense_general_eig_vs_numpy(n, descend):
+  rng = np.random.default_rng(100 + n)
+  m = rng.random((n, n))           # complex pairs are typical for n >= 3
+  if n >= 2:
+    m[0, 1] += 0.5                 # never symmetric
+  w, v = sca.utils.compute_sorted_eigenvectors(m, descend=descend)
+  wr, vr = reference_sorted(m, descend)
+  assert w.shape == (n,) and v.shape == (n, n)
+  np.testing.assert_allclose(w, wr, rtol=0, atol=1e-12 * max(1.0, np.abs(wr).max()))
+  # columns of equal real part (conjugate pairs) may swap; their real parts are identical
+  assert column_error(v, vr) < 1e-10
+
+
+def test_dense_general_eig_defective_and_triangular():
+  # already triangular, repeated eigenvalues (a Jordan block): eigenvalues must still come out
+  m = np.array([[2.0, 1.0, 0.0], [0.0, 2.0, 1.0], [0.0, 0.0, 3.0]])
+  w, _ = sca.utils.compute_sorted_eigenvectors(m)
+  np.testing.assert_allclose(w, [3.0, 2.0, 2.0], atol=1e-7)
+  # rotation-like block: purely complex pair, real parts both 0.5
+  m = np.array([[0.5, -2.0, 0.0], [2.0, 0.5, 0.0], [0.1, 0.2, -1.0]])
+  w, v = sca.utils.compute_sorted_eigenvectors(m)
+  wr, vr = reference_sorted(m)
+  np.testing.assert_allclose(w, wr, atol=1e-13)
+  assert column_error(v, vr) < 1e-12
+
+
+def thresholded(n, d, k, seed, p=0.9):
+  x = so.blobs(n, d, k, seed=seed)
+  return so.row_wise_threshold(so.affinity(x), p, 0.01, so.THRESHOLD_PERCENTILE), x
+
+
+@pytest.mark.parametrize("n,k", [(65, 2), (300, 3), (1000, 5), (2500, 4)])
+def test_arnoldi_top_eigenpairs_vs_numpy(n, k):
+  m, _ = thresholded(n, 16, k, seed=n)
+  assert not np.allclose(m, m.T)
+  count = k + 1                    # the cluster eigenvalues and the edge of the bulk
+  w, v = sca.utils.compute_sorted_eigenvectors(m, descend=True, count=count)
+  wr, vr = reference_sorted(m)
+  np.testing.assert_allclose(w, wr[:count], rtol=1e-8, atol=1e-9 * np.abs(wr).max())
+  # the k cluster eigenvectors are well separated; compare those
+  assert column_error(v[:, :k], vr[:, :k]) < 1e-6
+  w2, _ = sca.utils.compute_sorted_eigenvectors(-m, descend=False, count=count)
+  np.testing.assert_allclose(w2, -wr[:count], rtol=1e-8, atol=1e-9 * np.abs(wr).max())
+
+
+# --- the reference's AutoTune tests: [RowWiseThreshold] + GraphCut (non-symmetric) -----
+def threshold_only_options(**kw):
+  return sca.RefinementOptions(thresholding_type=sca.ThresholdType.Percentile,
+                               refinement_sequence=[sca.RefinementName.RowWiseThreshold], **kw)
+
+
+def threshold_only_config(**kw):
+  base = dict(sequence=(so.OP_ROW_WISE_THRESHOLD,), threshold_type=so.THRESHOLD_PERCENTILE,
+              laplacian_type=so.LAPLACIAN_GRAPH_CUT, row_wise_renorm=True)
+  base.update(kw)
+  return so.OracleConfig(**base)
+
+
+def test_6by2_auto_tune_reference_known_answer():
+  # reference tests/spectral_clusterer_test.py:156-184
+  clusterer = sca.SpectralClusterer(
+      max_clusters=2, refinement_options=threshold_only_options(),
+      autotune=sca.AutoTune(p_percentile_min=0.60, p_percentile_max=0.95,
+                            init_search_step=0.05, search_level=1),
+      laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  labels = sca.utils.enforce_ordered_labels(clusterer.predict(TOY))
+  np.testing.assert_equal(labels, [0, 0, 1, 1, 0, 1])
+  assert clusterer.last_diag.symmetry_state == 3
+  assert clusterer.last_diag.eig_path == 3       # dense general solver
+
+
+def test_1000by6_auto_tune_reference_known_answer():
+  # reference tests/spectral_clusterer_test.py:215-241 (seeded noise here)
+  rng = np.random.default_rng(7)
+  matrix = np.array([[1.0, 0, 0, 0, 0, 0]] * 400 + [[0, 1.0, 0, 0, 0, 0]] * 300 +
+                    [[0, 0, 2.0, 0, 0, 0]] * 200 + [[0, 0, 0, 1.0, 0, 0]] * 100)
+  matrix = matrix + (rng.random((1000, 6)) * 2 - 1) * 0.1
+  clusterer = sca.SpectralClusterer(
+      max_clusters=4, refinement_options=threshold_only_options(),
+      autotune=sca.AutoTune(p_percentile_min=0.9, p_percentile_max=0.95,
+                            init_search_step=0.03, search_level=1),
+      laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  labels = sca.utils.enforce_ordered_labels(clusterer.predict(matrix))
+  np.testing.assert_equal(labels, [0] * 400 + [1] * 300 + [2] * 200 + [3] * 100)
+  assert clusterer.last_diag.eig_path == 4       # block Arnoldi
+
+
+@pytest.mark.parametrize("lap", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("n", [40, 500])
+def test_threshold_only_every_laplacian_vs_oracle(lap, n):
+  x = so.blobs(n, 16, 3, seed=3 * n + lap)
+  cfg = threshold_only_config(laplacian_type=lap, p_percentile=0.9, min_clusters=2,
+                              max_clusters=6, row_wise_renorm=False)
+  dump = {}
+  want = so.predict(x, cfg, dump)
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=6,
+      refinement_options=threshold_only_options(p_percentile=0.9),
+      laplacian_type=sca.LaplacianType(lap) if lap else None)
+  got = clusterer.predict(x)
+  diag = clusterer.last_diag
+  assert diag.symmetry_state == 3
+  assert diag.n_clusters == dump["n_clusters"]
+  descend = lap in (0, 1)
+  idx = so.consumed_eigen_indices(n, 6, descend, dump["eigenvalues"] if descend else None,
+                                  1e-2 if descend else None)
+  w = diag.eigenvalue_array()
+  ref = dump["eigenvalues"]
+  # the two eigenvalues that form the maximum gap decide n_clusters and max_delta: tight.
+  # The other consumed ones sit in a dense bulk where the general solver only proves that
+  # they cannot produce a larger gap: loose.
+  k_raw = diag.n_clusters_raw
+  for i in idx:
+    tol = 1e-5 if i in (k_raw - 1, k_raw) else 5e-3
+    assert abs(w[i] - ref[i]) <= tol * max(abs(ref[i]), 1e-12), (i, w[i], ref[i])
+  np.testing.assert_allclose(diag.max_delta, dump["max_delta"], rtol=1e-5)
+  assert so.adjusted_rand_index(got, want) == 1.0
+
+
+def test_row_wise_normalize_after_threshold_is_general_too():
+  """[Threshold, RowWiseNormalize]: the normalisation is materialised (no symmetric fold)."""
+  x = so.blobs(400, 24, 4, seed=9)
+  seq = (so.OP_ROW_WISE_THRESHOLD, so.OP_ROW_WISE_NORMALIZE)
+  cfg = so.OracleConfig(min_clusters=2, max_clusters=7, sequence=seq, p_percentile=0.92)
+  dump = {}
+  want = so.predict(x, cfg, dump)
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=7,
+      refinement_options=sca.RefinementOptions(
+          p_percentile=0.92, refinement_sequence=[sca.RefinementName.RowWiseThreshold,
+                                                  sca.RefinementName.RowWiseNormalize]))
+  got = clusterer.predict(x)
+  assert clusterer.last_diag.symmetry_state == 3
+  assert so.adjusted_rand_index(got, want) == 1.0
+
+
+def test_general_path_autotune_vs_oracle():
+  x = so.blobs(600, 32, 5, seed=21)
+  cfg = threshold_only_config(min_clusters=2, max_clusters=8)
+  want = so.predict(x, cfg, autotune=(0.6, 0.95, 0.05, 1, True))
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=8, refinement_options=threshold_only_options(),
+      autotune=sca.AutoTune(p_percentile_min=0.60, p_percentile_max=0.95,
+                            init_search_step=0.05, search_level=1),
+      laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  got = clusterer.predict(x)
+  assert so.adjusted_rand_index(got, want) == 1.0

@@ -266,10 +266,12 @@ def test_error_behaviour():
     sca.SpectralClusterer(min_clusters=1).predict(TOY)
   with pytest.raises(sca.UnsupportedOnDeviceError):
     sca.SpectralClusterer(max_spectral_size=3).predict(TOY)
-  # RowWiseThreshold alone leaves a genuinely non-symmetric matrix
-  with pytest.raises(sca.UnsupportedOnDeviceError):
-    sca.SpectralClusterer(refinement_options=sca.RefinementOptions(
-        refinement_sequence=[sca.RefinementName.RowWiseThreshold])).predict(TOY)
+  # RowWiseThreshold alone leaves a genuinely non-symmetric matrix: general eigen path
+  general = sca.SpectralClusterer(refinement_options=sca.RefinementOptions(
+      refinement_sequence=[sca.RefinementName.RowWiseThreshold]))
+  want = so.predict(TOY, so.OracleConfig(sequence=(so.OP_ROW_WISE_THRESHOLD,)))
+  assert so.adjusted_rand_index(general.predict(TOY), want) == 1.0
+  assert general.last_diag.symmetry_state == 3
   with pytest.raises(sca.UnsupportedOnDeviceError):
     sca.SpectralClusterer(custom_dist="euclidean").predict(TOY)
   with pytest.raises(TypeError):

@@ -3,7 +3,7 @@
 Run in the build container only (needs /root/reference, which does not exist
 on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general]
 
 `--large` additionally runs the two n=8192 configurations (about 150-160 s of
 CPU each).  Inputs are regenerated from seeds by `spectral_oracle.blobs`; only
@@ -209,11 +209,48 @@ def constraint_goldens():
   save("integration_n200.npz", truth=truth, scores=sc, q=q, **out)
 
 
+def general_goldens():
+  """8. Non-symmetric refined matrix (N2): the reference's AutoTune test shape
+  (tests/spectral_clusterer_test.py:156-241: [RowWiseThreshold] + GraphCut), where
+  np.linalg.eig works on a genuinely general matrix."""
+  for n, d, k, seed in ((60, 8, 3, 5), (300, 16, 4, 6)):
+    x = so.blobs(n, d, k, seed)
+    opts = ref_refinement.RefinementOptions(
+        thresholding_type=ref_refinement.ThresholdType.Percentile,
+        refinement_sequence=[ref_refinement.RefinementName.RowWiseThreshold])
+    tuner = ref_autotune.AutoTune(p_percentile_min=0.60, p_percentile_max=0.95,
+                                  init_search_step=0.05, search_level=1)
+    grid = np.array(tuner.get_percentile_range())
+    clusterer = ref_sc.SpectralClusterer(
+        min_clusters=2, max_clusters=6, refinement_options=opts, autotune=tuner,
+        laplacian_type=LAP[4], row_wise_renorm=True)
+    a = ref_utils.compute_affinity_matrix(x)
+    ratios, ks, deltas, w2 = [], [], [], []
+    for p in grid:
+      clusterer.refinement_options.p_percentile = p
+      refined = ref_refinement.RowWiseThreshold(
+          p, 0.01, ref_refinement.ThresholdType.Percentile, False, False).refine(a)
+      lap = ref_laplacian.compute_laplacian(refined, LAP[4])
+      w, _ = ref_utils.compute_sorted_eigenvectors(lap, descend=False)
+      _, kk, delta = clusterer._compute_eigenvectors_ncluster(a)
+      ratios.append(np.sqrt(1 - p) / delta)
+      ks.append(kk)
+      deltas.append(delta)
+      w2.append(w[:8])
+    labels = clusterer.predict(x)
+    save("general_n%d.npz" % n, n=n, d=d, k=k, seed=seed, grid=grid,
+         ratios=np.array(ratios), n_clusters=np.array(ks), max_delta=np.array(deltas),
+         eigenvalues=np.array(w2), labels=labels)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
   if "--constraints" in sys.argv:  # only section 7
     constraint_goldens()
+    return
+  if "--general" in sys.argv:  # only section 8
+    general_goldens()
     return
 
   # 1. The 6x2 toy of the reference tests, sigma=0, full stage dump, all
@@ -296,6 +333,7 @@ def main():
        best_p=np.float64(grid[int(np.argmin(ratios))]))
 
   constraint_goldens()
+  general_goldens()
 
   if large:
     for c in [(8192, 256, 8, 0, 4, 20), (8192, 256, 4, 1, 0, 7)]:

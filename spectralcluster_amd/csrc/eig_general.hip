@@ -179,8 +179,10 @@ __global__ __launch_bounds__(64) void k_gen_eig(const double* __restrict__ A, in
       const cd c = {HR(en, en - 1), HI(en, en - 1)};
       const cd d = {HR(en, en), HI(en, en)};
       const cd half = cscale(cadd(a, d), 0.5);
-      const cd det = csub(cmul(a, d), cmul(b, c));
-      const cd disc = csqrt_(csub(cmul(half, half), det));
+      // ((a - d) / 2)^2 + b c, not (tr / 2)^2 - det: for a nearly defective 2x2 (a ~ d,
+      // b c tiny) the latter cancels catastrophically and the iteration stagnates
+      const cd hd = cscale(csub(a, d), 0.5);
+      const cd disc = csqrt_(cadd(cmul(hd, hd), cmul(b, c)));
       const cd l1 = cadd(half, disc), l2 = csub(half, disc);
       const cd d1 = csub(l1, d), d2 = csub(l2, d);
       sh = (d1.re * d1.re + d1.im * d1.im) < (d2.re * d2.re + d2.im * d2.im) ? l1 : l2;

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 import spectral_oracle as so
+from conftest import golden
 
 import spectralcluster_amd as sca
 
@@ -64,6 +65,22 @@ def test_dense_general_eig_defective_and_triangular():
   wr, vr = reference_sorted(m)
   np.testing.assert_allclose(w, wr, atol=1e-13)
   assert column_error(v, vr) < 1e-12
+
+
+@pytest.mark.parametrize("n,d,k,seed", [(60, 8, 3, 5), (64, 8, 2, 2), (33, 6, 2, 3)])
+def test_dense_general_near_defective_laplacians(n, d, k, seed):
+  """Laplacians of heavily thresholded affinities carry a highly degenerate, nearly
+  defective eigenvalue 1 (2x2 blocks [[a, b], [c, a]] with c ~ 1e-13): the Wilkinson shift
+  must be computed without cancellation or the QR iteration stagnates."""
+  a = so.affinity(so.blobs(n, d, k, seed))
+  for lap in (2, 3, 4):
+    for p in (0.3, 0.4, 0.6, 0.7, 0.95):
+      m = so.laplacian(so.row_wise_threshold(a, p, 0.01, so.THRESHOLD_PERCENTILE), lap)
+      w, _ = sca.utils.compute_sorted_eigenvectors(m, descend=False)
+      wr = np.sort(np.linalg.eigvals(m).real)
+      np.testing.assert_allclose(w[:8], wr[:8], rtol=0, atol=1e-10 * np.abs(wr).max())
+      # the degenerate cluster itself is only defined to ~sqrt(eps) (Jordan-like blocks)
+      np.testing.assert_allclose(w, wr, rtol=0, atol=1e-6 * np.abs(wr).max())
 
 
 def thresholded(n, d, k, seed, p=0.9):
@@ -187,3 +204,30 @@ def test_general_path_autotune_vs_oracle():
       laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
   got = clusterer.predict(x)
   assert so.adjusted_rand_index(got, want) == 1.0
+
+
+@pytest.mark.parametrize("n", [60, 300])
+def test_general_matrix_autotune_vs_reference_golden(n):
+  """Outputs of the real reference (oracle/make_golden.py --general): per-p cluster counts,
+  maximum gaps and the AutoTune winner's labels on the non-symmetric path."""
+  g = golden("general_n%d.npz" % n)
+  x = so.blobs(n, int(g["d"]), int(g["k"]), int(g["seed"]))
+  def make():
+    return sca.SpectralClusterer(
+        min_clusters=2, max_clusters=6, refinement_options=threshold_only_options(),
+        autotune=sca.AutoTune(p_percentile_min=0.60, p_percentile_max=0.95,
+                              init_search_step=0.05, search_level=1),
+        laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  clusterer = make()
+  a = so.affinity(x)
+  for i, p in enumerate(g["grid"]):
+    clusterer.refinement_options.p_percentile = float(p)
+    _, k, delta = clusterer._compute_eigenvectors_ncluster(a)
+    assert k == int(g["n_clusters"][i])
+    np.testing.assert_allclose(delta, g["max_delta"][i], rtol=1e-5)
+    diag = clusterer.last_diag
+    w = diag.eigenvalue_array()
+    for j in (k - 1, k):   # the pair that forms the maximum gap
+      assert abs(w[j] - g["eigenvalues"][i][j]) <= 1e-5 * abs(g["eigenvalues"][i][j])
+  labels = make().predict(x)
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0

@@ -2,6 +2,8 @@
 REAL reference (tests/golden/*.npz, produced by oracle/make_golden.py which imports
 /root/reference) and against the reference's own known-answer test vectors."""
 
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -229,6 +231,27 @@ def test_integration_after_refinement_predict():
     _, k, delta = so.eig_ncluster(so.affinity(x), cfg, constraint_matrix=g["q"])
     assert k == int(g["n_clusters_" + tag])
     np.testing.assert_allclose(delta, float(g["max_delta_" + tag]), rtol=1e-8)
+
+
+@pytest.mark.parametrize("n", [60, 300])
+def test_general_matrix_autotune_vs_reference(n):
+  """[RowWiseThreshold] + GraphCut: np.linalg.eig on a genuinely non-symmetric matrix."""
+  g = golden("general_n%d.npz" % n)
+  x = so.blobs(n, int(g["d"]), int(g["k"]), int(g["seed"]))
+  cfg = so.OracleConfig(min_clusters=2, max_clusters=6, sequence=(so.OP_ROW_WISE_THRESHOLD,),
+                        threshold_type=so.THRESHOLD_PERCENTILE,
+                        laplacian_type=so.LAPLACIAN_GRAPH_CUT, row_wise_renorm=True)
+  grid = so.autotune_range(0.60, 0.95, 0.05)
+  np.testing.assert_array_equal(grid, g["grid"])
+  a = so.affinity(x)
+  for i, p in enumerate(grid):
+    dump = {}
+    _, k, delta = so.eig_ncluster(a, dataclasses.replace(cfg, p_percentile=p), dump)
+    assert k == int(g["n_clusters"][i])
+    np.testing.assert_allclose(delta, g["max_delta"][i], rtol=1e-9)
+    np.testing.assert_allclose(dump["eigenvalues"][1:8], g["eigenvalues"][i][1:8], rtol=1e-9)
+  labels = so.predict(x, cfg, autotune=(0.60, 0.95, 0.05, 1, True))
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
 
 
 def test_adjusted_rand_index():

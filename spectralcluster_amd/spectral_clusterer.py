@@ -4,10 +4,10 @@ reference `spectralcluster/spectral_clusterer.py`, with the dense hot path
 executed on one MI355X through the C ABI in `include/spectralcluster_amd.h`.
 
 Constraints (`constraint_options` + `predict(embeddings, constraint_matrix)`) run on the
-device too.  Out of the device scope: FallbackOptions /
-single-cluster check, max_spectral_size, non-cosine k-means, and refinement sequences
-whose result is not diagonally similar to a symmetric matrix.  Those raise
-`UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
+device too, and refinement sequences whose result is not
+diagonally similar to a symmetric matrix take the general eigen path (8f-N2).  Out of the
+device scope: FallbackOptions / single-cluster check, max_spectral_size, non-cosine
+k-means.  Those raise `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
 """
 
 from __future__ import annotations

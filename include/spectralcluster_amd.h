@@ -70,6 +70,8 @@ enum {
   SC_CONSTRAINT_PROPAGATION = 2
 };
 enum { SC_INTEGRATION_MAX = 1, SC_INTEGRATION_AVERAGE = 2 };
+/* linkage of the size-reduction / fallback agglomerative clustering */
+enum { SC_LINKAGE_COMPLETE = 1, SC_LINKAGE_AVERAGE = 2 };
 /* utils.py:10-17 EigenGapType */
 enum { SC_EIGENGAP_RATIO = 1, SC_EIGENGAP_NORMALIZED_DIFF = 2 };
 
@@ -234,6 +236,19 @@ int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* labels,
 int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,
                      int count, const sc_config* cfg, int64_t* const* labels,
                      sc_diag* diags);
+
+/*
+ * Size reduction before the spectral path (spectral_clusterer.py:170-199,
+ * multi_stage_clusterer.py:109-112, fallback_clusterer.py:108-113):
+ * sklearn.cluster.AgglomerativeClustering(metric="cosine", linkage=...).fit_predict(X)
+ * with n_clusters > 0, or n_clusters == 0 and a distance_threshold; labels are numbered as
+ * sklearn numbers them.  n_clusters_out (may be NULL) receives the cluster count.
+ */
+int sc_ahc(sc_handle h, const double* x, int n, int d, int linkage, int n_clusters,
+           double distance_threshold, int64_t* labels, int* n_clusters_out);
+/* utils.get_cluster_centroids (utils.py:159-176): out is (k, d), k = max(labels) + 1 */
+int sc_cluster_centroids(sc_handle h, const double* x, int n, int d, const int64_t* labels,
+                         int k, double* out);
 
 /* ---- single stages (ndarray in / ndarray out; parity tests and the
  *      per-op Python classes use these) ------------------------------------- */

@@ -3,7 +3,7 @@
 Run in the build container only (needs /root/reference, which does not exist
 on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general | --size-reduction]
 
 `--large` additionally runs the two n=8192 configurations (about 150-160 s of
 CPU each).  Inputs are regenerated from seeds by `spectral_oracle.blobs`; only
@@ -243,6 +243,40 @@ def general_goldens():
          eigenvalues=np.array(w2), labels=labels)
 
 
+def size_reduction_goldens():
+  """9. max_spectral_size (N4): AHC pre-clustering + spectral on the centroids."""
+  out = {}
+  # the reference's own test shape (tests/spectral_clusterer_test.py:71-89), seeded noise
+  rng = np.random.default_rng(71)
+  base = np.array([[1.0, 0, 0, 0, 0, 0]] * 400 + [[0, 1.0, 0, 0, 0, 0]] * 300 +
+                  [[0, 0, 2.0, 0, 0, 0]] * 200 + [[0, 0, 0, 1.0, 0, 0]] * 100)
+  x = base + (rng.random((1000, 6)) * 2 - 1) * 0.1
+  clusterer = ref_sc.SpectralClusterer(
+      refinement_options=icassp_options(sigma=0), max_spectral_size=100)
+  from sklearn.cluster import AgglomerativeClustering
+  out["x_1000by6"] = x
+  out["ahc_1000by6"] = AgglomerativeClustering(
+      n_clusters=100, metric="cosine", linkage="complete").fit_predict(x)
+  out["labels_1000by6"] = clusterer.predict(x)
+  for tag, (n, d, k, seed, mss, lap) in {"a": (1500, 32, 5, 91, 200, 0),
+                                         "b": (2500, 64, 4, 92, 300, 4)}.items():
+    xx = so.blobs(n, d, k, seed)
+    c = ref_sc.SpectralClusterer(min_clusters=2, max_clusters=7,
+                                 refinement_options=icassp_options(),
+                                 laplacian_type=LAP[lap], max_spectral_size=mss)
+    out["ahc_" + tag] = AgglomerativeClustering(
+        n_clusters=mss, metric="cosine", linkage="complete").fit_predict(xx)
+    out["labels_" + tag] = c.predict(xx)
+  # average linkage with a distance threshold (the agglomerative fallback's form,
+  # fallback_clusterer.py:108-113)
+  xx = so.blobs(400, 16, 6, 93)
+  for thr in (0.3, 0.5):
+    out["avg_thr%02d" % round(thr * 10)] = AgglomerativeClustering(
+        n_clusters=None, metric="cosine", linkage="average",
+        distance_threshold=thr).fit_predict(xx)
+  save("size_reduction.npz", **out)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
@@ -251,6 +285,9 @@ def main():
     return
   if "--general" in sys.argv:  # only section 8
     general_goldens()
+    return
+  if "--size-reduction" in sys.argv:  # only section 9
+    size_reduction_goldens()
     return
 
   # 1. The 6x2 toy of the reference tests, sigma=0, full stage dump, all
@@ -334,6 +371,7 @@ def main():
 
   constraint_goldens()
   general_goldens()
+  size_reduction_goldens()
 
   if large:
     for c in [(8192, 256, 8, 0, 4, 20), (8192, 256, 4, 1, 0, 7)]:

@@ -148,6 +148,11 @@ PROTOTYPES = {
     "sc_apply_constraint": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig)]),
     "sc_stage_constraint": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), _c_double_p,
                                            _c_double_p, ctypes.c_int, _c_double_p]),
+    "sc_ahc": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                              ctypes.c_int, ctypes.c_double, _c_int64_p,
+                              ctypes.POINTER(ctypes.c_int)]),
+    "sc_cluster_centroids": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int, ctypes.c_int,
+                                            _c_int64_p, ctypes.c_int, _c_double_p]),
     "sc_run_resident": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig),
                                        _c_int64_p, ctypes.POINTER(ScDiag)]),
     "sc_predict_batch": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),

@@ -4,6 +4,7 @@
 // Host code only decides and launches; every O(n) or larger computation runs in
 // the HIP kernels of this library.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,7 @@ struct sc_handle_s {
   // (column-major), residual partials, restart codes, dense Laplacian scratch
   DevBuf crvec, thetai, Vre, Vim, gpart, gsrc, genL;
   const double* vs_scale = nullptr;  // Vs = vs_scale .* V in orthonormalize (default cvec)
+  DevBuf ahc_size, ahc_chain, ahc_Z, ahc_lab, ahc_cent;  // size reduction (AHC) scratch
   // k-means workspace
   DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo;
   // pinned host scratch
@@ -266,7 +268,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->ahc_size, &h->ahc_chain, &h->ahc_Z, &h->ahc_lab, &h->ahc_cent, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -1736,6 +1738,171 @@ extern "C" int sc_predict_batch(sc_handle h, const double* const* xs, const int*
   if (nmax > 0) SC_TRY(sc_reserve(h, nmax, d));  // one arena sized for the largest member
   for (int i = 0; i < count; ++i)
     SC_TRY(sc_predict(h, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr));
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// N4: size reduction -- agglomerative clustering + centroids
+// ------------------------------------------------------------------------------
+namespace {
+// CPython heapq (Lib/heapq.py) on ints: sklearn's _hc_cut enumerates the heap ARRAY, so
+// the exact sift order defines the label numbering.
+void heap_siftdown(std::vector<long long>& heap, size_t startpos, size_t pos) {
+  const long long newitem = heap[pos];
+  while (pos > startpos) {
+    const size_t parentpos = (pos - 1) >> 1;
+    const long long parent = heap[parentpos];
+    if (newitem < parent) {
+      heap[pos] = parent;
+      pos = parentpos;
+      continue;
+    }
+    break;
+  }
+  heap[pos] = newitem;
+}
+void heap_siftup(std::vector<long long>& heap, size_t pos) {
+  const size_t endpos = heap.size(), startpos = pos;
+  const long long newitem = heap[pos];
+  size_t childpos = 2 * pos + 1;
+  while (childpos < endpos) {
+    const size_t rightpos = childpos + 1;
+    if (rightpos < endpos && !(heap[childpos] < heap[rightpos])) childpos = rightpos;
+    heap[pos] = heap[childpos];
+    pos = childpos;
+    childpos = 2 * pos + 1;
+  }
+  heap[pos] = newitem;
+  heap_siftdown(heap, startpos, pos);
+}
+void heap_push(std::vector<long long>& heap, long long item) {
+  heap.push_back(item);
+  heap_siftdown(heap, 0, heap.size() - 1);
+}
+void heap_pushpop(std::vector<long long>& heap, long long item) {
+  if (!heap.empty() && heap[0] < item) {
+    std::swap(item, heap[0]);
+    heap_siftup(heap, 0);
+  }
+}
+}  // namespace
+
+// sklearn.cluster.AgglomerativeClustering(metric="cosine", linkage=complete|average,
+// n_clusters=... | distance_threshold=...).fit_predict(X), label numbering included.
+extern "C" int sc_ahc(sc_handle h, const double* x, int n, int d, int linkage, int n_clusters,
+                      double distance_threshold, int64_t* labels, int* n_clusters_out) {
+  if (!h) return SC_ERR_INVALID;
+  if (!x || !labels || d <= 0) return fail(h, SC_ERR_INVALID, "embeddings must be (n, d)");
+  if (n < 2)
+    return fail(h, SC_ERR_INVALID,
+                "Found array with " + std::to_string(std::max(n, 0)) +
+                    " sample(s) while a minimum of 2 is required by AgglomerativeClustering.");
+  if (linkage != SC_LINKAGE_COMPLETE && linkage != SC_LINKAGE_AVERAGE)
+    return fail(h, SC_ERR_INVALID, "linkage must be complete or average");
+  if (n_clusters < 0 || n_clusters > n)
+    return fail(h, SC_ERR_INVALID, "Cannot extract more clusters than samples");
+  SC_HIP(h, hipSetDevice(h->device));
+  // cosine distances: the affinity stage's normalise + symmetric GEMM, then 1 - clip(c)
+  SC_TRY(sc_set_embeddings(h, x, n, d));
+  SC_TRY(ensure_tilemap(h, n));
+  hipStream_t s = h->stream;
+  const int ld = h->ldn;
+  launch_normalize_rows(s, ptr<double>(h->X), h->ldx, n, d, ptr<double>(h->Xn));
+  launch_gemm_nt(s, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx, ptr<double>(h->B1),
+                 ld, n, n, d, kEpiNone, true, ptr<double>(h->splitk), ptr<int2>(h->tilemap));
+  launch_cosine_distance(s, ptr<double>(h->B1), n, ld);
+  SC_TRY(grow(h, h->ahc_size, (size_t)n * sizeof(int)));
+  SC_TRY(grow(h, h->ahc_chain, (size_t)n * sizeof(int)));
+  SC_TRY(grow(h, h->ahc_Z, (size_t)n * 4 * sizeof(double)));
+  launch_ahc_nn_chain(s, ptr<double>(h->B1), ld, n, linkage, ptr<int>(h->ahc_size),
+                      ptr<int>(h->ahc_chain), ptr<double>(h->ahc_Z));
+  SC_TRY(check_last(h, "agglomerative clustering launch"));
+  std::vector<double> Z((size_t)(n - 1) * 4);
+  SC_HIP(h, hipMemcpyAsync(Z.data(), h->ahc_Z.p, Z.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipStreamSynchronize(s));
+  h->have_affinity = h->have_cropval = false;
+  // ---- scipy: stable sort by height, union-find relabelling (hierarchy.pyx `label`)
+  std::vector<int> order(n - 1);
+  for (int i = 0; i < n - 1; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int a, int b) { return Z[(size_t)a * 4 + 2] < Z[(size_t)b * 4 + 2]; });
+  std::vector<int> parent(2 * (size_t)n - 1);
+  for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
+  auto find = [&](int v) {
+    int r = v;
+    while (parent[r] != r) r = parent[r];
+    while (parent[v] != r) {
+      const int next = parent[v];
+      parent[v] = r;
+      v = next;
+    }
+    return r;
+  };
+  std::vector<std::array<long long, 2>> children(n - 1);
+  std::vector<double> heights(n - 1);
+  int next_label = n;
+  for (int i = 0; i < n - 1; ++i) {
+    const int m = order[i];
+    const int xr = find((int)Z[(size_t)m * 4]), yr = find((int)Z[(size_t)m * 4 + 1]);
+    children[i] = {std::min(xr, yr), std::max(xr, yr)};
+    heights[i] = Z[(size_t)m * 4 + 2];
+    parent[xr] = next_label;
+    parent[yr] = next_label;
+    ++next_label;
+  }
+  // ---- sklearn: number of clusters, then _hc_cut
+  int k = n_clusters;
+  if (k == 0) {  // distance_threshold mode
+    k = 1;
+    for (int i = 0; i < n - 1; ++i) k += heights[i] >= distance_threshold;
+  }
+  if (n_clusters_out) *n_clusters_out = k;
+  std::vector<long long> nodes;
+  nodes.push_back(-(std::max(children[n - 2][0], children[n - 2][1]) + 1));
+  for (int it = 0; it < k - 1; ++it) {
+    const auto c = children[(size_t)(-nodes[0] - n)];
+    heap_push(nodes, -c[0]);
+    heap_pushpop(nodes, -c[1]);
+  }
+  std::vector<long long> stack;
+  for (size_t i = 0; i < nodes.size(); ++i) {
+    stack.assign(1, -nodes[i]);
+    while (!stack.empty()) {
+      const long long v = stack.back();
+      stack.pop_back();
+      if (v < n) {
+        labels[v] = (int64_t)i;
+      } else {
+        stack.push_back(children[(size_t)(v - n)][0]);
+        stack.push_back(children[(size_t)(v - n)][1]);
+      }
+    }
+  }
+  return SC_OK;
+}
+
+// utils.get_cluster_centroids (reference utils.py:159-176): (k, d) means, k = max(labels)+1
+extern "C" int sc_cluster_centroids(sc_handle h, const double* x, int n, int d,
+                                    const int64_t* labels, int k, double* out) {
+  if (!h) return SC_ERR_INVALID;
+  if (!x || !labels || !out || n <= 0 || d <= 0 || k <= 0)
+    return fail(h, SC_ERR_INVALID, "embeddings must be (n, d), labels (n,)");
+  SC_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  SC_TRY(grow(h, h->ahc_lab, (size_t)n * sizeof(int)));
+  SC_TRY(grow(h, h->ahc_cent, (size_t)(n + k) * d * sizeof(double)));
+  std::vector<int> lab32(n);
+  for (int i = 0; i < n; ++i) lab32[i] = (int)labels[i];
+  double* xd = ptr<double>(h->ahc_cent);
+  double* cd_ = xd + (size_t)n * d;
+  SC_HIP(h, hipMemcpyAsync(xd, x, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, s));
+  SC_HIP(h, hipMemcpyAsync(h->ahc_lab.p, lab32.data(), (size_t)n * sizeof(int),
+                           hipMemcpyHostToDevice, s));
+  launch_cluster_centroids(s, xd, d, n, d, ptr<int>(h->ahc_lab), k, cd_);
+  SC_TRY(check_last(h, "centroid launch"));
+  SC_HIP(h, hipMemcpyAsync(out, cd_, (size_t)k * d * sizeof(double), hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipStreamSynchronize(s));
   return SC_OK;
 }
 

@@ -196,6 +196,15 @@ void launch_gen_gather(hipStream_t s, const double* Vre, const double* Vim, int 
 void launch_scaling_general(hipStream_t s, const double* deg, int n, int laplacian_type,
                             double* cl, double* cr, double* p);
 
+// ---- size reduction (ahc.hip) ----------------------------------------------------------
+void launch_cosine_distance(hipStream_t s, double* c, int n, int ld);
+// nearest-neighbour-chain agglomeration on the n x n distance matrix D (destroyed);
+// method 1 complete, 2 average; Z: (n - 1) x 4 (slot x, slot y, height, size), merge order
+void launch_ahc_nn_chain(hipStream_t s, double* D, int ld, int n, int method, int* size,
+                         int* chain, double* Z);
+void launch_cluster_centroids(hipStream_t s, const double* X, int ldx, int n, int d,
+                              const int* labels, int k, double* out);
+
 // ---- k-means -------------------------------------------------------------------
 struct KmeansWorkspace {
   double* Xc = nullptr;       // kMaxVectors x n centred copy (column-major)

@@ -5,9 +5,9 @@ executed on one MI355X through the C ABI in `include/spectralcluster_amd.h`.
 
 Constraints (`constraint_options` + `predict(embeddings, constraint_matrix)`) run on the
 device too, and refinement sequences whose result is not
-diagonally similar to a symmetric matrix take the general eigen path (8f-N2).  Out of the
-device scope: FallbackOptions / single-cluster check, max_spectral_size, non-cosine
-k-means.  Those raise `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
+diagonally similar to a symmetric matrix take the general eigen path (8f-N2);
+`max_spectral_size` pre-clusters on the device (cosine complete-linkage AHC, 8f-N4).  Out of the
+device scope: FallbackOptions / single-cluster check, non-cosine k-means.  Those raise `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
 """
 
 from __future__ import annotations
@@ -89,12 +89,6 @@ class SpectralClusterer:
       raise _lib.UnsupportedOnDeviceError(
           "min_clusters=1 triggers the reference's single-cluster check "
           "(fallback_clusterer.check_single_cluster), which is out of scope")
-    if self.max_spectral_size is not None:
-      if constraint_matrix is not None:  # reference spectral_clusterer.py:240-242
-        raise RuntimeError(
-            "Cannot handle constraint_matrix when max_spectral_size is set")
-      raise _lib.UnsupportedOnDeviceError(
-          "max_spectral_size (AHC pre-clustering) is out of scope")
 
   def build_config(self, p_percentile: typing.Optional[float] = None) -> _lib.ScConfig:
     """Flatten the constructor arguments into an `sc_config`."""
@@ -187,6 +181,15 @@ class SpectralClusterer:
     vectors = self._download_eigenvectors(handle, a.shape[0])
     return vectors, int(diag.n_clusters_raw), float(diag.max_delta)
 
+  def _reduce_size_and_predict(self, embeddings: np.ndarray) -> np.ndarray:
+    """Complete-linkage cosine AHC down to `max_spectral_size` clusters, spectral
+    clustering of their centroids, labels chained back (reference :170-199)."""
+    ahc_labels = utils.cosine_agglomerative_clustering(
+        embeddings, n_clusters=self.max_spectral_size, linkage="complete")
+    ahc_centroids = utils.get_cluster_centroids(embeddings, ahc_labels)
+    spectral_labels = self.predict(ahc_centroids)
+    return utils.chain_labels(ahc_labels, spectral_labels)
+
   def predict(self, embeddings: np.ndarray, constraint_matrix=None) -> np.ndarray:
     """Cluster `embeddings` (n_samples, n_features); returns int64 labels
     (reference spectral_clusterer.py:201-314)."""
@@ -196,6 +199,16 @@ class SpectralClusterer:
       raise ValueError("embeddings must be 2-dimensional")
     self._scope_check(constraint_matrix)
     n = embeddings.shape[0]
+    if self.max_spectral_size is not None and n > self.max_spectral_size:
+      # reference spectral_clusterer.py:236-248
+      if constraint_matrix is not None:
+        raise RuntimeError(
+            "Cannot handle constraint_matrix when max_spectral_size is set")
+      if (self.max_spectral_size < 2 or
+          (self.max_clusters and self.max_spectral_size <= self.max_clusters) or
+          (self.min_clusters and self.max_spectral_size <= self.min_clusters)):
+        raise ValueError("max_spectral_size should be a relatively big number")
+      return self._reduce_size_and_predict(embeddings)
     handle = self._handle()
     default_tail = (self.post_eigen_cluster_function is custom_distance_kmeans.run_kmeans)
     if default_tail and self.custom_dist != "cosine":
@@ -287,7 +300,7 @@ class SpectralClusterer:
     independent handles -- one HIP stream and one arena each -- driven by one host
     thread per handle (ctypes releases the GIL during the calls).
     """
-    if self.autotune is not None:
+    if self.autotune is not None or self.max_spectral_size is not None:
       return [self.predict(u) for u in utterances]
     self._scope_check()
     if not utterances:

@@ -98,3 +98,65 @@ def enforce_ordered_labels(labels: np.ndarray) -> np.ndarray:
   for pos, value in enumerate(labels.tolist()):
     out[pos] = order.setdefault(value, len(order))
   return out
+
+
+def get_cluster_centroids(embeddings: np.ndarray, labels: np.ndarray) -> np.ndarray:
+  """Mean embedding of every cluster, (max(labels) + 1, n_features) (reference
+  utils.py:159-176); the segmented mean runs on the device and adds the members in index
+  order, as `np.mean(axis=0)` does."""
+  x = np.ascontiguousarray(embeddings, dtype=np.float64)
+  lab = np.ascontiguousarray(labels, dtype=np.int64)
+  if x.ndim != 2 or lab.shape != (x.shape[0],):
+    raise ValueError("embeddings must be (n_samples, n_features), labels (n_samples,)")
+  k = int(lab.max()) + 1
+  out = np.empty((k, x.shape[1]), dtype=np.float64)
+  handle = _lib.default_handle()
+  handle.check(handle.lib.sc_cluster_centroids(
+      handle.raw, _lib.as_double_p(x), x.shape[0], x.shape[1], _lib.as_int64_p(lab), k,
+      _lib.as_double_p(out)))
+  return out
+
+
+def chain_labels(pre_labels: typing.Optional[np.ndarray],
+                 main_labels: np.ndarray) -> np.ndarray:
+  """Labels of the samples given the labels of their pre-clusters (reference
+  utils.py:179-206).  Like the reference the result is float64 (it fills `np.zeros`)."""
+  if pre_labels is None:
+    return main_labels
+  count = int(max(pre_labels) + 1)
+  if count != main_labels.shape[0]:
+    raise ValueError("pre_labels has {} values while main_labels has {} rows.".format(
+        count, main_labels.shape[0]))
+  return np.asarray(main_labels, dtype=np.float64)[np.asarray(pre_labels, dtype=np.int64)]
+
+
+LINKAGE_CODES = {"complete": 1, "average": 2}
+
+
+def cosine_agglomerative_clustering(embeddings: np.ndarray,
+                                    n_clusters: typing.Optional[int] = None,
+                                    linkage: str = "complete",
+                                    distance_threshold: typing.Optional[float] = None
+                                    ) -> np.ndarray:
+  """`sklearn.cluster.AgglomerativeClustering(n_clusters=..., metric="cosine",
+  linkage=..., distance_threshold=...).fit_predict(embeddings)` on the device -- the
+  pre-clusterer of the reference (spectral_clusterer.py:170-199,
+  multi_stage_clusterer.py:109-112) and its agglomerative fallback
+  (fallback_clusterer.py:108-113).  Labels are numbered exactly as sklearn numbers them
+  (its heap-ordered tree cut); the downstream GaussianBlur depends on that order."""
+  if linkage not in LINKAGE_CODES:
+    raise _lib.UnsupportedOnDeviceError("linkage must be 'complete' or 'average'")
+  if (n_clusters is None) == (distance_threshold is None):
+    raise ValueError("Exactly one of n_clusters and distance_threshold has to be set, "
+                     "and the other needs to be None.")
+  x = np.ascontiguousarray(embeddings, dtype=np.float64)
+  if x.ndim != 2:
+    raise ValueError("embeddings must be 2-dimensional")
+  labels = np.empty(x.shape[0], dtype=np.int64)
+  found = ctypes.c_int(0)
+  handle = _lib.default_handle()
+  handle.check(handle.lib.sc_ahc(
+      handle.raw, _lib.as_double_p(x), x.shape[0], x.shape[1], LINKAGE_CODES[linkage],
+      int(n_clusters or 0), float(distance_threshold or 0.0), _lib.as_int64_p(labels),
+      ctypes.byref(found)))
+  return labels

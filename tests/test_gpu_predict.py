@@ -264,8 +264,8 @@ def test_error_behaviour():
     clusterer.predict(np.zeros(5))
   with pytest.raises(sca.UnsupportedOnDeviceError):
     sca.SpectralClusterer(min_clusters=1).predict(TOY)
-  with pytest.raises(sca.UnsupportedOnDeviceError):
-    sca.SpectralClusterer(max_spectral_size=3).predict(TOY)
+  reduced = sca.SpectralClusterer(max_spectral_size=3).predict(TOY)   # 6 -> 3 centroids
+  assert reduced.shape == (6,) and reduced.dtype == np.float64
   # RowWiseThreshold alone leaves a genuinely non-symmetric matrix: general eigen path
   general = sca.SpectralClusterer(refinement_options=sca.RefinementOptions(
       refinement_sequence=[sca.RefinementName.RowWiseThreshold]))

@@ -254,6 +254,32 @@ def test_general_matrix_autotune_vs_reference(n):
   assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
 
 
+def test_size_reduction_vs_reference():
+  g = golden("size_reduction.npz")
+  x = g["x_1000by6"]
+  assert np.array_equal(so.agglomerative(x, 100, "complete"), g["ahc_1000by6"])
+  cfg = so.icassp2018_config(min_clusters=None, max_clusters=None, gaussian_blur_sigma=0)
+  got = so.reduce_size_and_predict(x, cfg, 100)
+  assert got.dtype == np.float64 and g["labels_1000by6"].dtype == np.float64
+  assert so.adjusted_rand_index(got.astype(int), g["labels_1000by6"].astype(int)) == 1.0
+  assert np.array_equal(so.ordered_labels(got.astype(int)),
+                        [0] * 400 + [1] * 300 + [2] * 200 + [3] * 100)
+  xx = so.blobs(1500, 32, 5, 91)
+  dump = {}
+  got = so.reduce_size_and_predict(xx, so.icassp2018_config(), 200, dump)
+  assert np.array_equal(dump["ahc_labels"], g["ahc_a"])
+  assert so.adjusted_rand_index(got.astype(int), g["labels_a"].astype(int)) == 1.0
+  # centroids: np.mean(axis=0) adds the members in index order
+  c = so.get_cluster_centroids(xx, g["ahc_a"])
+  members = np.flatnonzero(g["ahc_a"] == 3)
+  acc = np.zeros(32)
+  for i in members:
+    acc = acc + xx[i]
+  assert np.array_equal(c[3], acc / len(members))
+  with pytest.raises(ValueError):
+    so.chain_labels(np.array([0, 1, 2]), np.array([0, 1]))
+
+
 def test_adjusted_rand_index():
   from sklearn.metrics import adjusted_rand_score
   rng = np.random.default_rng(0)

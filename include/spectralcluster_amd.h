@@ -250,6 +250,21 @@ int sc_ahc(sc_handle h, const double* x, int n, int d, int linkage, int n_cluste
 int sc_cluster_centroids(sc_handle h, const double* x, int n, int d, const int64_t* labels,
                          int k, double* out);
 
+/*
+ * Fallback decisions of the callers (fallback_clusterer.py, naive_clusterer.py).
+ * sc_affinity_stats: out[4] = {affinity.min(), np.diag(affinity, 1).min(), mean,
+ *   np.std(affinity)} of the RESIDENT affinity (fallback_clusterer.py:137-153).
+ * sc_affinity_gmm_bic: BIC of sklearn-default 1- and 2-component Gaussian mixtures fitted
+ *   to the resident affinity's entries j >= i + diagonal_offset (:154-173).
+ * sc_naive_cluster: NaiveClusterer.predict (naive_clusterer.py:57-105) continuing from a
+ *   state of *n_centroids centroids (row-major, `capacity` rows >= *n_centroids + n).
+ */
+int sc_affinity_stats(sc_handle h, double* out);
+int sc_affinity_gmm_bic(sc_handle h, int diagonal_offset, double* bic1, double* bic2);
+int sc_naive_cluster(sc_handle h, const double* x, int n, int d, double threshold,
+                     double adaptation_threshold, double* centroids, int32_t* counts,
+                     int32_t* n_centroids, int capacity, int64_t* labels);
+
 /* ---- single stages (ndarray in / ndarray out; parity tests and the
  *      per-op Python classes use these) ------------------------------------- */
 /* utils.compute_affinity_matrix (utils.py:20-41) */

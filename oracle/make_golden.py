@@ -3,7 +3,7 @@
 Run in the build container only (needs /root/reference, which does not exist
 on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general | --size-reduction]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general | --size-reduction | --fallback]
 
 `--large` additionally runs the two n=8192 configurations (about 150-160 s of
 CPU each).  Inputs are regenerated from seeds by `spectral_oracle.blobs`; only
@@ -277,6 +277,73 @@ def size_reduction_goldens():
   save("size_reduction.npz", **out)
 
 
+def fallback_goldens():
+  """10. Fallback decisions + multi-stage streaming (N4)."""
+  from spectralcluster import fallback_clusterer as ref_fb
+  from spectralcluster import multi_stage_clusterer as ref_ms
+  from spectralcluster import naive_clusterer as ref_naive
+  out = {}
+  # naive clusterer on a stream of noisy speakers
+  x = so.blobs(300, 16, 4, 101, noise=0.6)
+  for tag, (thr, ad) in {"t5": (0.5, None), "t7a9": (0.7, 0.9)}.items():
+    nc = ref_naive.NaiveClusterer(thr, ad)
+    out["naive_" + tag] = nc.predict(x)
+    out["naive_counts_" + tag] = np.array([c.count for c in nc.centroids])
+    out["naive_cent_" + tag] = np.stack([c.embedding for c in nc.centroids])
+  # single-cluster conditions on affinities of one / several speakers
+  one = so.blobs(80, 16, 1, 102, noise=0.2)
+  many = so.blobs(80, 16, 3, 103, noise=0.2)
+  for name, xx in (("one", one), ("many", many)):
+    a = ref_utils.compute_affinity_matrix(xx)
+    out["stats_" + name] = np.array([a.min(), np.diag(a, k=1).min(), a.mean(), np.std(a)])
+    for cond in ("AllAffinity", "NeighborAffinity", "AffinityStd", "FallbackClusterer"):
+      for thr in (0.5, 0.75, 0.9):
+        opts = ref_fb.FallbackOptions(
+            single_cluster_condition=getattr(ref_fb.SingleClusterCondition, cond),
+            single_cluster_affinity_threshold=thr,
+            fallback_clusterer_type=ref_fb.FallbackClustererType.Agglomerative)
+        out["single_%s_%s_%02d" % (name, cond, round(thr * 100))] = np.bool_(
+            ref_fb.check_single_cluster(opts, xx, a))
+    # the GMM start is randomly seeded in the reference: record a majority over seeds
+    votes = [ref_fb.check_single_cluster(ref_fb.FallbackOptions(), xx, a) for _ in range(5)]
+    out["single_%s_gmm" % name] = np.bool_(sum(votes) >= 3)
+    out["single_%s_gmm_votes" % name] = np.array(votes)
+  # predict() with min_clusters=1 and with too few embeddings
+  for name, xx in (("one", one), ("many", many)):
+    c = ref_sc.SpectralClusterer(min_clusters=1, max_clusters=6,
+                                 refinement_options=icassp_options(),
+                                 fallback_options=ref_fb.FallbackOptions(
+                                     single_cluster_condition=ref_fb.SingleClusterCondition.AffinityStd,
+                                     single_cluster_affinity_threshold=0.05))
+    out["predict_min1_" + name] = c.predict(xx)
+  c = ref_sc.SpectralClusterer(refinement_options=icassp_options(),
+                               fallback_options=ref_fb.FallbackOptions(
+                                   spectral_min_embeddings=100,
+                                   fallback_clusterer_type=ref_fb.FallbackClustererType.Agglomerative,
+                                   agglomerative_threshold=0.4))
+  out["predict_few"] = c.predict(many)
+  # multi-stage streaming: labels after selected steps of a seeded stream
+  rng = np.random.default_rng(104)
+  base = np.array([[1.0, 0, 0, 0, 0, 0]] * 100 + [[0, 1.0, 0, 0, 0, 0]] * 200 +
+                  [[0, 0, 2.0, 0, 0, 0]] * 300 + [[0, 0, 0, 1.0, 0, 0]] * 400)
+  stream = base + (rng.random((1000, 6)) * 2 - 1) * 0.02
+  stream = stream[rng.permutation(1000)][:360]
+  out["stream"] = stream
+  for tag, defl in (("none", ref_ms.Deflicker.NoDeflicker),
+                    ("hungarian", ref_ms.Deflicker.Hungarian)):
+    opts = ref_refinement.RefinementOptions(
+        gaussian_blur_sigma=0, p_percentile=0.2,
+        refinement_sequence=ref_configs.ICASSP2018_REFINEMENT_SEQUENCE)
+    main = ref_sc.SpectralClusterer(refinement_options=opts, stop_eigenvalue=0.01)
+    ms = ref_ms.MultiStageClusterer(main_clusterer=main, fallback_threshold=0.5, L=20,
+                                    U1=60, U2=120, deflicker=defl)
+    for step, e in enumerate(stream, 1):
+      labels = ms.streaming_predict(e)
+      if step in (10, 30, 61, 119, 120, 121, 200, 360):
+        out["ms_%s_%d" % (tag, step)] = np.asarray(labels)
+  save("fallback.npz", **out)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
@@ -288,6 +355,9 @@ def main():
     return
   if "--size-reduction" in sys.argv:  # only section 9
     size_reduction_goldens()
+    return
+  if "--fallback" in sys.argv:  # only section 10
+    fallback_goldens()
     return
 
   # 1. The 6x2 toy of the reference tests, sigma=0, full stage dump, all
@@ -372,6 +442,7 @@ def main():
   constraint_goldens()
   general_goldens()
   size_reduction_goldens()
+  fallback_goldens()
 
   if large:
     for c in [(8192, 256, 8, 0, 4, 20), (8192, 256, 4, 1, 0, 7)]:

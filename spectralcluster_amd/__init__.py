@@ -9,7 +9,10 @@ from spectralcluster_amd import autotune
 from spectralcluster_amd import configs
 from spectralcluster_amd import constraint
 from spectralcluster_amd import custom_distance_kmeans
+from spectralcluster_amd import fallback_clusterer
 from spectralcluster_amd import laplacian
+from spectralcluster_amd import multi_stage_clusterer
+from spectralcluster_amd import naive_clusterer
 from spectralcluster_amd import refinement
 from spectralcluster_amd import spectral_clusterer
 from spectralcluster_amd import utils
@@ -20,6 +23,11 @@ ConstraintOptions = constraint.ConstraintOptions
 ConstraintName = constraint.ConstraintName
 IntegrationType = constraint.IntegrationType
 ConstraintMatrix = constraint.ConstraintMatrix
+FallbackOptions = fallback_clusterer.FallbackOptions
+SingleClusterCondition = fallback_clusterer.SingleClusterCondition
+FallbackClustererType = fallback_clusterer.FallbackClustererType
+MultiStageClusterer = multi_stage_clusterer.MultiStageClusterer
+Deflicker = multi_stage_clusterer.Deflicker
 LaplacianType = laplacian.LaplacianType
 RefinementName = refinement.RefinementName
 RefinementOptions = refinement.RefinementOptions

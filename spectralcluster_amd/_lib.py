@@ -153,6 +153,13 @@ PROTOTYPES = {
                               ctypes.POINTER(ctypes.c_int)]),
     "sc_cluster_centroids": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int, ctypes.c_int,
                                             _c_int64_p, ctypes.c_int, _c_double_p]),
+    "sc_affinity_stats": (ctypes.c_int, [_handle_t, _c_double_p]),
+    "sc_affinity_gmm_bic": (ctypes.c_int, [_handle_t, ctypes.c_int, _c_double_p, _c_double_p]),
+    "sc_naive_cluster": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_double, _c_double_p,
+                                        ctypes.POINTER(ctypes.c_int32),
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.c_int,
+                                        _c_int64_p]),
     "sc_run_resident": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig),
                                        _c_int64_p, ctypes.POINTER(ScDiag)]),
     "sc_predict_batch": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),

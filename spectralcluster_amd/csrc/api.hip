@@ -53,6 +53,7 @@ struct sc_handle_s {
   DevBuf crvec, thetai, Vre, Vim, gpart, gsrc, genL;
   const double* vs_scale = nullptr;  // Vs = vs_scale .* V in orthonormalize (default cvec)
   DevBuf ahc_size, ahc_chain, ahc_Z, ahc_lab, ahc_cent;  // size reduction (AHC) scratch
+  DevBuf fb_part, fb_small, fb_x, fb_cent, fb_int;      // fallback decisions scratch
   // k-means workspace
   DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo;
   // pinned host scratch
@@ -268,7 +269,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->ahc_size, &h->ahc_chain, &h->ahc_Z, &h->ahc_lab, &h->ahc_cent, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->ahc_size, &h->ahc_chain, &h->ahc_Z, &h->ahc_lab, &h->ahc_cent, &h->fb_part, &h->fb_small, &h->fb_x, &h->fb_cent, &h->fb_int, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -936,6 +937,20 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
   return dc;
 }
 
+// One CholQR pass on W (n x 8) with the orthonormality-defect flag of its input armed
+// (flags[10]); stores the result into Q[:, store_col ...] and Vs when store_col >= 0.
+static int cholqr_pass(sc_handle h, int n, int store_col) {
+  hipStream_t s = h->stream;
+  double* W = ptr<double>(h->W);
+  launch_proj_partial(s, W, kEigBlock, kEigBlock, W, n, ptr<double>(h->partial));
+  launch_reduce_chol(s, ptr<double>(h->partial), proj_blocks(n), ptr<double>(h->Rinv), nullptr,
+                     nullptr, ptr<int>(h->flags), ptr<int>(h->flags) + 10, 2);
+  launch_apply_rinv(s, W, n, ptr<double>(h->Rinv), store_col >= 0 ? ptr<double>(h->Q) : nullptr,
+                    kLdq, store_col >= 0 ? store_col : 0,
+                    h->vs_scale ? h->vs_scale : ptr<double>(h->cvec), ptr<double>(h->Vs));
+  return SC_OK;
+}
+
 // Orthonormalise W (n x 16) against Q[:, 0:m] and within itself.
 //   record: accumulate the projection coefficients into T columns [col0, col0+16)
 //   store_col: column of Q to receive the result (< 0: do not store)
@@ -958,19 +973,15 @@ static int orthonormalize(sc_handle h, int n, int m, bool record, int col0, int 
   // CholQR2
   launch_proj_partial(s, W, kEigBlock, kEigBlock, W, n, part);
   launch_reduce_chol(s, part, proj_blocks(n), ptr<double>(h->Rinv),
-                     save_gram ? ptr<double>(h->G) : nullptr, hsq, ptr<int>(h->flags));
+                     save_gram ? ptr<double>(h->G) : nullptr, hsq, ptr<int>(h->flags),
+                     ptr<int>(h->flags) + 11, 1);
   launch_apply_rinv(s, W, n, ptr<double>(h->Rinv), nullptr, 0, 0, nullptr, nullptr);
-  launch_proj_partial(s, W, kEigBlock, kEigBlock, W, n, part);
-  launch_reduce_chol(s, part, proj_blocks(n), ptr<double>(h->Rinv), nullptr, nullptr,
-                     ptr<int>(h->flags));
-  launch_apply_rinv(s, W, n, ptr<double>(h->Rinv), store_col >= 0 ? Q : nullptr, kLdq,
-                    store_col >= 0 ? store_col : 0,
-                    h->vs_scale ? h->vs_scale : ptr<double>(h->cvec), ptr<double>(h->Vs));
+  SC_TRY(cholqr_pass(h, n, store_col));
   return check_last(h, "orthonormalize launch");
 }
 
 static int read_flags(sc_handle h, int* mask) {
-  SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, 8 * sizeof(int), hipMemcpyDeviceToHost,
+  SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, 12 * sizeof(int), hipMemcpyDeviceToHost,
                            h->stream));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   *mask = h->h_flags[0];
@@ -990,6 +1001,15 @@ static int finish_block(sc_handle h, int n, int m, int store_col, uint64_t* seed
   for (int attempt = 0; attempt < 4; ++attempt) {
     int mask = 0;
     SC_TRY(read_flags(h, &mask));
+    // CholQR2 only orthonormalises blocks of condition < ~1e8; a numerically low-rank
+    // operator produces worse ones: keep passing until the input Gram matrix was near I
+    for (int extra = 0;
+         extra < 3 && mask == 0 && (h->h_flags[10] != 0 || h->h_flags[11] != 0); ++extra) {
+      // (the projection coefficients already recorded in T stay: this round only removes
+      // rounding-level components)
+      SC_TRY(orthonormalize(h, n, m, false, 0, store_col, false));
+      SC_TRY(read_flags(h, &mask));
+    }
     if (mask == 0) return SC_OK;
     launch_refill_deficient(h->stream, ptr<double>(h->W), n, ptr<int>(h->flags), ++(*seed));
     SC_TRY(orthonormalize(h, n, m, false, 0, store_col, false));
@@ -1539,6 +1559,20 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
                            ptr<double>(h->pvec), ptr<double>(h->tvec));
   }
   SC_TRY(check_last(h, "scaling launch"));
+  if (getenv("SC_EIG_TRACE") && atoi(getenv("SC_EIG_TRACE")) > 2 && symmetric) {
+    std::vector<double> rm(n), rs(n);
+    hipMemcpyAsync(rm.data(), h->rowmax.p, n * sizeof(double), hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(rs.data(), h->rowsum.p, n * sizeof(double), hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    int imin = 0, imax = 0;
+    for (int i = 0; i < n; ++i) {
+      if (rm[i] < rm[imin]) imin = i;
+      if (rm[i] > rm[imax]) imax = i;
+    }
+    fprintf(stderr, "[sc] scaling: fused stats %d; rowmax min %.6g at %d, max %.6g at %d; "
+            "rowsum[%d] %.6g\n", (int)have_row_stats, rm[imin], imin, rm[imax], imax, imin,
+            rs[imin]);
+  }
   int e_after_scaling;
   ev_rec(h, &e_after_scaling);
   // ---- eigen + eigengap
@@ -1903,6 +1937,162 @@ extern "C" int sc_cluster_centroids(sc_handle h, const double* x, int n, int d,
   SC_TRY(check_last(h, "centroid launch"));
   SC_HIP(h, hipMemcpyAsync(out, cd_, (size_t)k * d * sizeof(double), hipMemcpyDeviceToHost, s));
   SC_HIP(h, hipStreamSynchronize(s));
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// N4: fallback decisions (reference fallback_clusterer.py, naive_clusterer.py)
+// ------------------------------------------------------------------------------
+// out = {affinity.min(), np.diag(affinity, k=1).min(), mean, np.std(affinity)} of the
+// resident affinity (single-cluster conditions AllAffinity / NeighborAffinity / AffinityStd)
+extern "C" int sc_affinity_stats(sc_handle h, double* out) {
+  if (!h) return SC_ERR_INVALID;
+  if (!out) return fail(h, SC_ERR_INVALID, "out is NULL");
+  if (!h->have_affinity) return fail(h, SC_ERR_INVALID, "no affinity resident");
+  SC_HIP(h, hipSetDevice(h->device));
+  const int n = h->n;
+  SC_TRY(grow(h, h->fb_part, (size_t)n * 8 * sizeof(double)));
+  SC_TRY(grow(h, h->fb_small, 32 * sizeof(double)));
+  launch_affinity_stats(h->stream, ptr<double>(h->A0), n, h->ldn, ptr<double>(h->fb_part),
+                        ptr<double>(h->fb_small));
+  SC_TRY(check_last(h, "affinity statistics launch"));
+  SC_HIP(h, hipMemcpyAsync(out, h->fb_small.p, 4 * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  return SC_OK;
+}
+
+// BIC of a 1- and a 2-component Gaussian mixture fitted to affinity[i][j], j >= i + offset
+// (fallback_clusterer.py:154-173).  sklearn's GaussianMixture defaults: full covariance,
+// reg_covar 1e-6, tol 1e-3 on the mean log-likelihood, max_iter 100, k-means start.  The
+// reference's k-means start is randomly seeded; here it is the deterministic 1-D 2-means
+// from (min, max), which is the fixed point those seeds reach on separable data.
+extern "C" int sc_affinity_gmm_bic(sc_handle h, int diagonal_offset, double* bic1,
+                                   double* bic2) {
+  if (!h) return SC_ERR_INVALID;
+  if (!bic1 || !bic2) return fail(h, SC_ERR_INVALID, "NULL output");
+  if (!h->have_affinity) return fail(h, SC_ERR_INVALID, "no affinity resident");
+  const int n = h->n;
+  if (diagonal_offset < 0 || diagonal_offset >= n - 1)
+    return fail(h, SC_ERR_INVALID,
+                "single_cluster_affinity_diagonal_offset must be significantly smaller than "
+                "affinity matrix dimension");
+  SC_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  SC_TRY(grow(h, h->fb_part, (size_t)n * 8 * sizeof(double)));
+  SC_TRY(grow(h, h->fb_small, 32 * sizeof(double)));
+  double* params_d = ptr<double>(h->fb_small);
+  double* sums_d = params_d + 8;
+  const double* a = ptr<double>(h->A0);
+  const int ld = h->ldn;
+  const double m = (double)(n - diagonal_offset);
+  const double count = m * (m + 1.0) / 2.0;
+  const double reg = 1e-6, tiny = 10.0 * 2.220446049250313e-16;
+  double sums[8];
+  auto pass = [&](int components, int mode, const double* params) -> int {
+    SC_HIP(h, hipMemcpyAsync(params_d, params, 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_gmm_pass(s, a, n, ld, diagonal_offset, components, mode, params_d,
+                    ptr<double>(h->fb_part), sums_d);
+    SC_HIP(h, hipMemcpyAsync(sums, sums_d, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipStreamSynchronize(s));
+    return SC_OK;
+  };
+  // M-step of sklearn's _estimate_gaussian_parameters from the pass sums
+  auto m_step = [&](int components, double* params) {
+    double wsum = 0.0;
+    for (int c = 0; c < components; ++c) {
+      const double nk = sums[3 * c] + tiny;
+      const double mu = sums[3 * c + 1] / nk;
+      const double var = (sums[3 * c + 2] - 2.0 * mu * sums[3 * c + 1] + mu * mu * sums[3 * c]) / nk;
+      params[3 * c] = nk / count;
+      params[3 * c + 1] = mu;
+      params[3 * c + 2] = var + reg;
+      wsum += params[3 * c];
+    }
+    for (int c = 0; c < components; ++c) params[3 * c] /= wsum;
+  };
+  auto fit = [&](int components, double* bic) -> int {
+    double params[6] = {1.0, 0.0, 1.0, 0.0, 0.0, 1.0};
+    if (components == 1) {
+      SC_TRY(pass(1, 1, params));  // r0 = 1 everywhere: plain moments
+      m_step(1, params);
+    } else {
+      // 2-means start from the extremes, Lloyd steps until the inertia stops moving
+      launch_gmm_range(s, a, n, ld, diagonal_offset, ptr<double>(h->fb_part), sums_d);
+      double range[2];
+      SC_HIP(h, hipMemcpyAsync(range, sums_d, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+      SC_HIP(h, hipStreamSynchronize(s));
+      params[1] = range[0];
+      params[4] = range[1];
+      double prev_inertia = -1.0;
+      for (int it = 0; it < 300; ++it) {
+        SC_TRY(pass(2, 0, params));
+        const double inertia = sums[6];
+        if (sums[0] > 0.0) params[1] = sums[1] / sums[0];
+        if (sums[3] > 0.0) params[4] = sums[4] / sums[3];
+        if (inertia == prev_inertia) break;
+        prev_inertia = inertia;
+      }
+      SC_TRY(pass(2, 0, params));  // responsibilities = the final hard labels
+      m_step(2, params);
+    }
+    double prev = -__builtin_huge_val();
+    for (int it = 0; it < 100; ++it) {
+      SC_TRY(pass(components, 1, params));  // E-step under params (+ sums of the M-step)
+      const double lower_bound = sums[6] / count;
+      m_step(components, params);
+      if (std::fabs(lower_bound - prev) < 1e-3) break;
+      prev = lower_bound;
+    }
+    SC_TRY(pass(components, 1, params));
+    const double n_params = components == 1 ? 2.0 : 5.0;
+    *bic = -2.0 * sums[6] + n_params * std::log(count);
+    return SC_OK;
+  };
+  SC_TRY(fit(1, bic1));
+  SC_TRY(fit(2, bic2));
+  return SC_OK;
+}
+
+// NaiveClusterer.predict (naive_clusterer.py:57-105) continuing from the given state:
+// centroids (capacity x d, the first *n_centroids rows valid), counts, labels out.
+extern "C" int sc_naive_cluster(sc_handle h, const double* x, int n, int d, double threshold,
+                                double adaptation_threshold, double* centroids, int32_t* counts,
+                                int32_t* n_centroids, int capacity, int64_t* labels) {
+  if (!h) return SC_ERR_INVALID;
+  if (!x || !centroids || !counts || !n_centroids || !labels || n <= 0 || d <= 0)
+    return fail(h, SC_ERR_INVALID, "embeddings must be (n, d)");
+  if (*n_centroids < 0 || *n_centroids + n > capacity)
+    return fail(h, SC_ERR_INVALID, "centroid capacity must cover n_centroids + n");
+  SC_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  SC_TRY(grow(h, h->fb_x, (size_t)n * d * sizeof(double)));
+  SC_TRY(grow(h, h->fb_cent, (size_t)capacity * d * sizeof(double)));
+  SC_TRY(grow(h, h->fb_int, ((size_t)capacity + n + 4) * sizeof(int)));
+  int* counts_d = ptr<int>(h->fb_int);
+  int* k_d = counts_d + capacity;
+  int* labels_d = k_d + 4;
+  const int k0 = *n_centroids;
+  SC_HIP(h, hipMemcpyAsync(h->fb_x.p, x, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, s));
+  if (k0 > 0) {
+    SC_HIP(h, hipMemcpyAsync(h->fb_cent.p, centroids, (size_t)k0 * d * sizeof(double),
+                             hipMemcpyHostToDevice, s));
+    SC_HIP(h, hipMemcpyAsync(counts_d, counts, (size_t)k0 * sizeof(int), hipMemcpyHostToDevice, s));
+  }
+  SC_HIP(h, hipMemcpyAsync(k_d, n_centroids, sizeof(int), hipMemcpyHostToDevice, s));
+  launch_naive_cluster(s, ptr<double>(h->fb_x), n, d, threshold, adaptation_threshold,
+                       ptr<double>(h->fb_cent), counts_d, k_d, labels_d);
+  SC_TRY(check_last(h, "naive clusterer launch"));
+  std::vector<int> lab(n);
+  SC_HIP(h, hipMemcpyAsync(lab.data(), labels_d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipMemcpyAsync(n_centroids, k_d, sizeof(int), hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipStreamSynchronize(s));
+  const int k1 = *n_centroids;
+  SC_HIP(h, hipMemcpyAsync(centroids, h->fb_cent.p, (size_t)k1 * d * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipMemcpyAsync(counts, counts_d, (size_t)k1 * sizeof(int), hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) labels[i] = lab[i];
   return SC_OK;
 }
 

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_update_block(
 __global__ __launch_bounds__(256) void k_reduce_chol(
     const double* __restrict__ partial, int nparts, double* __restrict__ Rinv,
     double* __restrict__ Gsave, const double* __restrict__ hsq,
-    int* __restrict__ flags) {
+    int* __restrict__ flags, int* __restrict__ defect_flag, int flag_mode) {
   __shared__ double G[B][B + 1];
   __shared__ double R[B][B + 1];
   __shared__ double Ri[B][B + 1];
@@ -257,6 +257,19 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
   }
   if (tid == 0) s_mask = 0;
   __syncthreads();
+  __shared__ int s_defect;
+  if (tid == 0) {
+    // flag_mode 2 (second CholQR pass): G is the Gram matrix of the block the first pass
+    // produced; far from I means that pass met a block of condition > 1e8.
+    double defect = 0.0;
+    if (flag_mode == 2)
+      for (int i = 0; i < B; ++i)
+        for (int j = 0; j < B; ++j) {
+          if (gdiag[i] == 0.0 || gdiag[j] == 0.0) continue;  // dropped columns
+          defect = fmax(defect, fabs(G[i][j] - (i == j ? 1.0 : 0.0)));
+        }
+    s_defect = defect > 0.1 ? 1 : 0;
+  }
   for (int j = 0; j < B; ++j) {
     if (tid == 0) {
       const double d = G[j][j];
@@ -294,7 +307,22 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
   }
   __syncthreads();
   if (active) Rinv[tid] = Ri[ra][cb];
-  if (tid == 0) flags[0] = s_mask;
+  if (tid == 0) {
+    flags[0] = s_mask;
+    if (defect_flag != nullptr) {
+      // An ill-conditioned block (pivot ratio > 1e3: the operator is numerically low-rank)
+      // gets its small columns from R^-1 entries of that size, which amplify the absolute
+      // Q-orthogonality error of the large columns: the caller must project against the
+      // basis once more (twice-is-enough holds for the normalised block only).
+      double pmax = 0.0, pmin = __builtin_huge_val();
+      for (int j = 0; j < B; ++j)
+        if (piv[j] > 0.0) {
+          pmax = fmax(pmax, piv[j]);
+          pmin = fmin(pmin, piv[j]);
+        }
+      *defect_flag = (s_defect != 0 || pmax > 1e3 * pmin) ? 1 : 0;
+    }
+  }
 }
 
 // W <- W * Rinv; optional copies: Qdst[:, col0 + j] and Vs = c .* W; RB rows/workgroup
@@ -718,9 +746,10 @@ void launch_update_block(hipStream_t s, const double* Q, int ldq, int m,
                      Hbuf, W, n);
 }
 void launch_reduce_chol(hipStream_t s, const double* partial, int nparts, double* Rinv,
-                        double* Gsave, const double* hsq, int* flags) {
+                        double* Gsave, const double* hsq, int* flags, int* defect_flag,
+                        int flag_mode) {
   hipLaunchKernelGGL(k_reduce_chol, dim3(1), dim3(256), 0, s, partial, nparts,
-                     Rinv, Gsave, hsq, flags);
+                     Rinv, Gsave, hsq, flags, defect_flag, flag_mode);
 }
 void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
                        double* Qdst, int ldq, int col0, const double* cvec,

@@ -138,8 +138,11 @@ void launch_reduce_H(hipStream_t s, const double* partial, int nparts, int m, do
 void launch_update_block(hipStream_t s, const double* Q, int ldq, int m,
                          const double* Hbuf, double* W, int n);
 // Gram reduce + Cholesky: Rinv (16x16 upper), optional copy of G, flags mask.
+// defect_flag (optional): set to 1 when the block was ill-conditioned (pivot ratio > 1e3)
+// or, with flag_mode 2, when the input Gram matrix is far from I (see k_reduce_chol)
 void launch_reduce_chol(hipStream_t s, const double* partial, int nparts, double* Rinv,
-                        double* Gsave, const double* hsq, int* flags);
+                        double* Gsave, const double* hsq, int* flags,
+                        int* defect_flag = nullptr, int flag_mode = 1);
 // W <- W * Rinv ; optionally also store into Q[:, col0:col0+16] and Vs = c .* W
 void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
                        double* Qdst, int ldq, int col0, const double* cvec,
@@ -204,6 +207,19 @@ void launch_ahc_nn_chain(hipStream_t s, double* D, int ld, int n, int method, in
                          int* chain, double* Z);
 void launch_cluster_centroids(hipStream_t s, const double* X, int ldx, int n, int d,
                               const int* labels, int k, double* out);
+
+// ---- fallback decisions (fallback.hip) ---------------------------------------------------
+void launch_naive_cluster(hipStream_t s, const double* X, int n, int d, double threshold,
+                          double adapt_threshold, double* centroids, int* counts,
+                          int* n_centroids, int* labels);
+// out = {min, min of the first superdiagonal, mean, population std}; partial: n x 8 doubles
+void launch_affinity_stats(hipStream_t s, const double* a, int n, int ld, double* partial,
+                           double* out);
+// one pass of the 1-D mixture over a[i][j], j >= i + offset; sums: 7 doubles (see fallback.hip)
+void launch_gmm_pass(hipStream_t s, const double* a, int n, int ld, int offset, int components,
+                     int mode, const double* params, double* partial, double* sums);
+void launch_gmm_range(hipStream_t s, const double* a, int n, int ld, int offset,
+                      double* partial, double* out);
 
 // ---- k-means -------------------------------------------------------------------
 struct KmeansWorkspace {

@@ -6,8 +6,9 @@ executed on one MI355X through the C ABI in `include/spectralcluster_amd.h`.
 Constraints (`constraint_options` + `predict(embeddings, constraint_matrix)`) run on the
 device too, and refinement sequences whose result is not
 diagonally similar to a symmetric matrix take the general eigen path (8f-N2);
-`max_spectral_size` pre-clusters on the device (cosine complete-linkage AHC, 8f-N4).  Out of the
-device scope: FallbackOptions / single-cluster check, non-cosine k-means.  Those raise `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
+`max_spectral_size` pre-clusters on the device (cosine complete-linkage AHC) and
+`fallback_options` (too-few-embeddings fallback, single-cluster test for min_clusters=1) run
+there too (8f-N4).  Out of the device scope: non-cosine k-means.  Those raise `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
 """
 
 from __future__ import annotations
@@ -21,6 +22,7 @@ from spectralcluster_amd import _lib
 from spectralcluster_amd import autotune as autotune_lib
 from spectralcluster_amd import constraint as constraint_lib
 from spectralcluster_amd import custom_distance_kmeans
+from spectralcluster_amd import fallback_clusterer
 from spectralcluster_amd import laplacian
 from spectralcluster_amd import refinement
 from spectralcluster_amd import utils
@@ -62,7 +64,7 @@ class SpectralClusterer:
     self.max_clusters = max_clusters
     self.refinement_options = refinement_options or RefinementOptions()
     self.autotune = autotune
-    self.fallback_options = fallback_options
+    self.fallback_options = fallback_options or fallback_clusterer.FallbackOptions()
     self.laplacian_type = laplacian_type
     self.row_wise_renorm = row_wise_renorm
     self.stop_eigenvalue = stop_eigenvalue
@@ -81,14 +83,9 @@ class SpectralClusterer:
     return _lib.default_handle(self.device)
 
   def _scope_check(self, constraint_matrix=None):
-    if self.fallback_options is not None:
-      raise _lib.UnsupportedOnDeviceError(
-          "fallback_options (FallbackClusterer / single-cluster check) is outside "
-          "the device hot path")
-    if self.min_clusters == 1:
-      raise _lib.UnsupportedOnDeviceError(
-          "min_clusters=1 triggers the reference's single-cluster check "
-          "(fallback_clusterer.check_single_cluster), which is out of scope")
+    """Nothing of the constructor surface is out of the device scope any more, except
+    non-cosine k-means (checked in predict)."""
+    del constraint_matrix
 
   def build_config(self, p_percentile: typing.Optional[float] = None) -> _lib.ScConfig:
     """Flatten the constructor arguments into an `sc_config`."""
@@ -199,6 +196,9 @@ class SpectralClusterer:
       raise ValueError("embeddings must be 2-dimensional")
     self._scope_check(constraint_matrix)
     n = embeddings.shape[0]
+    if n < self.fallback_options.spectral_min_embeddings:
+      # too few embeddings for spectral clustering (reference :229-233)
+      return fallback_clusterer.FallbackClusterer(self.fallback_options).predict(embeddings)
     if self.max_spectral_size is not None and n > self.max_spectral_size:
       # reference spectral_clusterer.py:236-248
       if constraint_matrix is not None:
@@ -216,7 +216,16 @@ class SpectralClusterer:
           "only custom_dist='cosine' is implemented on the device path")
     constrained = self._set_constraint(handle, n, constraint_matrix)
 
-    if (self.autotune is None and default_tail
+    single_check = self.min_clusters == 1
+    by_fallback = (self.fallback_options.single_cluster_condition ==
+                   fallback_clusterer.SingleClusterCondition.FallbackClusterer)
+    if single_check and by_fallback:
+      # this condition only needs the embeddings; it runs on the same device handle, so
+      # it goes first and the affinity is built afterwards (reference :253-256)
+      if fallback_clusterer.check_single_cluster(self.fallback_options, embeddings, None):
+        return np.array([0] * n)
+
+    if (self.autotune is None and default_tail and not single_check
         and self.affinity_function is utils.compute_affinity_matrix):
       # the whole path in one call: H2D(X), device pipeline, D2H(labels)
       x = np.ascontiguousarray(embeddings, dtype=np.float64)
@@ -229,6 +238,11 @@ class SpectralClusterer:
       return labels
 
     self._upload(handle, embeddings)
+    if single_check and not by_fallback:
+      # single-vs-multi cluster(s) decision on the resident affinity (reference :253-256)
+      if fallback_clusterer.check_single_cluster(self.fallback_options, embeddings, None,
+                                                 _resident_on=handle):
+        return np.array([0] * n)
     if constrained and self.constraint_options.apply_before_refinement:
       # reference :259-264 -- once, before the AutoTune sweep re-reads the affinity
       handle.check(handle.lib.sc_apply_constraint(handle.raw, self.build_config()))
@@ -300,7 +314,8 @@ class SpectralClusterer:
     independent handles -- one HIP stream and one arena each -- driven by one host
     thread per handle (ctypes releases the GIL during the calls).
     """
-    if self.autotune is not None or self.max_spectral_size is not None:
+    if (self.autotune is not None or self.max_spectral_size is not None or
+        self.min_clusters == 1 or self.fallback_options.spectral_min_embeddings > 1):
       return [self.predict(u) for u in utterances]
     self._scope_check()
     if not utterances:

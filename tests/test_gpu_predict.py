@@ -262,8 +262,7 @@ def test_error_behaviour():
     clusterer.predict([[1.0, 2.0]])
   with pytest.raises(ValueError):
     clusterer.predict(np.zeros(5))
-  with pytest.raises(sca.UnsupportedOnDeviceError):
-    sca.SpectralClusterer(min_clusters=1).predict(TOY)
+  assert sca.SpectralClusterer(min_clusters=1).predict(TOY).shape == (6,)  # GMM/BIC check runs
   reduced = sca.SpectralClusterer(max_spectral_size=3).predict(TOY)   # 6 -> 3 centroids
   assert reduced.shape == (6,) and reduced.dtype == np.float64
   # RowWiseThreshold alone leaves a genuinely non-symmetric matrix: general eigen path

@@ -193,6 +193,66 @@ def test_constraint_host_side():
     op.adjust_affinity(np.zeros(3), np.zeros((3, 3)))
 
 
+def test_match_labels_reference_known_answers():
+  # reference tests/multi_stage_clusterer_test.py:11-60
+  from spectralcluster_amd import multi_stage_clusterer as ms
+  cases = [([1, 0], [0], [0, 1]),
+           ([0, 1, 2, 3, 4, 5], [0, 0, 0, 1, 2], [0, 3, 4, 1, 2, 5]),
+           ([0, 0, 0, 1, 1, 1, 2, 2], [0, 0, 1, 2, 2, 3, 4], [0, 0, 0, 2, 2, 2, 4, 4]),
+           ([1, 1, 1, 0, 0, 1], [0, 0, 0, 1, 1], [0, 0, 0, 1, 1, 0]),
+           ([1, 1, 1, 0, 0, 2], [0, 0, 0, 1, 1], [0, 0, 0, 1, 1, 2]),
+           ([0, 1, 1, 0, 0, 2], [0, 0, 0, 1, 1], [1, 0, 0, 1, 1, 2]),
+           ([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5], [0, 0, 3, 3, 1, 1, 4, 4, 5, 5, 2],
+            [0, 0, 3, 3, 1, 1, 4, 4, 5, 5, 2, 2])]
+  for current, previous, expected in cases:
+    np.testing.assert_equal(ms.match_labels(np.array(current), np.array(previous)), expected)
+  with pytest.raises(ValueError):
+    ms.match_labels(np.array([0, 1]), np.array([0, 1]))
+
+
+def test_linear_sum_assignment_matches_scipy():
+  """The reference calls scipy's solver; ours must return the same assignment, ties
+  included (it drives the label numbering of the Hungarian deflicker)."""
+  from scipy.optimize import linear_sum_assignment as scipy_lsa
+  from spectralcluster_amd import multi_stage_clusterer as ms
+  rng = np.random.default_rng(0)
+  for _ in range(1500):
+    shape = rng.integers(1, 8, size=2)
+    cost = rng.integers(0, 4, size=shape)
+    maximize = bool(rng.integers(0, 2))
+    want = scipy_lsa(cost, maximize=maximize)
+    got = ms.linear_sum_assignment(cost, maximize=maximize)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+  cost = rng.random((5, 9))
+  np.testing.assert_array_equal(ms.linear_sum_assignment(cost)[1], scipy_lsa(cost)[1])
+
+
+def test_fallback_surface_mirrors_reference():
+  fo = sca.FallbackOptions()
+  assert (fo.spectral_min_embeddings, fo.single_cluster_condition,
+          fo.single_cluster_affinity_threshold, fo.single_cluster_affinity_diagonal_offset,
+          fo.fallback_clusterer_type, fo.agglomerative_threshold, fo.naive_threshold,
+          fo.naive_adaptation_threshold) == (
+              1, sca.SingleClusterCondition.AffinityGmmBic, 0.75, 1,
+              sca.FallbackClustererType.Naive, 0.5, 0.5, None)
+  assert [m.name for m in sca.SingleClusterCondition] == [
+      "AffinityGmmBic", "AllAffinity", "NeighborAffinity", "AffinityStd", "FallbackClusterer"]
+  assert [m.name for m in sca.Deflicker] == ["NoDeflicker", "OrderBased", "Hungarian"]
+  # a clusterer without explicit options gets the defaults (reference :93-96)
+  assert sca.SpectralClusterer().fallback_options == fo
+  main = sca.SpectralClusterer()
+  stage = sca.MultiStageClusterer(main, fallback_threshold=0.3, L=11, U1=22, U2=33)
+  assert (main.fallback_options.spectral_min_embeddings,
+          main.fallback_options.agglomerative_threshold,
+          main.fallback_options.single_cluster_condition,
+          main.fallback_options.fallback_clusterer_type, stage.U1, stage.U2) == (
+              11, 0.3, sca.SingleClusterCondition.FallbackClusterer,
+              sca.FallbackClustererType.Agglomerative, 22, 33)
+  with pytest.raises(ValueError):
+    sca.naive_clusterer.NaiveClusterer(0.5, 0.4)
+
+
 def test_enforce_ordered_labels():
   # reference tests/utils_test.py (TestEnforceOrderedLabels)
   got = sca.utils.enforce_ordered_labels(np.array([9, 9, 1, 1, 9, 5]))

@@ -160,3 +160,31 @@ def test_multi_stream_batch_is_deterministic():
   again = c.predict_batch(utts, streams=4)
   for a, b, d in zip(one, four, again):
     assert np.array_equal(a, b) and np.array_equal(b, d)
+
+
+@pytest.mark.parametrize("n", [136, 200, 520])
+def test_numerically_low_rank_operator(n):
+  """Tight clusters + a threshold that removes nothing: the refined matrix has three
+  eigenvalues of order n and the rest below 1e-5.  Op * V is then a block of condition
+  > 1e8; its small columns come out of R^-1 entries that amplify the large columns' rounding
+  against the basis, so the block must be projected against the basis once more (a
+  regression: the Ritz values drifted above lambda_max and the solve never converged)."""
+  rng = np.random.default_rng(n)
+  counts = [n // 10, n // 5, 3 * n // 10, n - n // 10 - n // 5 - 3 * n // 10]
+  base = np.concatenate([np.tile(row, (c, 1)) for row, c in zip(
+      ([1.0, 0, 0, 0, 0, 0], [0, 1.0, 0, 0, 0, 0], [0, 0, 2.0, 0, 0, 0], [0, 0, 0, 1.0, 0, 0]),
+      counts)])
+  x = base + (rng.random((n, 6)) * 2 - 1) * 0.02
+  opts = sca.RefinementOptions(gaussian_blur_sigma=0, p_percentile=0.2,
+                               refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
+  clusterer = sca.SpectralClusterer(refinement_options=opts, stop_eigenvalue=0.01)
+  got = clusterer.predict(x)
+  cfg = so.icassp2018_config(min_clusters=None, max_clusters=None, gaussian_blur_sigma=0,
+                             p_percentile=0.2, stop_eigenvalue=0.01)
+  dump = {}
+  want = so.predict(x, cfg, dump)
+  assert clusterer.last_diag.n_clusters == dump["n_clusters"]
+  assert so.adjusted_rand_index(got, want) == 1.0
+  w = clusterer.last_diag.eigenvalue_array()
+  k = dump["n_clusters"]
+  np.testing.assert_allclose(w[:k], dump["eigenvalues"][:k], rtol=1e-6)

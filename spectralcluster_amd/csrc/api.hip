@@ -1267,7 +1267,13 @@ static int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_t
       launch_copy_block(s, W, kEigBlock, OpQ + m, kLdq, n, kEigBlock);
       ++passes;
       m += kEigBlock;
-      const bool check = next_start >= start_blocks.size() && m >= first_check;
+      // Rayleigh-Ritz (a serial ~m^3 solve in one wavefront) is the expensive step: every
+      // block early in the first cycle, where convergence is expected, then every other
+      // block, and only with a full basis once restarts have begun
+      const bool check = next_start >= start_blocks.size() && m >= first_check &&
+                         (cycles == 0 ? (m <= 4 * kEigBlock || m % (2 * kEigBlock) == 0 ||
+                                         m + kEigBlock > cap)
+                                      : (m + kEigBlock > cap));
       if (check) {
         // H = Q^T (Op Q), one 8-column block at a time
         for (int jb = 0; jb < m; jb += kEigBlock) {

@@ -231,3 +231,67 @@ def test_general_matrix_autotune_vs_reference_golden(n):
       assert abs(w[j] - g["eigenvalues"][i][j]) <= 1e-5 * abs(g["eigenvalues"][i][j])
   labels = make().predict(x)
   assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+
+
+# --- randomised sweep over non-symmetric configurations ------------------------------------
+SEQUENCES = {
+    "thr": (so.OP_ROW_WISE_THRESHOLD,),
+    "crop_blur_thr": (so.OP_CROP_DIAGONAL, so.OP_GAUSSIAN_BLUR, so.OP_ROW_WISE_THRESHOLD),
+    "thr_norm": (so.OP_ROW_WISE_THRESHOLD, so.OP_ROW_WISE_NORMALIZE),
+    "sym_thr": (so.OP_ROW_WISE_THRESHOLD, so.OP_SYMMETRIZE, so.OP_ROW_WISE_THRESHOLD),
+    "diffuse_thr": (so.OP_CROP_DIAGONAL, so.OP_DIFFUSE, so.OP_ROW_WISE_THRESHOLD),
+}
+
+
+def _general_fuzz_cases():
+  rng = np.random.default_rng(77)
+  cases = []
+  for i in range(30):
+    n = int(rng.choice([int(rng.integers(12, 64)), int(rng.integers(65, 900))]))
+    d = int(rng.integers(4, 40))
+    k = int(rng.integers(2, 6))
+    lap = int(rng.choice([0, 1, 2, 3, 4]))
+    gap = str(rng.choice(["Ratio", "Ratio", "NormalizedDiff"]))
+    seq = str(rng.choice(list(SEQUENCES)))
+    p = float(rng.choice([0.95, 0.85, 0.6, 0.4]))
+    ttype = int(rng.choice([so.THRESHOLD_ROW_MAX, so.THRESHOLD_PERCENTILE]))
+    binarize = bool(rng.integers(0, 2))
+    maxc = int(rng.choice([5, 8, 12]))
+    noise = float(rng.choice([0.2, 0.4]))
+    cases.append((i, n, d, k, lap, gap, seq, p, ttype, binarize, maxc, noise))
+  return cases
+
+
+@pytest.mark.parametrize("case", _general_fuzz_cases(), ids=lambda c: "gfuzz%d" % c[0])
+def test_fuzz_general_path_vs_oracle(case):
+  i, n, d, k, lap, gap, seq, p, ttype, binarize, maxc, noise = case
+  x = so.blobs(n, d, k, seed=5000 + i, noise=noise)
+  cfg = so.OracleConfig(
+      min_clusters=2, max_clusters=maxc, sequence=SEQUENCES[seq], gaussian_blur_sigma=1,
+      p_percentile=p, threshold_type=ttype, binarize=binarize, laplacian_type=lap,
+      eigengap_type=so.EIGENGAP_RATIO if gap == "Ratio" else so.EIGENGAP_NORMALIZED_DIFF)
+  dump = {}
+  want = so.predict(x, cfg, dump)
+  names = {so.OP_CROP_DIAGONAL: "CropDiagonal", so.OP_GAUSSIAN_BLUR: "GaussianBlur",
+           so.OP_ROW_WISE_THRESHOLD: "RowWiseThreshold", so.OP_SYMMETRIZE: "Symmetrize",
+           so.OP_DIFFUSE: "Diffuse", so.OP_ROW_WISE_NORMALIZE: "RowWiseNormalize"}
+  options = sca.RefinementOptions(
+      gaussian_blur_sigma=1, p_percentile=p,
+      thresholding_type=sca.ThresholdType(ttype), thresholding_with_binarization=binarize,
+      refinement_sequence=[getattr(sca.RefinementName, names[op]) for op in SEQUENCES[seq]])
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=maxc, refinement_options=options,
+      laplacian_type=sca.LaplacianType(lap) if lap else None,
+      eigengap_type=getattr(sca.EigenGapType, gap))
+  got = clusterer.predict(x)
+  diag = clusterer.last_diag
+  assert diag.symmetry_state == 3
+  if dump["max_delta"] < 1e-9:
+    # exactly degenerate spectrum (e.g. binarised threshold of a diffused matrix: eigenvalues
+    # 0, 1, 1, 1, ...): every gap is rounding noise, in the reference too -- nothing to match
+    assert got.shape == (n,)
+    return
+  assert diag.n_clusters == dump["n_clusters"]
+  loose = gap == "NormalizedDiff" and lap not in (0, 1)
+  np.testing.assert_allclose(diag.max_delta, dump["max_delta"], rtol=2e-4 if loose else 1e-5)
+  assert so.adjusted_rand_index(got, want) == 1.0

@@ -279,3 +279,57 @@ def test_stale_constraint_is_not_reused():
   np.testing.assert_array_equal(first, again)
   batch = clusterer.predict_batch([x, x], streams=1)
   np.testing.assert_array_equal(batch[0], first)
+
+
+# --- randomised sweep over constraint configurations ----------------------------------------
+def _constraint_fuzz_cases():
+  rng = np.random.default_rng(404)
+  cases = []
+  for i in range(16):
+    n = int(rng.integers(30, 600))
+    k = int(rng.integers(2, 5))
+    name = int(rng.choice([so.CONSTRAINT_AFFINITY_INTEGRATION, so.CONSTRAINT_PROPAGATION]))
+    before = bool(rng.integers(0, 2))
+    kind = int(rng.choice([so.INTEGRATION_MAX, so.INTEGRATION_AVERAGE]))
+    alpha = float(rng.choice([0.2, 0.4, 0.6, 0.8]))
+    seq = str(rng.choice(["ttd", "icassp_nonorm"]))
+    lap = int(rng.choice([0, 4]))
+    sym_q = bool(rng.integers(0, 4))     # one in four gets a non-symmetric constraint matrix
+    cases.append((i, n, k, name, before, kind, alpha, seq, lap, sym_q))
+  return cases
+
+
+@pytest.mark.parametrize("case", _constraint_fuzz_cases(), ids=lambda c: "cfuzz%d" % c[0])
+def test_fuzz_constraints_vs_oracle(case):
+  i, n, k, name, before, kind, alpha, seq, lap, sym_q = case
+  x, _, scores = so.turn_blobs(n, 24, k, seed=7000 + i, noise=0.8)
+  q = so.constraint_matrix_diagonals(list(scores), 1)
+  if not sym_q:
+    q = np.triu(q)                        # cannot-/must-links recorded one way only
+  if seq == "ttd":
+    ocfg = so.turntodiarize_config(p_percentile=0.9, laplacian_type=lap, row_wise_renorm=False)
+    options = toy_refinement()
+    options.p_percentile = 0.9
+  else:
+    ocfg = so.icassp2018_config(sequence=so.ICASSP2018_SEQUENCE[:-1], laplacian_type=lap)
+    options = sca.RefinementOptions(gaussian_blur_sigma=1, p_percentile=0.95,
+                                    refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE[:-1])
+  import dataclasses
+  ocfg = dataclasses.replace(ocfg, min_clusters=2, max_clusters=7, constraint_name=name,
+                             apply_before_refinement=before, integration_type=kind,
+                             constraint_propagation_alpha=alpha)
+  dump = {}
+  want = so.predict(x, ocfg, dump, constraint_matrix=q)
+  clusterer = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=7, refinement_options=options,
+      laplacian_type=sca.LaplacianType(lap) if lap else None,
+      constraint_options=sca.ConstraintOptions(
+          constraint_name=sca.ConstraintName(name), apply_before_refinement=before,
+          integration_type=sca.IntegrationType(kind), constraint_propagation_alpha=alpha))
+  got = clusterer.predict(x, q)
+  diag = clusterer.last_diag
+  if dump["max_delta"] < 1e-9:
+    return
+  assert diag.n_clusters == dump["n_clusters"]
+  np.testing.assert_allclose(diag.max_delta, dump["max_delta"], rtol=1e-5)
+  assert so.adjusted_rand_index(got, want) == 1.0

@@ -39,7 +39,8 @@ typedef enum sc_status {
   SC_ERR_OOM = -2,           /* device allocation failed */
   SC_ERR_HIP = -3,           /* HIP runtime error */
   SC_ERR_NOT_CONVERGED = -4, /* eigensolver did not reach tolerance */
-  SC_ERR_UNSUPPORTED = -5    /* configuration outside the device path */
+  SC_ERR_UNSUPPORTED = -5,   /* configuration outside the device path */
+  SC_ERR_NON_FINITE = -6     /* NaN / inf reached the eigen stage (numpy: LinAlgError) */
 } sc_status;
 
 /* refinement.py:11-18 RefinementName */

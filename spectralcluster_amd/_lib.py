@@ -24,6 +24,7 @@ SC_ERR_OOM = -2
 SC_ERR_HIP = -3
 SC_ERR_NOT_CONVERGED = -4
 SC_ERR_UNSUPPORTED = -5
+SC_ERR_NON_FINITE = -6
 
 STAGE_NAMES = ("affinity", "refine", "diffuse", "scaling", "eig", "kmeans",
                "total")
@@ -290,6 +291,8 @@ class Handle:
     msg = self.last_error() or "status %d" % rc
     if rc == SC_ERR_INVALID:
       raise invalid_exc(msg)
+    if rc == SC_ERR_NON_FINITE:
+      raise np.linalg.LinAlgError(msg)   # what np.linalg.eig raises (a ValueError)
     if rc == SC_ERR_UNSUPPORTED:
       raise UnsupportedOnDeviceError(msg)
     if rc == SC_ERR_NOT_CONVERGED:

@@ -41,6 +41,7 @@ struct sc_handle_s {
   DevBuf Cq, cp[5], symflag;
   bool have_constraint = false, constraint_symmetric = false, constraint_applied = false;
   bool affinity_symmetric = true;
+  bool affinity_from_embeddings = false;  // symflag[1] then says whether a row was NaN
   int qn = 0;
   int tilemap_nt = 0;     // tile-grid size the resident tilemap was built for
   DevBuf blurw;           // device copy of the blur weights
@@ -732,8 +733,11 @@ extern "C" int sc_compute_affinity(sc_handle h) {
   if (!h->have_x) return fail(h, SC_ERR_INVALID, "no embeddings resident");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_tilemap(h, h->n));
+  SC_TRY(grow(h, h->symflag, 16));
+  SC_HIP(h, hipMemsetAsync(ptr<int>(h->symflag) + 1, 0, sizeof(int), h->stream));
   launch_normalize_rows(h->stream, ptr<double>(h->X), h->ldx, h->n, h->d,
-                        ptr<double>(h->Xn));
+                        ptr<double>(h->Xn), ptr<int>(h->symflag) + 1);
+  h->affinity_from_embeddings = true;
   // CropDiagonal's fill value (max_{j != i} A_ij, >= 0) comes out of the GEMM epilogue
   GemmRowStats rs{2, ptr<double>(h->statp), nullptr, ptr<double>(h->cropval), nullptr};
   launch_gemm_nt(h->stream, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx,
@@ -762,6 +766,7 @@ extern "C" int sc_set_affinity(sc_handle h, const double* a, int n) {
   h->have_affinity = true;
   h->have_cropval = false;
   h->constraint_applied = false;
+  h->affinity_from_embeddings = false;
   return SC_OK;
 }
 
@@ -951,6 +956,8 @@ static int cholqr_pass(sc_handle h, int n, int store_col) {
   return SC_OK;
 }
 
+static const char kNonFiniteMessage[] = "Array must not contain infs or NaNs";
+
 // Orthonormalise W (n x 16) against Q[:, 0:m] and within itself.
 //   record: accumulate the projection coefficients into T columns [col0, col0+16)
 //   store_col: column of Q to receive the result (< 0: do not store)
@@ -981,10 +988,11 @@ static int orthonormalize(sc_handle h, int n, int m, bool record, int col0, int 
 }
 
 static int read_flags(sc_handle h, int* mask) {
-  SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, 12 * sizeof(int), hipMemcpyDeviceToHost,
+  SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, 13 * sizeof(int), hipMemcpyDeviceToHost,
                            h->stream));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   *mask = h->h_flags[0];
+  if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
   if (h->h_flags[1] > 0 && getenv("SC_EIG_TRACE")) {
     fprintf(stderr, "[sc] jacobi sweeps=%d  %.1f us  %.0f MHz shader clock\n", h->h_flags[1],
             h->h_flags[2] * 0.01, h->h_flags[3] * 1024.0 / (h->h_flags[2] * 0.01));
@@ -1040,7 +1048,10 @@ static int sym_topk(sc_handle h, const double* S, int ld, int n, const EigReques
                   nullptr, ptr<double>(h->Yt), ptr<int>(h->flags));
     SC_TRY(check_last(h, "jacobi launch"));
     SC_HIP(h, hipMemcpyAsync(h->h_theta, theta_d, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipMemcpyAsync(h->h_flags + 12, ptr<int>(h->flags) + 12, sizeof(int),
+                             hipMemcpyDeviceToHost, s));
     SC_HIP(h, hipStreamSynchronize(s));
+    if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
     for (int i = 0; i < n; ++i) h->h_theta[kLdq + i] = 0.0;
     dc = analyze(rq, h->h_theta, h->h_theta + kLdq, n, n, true);
     if (!dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
@@ -1199,7 +1210,10 @@ static int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_t
     SC_HIP(h, hipMemcpyAsync(th, theta_d, count * sizeof(double), hipMemcpyDeviceToHost, s));
     SC_HIP(h, hipMemcpyAsync(thi, thetai_d, count * sizeof(double), hipMemcpyDeviceToHost, s));
     SC_HIP(h, hipMemcpyAsync(h->h_flags + 8, info_d, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipMemcpyAsync(h->h_flags + 12, ptr<int>(h->flags) + 12, sizeof(int),
+                             hipMemcpyDeviceToHost, s));
     SC_HIP(h, hipStreamSynchronize(s));
+    if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
     if (h->h_flags[8] != 0)
       return fail(h, SC_ERR_NOT_CONVERGED, "QR iteration of the projected eigenproblem failed");
     return SC_OK;
@@ -1564,6 +1578,16 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
                            cfg->laplacian_type, folded_rownorm ? 1 : 0, ptr<double>(h->cvec),
                            ptr<double>(h->pvec), ptr<double>(h->tvec));
   }
+  // a NaN / inf anywhere in the refined matrix (zero embedding rows, an all-zero refined row
+  // under RowWiseNormalize, ...) reaches its row sums, hence c / p: np.linalg.eig raises on
+  // such input; the flag is read with the solver's first host sync
+  SC_TRY(ensure_eig(h, n));
+  if (h->affinity_from_embeddings)  // a zero embedding row: its NaNs may have been dropped
+    SC_HIP(h, hipMemcpyAsync(ptr<int>(h->flags) + 12, ptr<int>(h->symflag) + 1, sizeof(int),
+                             hipMemcpyDeviceToDevice, s));
+  else
+    SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 12, 0, sizeof(int), s));
+  launch_check_finite(s, ptr<double>(h->cvec), ptr<double>(h->pvec), n, ptr<int>(h->flags) + 12);
   SC_TRY(check_last(h, "scaling launch"));
   if (getenv("SC_EIG_TRACE") && atoi(getenv("SC_EIG_TRACE")) > 2 && symmetric) {
     std::vector<double> rm(n), rs(n);
@@ -2205,6 +2229,8 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   sc_diag* dg = diag ? diag : &local;
   memset(dg, 0, sizeof(*dg));
   h->nev = 0;
+  SC_TRY(ensure_eig(h, n));
+  SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 12, 0, sizeof(int), h->stream));
   SC_TRY(sym_topk(h, S, ld, n, rq, dg, &dc, &w));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < count; ++i) values[i] = w[i];
@@ -2259,6 +2285,8 @@ extern "C" int sc_stage_eig(sc_handle h, const double* m, int n, int count, int 
   sc_diag* dg = diag ? diag : &local;
   memset(dg, 0, sizeof(*dg));
   h->nev = 0;
+  SC_TRY(ensure_eig(h, n));
+  SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 12, 0, sizeof(int), h->stream));
   SC_TRY(gen_topk(h, S, ld, n, SC_LAPLACIAN_NONE, rq, dg, &dc, &w));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < count; ++i) values[i] = w[i];

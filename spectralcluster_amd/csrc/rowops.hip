@@ -40,13 +40,17 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
 
 // ---- A1: rows of X to unit L2 norm (utils.py:32-33) -------------------------
 __global__ __launch_bounds__(kRowThreads) void k_normalize_rows(
-    const double* __restrict__ X, int ldx, int n, int d, double* __restrict__ Xn) {
+    const double* __restrict__ X, int ldx, int n, int d, double* __restrict__ Xn,
+    int* __restrict__ bad_rows) {
   __shared__ double sm[4];
   const int row = blockIdx.x;
   const double* x = X + (size_t)row * ldx;
   double acc = 0.0;
   for (int j = threadIdx.x; j < d; j += kRowThreads) acc += x[j] * x[j];
   const double norm = sqrt(block_sum(acc, sm));
+  // a zero (or non-finite) row turns into NaNs below, like utils.py:33; later max-type
+  // kernels would drop them where np.maximum keeps them, so the fact is recorded here
+  if (bad_rows != nullptr && threadIdx.x == 0 && !(norm > 0.0 && isfinite(norm))) *bad_rows = 1;
   double* o = Xn + (size_t)row * ldx;
   for (int j = threadIdx.x; j < ldx; j += kRowThreads)
     o[j] = j < d ? x[j] / norm : 0.0;
@@ -418,6 +422,14 @@ __global__ void k_scaling_vectors(const double* __restrict__ rowmax,
   t[i] = tv;
 }
 
+// flag = 1 if any entry of a or b is NaN / inf (np.linalg.eig raises on such input)
+__global__ void k_check_finite(const double* __restrict__ a, const double* __restrict__ b,
+                               int n, int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!isfinite(a[i]) || !isfinite(b[i])) *flag = 1;
+}
+
 // ---- L1: materialised Laplacian for the stage API (laplacian.py:24-60) --------
 __global__ __launch_bounds__(kRowThreads) void k_row_sum(
     const double* __restrict__ in, int n, int ld, double* __restrict__ rowsum) {
@@ -481,9 +493,9 @@ __global__ __launch_bounds__(256) void k_symmetrize(const double* __restrict__ i
 
 // -------------------------------------------------------------------------------
 void launch_normalize_rows(hipStream_t s, const double* X, int ldx, int n, int d,
-                           double* Xn) {
+                           double* Xn, int* bad_rows) {
   hipLaunchKernelGGL(k_normalize_rows, dim3(n), dim3(kRowThreads), 0, s, X, ldx, n,
-                     d, Xn);
+                     d, Xn, bad_rows);
 }
 void launch_crop_diagonal(hipStream_t s, const double* in, double* out, int n,
                           int ld) {
@@ -559,6 +571,9 @@ void launch_scaling_vectors(hipStream_t s, const double* rowmax,
                             int row_normalized, double* c, double* p, double* t) {
   hipLaunchKernelGGL(k_scaling_vectors, dim3((n + 255) / 256), dim3(256), 0, s,
                      rowmax, rowsum, n, laplacian_type, row_normalized, c, p, t);
+}
+void launch_check_finite(hipStream_t s, const double* a, const double* b, int n, int* flag) {
+  hipLaunchKernelGGL(k_check_finite, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, flag);
 }
 void launch_laplacian(hipStream_t s, const double* in, double* out, int n, int ld,
                       int laplacian_type, double* deg_ws) {

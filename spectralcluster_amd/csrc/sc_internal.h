@@ -54,8 +54,9 @@ int gemm_tile_dim(int n);
 int gemm_resident_slots();
 size_t gemm_splitk_workspace_bytes();
 
+// bad_rows (optional): set to 1 when a row has zero or non-finite norm (its affinities are NaN)
 void launch_normalize_rows(hipStream_t s, const double* X, int ldx, int n, int d,
-                           double* Xn);
+                           double* Xn, int* bad_rows = nullptr);
 void launch_crop_diagonal(hipStream_t s, const double* in, double* out, int n,
                           int ld);
 void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
@@ -103,6 +104,8 @@ void launch_scaling_vectors(hipStream_t s, const double* rowmax,
                             int row_normalized, double* c, double* p, double* t);
 void launch_laplacian(hipStream_t s, const double* in, double* out, int n, int ld,
                       int laplacian_type, double* deg_ws);
+// *flag = 1 if a or b holds a NaN / inf
+void launch_check_finite(hipStream_t s, const double* a, const double* b, int n, int* flag);
 
 // ---- eigensolver -------------------------------------------------------------
 struct EigWorkspace {

@@ -188,3 +188,26 @@ def test_numerically_low_rank_operator(n):
   w = clusterer.last_diag.eigenvalue_array()
   k = dump["n_clusters"]
   np.testing.assert_allclose(w[:k], dump["eigenvalues"][:k], rtol=1e-6)
+
+
+def test_non_finite_input_raises_like_numpy():
+  """A zero embedding row makes the cosine affinity NaN (reference utils.py:33, no guard);
+  np.linalg.eig then raises LinAlgError (a ValueError): "Array must not contain infs or
+  NaNs".  The device path reports the same instead of iterating on garbage."""
+  for n in (40, 300):                       # dense and Krylov paths
+    x = so.blobs(n, 8, 3, seed=n)
+    x[n // 2] = 0.0
+    for clusterer in (
+        sca.SpectralClusterer(min_clusters=2, max_clusters=7,
+                              refinement_options=sca.configs.icassp2018_refinement_options),
+        sca.SpectralClusterer(max_clusters=5, laplacian_type=sca.LaplacianType.GraphCut,
+                              refinement_options=sca.RefinementOptions(
+                                  refinement_sequence=[sca.RefinementName.RowWiseThreshold]))):
+      with pytest.raises(ValueError, match="infs or NaNs"):
+        clusterer.predict(x)
+    # the handle stays usable
+    good = so.blobs(n, 8, 3, seed=n)
+    labels = sca.configs.icassp2018_clusterer.predict(good)
+    assert so.adjusted_rand_index(labels, so.predict(good, so.icassp2018_config())) == 1.0
+  w, _ = sca.utils.compute_sorted_eigenvectors(np.diag([3.0, 2.0, 1.0]))
+  np.testing.assert_allclose(w, [3.0, 2.0, 1.0])

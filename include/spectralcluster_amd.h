@@ -73,6 +73,16 @@ enum {
 enum { SC_INTEGRATION_MAX = 1, SC_INTEGRATION_AVERAGE = 2 };
 /* linkage of the size-reduction / fallback agglomerative clustering */
 enum { SC_LINKAGE_COMPLETE = 1, SC_LINKAGE_AVERAGE = 2 };
+/* custom_dist of run_kmeans (custom_distance_kmeans.py:13-52): the scipy cdist metric
+ * names that run on the device.  (A falsy custom_dist makes the reference call .predict()
+ * on an unfitted sklearn KMeans, :33-36/:51 -- it always raises; the host side mirrors that.) */
+enum {
+  SC_KMEANS_COSINE = 0,
+  SC_KMEANS_EUCLIDEAN = 1,
+  SC_KMEANS_SQEUCLIDEAN = 2,
+  SC_KMEANS_CITYBLOCK = 3,
+  SC_KMEANS_CHEBYSHEV = 4
+};
 /* utils.py:10-17 EigenGapType */
 enum { SC_EIGENGAP_RATIO = 1, SC_EIGENGAP_NORMALIZED_DIFF = 2 };
 
@@ -132,7 +142,8 @@ typedef struct sc_config {
   int32_t constraint_before_refinement; /* apply_before_refinement */
   int32_t integration_type;      /* SC_INTEGRATION_* */
   double constraint_alpha;       /* constraint_propagation_alpha (0.6) */
-  int32_t reserved[6];
+  int32_t kmeans_metric;         /* SC_KMEANS_* (custom_dist, spectral_clusterer.py:38) */
+  int32_t reserved[5];
 } sc_config;
 
 typedef struct sc_diag {
@@ -315,6 +326,10 @@ int sc_eigengap(const double* eigenvalues, int count, int max_clusters,
  * NULL, else (k, k) final centroids. */
 int sc_stage_kmeans(sc_handle h, const double* e, int n, int k, int max_iter,
                     int64_t* labels, double* centroids_out, int* iterations);
+/* the same with custom_dist = SC_KMEANS_* */
+int sc_stage_kmeans_metric(sc_handle h, const double* e, int n, int k, int max_iter,
+                           int metric, int64_t* labels, double* centroids_out,
+                           int* iterations);
 
 #ifdef __cplusplus
 }

@@ -344,6 +344,19 @@ def fallback_goldens():
   save("fallback.npz", **out)
 
 
+def kmeans_metric_goldens():
+  """4b. run_kmeans with the other custom_dist values and with the plain KMeans."""
+  km = {}
+  for tag, (n, k, seed) in {"a": (500, 4, 11), "b": (1500, 7, 12), "c": (300, 2, 13)}.items():
+    r2 = np.random.default_rng(seed)
+    cent = r2.standard_normal((k, k))
+    e = cent[r2.integers(0, k, n)] * 0.6 + 0.35 * r2.standard_normal((n, k))
+    km["e_" + tag] = e
+    for metric in ("euclidean", "sqeuclidean", "cityblock", "chebyshev"):
+      km["labels_%s_%s" % (tag, metric)] = ref_kmeans.run_kmeans(e, k, metric, 300)
+  save("kmeans_metrics.npz", **km)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
@@ -358,6 +371,9 @@ def main():
     return
   if "--fallback" in sys.argv:  # only section 10
     fallback_goldens()
+    return
+  if "--kmeans-metrics" in sys.argv:  # only section 4b
+    kmeans_metric_goldens()
     return
 
   # 1. The 6x2 toy of the reference tests, sigma=0, full stage dump, all
@@ -409,6 +425,7 @@ def main():
     km["centers_" + tag] = est.cluster_centers_
     km["labels_" + tag] = ref_kmeans.run_kmeans(e, k, "cosine", 300)
   save("kmeans.npz", **km)
+  kmeans_metric_goldens()
 
   # 5. End-to-end, seeds only.
   cases = [(200, 32, 4, 200, 0, 7), (200, 32, 4, 200, 4, 7),

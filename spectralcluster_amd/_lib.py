@@ -75,7 +75,8 @@ class ScConfig(ctypes.Structure):
       ("constraint_before_refinement", ctypes.c_int32),
       ("integration_type", ctypes.c_int32),
       ("constraint_alpha", ctypes.c_double),
-      ("reserved", ctypes.c_int32 * 6),
+      ("kmeans_metric", ctypes.c_int32),
+      ("reserved", ctypes.c_int32 * 5),
   ]
 
 
@@ -190,7 +191,36 @@ PROTOTYPES = {
     "sc_stage_kmeans": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, _c_int64_p,
                                        _c_double_p, _c_int_p]),
+    "sc_stage_kmeans_metric": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              _c_int64_p, _c_double_p, _c_int_p]),
 }
+
+# custom_dist values that run on the device (scipy cdist names)
+KMEANS_METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3,
+                  "chebyshev": 4}
+
+
+class NotFittedError(ValueError, AttributeError):
+  """Same bases as sklearn.exceptions.NotFittedError, which the reference raises for a
+  falsy custom_dist."""
+
+
+def kmeans_metric_code(custom_dist) -> int:
+  """sc_config.kmeans_metric for a `custom_dist` argument (reference
+  custom_distance_kmeans.py:13-52)."""
+  if not custom_dist:
+    # reference :33-36 builds an sklearn KMeans and :51 calls .predict() on it without
+    # ever fitting it: custom_dist=None / "" always ends in sklearn's NotFittedError
+    raise NotFittedError(
+        "This KMeans instance is not fitted yet. Call 'fit' with appropriate arguments "
+        "before using this estimator.")
+  if isinstance(custom_dist, str) and custom_dist in KMEANS_METRICS:
+    return KMEANS_METRICS[custom_dist]
+  raise UnsupportedOnDeviceError(
+      "custom_dist=%r: the device path implements %s; other scipy metrics and callables "
+      "are not on it" % (custom_dist, ", ".join(sorted(KMEANS_METRICS))))
+
 
 _lib = None
 _lib_lock = threading.Lock()

@@ -1675,7 +1675,13 @@ extern "C" int sc_get_eigenvectors(sc_handle h, double* out, int n, int ncols) {
 // k-means tail
 // ------------------------------------------------------------------------------
 static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k, int max_iter,
-                            int64_t* labels, double* centroids_out, int* iterations) {
+                            int64_t* labels, double* centroids_out, int* iterations,
+                            int metric = kKmeansCosine) {
+  if (metric != kKmeansCosine && metric != kKmeansEuclidean && metric != kKmeansSqeuclidean &&
+      metric != kKmeansCityblock && metric != kKmeansChebyshev)
+    return fail(h, SC_ERR_UNSUPPORTED,
+                "custom_dist on the device: cosine, euclidean, sqeuclidean, cityblock, "
+                "chebyshev");
   if (max_iter <= 0)
     return fail(h, SC_ERR_INVALID, "Number of iterations should be a positive number");
   if (n < k) return fail(h, SC_ERR_INVALID, "n_samples should be >= n_clusters");
@@ -1703,12 +1709,13 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   ws.labels32 = ptr<int>(h->klab32);
   ws.labels64 = ptr<long long>(h->klab64);
   ws.info = ptr<int>(h->kinfo);
-  launch_kmeans(h->stream, E, lde, n, k, max_iter, first, trials, ws);
+  SC_HIP(h, hipMemsetAsync(h->kinfo.p, 0, 8 * sizeof(int), h->stream));
+  launch_kmeans(h->stream, E, lde, n, k, max_iter, first, trials, ws, metric);
   SC_TRY(check_last(h, "kmeans launch"));
   SC_HIP(h, hipMemcpyAsync(labels, h->klab64.p, (size_t)n * sizeof(int64_t),
                            hipMemcpyDeviceToHost, h->stream));
   int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  SC_HIP(h, hipMemcpyAsync(info, h->kinfo.p, 5 * sizeof(int), hipMemcpyDeviceToHost,
+  SC_HIP(h, hipMemcpyAsync(info, h->kinfo.p, 6 * sizeof(int), hipMemcpyDeviceToHost,
                            h->stream));
   if (centroids_out)
     SC_HIP(h, hipMemcpyAsync(centroids_out, h->kcent.p, (size_t)k * k * sizeof(double),
@@ -1743,7 +1750,8 @@ extern "C" int sc_cluster(sc_handle h, const sc_config* cfg, int n_clusters, int
     E = ptr<double>(h->Ek);
   }
   int iters = 0;
-  SC_TRY(kmeans_on_device(h, E, lde, n, n_clusters, cfg->max_iter, labels, nullptr, &iters));
+  SC_TRY(kmeans_on_device(h, E, lde, n, n_clusters, cfg->max_iter, labels, nullptr, &iters,
+                          cfg->kmeans_metric));
   ev_rec(h, &e1);
   SC_HIP(h, hipStreamSynchronize(h->stream));
   if (diag) {
@@ -2298,8 +2306,9 @@ extern "C" int sc_stage_eig(sc_handle h, const double* m, int n, int count, int 
   return SC_OK;
 }
 
-extern "C" int sc_stage_kmeans(sc_handle h, const double* e, int n, int k, int max_iter,
-                               int64_t* labels, double* centroids_out, int* iterations) {
+extern "C" int sc_stage_kmeans_metric(sc_handle h, const double* e, int n, int k, int max_iter,
+                                      int metric, int64_t* labels, double* centroids_out,
+                                      int* iterations) {
   if (!h) return SC_ERR_INVALID;
   if (!e || !labels || n <= 0 || k <= 0) return fail(h, SC_ERR_INVALID, "bad k-means input");
   if (k > kMaxVectors)
@@ -2311,5 +2320,11 @@ extern "C" int sc_stage_kmeans(sc_handle h, const double* e, int n, int k, int m
   launch_to_colmajor(h->stream, ptr<double>(h->Eio), n, k, ptr<double>(h->Ek),
                      round_up(n, 16));
   return kmeans_on_device(h, ptr<double>(h->Ek), round_up(n, 16), n, k, max_iter, labels,
-                          centroids_out, iterations);
+                          centroids_out, iterations, metric);
+}
+
+extern "C" int sc_stage_kmeans(sc_handle h, const double* e, int n, int k, int max_iter,
+                               int64_t* labels, double* centroids_out, int* iterations) {
+  return sc_stage_kmeans_metric(h, e, n, k, max_iter, SC_KMEANS_COSINE, labels, centroids_out,
+                                iterations);
 }

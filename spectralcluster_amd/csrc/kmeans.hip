@@ -70,7 +70,7 @@ __global__ void k_to_colmajor(const double* __restrict__ src, int n, int k,
 // member rows, then the k partial sums are reduced wave -> LDS -> fixed-order total
 // (deterministic).
 //   mode 0 (Lloyd, centred data):  mean of members + mean[j]; empty cluster keeps seed
-//   mode 1 (cosine loop):          mean of members iff some member index > 0
+//   mode 1 (custom-distance loop): mean of members iff some member index > 0
 __device__ __forceinline__ void cluster_means(const double* __restrict__ data, int ld,
                                               int n, int k, const int* __restrict__ lab,
                                               double* cent, const double* mean, int mode,
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     double* __restrict__ closest, double* __restrict__ cand_d,
     double* __restrict__ enorm, const double* __restrict__ rnd,
     double* __restrict__ cent_out, int* __restrict__ labels32,
-    long long* __restrict__ labels64, int* __restrict__ info) {
+    long long* __restrict__ labels64, int* __restrict__ info, int metric) {
   __shared__ double sm[KW];
   __shared__ double mean[kMaxVectors];
   __shared__ double cent[kMaxVectors * kMaxVectors];   // k x k, stride k
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(KT) void k_kmeans(
   // seeds, each of which is its own nearest centre); best_centers += X_mean
   cluster_means(XcT, n, n, k, labels32, cent, mean, 0, wpart, counts, nzcounts);
 
-  // ---- CustomKMeans.predict, cosine (custom_distance_kmeans.py:118-141) --------
+  // ---- CustomKMeans.predict (custom_distance_kmeans.py:118-141), scipy cdist metric --
   if (tid == 0) info[3] = (int)(wall_clock64() - t_start);
   double prev = 0.0;
   int it = 0;
@@ -355,15 +355,32 @@ __global__ __launch_bounds__(KT) void k_kmeans(
         for (int j = 0; j < k; ++j) {
           const double x = ET[(size_t)j * lde + r];
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (c0 + q < k) dot[q] += x * cent[(c0 + q) * k + j];
+          for (int q = 0; q < 8; ++q) {
+            if (c0 + q < k) {
+              const double cv = cent[(c0 + q) * k + j];
+              if (metric == kKmeansCosine) {
+                dot[q] += x * cv;
+              } else if (metric == kKmeansCityblock) {
+                dot[q] += fabs(x - cv);
+              } else if (metric == kKmeansChebyshev) {
+                dot[q] = fmax(dot[q], fabs(x - cv));
+              } else {  // (squared) Euclidean
+                dot[q] += (x - cv) * (x - cv);
+              }
+            }
+          }
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           if (c0 + q < k) {
-            double cosine = dot[q] / (nu * cnorm[c0 + q]);
-            if (fabs(cosine) > 1.0) cosine = copysign(1.0, cosine);
-            const double d = 1.0 - cosine;
+            double d;
+            if (metric == kKmeansCosine) {
+              double cosine = dot[q] / (nu * cnorm[c0 + q]);
+              if (fabs(cosine) > 1.0) cosine = copysign(1.0, cosine);
+              d = 1.0 - cosine;
+            } else {
+              d = metric == kKmeansEuclidean ? sqrt(dot[q]) : dot[q];
+            }
             if (d < bd) { bd = d; best = c0 + q; }
           }
         }
@@ -834,8 +851,9 @@ void launch_to_colmajor(hipStream_t s, const double* src, int n, int k, double* 
 
 void launch_kmeans(hipStream_t s, const double* ET, int lde, int n, int k,
                    int max_iter, int first_center, int trials,
-                   const KmeansWorkspace& ws) {
-  if (k <= 8 && n <= 16 * 512 && trials <= 8 && !getenv("SC_KMEANS_GENERIC")) {
+                   const KmeansWorkspace& ws, int metric) {
+  if (metric == kKmeansCosine && k <= 8 && n <= 16 * 512 && trials <= 8 &&
+      !getenv("SC_KMEANS_GENERIC")) {
     // register-resident fast path: 512 threads (256 VGPRs each), contiguous rows per thread
     if (n <= 8 * 512)
       hipLaunchKernelGGL((k_kmeans_fast<8, 512>), dim3(1), dim3(512), 0, s, ET, lde, n, k,
@@ -850,7 +868,7 @@ void launch_kmeans(hipStream_t s, const double* ET, int lde, int n, int k,
   hipLaunchKernelGGL(k_kmeans, dim3(1), dim3(KT), 0, s, ET, lde, n, k, max_iter,
                      first_center, trials, ws.Xc, ws.xsq, ws.closest, ws.cand,
                      ws.enorm, ws.rnd, ws.centroids, ws.labels32, ws.labels64,
-                     ws.info);
+                     ws.info, metric);
 }
 
 }  // namespace sc

@@ -240,8 +240,16 @@ struct KmeansWorkspace {
 void launch_row_renorm(hipStream_t s, double* ET, int lde, int n, int k);
 void launch_to_colmajor(hipStream_t s, const double* src, int n, int k, double* dst,
                         int ldt);
+// metric of the custom-distance loop (scipy cdist names)
+enum {
+  kKmeansCosine = 0,
+  kKmeansEuclidean = 1,
+  kKmeansSqeuclidean = 2,
+  kKmeansCityblock = 3,
+  kKmeansChebyshev = 4
+};
 void launch_kmeans(hipStream_t s, const double* ET, int lde, int n, int k,
                    int max_iter, int first_center, int trials,
-                   const KmeansWorkspace& ws);
+                   const KmeansWorkspace& ws, int metric = kKmeansCosine);
 
 }  // namespace sc

@@ -8,7 +8,8 @@ device too, and refinement sequences whose result is n
 diagonally similar to a symmetric matrix take the general eigen path (8f-N2);
 `max_spectral_size` pre-clusters on the device (cosine complete-linkage AHC) and
 `fallback_options` (too-few-embeddings fallback, single-cluster test for min_clusters=1) run
-there too (8f-N4).  Out of the device scope: non-cosine k-means.  Those raise `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
+there too (8f-N4).  `custom_dist`: cosine, euclidean, sqeuclidean, cityblock, chebyshev;
+other scipy metrics and callables are out of the device scope.  Those raise `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
 """
 
 from __future__ import annotations
@@ -108,6 +109,8 @@ class SpectralClusterer:
     cfg.stop_eigenvalue = float(self.stop_eigenvalue)
     cfg.row_wise_renorm = int(bool(self.row_wise_renorm))
     cfg.max_iter = int(self.max_iter)
+    if self.post_eigen_cluster_function is custom_distance_kmeans.run_kmeans:
+      cfg.kmeans_metric = _lib.kmeans_metric_code(self.custom_dist)
     if self.constraint_options is not None:
       self.constraint_options.to_config(cfg)
     return cfg
@@ -211,9 +214,8 @@ class SpectralClusterer:
       return self._reduce_size_and_predict(embeddings)
     handle = self._handle()
     default_tail = (self.post_eigen_cluster_function is custom_distance_kmeans.run_kmeans)
-    if default_tail and self.custom_dist != "cosine":
-      raise _lib.UnsupportedOnDeviceError(
-          "only custom_dist='cosine' is implemented on the device path")
+    if default_tail:
+      _lib.kmeans_metric_code(self.custom_dist)  # raises for metrics that are not on the device
     constrained = self._set_constraint(handle, n, constraint_matrix)
 
     single_check = self.min_clusters == 1

@@ -272,7 +272,19 @@ def test_error_behaviour():
   assert so.adjusted_rand_index(general.predict(TOY), want) == 1.0
   assert general.last_diag.symmetry_state == 3
   with pytest.raises(sca.UnsupportedOnDeviceError):
-    sca.SpectralClusterer(custom_dist="euclidean").predict(TOY)
+    sca.SpectralClusterer(custom_dist="mahalanobis").predict(TOY)
+  with pytest.raises((ValueError, AttributeError), match="not fitted"):
+    sca.SpectralClusterer(custom_dist=None).predict(TOY)   # the reference raises too
+  # the other device metrics run end to end
+  x = so.blobs(300, 16, 3, seed=4)
+  for metric in ("euclidean", "cityblock"):
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, custom_dist=metric,
+                              refinement_options=icassp_options())
+    got = c.predict(x)
+    dump = {}
+    so.predict(x, so.icassp2018_config(), dump)
+    want = so.run_kmeans_metric(dump["spectral_embeddings"], dump["n_clusters"], 300, metric)
+    assert so.adjusted_rand_index(got, want) == 1.0
   with pytest.raises(TypeError):
     sca.SpectralClusterer(laplacian_type="GraphCut").predict(TOY)
 

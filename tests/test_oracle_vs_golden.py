@@ -280,6 +280,20 @@ def test_size_reduction_vs_reference():
     so.chain_labels(np.array([0, 1, 2]), np.array([0, 1]))
 
 
+def test_kmeans_other_metrics_vs_reference():
+  g = golden("kmeans_metrics.npz")
+  for tag, k in (("a", 4), ("b", 7), ("c", 2)):
+    for metric in ("euclidean", "sqeuclidean", "cityblock", "chebyshev"):
+      got = so.run_kmeans_metric(g["e_" + tag], k, 300, metric)
+      assert np.array_equal(got, g["labels_%s_%s" % (tag, metric)])
+  # cosine through the generic function equals the bit-exact restatement
+  e = g["e_a"]
+  assert np.array_equal(so.run_kmeans_metric(e, 4, 300, "cosine"), so.run_kmeans(e, 4, 300))
+  from sklearn.exceptions import NotFittedError
+  with pytest.raises(NotFittedError):   # the reference's latent bug (:33-36, :51)
+    so.run_kmeans_metric(e, 4, 300, None)
+
+
 def test_adjusted_rand_index():
   from sklearn.metrics import adjusted_rand_score
   rng = np.random.default_rng(0)

@@ -28,8 +28,9 @@ constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 16;
 
-// 16-byte chunk kc (k = 2kc, 2kc+1) of row `row`: both elements land in one aligned
-// chunk, in swapped order for odd rows.
+// 16-byte chunk kc (k = 2kc, 2kc+1) of row `row` sits at chunk position kc ^ ((row >> 1) & 7)
+// of the row's 128 bytes: the 16 lanes of a ds_read_b128 group (rows li = 0..15, one kc)
+// then cover 16 distinct 16-byte slots of a 256-byte bank window -- conflict-free.
 __device__ __forceinline__ int lds_chunk_off(int row, int kc) {
   return row * BK + ((2 * kc) ^ (row & 14));
 }
@@ -225,7 +226,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   const double* bptr[4];
   int lds_off[4];
   int kcol[4];
-  bool swap[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = tid + 256 * q;
@@ -238,7 +238,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     aptr[q] = A + (size_t)ga * lda + 2 * kc;
     bptr[q] = B + (size_t)gb * ldb + 2 * kc;
     lds_off[q] = lds_chunk_off(r, kc);
-    swap[q] = r & 1;
     kcol[q] = 2 * kc;
   }
 
@@ -277,10 +276,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
         if (k >= K) { va.x = 0.0; vb.x = 0.0; }
         if (k + 1 >= K) { va.y = 0.0; vb.y = 0.0; }
       }
-      if (swap[q]) {
-        va = make_double2(va.y, va.x);
-        vb = make_double2(vb.y, vb.x);
-      }
       *reinterpret_cast<double2*>(&As[buf][lds_off[q]]) = va;
       *reinterpret_cast<double2*>(&Bs[buf][lds_off[q]]) = vb;
     }
@@ -309,18 +304,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     const double* Bc = Bs[cur];
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int koff = (4 * s + lg) ^ li;
-      double a[4], b[4];
+    for (int p = 0; p < 2; ++p) {
+      // k-slot lg of the two MFMA steps of this pair carries k = 8p + 2lg and 8p + 2lg + 1:
+      // one 16-byte LDS read per fragment feeds both steps (the order in which the K sum is
+      // taken is free, as long as A and B agree on it)
+      const int koff = (2 * (4 * p + lg)) ^ (li & 14);
+      double2 a[4], b[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) a[m] = Ac[arow + m * 16 * BK + koff];
+      for (int m = 0; m < 4; ++m)
+        a[m] = *reinterpret_cast<const double2*>(Ac + arow + m * 16 * BK + koff);
 #pragma unroll
-      for (int nn = 0; nn < 4; ++nn) b[nn] = Bc[brow + nn * 16 * BK + koff];
+      for (int nn = 0; nn < 4; ++nn)
+        b[nn] = *reinterpret_cast<const double2*>(Bc + brow + nn * 16 * BK + koff);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn)
-          acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[nn],
+          acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].x, b[nn].x,
+                                                            acc[m][nn], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+          acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[nn].y,
                                                             acc[m][nn], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_wide(const double* __restrict__
   _Pragma("unroll") for (int m = M0; m < M1; ++m) {                                        \
     _Pragma("unroll") for (int nn = 0; nn < 8; ++nn)                                       \
         acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[m].x, B_[nn].x, acc[m][nn], 0, 0, 0); \
+  }                                                                                        \
+  _Pragma("unroll") for (int m = M0; m < M1; ++m) {                                        \
     _Pragma("unroll") for (int nn = 0; nn < 8; ++nn)                                       \
         acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[m].y, B_[nn].y, acc[m][nn], 0, 0, 0); \
   }

@@ -65,6 +65,15 @@ struct sc_handle_s {
 };
 
 static constexpr int kMaxCols = 128;  // eigenvector columns the arena can hold
+// Leading dimension of the n x n matrices.  A row stride that is a multiple of 4 KiB maps
+// the 128 rows of an operand panel onto the same few L2 sets (the GEMM reads one 128-byte
+// line per row and K-tile): such strides get one extra 128-byte line.
+static inline int matrix_ld(int n) {
+  int ld = round_up(n, 16);
+  if (ld % 512 == 0) ld += 16;
+  return ld;
+}
+
 // eigenvectors are column-major on the device: column j at E + j * lde, lde = round_up(n, 16)
 
 #define SC_HIP(h, call)                                                         \
@@ -105,7 +114,7 @@ static T* ptr(const DevBuf& b) {
 }
 
 static int ensure_matrices(sc_handle h, int n, int d) {
-  const size_t ldn = round_up(n, 16);
+  const size_t ldn = matrix_ld(n);
   const size_t nn = (size_t)n * ldn * sizeof(double);
   SC_TRY(grow(h, h->A0, nn));
   SC_TRY(grow(h, h->B1, nn));
@@ -651,7 +660,7 @@ extern "C" int sc_set_constraint(sc_handle h, const double* q, int n) {
   if (!h) return SC_ERR_INVALID;
   if (!q || n <= 0) return fail(h, SC_ERR_INVALID, "constraint matrix must be (n, n)");
   SC_HIP(h, hipSetDevice(h->device));
-  const int ld = round_up(n, 16);
+  const int ld = matrix_ld(n);
   SC_TRY(grow(h, h->Cq, (size_t)n * ld * sizeof(double)));
   SC_TRY(h2d_matrix(h, q, n, n, ptr<double>(h->Cq), ld));
   SC_TRY(device_is_symmetric(h, ptr<double>(h->Cq), n, ld, &h->constraint_symmetric));
@@ -718,7 +727,7 @@ extern "C" int sc_set_embeddings(sc_handle h, const double* x, int n, int d) {
   SC_TRY(ensure_matrices(h, n, d));
   h->n = n;
   h->d = d;
-  h->ldn = round_up(n, 16);
+  h->ldn = matrix_ld(n);
   h->ldx = round_up(d, 16);
   h->have_affinity = h->have_cropval = false;
   h->n_vec = 0;
@@ -758,7 +767,7 @@ extern "C" int sc_set_affinity(sc_handle h, const double* a, int n) {
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
   h->n = n;
-  h->ldn = round_up(n, 16);
+  h->ldn = matrix_ld(n);
   h->have_x = false;
   h->n_vec = 0;
   SC_TRY(h2d_matrix(h, a, n, n, ptr<double>(h->A0), h->ldn));
@@ -2152,7 +2161,7 @@ extern "C" int sc_stage_refine(sc_handle h, int op, const sc_config* cfg, const 
   if (!in || !out || n <= 0) return fail(h, SC_ERR_INVALID, "affinity must be (n, n)");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
-  const int ld = round_up(n, 16);
+  const int ld = matrix_ld(n);
   h->have_affinity = h->have_cropval = false;
   h->have_x = false;
   h->n_vec = 0;
@@ -2169,7 +2178,7 @@ extern "C" int sc_stage_laplacian(sc_handle h, int laplacian_type, const double*
     return fail(h, SC_ERR_INVALID, "laplacian_type must be a LaplacianType");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
-  const int ld = round_up(n, 16);
+  const int ld = matrix_ld(n);
   h->have_affinity = h->have_cropval = false;
   h->have_x = false;
   h->n_vec = 0;
@@ -2202,7 +2211,7 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
     return fail(h, SC_ERR_UNSUPPORTED, "at most 64 eigenpairs for n > 128");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
-  const int ld = round_up(n, 16);
+  const int ld = matrix_ld(n);
   h->n = n;
   h->ldn = ld;
   h->have_affinity = h->have_cropval = false;
@@ -2260,7 +2269,7 @@ extern "C" int sc_stage_eig(sc_handle h, const double* m, int n, int count, int 
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
   SC_TRY(ensure_gen(h, n));
-  const int ld = round_up(n, 16);
+  const int ld = matrix_ld(n);
   h->n = n;
   h->ldn = ld;
   h->have_affinity = h->have_cropval = false;

@@ -230,15 +230,9 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
     const double* __restrict__ partial, int nparts, double* __restrict__ Rinv,
     double* __restrict__ Gsave, const double* __restrict__ hsq,
     int* __restrict__ flags, int* __restrict__ defect_flag, int flag_mode) {
-  __shared__ double G[B][B + 1];
-  __shared__ double R[B][B + 1];
-  __shared__ double Ri[B][B + 1];
-  __shared__ double gdiag[B];
-  __shared__ double piv[B];
-  __shared__ int s_mask;
+  static_assert(B == 8, "the factorisation below maps the 8 x 8 matrix onto one wavefront");
+  __shared__ double G[B * B];
   const int tid = threadIdx.x;
-  const bool active = tid < B * B;
-  const int ra = active ? tid / B : 0, cb = active ? tid % B : 0;
   {
     // Gram entry e summed by (256 / (B*B)) lanes, fixed-order butterfly
     constexpr int kLanes = 256 / (B * B);
@@ -248,80 +242,67 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
 #pragma unroll
     for (int o = 1; o < kLanes; o <<= 1) g += __shfl_xor(g, o);
     if (sub == 0) {
-      G[e / B][e % B] = g;
+      G[e] = g;
       if (Gsave) Gsave[e] = g;
-      R[e / B][e % B] = 0.0;
-      Ri[e / B][e % B] = 0.0;
-      if (e / B == e % B) gdiag[e / B] = g;
-    }
-  }
-  if (tid == 0) s_mask = 0;
-  __syncthreads();
-  __shared__ int s_defect;
-  if (tid == 0) {
-    // flag_mode 2 (second CholQR pass): G is the Gram matrix of the block the first pass
-    // produced; far from I means that pass met a block of condition > 1e8.
-    double defect = 0.0;
-    if (flag_mode == 2)
-      for (int i = 0; i < B; ++i)
-        for (int j = 0; j < B; ++j) {
-          if (gdiag[i] == 0.0 || gdiag[j] == 0.0) continue;  // dropped columns
-          defect = fmax(defect, fabs(G[i][j] - (i == j ? 1.0 : 0.0)));
-        }
-    s_defect = defect > 0.1 ? 1 : 0;
-  }
-  for (int j = 0; j < B; ++j) {
-    if (tid == 0) {
-      const double d = G[j][j];
-      const double total = gdiag[j] + (hsq ? hsq[j] : 0.0);
-      if (!(d > 1e-22 * total) || !(d > 0.0)) {
-        s_mask |= 1 << j;
-        piv[j] = 0.0;  // dropped column
-      } else {
-        piv[j] = sqrt(d);
-      }
-    }
-    __syncthreads();
-    const double rj = piv[j];
-    if (tid < B) {
-      double v = 0.0;
-      if (rj != 0.0) v = tid == j ? rj : (tid > j ? G[j][tid] / rj : 0.0);
-      R[j][tid] = v;
-    }
-    __syncthreads();
-    if (active && ra > j && cb > j) G[ra][cb] -= R[j][ra] * R[j][cb];
-    __syncthreads();
-  }
-  // R^-1 by back substitution, one column per thread (dropped columns stay zero)
-  if (tid < B) {
-    const int j = tid;
-    if (R[j][j] != 0.0) {
-      Ri[j][j] = 1.0 / R[j][j];
-      for (int i = j - 1; i >= 0; --i) {
-        if (R[i][i] == 0.0) continue;
-        double v = 0.0;
-        for (int k = i + 1; k <= j; ++k) v -= R[i][k] * Ri[k][j];
-        Ri[i][j] = v / R[i][i];
-      }
     }
   }
   __syncthreads();
-  if (active) Rinv[tid] = Ri[ra][cb];
-  if (tid == 0) {
-    flags[0] = s_mask;
-    if (defect_flag != nullptr) {
-      // An ill-conditioned block (pivot ratio > 1e3: the operator is numerically low-rank)
-      // gets its small columns from R^-1 entries of that size, which amplify the absolute
-      // Q-orthogonality error of the large columns: the caller must project against the
-      // basis once more (twice-is-enough holds for the normalised block only).
-      double pmax = 0.0, pmin = __builtin_huge_val();
-      for (int j = 0; j < B; ++j)
-        if (piv[j] > 0.0) {
-          pmax = fmax(pmax, piv[j]);
-          pmin = fmin(pmin, piv[j]);
-        }
-      *defect_flag = (s_defect != 0 || pmax > 1e3 * pmin) ? 1 : 0;
+  if (tid >= 64) return;
+  // ---- wave 0: lane (i, j) = (tid / 8, tid % 8) owns entry (i, j); the right-looking
+  // Cholesky and the triangular inverse exchange rows / columns through shuffles, so the
+  // whole factorisation runs without a barrier
+  const int i = tid >> 3, j = tid & 7;
+  double g = G[tid];
+  const double gii = __shfl(g, i * 9), gjj = __shfl(g, j * 9);  // original diagonal
+  double defect = 0.0;
+  if (flag_mode == 2 && gii != 0.0 && gjj != 0.0) defect = fabs(g - (i == j ? 1.0 : 0.0));
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) defect = fmax(defect, __shfl_xor(defect, o));
+  double r = 0.0;  // R[i][j]
+  int mask = 0;
+  double pmax = 0.0, pmin = __builtin_huge_val();
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    const double d = __shfl(g, k * 9);
+    const double total = __shfl(gii, k * 8) + (hsq ? hsq[k] : 0.0);
+    const bool drop = !(d > 1e-22 * total) || !(d > 0.0);
+    const double rk = drop ? 0.0 : sqrt(d);
+    if (drop) {
+      mask |= 1 << k;
+    } else {
+      pmax = fmax(pmax, rk);
+      pmin = fmin(pmin, rk);
     }
+    double row = 0.0;  // R[k][j] on the lanes of row k
+    if (i == k && !drop) row = j == k ? rk : (j > k ? g / rk : 0.0);
+    if (i == k) r = row;
+    const double rki = __shfl(row, k * 8 + i), rkj = __shfl(row, k * 8 + j);
+    if (i > k && j > k) g -= rki * rkj;
+  }
+  // R^-1 by back substitution, rows from the bottom up (dropped columns stay zero)
+  const double rii = __shfl(r, i * 9), rjj = __shfl(r, j * 9);
+  double ri = 0.0;  // Rinv[i][j]
+#pragma unroll
+  for (int srow = B - 1; srow >= 0; --srow) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = srow + 1; k < B; ++k) {
+      const double rsk = __shfl(r, srow * 8 + k), rkj = __shfl(ri, k * 8 + j);
+      if (k <= j) v -= rsk * rkj;
+    }
+    if (i == srow && j >= i && rii != 0.0 && rjj != 0.0)
+      ri = i == j ? 1.0 / rii : v / rii;
+  }
+  Rinv[tid] = ri;
+  if (tid == 0) {
+    flags[0] = mask;
+    // An ill-conditioned block (pivot ratio > 1e3: the operator is numerically low-rank)
+    // gets its small columns from R^-1 entries of that size, which amplify the absolute
+    // Q-orthogonality error of the large columns: the caller must project against the
+    // basis once more (twice-is-enough holds for the normalised block only).  flag_mode 2
+    // (second CholQR pass): a Gram matrix far from I means the first pass met a block of
+    // condition > 1e8.
+    if (defect_flag != nullptr) *defect_flag = (defect > 0.1 || pmax > 1e3 * pmin) ? 1 : 0;
   }
 }
 

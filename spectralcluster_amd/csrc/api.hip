@@ -1453,7 +1453,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   bool symmetric = h->affinity_symmetric;  // cosine affinity: always
   const bool constrain_after = constraint_active(h, cfg, false);
   bool folded_rownorm = false;
-  int e_begin, e_tmp, e_after_refine;
+  int e_begin, e_after_refine;
   float diffuse_ms_events[SC_MAX_OPS][2];
   int n_diffuse = 0;
   ev_rec(h, &e_begin);
@@ -1654,7 +1654,6 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
     diag->stage_ms[SC_STAGE_SCALING] = ev_ms(h, e_after_refine, e_after_scaling);
     diag->stage_ms[SC_STAGE_EIG] = ev_ms(h, e_after_scaling, e_after_eig);
   }
-  (void)e_tmp;
   return SC_OK;
 }
 

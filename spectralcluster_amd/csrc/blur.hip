@@ -144,6 +144,129 @@ __global__ __launch_bounds__(256) void k_gaussian_blur_r(
   }
 }
 
+// Streaming path for large matrices (n >= kStreamMinN): no LDS, no barrier.  A wave walks
+// down a strip of 256 input columns (4 adjacent columns per lane: one 32-byte load per lane
+// and row, 2 KiB contiguous per wave) over 64 output rows, keeping the 2R+1 rows of the
+// vertical stencil -- plus kAhead rows already in flight -- in a register ring whose slot
+// indices are compile-time (the row loop is unrolled by the ring size).  The horizontal taps
+// of a lane's 4 outputs come from its own registers and its R/4 neighbour lanes on each side
+// (2R/4 shuffles of 4 doubles per 4 outputs, against 2R per output in the tile kernel above);
+// stores are 32 contiguous bytes per lane.  Read amplification: (64 + 2R)/64 vertically,
+// 256/(256 - 2R) horizontally.  Same summation order as scipy in both passes.
+constexpr int kStreamMinN = 512;
+constexpr int kStreamRows = 64;   // output rows per wave
+constexpr int kAhead = 3;         // rows loaded ahead of the vertical stencil
+template <int R>
+__global__ __launch_bounds__(256) void k_gaussian_blur_stream(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    const double* __restrict__ weights, const double* __restrict__ diag,
+    double* __restrict__ rowmax) {
+  static_assert(R % 4 == 0, "neighbour lanes carry 4 columns each");
+  constexpr int S = 2 * R + 1 + kAhead;  // ring slots
+  constexpr int NB = R / 4;              // neighbour lanes per side
+  constexpr int OW = 256 - 2 * R;        // output columns per strip
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * OW;                                // first output column
+  const int r0 = (blockIdx.y * 4 + wv) * kStreamRows;            // first output row
+  if (r0 >= n) return;
+  const int rend = min(n, r0 + kStreamRows);
+  double w[R + 1];
+#pragma unroll
+  for (int j = 0; j <= R; ++j) w[j] = weights[R - j];
+  // the lane's 4 input columns (scipy "reflect"), and whether the whole strip is interior
+  const int q0 = 4 * lane;
+  int gjin[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int g = j0 - R + q0 + e;
+    g = g < 0 ? -g - 1 : g;
+    g = g >= n ? 2 * n - 1 - g : g;
+    gjin[e] = g < 0 ? 0 : g;  // overhang of the last strip (never stored)
+  }
+  const bool interior = j0 - R >= 0 && j0 - R + 255 < n;
+  auto load_row = [&](int r, double (&dst)[4]) {
+    int gi = r;
+    gi = gi < 0 ? -gi - 1 : gi;
+    gi = gi >= n ? 2 * n - 1 - gi : gi;
+    gi = gi < 0 ? 0 : (gi >= n ? n - 1 : gi);
+    const double* row = in + (size_t)gi * ld;
+    if (interior) {
+      const double2 lo = *reinterpret_cast<const double2*>(row + j0 - R + q0);
+      const double2 hi = *reinterpret_cast<const double2*>(row + j0 - R + q0 + 2);
+      dst[0] = lo.x; dst[1] = lo.y; dst[2] = hi.x; dst[3] = hi.y;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e] = row[gjin[e]];
+    }
+    if (diag != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gjin[e] == gi) dst[e] = diag[gi];
+    }
+  };
+  double win[S][4];
+#pragma unroll
+  for (int q = 0; q < S - 1; ++q) load_row(r0 - R + q, win[q]);
+  // output column of (lane, e): j0 + q0 + e - R, valid for R <= q0 + e < 256 - R
+  const int gjo0 = j0 + q0 - R;
+  const bool lane_ok = q0 >= R && q0 + 3 < 256 - R;
+  const bool full_store = lane_ok && gjo0 + 3 < n;
+  for (int o = r0; o < rend; o += S) {
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+      const int gi = o + u;
+      if (gi >= rend) break;  // wave-uniform
+      load_row(gi + R + kAhead, win[(u + S - 1) % S]);
+      double t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double acc = win[(u + R) % S][e] * w[0];
+#pragma unroll
+        for (int j = R; j >= 1; --j)
+          acc += (win[(u + R - j) % S][e] + win[(u + R + j) % S][e]) * w[j];
+        t[e] = acc;
+      }
+      // horizontal: own 4 values + NB neighbour lanes on each side
+      double ext[(2 * NB + 1) * 4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ext[NB * 4 + e] = t[e];
+#pragma unroll
+      for (int d = 1; d <= NB; ++d) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ext[(NB - d) * 4 + e] = __shfl_up(t[e], d);
+          ext[(NB + d) * 4 + e] = __shfl_down(t[e], d);
+        }
+      }
+      double res[4];
+      double m = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double acc = ext[NB * 4 + e] * w[0];
+#pragma unroll
+        for (int j = R; j >= 1; --j)
+          acc += (ext[NB * 4 + e - j] + ext[NB * 4 + e + j]) * w[j];
+        res[e] = acc;
+        if (lane_ok && gjo0 + e < n) m = fmax(m, acc);
+      }
+      double* orow = out + (size_t)gi * ld + gjo0;
+      if (full_store) {
+        *reinterpret_cast<double2*>(orow) = make_double2(res[0], res[1]);
+        *reinterpret_cast<double2*>(orow + 2) = make_double2(res[2], res[3]);
+      } else if (lane_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gjo0 + e < n) orow[e] = res[e];
+      }
+      if (rowmax != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+        if (lane == 0) rowmax[(size_t)gi * gridDim.x + blockIdx.x] = m;
+      }
+    }
+  }
+}
+
 __global__ void k_copy_matrix(const double* __restrict__ in,
                               double* __restrict__ out, int n, int ld) {
   const size_t total = (size_t)n * ld;
@@ -159,7 +282,7 @@ void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
 
 // tile columns of the fast path for `radius` (row-max partials per row)
 int blur_tile_columns(int n, int radius) {
-  const int ow = 64 - 2 * radius;
+  const int ow = (n >= kStreamMinN ? 256 : 64) - 2 * radius;
   return (n + ow - 1) / ow;
 }
 
@@ -168,6 +291,16 @@ bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, in
                                 int radius, const double* weights_dev, const double* diag,
                                 double* rowmax_partials) {
   dim3 grid((n + TW - 1) / TW, (n + TH - 1) / TH);
+  if ((radius == 4 || radius == 8) && n >= kStreamMinN) {
+    dim3 sgrid(blur_tile_columns(n, radius), (n + 4 * kStreamRows - 1) / (4 * kStreamRows));
+    if (radius == 4)
+      hipLaunchKernelGGL((k_gaussian_blur_stream<4>), sgrid, dim3(256), 0, s, in, out, n, ld,
+                         weights_dev, diag, rowmax_partials);
+    else
+      hipLaunchKernelGGL((k_gaussian_blur_stream<8>), sgrid, dim3(256), 0, s, in, out, n, ld,
+                         weights_dev, diag, rowmax_partials);
+    return rowmax_partials != nullptr;
+  }
   if ((radius == 4 || radius == 8) && n >= 128) {
     dim3 fgrid(blur_tile_columns(n, radius), (n + kBlurRows - 1) / kBlurRows);
     if (radius == 4)

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void k_gemm_tail_stats(const double* __restric
     tj = t;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int lr = wave; lr < BM; lr += 4) {
+  // blockIdx.z: 8 groups of 16 rows, so the few tail tiles still spread over the chip
+  for (int lr = blockIdx.z * 16 + wave; lr < blockIdx.z * 16 + 16; lr += 4) {
     const int row = ti * BM + lr;
     if (row >= M) break;
     double mx = -INFINITY, sm = 0.0;
@@ -534,7 +535,7 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     hipLaunchKernelGGL((k_gemm_reduce<EPI, SYM>), dim3(rem, 16), dim3(256), 0, s, g_partial,
                        C, ldc, M, N, tm, tn, full, ksplit, tilemap, addend);
     if (stats.mode != 0)
-      hipLaunchKernelGGL((k_gemm_tail_stats<SYM>), dim3(rem, SYM ? 2 : 1), dim3(256), 0, s, C,
+      hipLaunchKernelGGL((k_gemm_tail_stats<SYM>), dim3(rem, SYM ? 2 : 1, 8), dim3(256), 0, s, C,
                          ldc, M, N, tm, tn, full, tilemap, stats);
   }
   if (stats.mode != 0)

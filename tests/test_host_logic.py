@@ -29,6 +29,13 @@ def test_library_exports_every_declared_symbol():
   assert lib.sc_abi_version() == 2
 
 
+def test_graft_entry_build_runs():
+  """The driver's "does it build" check: make + import + ABI/header agreement."""
+  import importlib
+  entry = importlib.import_module("__graft_entry__")
+  entry.build()
+
+
 def test_struct_layout_matches_header():
   # sizes implied by the C declaration (natural alignment)
   cfg = _lib.ScConfig()

@@ -4,7 +4,7 @@
 `sc_stage_constraint`; inside `SpectralClusterer.predict` the constraint matrix stays
 resident and the same kernels run in the pipeline (`sc_set_constraint`).  The E2CP
 inverse `(I - alpha * A_norm)^-1` is evaluated as a Neumann product of fp64 MFMA GEMMs
-(see `csrc/api.hip: constraint_propagation`), which needs |alpha| < 1 and a
+(see `csrc/constraint_api.hip: constraint_propagation`), which needs |alpha| < 1 and a
 non-negative affinity; anything else raises `UnsupportedOnDeviceError`.
 """
 

@@ -12,7 +12,7 @@
 //     inherently sequential (about 3 n steps); each step is a coalesced scan of one row of
 //     the n x n distance matrix (first index of the minimum, the previous chain element wins
 //     ties, exactly scipy's loop) or a Lance-Williams update of one row + column;
-//   * the O(n log n) tree bookkeeping (sort, relabel, heap cut) runs on the host in api.hip.
+//   * the O(n log n) tree bookkeeping (sort, relabel, heap cut) runs on the host in callers_api.hip.
 #include <hip/hip_runtime.h>
 
 #include "sc_internal.h"

@@ -1,6 +1,6 @@
 // Constraint operators of the caller-side step before / after refinement
 // (reference constraint.py:95-164): elementwise kernels.  The matrix inverse of
-// ConstraintPropagation is composed from these and the fp64 MFMA GEMM in api.hip.
+// ConstraintPropagation is composed from these and the fp64 MFMA GEMM in constraint_api.hip.
 #include <hip/hip_runtime.h>
 
 #include "sc_internal.h"

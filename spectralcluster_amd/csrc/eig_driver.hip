@@ -1,0 +1,623 @@
+// Host-side control loops of the two eigen paths: block Lanczos (symmetric operator) and
+// block Arnoldi (general matrix) -- basis growth, full re-orthogonalisation, Rayleigh-Ritz,
+// the convergence analysis that replays the eigengap rule, restarts.  Every O(n) or larger
+// computation is a kernel of eig.hip / eig_general.hip.
+#include "handle.h"
+
+// ------------------------------------------------------------------------------
+// symmetric top-k eigensolver driver
+// ------------------------------------------------------------------------------
+
+// Inspect Ritz values theta[0..m) (descending) + residual estimates.
+static EigDecision analyze(const EigRequest& rq, const double* theta, const double* resid,
+                           int m, int n, bool exact) {
+  EigDecision dc;
+  std::vector<double> w(m);
+  for (int i = 0; i < m; ++i) w[i] = rq.descend ? theta[i] : -theta[i];
+  const double scale = std::max(std::fabs(theta[0]), std::fabs(theta[m - 1]));
+  int kw;
+  if (rq.fixed_count > 0) {
+    kw = std::min(rq.fixed_count, n);
+  } else if (rq.max_clusters > 0) {
+    kw = std::min(n, rq.max_clusters + 1);
+  } else if (rq.descend) {
+    // max_clusters None: everything >= stop_eigenvalue, plus the first one below
+    int c = 0;
+    while (c < m && !(w[c] < rq.stop_eigenvalue)) ++c;
+    if (c >= m && m < n) return dc;  // have not reached the stop value yet
+    kw = std::min(c + 1, n);
+  } else {
+    kw = n;  // ascending without max_clusters reads every eigenvalue
+  }
+  if (kw > m) {
+    if (kw > kEigBasisCap / 2 && !exact) dc.unsupported = true;
+    return dc;
+  }
+  dc.enough = true;
+  dc.kw = kw;
+  if (rq.fixed_count > 0) {
+    dc.kvec = kw;
+  } else {
+    // np.max(eigenvalues) is taken over the WHOLE spectrum (utils.py:110,123): the
+    // first value when descending, the far end of the Ritz spectrum when ascending.
+    const double wmax = rq.descend ? w[0] : w[m - 1];
+    eigengap_core(w.data(), kw, rq.max_clusters, rq.use_stop ? rq.stop_eigenvalue : 0.0,
+                  rq.eigengap_type, rq.descend, wmax, &dc.n_clusters_raw, &dc.max_delta);
+    dc.kvec = std::max(dc.n_clusters_raw, rq.min_clusters);
+    if (dc.kvec < 1) dc.kvec = 1;
+    if (dc.kvec > m) dc.kvec = m;
+  }
+  if (exact) {
+    dc.converged = true;
+    return dc;
+  }
+  bool ok = true;
+  const double floor_abs = 1e-14 * scale;
+  // values actually read by the eigengap loop
+  int first = rq.descend ? 0 : 1, last = kw - 1;
+  if (rq.fixed_count > 0) first = 0;
+  if (rq.descend && rq.use_stop && rq.fixed_count == 0) {
+    for (int i = 0; i < kw; ++i)
+      if (w[i] < rq.stop_eigenvalue) { last = i; break; }
+  }
+  const bool aware = rq.decision_aware && rq.fixed_count == 0;
+  const int kb = dc.n_clusters_raw;  // the maximum gap sits between w[kb - 1] and w[kb]
+  for (int i = first; i <= last; ++i) {
+    const bool decisive = !aware || i == kb - 1 || i == kb ||
+                          (rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF && rq.descend && i == 0);
+    const double rel = decisive ? rq.value_tol : std::max(rq.value_tol, 1e-3);
+    const double tol = std::max(rel * std::fabs(w[i]), floor_abs);
+    if (!(resid[i] <= tol)) {
+      if (ok) { dc.fail_kind = 1; dc.fail_index = i; }
+      ok = false;
+    }
+    dc.max_resid = std::max(dc.max_resid, resid[i]);
+  }
+  if (aware && ok) {
+    // interval check: eigenvalue i lies within err(i) of w[i] (10 x residual: a safety
+    // factor for the departure from normality)
+    auto err = [&](int i) { return 10.0 * resid[i]; };
+    const double eps = 1e-10;
+    const double wmax = rq.descend ? w[0] : w[m - 1];
+    auto gap_bounds = [&](int lo_i, int hi_i, double* lower, double* upper) {
+      // Ratio: w[hi_i] / (w[lo_i] + eps); NormalizedDiff: (w[hi_i] - w[lo_i]) / wmax,
+      // where hi_i is the numerator index
+      const double a = w[hi_i], b = w[lo_i], ea = err(hi_i), eb = err(lo_i);
+      if (rq.eigengap_type == SC_EIGENGAP_RATIO) {
+        const double den_lo = b - eb + eps, den_hi = b + eb + eps;
+        *upper = den_lo > 0.0 ? (a + ea) / den_lo : 1e300;
+        *lower = den_hi > 0.0 ? (a - ea) / den_hi : -1e300;
+      } else {
+        *upper = (a - b + ea + eb) / wmax;
+        *lower = (a - b - ea - eb) / wmax;
+      }
+    };
+    double best_lo = 0.0, dummy;
+    if (kb >= 1) {
+      if (rq.descend) gap_bounds(kb, kb - 1, &best_lo, &dummy);
+      else gap_bounds(kb - 1, kb, &best_lo, &dummy);
+    }
+    const int end = kw;
+    if (rq.descend) {
+      for (int i = 1; i < end && ok; ++i) {
+        if (rq.use_stop) {
+          if (std::fabs(w[i - 1] - rq.stop_eigenvalue) <= err(i - 1)) {
+            ok = false; dc.fail_kind = 4; dc.fail_index = i - 1;
+            break;
+          }
+          if (w[i - 1] < rq.stop_eigenvalue) break;
+        }
+        if (i == kb) continue;
+        double lo, up;
+        gap_bounds(i, i - 1, &lo, &up);
+        if (!(up < best_lo) && !(kb == 0 && up <= 0.0)) {
+          ok = false; dc.fail_kind = 4; dc.fail_index = i;
+        }
+      }
+    } else {
+      for (int i = 1; i < end - 1 && ok; ++i) {
+        if (i + 1 == kb) continue;
+        double lo, up;
+        gap_bounds(i, i + 1, &lo, &up);
+        if (!(up < best_lo) && !(kb == 0 && up <= 0.0)) {
+          ok = false; dc.fail_kind = 4; dc.fail_index = i;
+        }
+      }
+    }
+  }
+  if (!rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF && rq.fixed_count == 0) {
+    // np.max(eigenvalues): the far end of the spectrum only normalises the gaps (it
+    // cannot change n_clusters) and sits on the edge of a dense bulk where Krylov
+    // methods converge like 1/degree^2: accept a 1e-4 residual bound there.
+    const double tol = std::max(std::max(rq.value_tol, 1e-4) * std::fabs(w[m - 1]), floor_abs);
+    if (!(resid[m - 1] <= tol)) {
+      if (ok) { dc.fail_kind = 2; dc.fail_index = m - 1; }
+      ok = false;
+    }
+  }
+  for (int i = 0; i < dc.kvec; ++i) {
+    if (!(resid[i] <= std::max(rq.vector_tol * scale, floor_abs))) {
+      if (ok) { dc.fail_kind = 3; dc.fail_index = i; }
+      ok = false;
+    }
+    dc.max_resid = std::max(dc.max_resid, resid[i]);
+  }
+  dc.converged = ok;
+  return dc;
+}
+
+// One CholQR pass on W (n x 8) with the orthonormality-defect flag of its input armed
+// (flags[10]); stores the result into Q[:, store_col ...] and Vs when store_col >= 0.
+static int cholqr_pass(sc_handle h, int n, int store_col) {
+  hipStream_t s = h->stream;
+  double* W = ptr<double>(h->W);
+  launch_proj_partial(s, W, kEigBlock, kEigBlock, W, n, ptr<double>(h->partial));
+  launch_reduce_chol(s, ptr<double>(h->partial), proj_blocks(n), ptr<double>(h->Rinv), nullptr,
+                     nullptr, ptr<int>(h->flags), ptr<int>(h->flags) + 10, 2);
+  launch_apply_rinv(s, W, n, ptr<double>(h->Rinv), store_col >= 0 ? ptr<double>(h->Q) : nullptr,
+                    kLdq, store_col >= 0 ? store_col : 0,
+                    h->vs_scale ? h->vs_scale : ptr<double>(h->cvec), ptr<double>(h->Vs));
+  return SC_OK;
+}
+
+static const char kNonFiniteMessage[] = "Array must not contain infs or NaNs";
+
+// Orthonormalise W (n x 16) against Q[:, 0:m] and within itself.
+//   record: accumulate the projection coefficients into T columns [col0, col0+16)
+//   store_col: column of Q to receive the result (< 0: do not store)
+static int orthonormalize(sc_handle h, int n, int m, bool record, int col0, int store_col,
+                          bool save_gram) {
+  hipStream_t s = h->stream;
+  double* Q = ptr<double>(h->Q);
+  double* W = ptr<double>(h->W);
+  double* part = ptr<double>(h->partial);
+  double* hsq = ptr<double>(h->hsq);
+  SC_HIP(h, hipMemsetAsync(hsq, 0, 16 * sizeof(double), s));
+  if (m > 0) {
+    for (int pass = 0; pass < 2; ++pass) {
+      launch_proj_partial(s, Q, kLdq, m, W, n, part);
+      launch_reduce_H(s, part, proj_blocks(n), m, ptr<double>(h->Hbuf),
+                      record ? ptr<double>(h->T) : nullptr, kLdq, col0, pass, hsq);
+      launch_update_block(s, Q, kLdq, m, ptr<double>(h->Hbuf), W, n);
+    }
+  }
+  // CholQR2
+  launch_proj_partial(s, W, kEigBlock, kEigBlock, W, n, part);
+  launch_reduce_chol(s, part, proj_blocks(n), ptr<double>(h->Rinv),
+                     save_gram ? ptr<double>(h->G) : nullptr, hsq, ptr<int>(h->flags),
+                     ptr<int>(h->flags) + 11, 1);
+  launch_apply_rinv(s, W, n, ptr<double>(h->Rinv), nullptr, 0, 0, nullptr, nullptr);
+  SC_TRY(cholqr_pass(h, n, store_col));
+  return check_last(h, "orthonormalize launch");
+}
+
+static int read_flags(sc_handle h, int* mask) {
+  SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, 13 * sizeof(int), hipMemcpyDeviceToHost,
+                           h->stream));
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  *mask = h->h_flags[0];
+  if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+  if (h->h_flags[1] > 0 && getenv("SC_EIG_TRACE")) {
+    fprintf(stderr, "[sc] jacobi sweeps=%d  %.1f us  %.0f MHz shader clock\n", h->h_flags[1],
+            h->h_flags[2] * 0.01, h->h_flags[3] * 1024.0 / (h->h_flags[2] * 0.01));
+    fprintf(stderr, "[sc]   thread-0 kcycles: param %d  barrier1 %d  update %d  barrier2 %d\n",
+            h->h_flags[4], h->h_flags[5], h->h_flags[6], h->h_flags[7]);
+    hipMemsetAsync(ptr<int>(h->flags) + 1, 0, 2 * sizeof(int), h->stream);
+  }
+  return SC_OK;
+}
+
+// Make sure the block in W is a full-rank orthonormal block; repairs dependent
+// columns with random vectors (bounded retries).
+static int finish_block(sc_handle h, int n, int m, int store_col, uint64_t* seed) {
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    int mask = 0;
+    SC_TRY(read_flags(h, &mask));
+    // CholQR2 only orthonormalises blocks of condition < ~1e8; a numerically low-rank
+    // operator produces worse ones: keep passing until the input Gram matrix was near I
+    for (int extra = 0;
+         extra < 3 && mask == 0 && (h->h_flags[10] != 0 || h->h_flags[11] != 0); ++extra) {
+      // (the projection coefficients already recorded in T stay: this round only removes
+      // rounding-level components)
+      SC_TRY(orthonormalize(h, n, m, false, 0, store_col, false));
+      SC_TRY(read_flags(h, &mask));
+    }
+    if (mask == 0) return SC_OK;
+    launch_refill_deficient(h->stream, ptr<double>(h->W), n, ptr<int>(h->flags), ++(*seed));
+    SC_TRY(orthonormalize(h, n, m, false, 0, store_col, false));
+  }
+  return fail(h, SC_ERR_NOT_CONVERGED, "could not build a full-rank Krylov block");
+}
+
+static void back_transform_cols(sc_handle h, int n, int cols) {
+  launch_back_transform(h->stream, ptr<double>(h->E), round_up(n, 16), n, cols,
+                        ptr<double>(h->tvec));
+}
+
+// S (n x n, ld) symmetric on the device; cvec/pvec/tvec already set.
+int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
+                    sc_diag* diag, EigDecision* out_dc, std::vector<double>* out_w) {
+  hipStream_t s = h->stream;
+  SC_TRY(ensure_eig(h, n));
+  double* theta_d = ptr<double>(h->theta);
+  double* resid_d = ptr<double>(h->resid);
+  const double* cvec = ptr<double>(h->cvec);
+  const double* pvec = ptr<double>(h->pvec);
+  EigDecision dc;
+  int m = 0, passes = 0, cycles = 0;
+
+  if (n <= kDenseMax) {
+    // ---- direct dense path: every eigenpair, one Jacobi launch
+    launch_jacobi(s, S, ld, n, 1, cvec, pvec, nullptr, theta_d, ptr<double>(h->Y), kLdq,
+                  nullptr, ptr<double>(h->Yt), ptr<int>(h->flags));
+    SC_TRY(check_last(h, "jacobi launch"));
+    SC_HIP(h, hipMemcpyAsync(h->h_theta, theta_d, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipMemcpyAsync(h->h_flags + 12, ptr<int>(h->flags) + 12, sizeof(int),
+                             hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipStreamSynchronize(s));
+    if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+    for (int i = 0; i < n; ++i) h->h_theta[kLdq + i] = 0.0;
+    dc = analyze(rq, h->h_theta, h->h_theta + kLdq, n, n, true);
+    if (!dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
+    m = n;
+    const int cols = n;  // all eigenvectors, like np.linalg.eig
+    launch_rowmajor_to_colmajor(s, ptr<double>(h->Y), kLdq, n, cols, ptr<double>(h->E),
+                                round_up(n, 16));
+    back_transform_cols(h, n, cols);
+    h->n_vec = cols;
+    if (diag) diag->eig_path = SC_EIG_PATH_DENSE_JACOBI;
+    dc.kw = n;
+  } else {
+    if (rq.fixed_count == 0 && rq.max_clusters == 0 && !rq.descend)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "max_clusters=None with a Laplacian needs every eigenvalue; only "
+                  "supported for n <= 128 on the device path");
+    uint64_t seed = 0x5eed5eedull;
+    // ---- start block
+    launch_random_block(s, ptr<double>(h->W), n, seed);
+    SC_TRY(orthonormalize(h, n, 0, false, 0, 0, false));
+    SC_TRY(finish_block(h, n, 0, 0, &seed));
+    SC_HIP(h, hipMemsetAsync(h->T.p, 0, (size_t)kLdq * kLdq * sizeof(double), s));
+    // basis cap: LDS Jacobi limit, and basis + next block must fit in R^n
+    const int cap = std::min(kEigBasisCap, ((n - kEigBlock) / kEigBlock) * kEigBlock);
+    const int first_check = std::min(3 * kEigBlock, cap);
+    bool done = false;
+    while (!done) {
+      // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
+      launch_block_matvec(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
+                          ptr<double>(h->Vs), ptr<double>(h->W));
+      ++passes;
+      m += kEigBlock;
+      SC_TRY(orthonormalize(h, n, m, true, m - kEigBlock, m, true));
+      // Rayleigh-Ritz is the expensive serial step: every block early on (where
+      // convergence is expected), then sparser, then once per restart cycle.
+      const bool check = cycles == 0 ? (m >= first_check && (m <= 4 * kEigBlock ||
+                                                               m % (2 * kEigBlock) == 0 ||
+                                                               m + kEigBlock > cap))
+                                     : (m + kEigBlock > cap);
+      if (check) {
+        launch_jacobi(s, ptr<double>(h->T), kLdq, m, 0, nullptr, nullptr, ptr<double>(h->G),
+                      theta_d, ptr<double>(h->Y), kLdq, resid_d, ptr<double>(h->Yt),
+                      ptr<int>(h->flags));
+        SC_TRY(check_last(h, "jacobi launch"));
+        SC_HIP(h, hipMemcpyAsync(h->h_theta, theta_d, m * sizeof(double),
+                                 hipMemcpyDeviceToHost, s));
+        SC_HIP(h, hipMemcpyAsync(h->h_theta + kLdq, resid_d, m * sizeof(double),
+                                 hipMemcpyDeviceToHost, s));
+      }
+      SC_TRY(finish_block(h, n, m, m, &seed));  // syncs the stream
+      if (check) {
+        dc = analyze(rq, h->h_theta, h->h_theta + kLdq, m, n, false);
+        if (getenv("SC_EIG_TRACE")) {
+          int worst = 0;
+          double wr = 0.0;
+          for (int i = 0; i < std::min(m, dc.kw > 0 ? dc.kw : m); ++i) {
+            const double r = h->h_theta[kLdq + i] / std::max(std::fabs(h->h_theta[i]), 1e-300);
+            if (r > wr) { wr = r; worst = i; }
+          }
+          fprintf(stderr, "[sc] lanczos pass %d m=%d cycle %d: enough=%d conv=%d kw=%d kvec=%d "
+                  "fail kind %d at %d (theta %.6g resid %.2e); far end theta=%.6g resid=%.2e\n",
+                  passes, m, cycles, dc.enough, dc.converged, dc.kw, dc.kvec, dc.fail_kind,
+                  dc.fail_index, dc.fail_index >= 0 ? h->h_theta[dc.fail_index] : 0.0,
+                  dc.fail_index >= 0 ? h->h_theta[kLdq + dc.fail_index] : 0.0, h->h_theta[m - 1],
+                  h->h_theta[kLdq + m - 1]);
+          (void)wr; (void)worst;
+        }
+        if (dc.unsupported)
+          return fail(h, SC_ERR_UNSUPPORTED,
+                      "more than 64 eigenvalues are needed (max_clusters=None with a "
+                      "slowly decaying spectrum); set max_clusters");
+        if (dc.enough && dc.converged) {
+          done = true;
+          break;
+        }
+      }
+      if (m + kEigBlock > cap) {
+        // ---- thick restart: keep the leading Ritz vectors + the new block
+        if (++cycles > rq.max_cycles)
+          return fail(h, SC_ERR_NOT_CONVERGED, "block Lanczos did not converge");
+        int want = dc.enough ? std::max(dc.kw, dc.kvec) : cap / 4;
+        int keep = round_up(want + kEigBlock, kEigBlock);
+        keep = std::max(kEigBlock, std::min(keep, cap - 2 * kEigBlock));
+        if (!rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF &&
+            rq.fixed_count == 0 && keep < m)
+          // np.max(eigenvalues) is the far end of the spectrum: keep that Ritz pair too
+          launch_swap_ritz(s, ptr<double>(h->Y), kLdq, m, theta_d, keep - 1, m - 1);
+        launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, keep,
+                             ptr<double>(h->Q2), kLdq, n, 0);
+        launch_copy_block(s, ptr<double>(h->Q) + m, kLdq, ptr<double>(h->Q2) + keep, kLdq, n,
+                          kEigBlock);
+        std::swap(h->Q, h->Q2);
+        launch_set_diag_T(s, ptr<double>(h->T), kLdq, kLdq, theta_d, keep);
+        SC_TRY(check_last(h, "restart launch"));
+        m = keep;
+      }
+    }
+    const int cols = std::min(std::max(dc.kw, dc.kvec), kMaxVectors);
+    launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, cols,
+                         ptr<double>(h->E), round_up(n, 16), n, 1);
+    back_transform_cols(h, n, cols);
+    SC_TRY(check_last(h, "ritz vector launch"));
+    h->n_vec = cols;
+    if (diag) diag->eig_path = SC_EIG_PATH_BLOCK_LANCZOS;
+  }
+  if (out_w) {
+    out_w->resize(dc.kw);
+    for (int i = 0; i < dc.kw; ++i) (*out_w)[i] = rq.descend ? h->h_theta[i] : -h->h_theta[i];
+  }
+  if (diag) {
+    diag->eig_matvec_passes = passes;
+    diag->eig_block = kEigBlock;
+    diag->eig_basis = m;
+    diag->eig_cycles = cycles;
+    diag->eig_max_residual = dc.max_resid;
+  }
+  *out_dc = dc;
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// general (non-symmetric) top-k eigensolver driver
+// ------------------------------------------------------------------------------
+// M (n x n, ld): the refined matrix, NOT diagonally similar to a symmetric one.
+// Operator  Op x = p .* x + cl .* (M (cr .* x))  (= M, or minus the Laplacian), whose
+// eigenvalues of largest real part are wanted; eigenvectors are those of the reference's
+// matrix itself (no similarity transform).  n <= 64: the dense solver on the materialised
+// matrix (every eigenpair, like np.linalg.eig).  Larger n: block Arnoldi with full
+// re-orthogonalisation, explicit Rayleigh-Ritz H = Q^T Op Q (basis <= 64), explicit
+// residuals ||Op v - theta v||, explicit restart from the wanted Ritz vectors (real and
+// imaginary parts of complex pairs).
+int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
+                    const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
+                    std::vector<double>* out_w) {
+  hipStream_t s = h->stream;
+  SC_TRY(ensure_eig(h, n));
+  SC_TRY(ensure_gen(h, n));
+  double* theta_d = ptr<double>(h->theta);
+  double* thetai_d = ptr<double>(h->thetai);
+  double* resid_d = ptr<double>(h->resid);
+  double* Yre = ptr<double>(h->Y);
+  double* Yim = ptr<double>(h->Yt);
+  double* Vre = ptr<double>(h->Vre);
+  double* Vim = ptr<double>(h->Vim);
+  int* info_d = ptr<int>(h->flags) + 8;
+  const int ldv = round_up(n, 16);
+  double* th = h->h_theta;             // [0, kLdq): Re theta, [kLdq, 2 kLdq): resid
+  double* thi = h->h_theta + 2 * kLdq;  // Im theta
+  EigDecision dc;
+  int m = 0, passes = 0, cycles = 0;
+  const bool is_lap = laplacian_type >= SC_LAPLACIAN_UNNORMALIZED;
+  const bool far_end = !rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF &&
+                       rq.fixed_count == 0;
+
+  auto fetch_ritz = [&](int count) -> int {
+    SC_HIP(h, hipMemcpyAsync(th, theta_d, count * sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipMemcpyAsync(thi, thetai_d, count * sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipMemcpyAsync(h->h_flags + 8, info_d, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipMemcpyAsync(h->h_flags + 12, ptr<int>(h->flags) + 12, sizeof(int),
+                             hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipStreamSynchronize(s));
+    if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+    if (h->h_flags[8] != 0)
+      return fail(h, SC_ERR_NOT_CONVERGED, "QR iteration of the projected eigenproblem failed");
+    return SC_OK;
+  };
+
+  if (n <= kGenMax) {
+    // ---- dense: eigen-decomposition of the reference's own matrix
+    const double* src = M;
+    if (is_lap) {
+      launch_laplacian(s, M, ptr<double>(h->genL), n, ld, laplacian_type, ptr<double>(h->deg));
+      src = ptr<double>(h->genL);
+    }
+    launch_gen_eig(s, src, ld, n, is_lap ? -1.0 : 1.0, n, theta_d, thetai_d, Yre, Yim, kLdq,
+                   info_d);
+    SC_TRY(check_last(h, "dense general eigensolver launch"));
+    SC_TRY(fetch_ritz(n));
+    for (int i = 0; i < n; ++i) th[kLdq + i] = 0.0;
+    dc = analyze(rq, th, th + kLdq, n, n, true);
+    if (!dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
+    launch_gen_ritz(s, nullptr, 0, n, n, Yre, Yim, kLdq, n, Vre, Vim, ldv);
+    launch_gen_phase(s, Vre, Vim, ldv, n, n, ptr<double>(h->E), ldv);
+    SC_TRY(check_last(h, "eigenvector normalisation launch"));
+    h->n_vec = n;
+    m = n;
+    dc.kw = n;
+    if (diag) diag->eig_path = SC_EIG_PATH_DENSE_GENERAL;
+  } else {
+    if (rq.fixed_count == 0 && rq.max_clusters == 0 && !rq.descend)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "max_clusters=None with a Laplacian needs every eigenvalue; only "
+                  "supported for n <= 64 on the general eigen path");
+    const double* cl = ptr<double>(h->cvec);
+    const double* cr = ptr<double>(h->crvec);
+    const double* pv = ptr<double>(h->pvec);
+    double* Q = ptr<double>(h->Q);
+    double* OpQ = ptr<double>(h->Q2);
+    double* W = ptr<double>(h->W);
+    h->vs_scale = cr;
+    struct Restore {
+      sc_handle h;
+      ~Restore() { h->vs_scale = nullptr; }
+    } restore{h};
+    const int cap = std::min(kGenMax, ((n - kEigBlock) / kEigBlock) * kEigBlock);
+    const int first_check = std::min(3 * kEigBlock, cap);
+    uint64_t seed = 0x9e3779b97f4a7c15ull;
+    std::vector<std::vector<int>> start_blocks;  // restart: codes 2*col+part, -1 = noise
+    size_t next_start = 0;
+    const int kMaxCheck = 32;  // Ritz pairs whose residual is evaluated
+    while (true) {
+      // ---- next block into W
+      if (next_start < start_blocks.size()) {
+        SC_HIP(h, hipMemcpyAsync(h->gsrc.p, start_blocks[next_start].data(),
+                                 kEigBlock * sizeof(int), hipMemcpyHostToDevice, s));
+        launch_gen_gather(s, Vre, Vim, ldv, n, ptr<int>(h->gsrc), ++seed, W);
+        SC_HIP(h, hipStreamSynchronize(s));  // the code vector is host memory
+        ++next_start;
+      } else if (m == 0) {
+        launch_random_block(s, W, n, seed);
+      } else {
+        launch_copy_block(s, OpQ + (m - kEigBlock), kLdq, W, kEigBlock, n, kEigBlock);
+      }
+      SC_TRY(orthonormalize(h, n, m, false, 0, m, false));
+      SC_TRY(finish_block(h, n, m, m, &seed));
+      launch_block_matvec(s, M, ld, n, cl, pv, Q + m, kLdq, ptr<double>(h->Vs), W);
+      launch_copy_block(s, W, kEigBlock, OpQ + m, kLdq, n, kEigBlock);
+      ++passes;
+      m += kEigBlock;
+      // Rayleigh-Ritz (a serial ~m^3 solve in one wavefront) is the expensive step: every
+      // block early in the first cycle, where convergence is expected, then every other
+      // block, and only with a full basis once restarts have begun
+      const bool check = next_start >= start_blocks.size() && m >= first_check &&
+                         (cycles == 0 ? (m <= 4 * kEigBlock || m % (2 * kEigBlock) == 0 ||
+                                         m + kEigBlock > cap)
+                                      : (m + kEigBlock > cap));
+      if (check) {
+        // H = Q^T (Op Q), one 8-column block at a time
+        for (int jb = 0; jb < m; jb += kEigBlock) {
+          launch_copy_block(s, OpQ + jb, kLdq, W, kEigBlock, n, kEigBlock);
+          launch_proj_partial(s, Q, kLdq, m, W, n, ptr<double>(h->partial));
+          launch_reduce_H(s, ptr<double>(h->partial), proj_blocks(n), m, ptr<double>(h->Hbuf),
+                          nullptr, 0, 0, 0, ptr<double>(h->hsq));
+          launch_copy_block(s, ptr<double>(h->Hbuf), kEigBlock, ptr<double>(h->T) + jb, kLdq,
+                            m, kEigBlock);
+        }
+        launch_gen_eig(s, ptr<double>(h->T), kLdq, m, 1.0, m, theta_d, thetai_d, Yre, Yim, kLdq,
+                       info_d);
+        const int c1 = std::min(m, kMaxCheck);
+        launch_gen_residual(s, Q, OpQ, kLdq, m, n, Yre, Yim, kLdq, theta_d, thetai_d, c1,
+                            ptr<double>(h->gpart), resid_d);
+        if (far_end && m - 1 >= c1)
+          launch_gen_residual(s, Q, OpQ, kLdq, m, n, Yre + (m - 1), Yim + (m - 1), kLdq,
+                              theta_d + (m - 1), thetai_d + (m - 1), 1, ptr<double>(h->gpart),
+                              resid_d + (m - 1));
+        SC_TRY(check_last(h, "Rayleigh-Ritz launch"));
+        for (int i = 0; i < m; ++i) th[kLdq + i] = 1e300;  // not evaluated = not converged
+        SC_HIP(h, hipMemcpyAsync(th + kLdq, resid_d, c1 * sizeof(double), hipMemcpyDeviceToHost,
+                                 s));
+        if (far_end && m - 1 >= c1)
+          SC_HIP(h, hipMemcpyAsync(th + kLdq + m - 1, resid_d + (m - 1), sizeof(double),
+                                   hipMemcpyDeviceToHost, s));
+        SC_TRY(fetch_ritz(m));
+        dc = analyze(rq, th, th + kLdq, m, n, false);
+        if (getenv("SC_EIG_TRACE"))
+          fprintf(stderr, "[sc] arnoldi pass %d m=%d cycle %d sweeps %d: enough=%d conv=%d kw=%d "
+                  "kvec=%d fail kind %d at %d (resid %.2e)\n", passes, m, cycles, h->h_flags[9],
+                  dc.enough, dc.converged, dc.kw, dc.kvec, dc.fail_kind, dc.fail_index,
+                  dc.fail_index >= 0 ? th[kLdq + dc.fail_index] : 0.0);
+        if (getenv("SC_EIG_TRACE") && atoi(getenv("SC_EIG_TRACE")) > 1) {
+          for (int i = 0; i < std::min(m, 12); ++i)
+            fprintf(stderr, "[sc]    ritz %2d  re %.12g  im %.3e  resid %.3e\n", i, th[i], thi[i],
+                    th[kLdq + i]);
+        }
+        if (dc.unsupported || (dc.enough && std::max(dc.kw, dc.kvec) > kMaxCheck))
+          return fail(h, SC_ERR_UNSUPPORTED,
+                      "the general eigen path reports at most 32 eigenpairs for n > 64; set "
+                      "max_clusters <= 31");
+        if (dc.enough && dc.converged) break;
+      }
+      if (m + kEigBlock > cap) {
+        // ---- explicit restart from the wanted Ritz vectors
+        if (++cycles > rq.max_cycles)
+          return fail(h, SC_ERR_NOT_CONVERGED, "block Arnoldi did not converge");
+        // (thick restart: the new basis is [wanted Ritz vectors | residual block], after
+        // which the Arnoldi recurrence continues from the residual block)
+        constexpr int kStash = 48;  // Vre columns [48, 56) hold the residual block
+        launch_copy_block(s, OpQ + (m - kEigBlock), kLdq, W, kEigBlock, n, kEigBlock);
+        SC_TRY(orthonormalize(h, n, m, false, 0, -1, false));
+        SC_TRY(finish_block(h, n, m, -1, &seed));
+        launch_rowmajor_to_colmajor(s, W, kEigBlock, n, kEigBlock, Vre + (size_t)kStash * ldv,
+                                    ldv);
+        const int want = dc.enough ? std::max(dc.kw, dc.kvec) : cap / 4;
+        const int avail = std::min(m, 40);  // Ritz vectors materialised: columns [0, avail)
+        launch_gen_ritz(s, Q, kLdq, m, n, Yre, Yim, kLdq, avail, Vre, Vim, ldv);
+        int vcols = avail;
+        const bool far_kept = far_end && m - 1 >= avail;
+        if (far_kept) {  // Ritz vector m-1 -> column `avail`
+          launch_gen_ritz(s, Q, kLdq, m, n, Yre + (m - 1), Yim + (m - 1), kLdq, 1,
+                          Vre + (size_t)avail * ldv, Vim + (size_t)avail * ldv, ldv);
+          vcols = avail + 1;
+        }
+        launch_gen_phase(s, Vre, Vim, ldv, n, vcols, nullptr, 0);
+        SC_TRY(check_last(h, "restart launch"));
+        const double scale = std::max(std::fabs(th[0]), std::fabs(th[m - 1]));
+        auto is_complex = [&](int i) { return std::fabs(thi[i]) > 1e-12 * std::max(scale, 1e-300); };
+        std::vector<int> codes;
+        if (far_kept) {
+          codes.push_back(2 * avail);
+          if (is_complex(m - 1)) codes.push_back(2 * avail + 1);
+        }
+        // Kept vectors must fill whole blocks: a random pad column r would break the
+        // relation Op [kept] in span(kept, residual block) -- (I - Q Q^T) Op r is not in the
+        // basis -- and the Ritz pairs then stall at the size of their component along r.
+        // So the kept set is extended, never padded.
+        const int max_cols = (std::max(1, cap / kEigBlock - 3)) * kEigBlock;
+        const int target = std::min(round_up(want + kEigBlock / 2, kEigBlock), max_cols);
+        for (int i = 0; i < avail; ++i) {
+          if ((int)codes.size() >= target && codes.size() % kEigBlock == 0) break;
+          if (!is_complex(i)) {
+            codes.push_back(2 * i);
+            continue;
+          }
+          bool partner_kept = false;  // its conjugate, earlier in the list
+          for (int j = 0; j < i; ++j)
+            if (is_complex(j) && std::fabs(th[j] - th[i]) <= 1e-9 * scale &&
+                std::fabs(thi[j] + thi[i]) <= 1e-9 * scale)
+              partner_kept = true;
+          if (partner_kept) continue;
+          codes.push_back(2 * i);
+          codes.push_back(2 * i + 1);
+        }
+        if ((int)codes.size() > max_cols) codes.resize(max_cols);
+        while (codes.size() % kEigBlock) codes.push_back(-1);  // last resort (tiny bases)
+        for (int j = 0; j < kEigBlock; ++j) codes.push_back(2 * (kStash + j));
+        start_blocks.clear();
+        for (size_t b = 0; b * kEigBlock < codes.size(); ++b)
+          start_blocks.emplace_back(codes.begin() + b * kEigBlock,
+                                    codes.begin() + (b + 1) * kEigBlock);
+        next_start = 0;
+        m = 0;
+      }
+    }
+    const int cols = std::min(std::max(dc.kw, dc.kvec), kMaxCheck);
+    launch_gen_ritz(s, Q, kLdq, m, n, Yre, Yim, kLdq, cols, Vre, Vim, ldv);
+    launch_gen_phase(s, Vre, Vim, ldv, n, cols, ptr<double>(h->E), ldv);
+    SC_TRY(check_last(h, "ritz vector launch"));
+    h->n_vec = cols;
+    if (diag) diag->eig_path = SC_EIG_PATH_BLOCK_ARNOLDI;
+  }
+  if (out_w) {
+    out_w->resize(dc.kw);
+    for (int i = 0; i < dc.kw; ++i) (*out_w)[i] = rq.descend ? th[i] : -th[i];
+  }
+  if (diag) {
+    diag->eig_matvec_passes = passes;
+    diag->eig_block = kEigBlock;
+    diag->eig_basis = m;
+    diag->eig_cycles = cycles;
+    diag->eig_max_residual = dc.max_resid;
+  }
+  *out_dc = dc;
+  return SC_OK;
+}
+

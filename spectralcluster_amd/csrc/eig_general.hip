@@ -15,7 +15,7 @@
 // lane k broadcasts at step k (wave shuffles).  The value carried from step k to k + 1 stays
 // in a register; LDS is touched once per step.
 //
-// Large problems use it as the Rayleigh-Ritz step of a block Arnoldi iteration (api.hip);
+// Large problems use it as the Rayleigh-Ritz step of a block Arnoldi iteration (eig_driver.hip);
 // the tall-skinny helpers for that (explicit residuals, Ritz vectors, LAPACK's phase
 // normalisation of complex eigenvectors) are below.
 #include <hip/hip_runtime.h>

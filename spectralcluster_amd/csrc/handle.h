@@ -1,0 +1,193 @@
+// Internal to the host side of the library (api.hip, eig_driver.hip, constraint_api.hip,
+// callers_api.hip): the handle with its device arena, error plumbing, and the helpers those
+// translation units share.  Not installed; the public surface is
+// include/spectralcluster_amd.h.
+#ifndef SPECTRALCLUSTER_AMD_HANDLE_H_
+#define SPECTRALCLUSTER_AMD_HANDLE_H_
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sc_internal.h"
+
+using namespace sc;
+
+// ------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct sc_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // current problem
+  int n = 0, d = 0, ldn = 0, ldx = 0;
+  bool have_x = false, have_affinity = false;
+  bool have_cropval = false;  // cropval = CropDiagonal fill values of A0 (affinity GEMM epilogue)
+  int n_vec = 0;          // eigenvector columns resident in E
+  // matrices
+  DevBuf X, Xn, A0, B1, B2;
+  // n-vectors
+  DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart, splitk, tilemap;
+  DevBuf cropval, statp;  // fused GEMM row statistics: result + per-tile partials
+  // constraints: Cq (resident constraint matrix), Neumann-product work matrices, flag word
+  DevBuf Cq, cp[5], symflag;
+  bool have_constraint = false, constraint_symmetric = false, constraint_applied = false;
+  bool affinity_symmetric = true;
+  bool affinity_from_embeddings = false;  // symflag[1] then says whether a row was NaN
+  int qn = 0;
+  int tilemap_nt = 0;     // tile-grid size the resident tilemap was built for
+  DevBuf blurw;           // device copy of the blur weights
+  // eigen workspace
+  DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
+      flags;
+  DevBuf E, Ek, Eio;      // eigenvectors (col-major), renormed copy, row-major I/O staging
+  // general (non-symmetric) eigen path: right scaling, Im(theta), complex Ritz vectors
+  // (column-major), residual partials, restart codes, dense Laplacian scratch
+  DevBuf crvec, thetai, Vre, Vim, gpart, gsrc, genL;
+  const double* vs_scale = nullptr;  // Vs = vs_scale .* V in orthonormalize (default cvec)
+  DevBuf ahc_size, ahc_chain, ahc_Z, ahc_lab, ahc_cent;  // size reduction (AHC) scratch
+  DevBuf fb_part, fb_small, fb_x, fb_cent, fb_int;      // fallback decisions scratch
+  // k-means workspace
+  DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo;
+  // pinned host scratch
+  double* h_theta = nullptr;  // 3 * kLdq doubles (theta, resid, Im theta)
+  int* h_flags = nullptr;
+  hipEvent_t ev[48];
+  int nev = 0;
+};
+
+constexpr int kMaxCols = 128;  // eigenvector columns the arena can hold
+// Leading dimension of the n x n matrices.  A row stride that is a multiple of 4 KiB maps
+// the 128 rows of an operand panel onto the same few L2 sets (the GEMM reads one 128-byte
+// line per row and K-tile): such strides get one extra 128-byte line.
+inline int matrix_ld(int n) {
+  int ld = round_up(n, 16);
+  if (ld % 512 == 0) ld += 16;
+  return ld;
+}
+
+// eigenvectors are column-major on the device: column j at E + j * lde, lde = round_up(n, 16)
+
+#define SC_HIP(h, call)                                                         \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);             \
+      return e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP;               \
+    }                                                                           \
+  } while (0)
+
+#define SC_TRY(expr)                \
+  do {                              \
+    int rc_ = (expr);               \
+    if (rc_ != SC_OK) return rc_;   \
+  } while (0)
+
+inline int fail(sc_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+inline int grow(sc_handle h, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return SC_OK;
+  if (b.p) {
+    SC_HIP(h, hipStreamSynchronize(h->stream));
+    SC_HIP(h, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  SC_HIP(h, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return SC_OK;
+}
+template <typename T>
+inline T* ptr(const DevBuf& b) {
+  return reinterpret_cast<T*>(b.p);
+}
+
+int ensure_matrices(sc_handle h, int n, int d);
+
+// (ti, tj) order of the symmetric GEMM tiles for problems of n rows (cached per handle)
+int ensure_tilemap(sc_handle h, int n);
+
+int ensure_eig(sc_handle h, int n);
+
+int ensure_gen(sc_handle h, int n);
+
+int ensure_kmeans(sc_handle h, int n);
+
+inline int check_last(sc_handle h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    h->err = std::string(what) + ": " + hipGetErrorString(e);
+    return SC_ERR_HIP;
+  }
+  return SC_OK;
+}
+
+
+// ---- shared between the translation units -------------------------------------------
+int h2d_matrix(sc_handle h, const double* src, int rows, int cols, double* dst, int ld);
+int d2h_matrix(sc_handle h, const double* src, int ld, int rows, int cols, double* dst);
+int validate_config(sc_handle h, const sc_config* cfg);
+// utils.compute_number_of_clusters on a host array (api.hip)
+void eigengap_core(const double* w, int count, int max_clusters, double stop_eigenvalue,
+                   int eigengap_type, int descend, double wmax, int* n_clusters,
+                   double* max_delta);
+
+// eigen drivers (eig_driver.hip)
+struct EigRequest {
+  int descend;          // 1: report largest first (w = theta); 0: w = -theta ascending
+  int max_clusters;     // 0 = None
+  int min_clusters;     // 0 = None
+  double stop_eigenvalue;
+  int eigengap_type;
+  int use_stop;         // stop_eigenvalue only on the descending branch
+  double value_tol, vector_tol;
+  int max_cycles;
+  int fixed_count;      // > 0: plain "count extreme eigenpairs" request (stage API)
+  // General path only.  Consumed eigenvalues deep in a dense bulk converge arbitrarily
+  // slowly in a small Krylov basis, yet cannot influence the result: only the two values
+  // that form the maximum gap (and the normaliser of NormalizedDiff) are held to value_tol;
+  // the others must be accurate enough that, with their residual intervals, no other gap
+  // can reach the maximum and no comparison with stop_eigenvalue can flip.
+  int decision_aware = 0;
+};
+
+struct EigDecision {
+  bool enough = false;     // basis large enough to take a decision
+  bool converged = false;
+  int kw = 0;              // eigenvalues reported
+  int kvec = 0;            // vectors that must be accurate
+  int n_clusters_raw = 0;
+  double max_delta = 0.0;
+  double max_resid = 0.0;
+  bool unsupported = false;
+  int fail_kind = 0;       // 1 consumed value, 2 far-end value, 3 vector, 4 decision (trace)
+  int fail_index = -1;
+};
+
+int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq, sc_diag* diag,
+             EigDecision* out_dc, std::vector<double>* out_w);
+int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
+             const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
+             std::vector<double>* out_w);
+
+// constraints (constraint_api.hip)
+int device_is_symmetric(sc_handle h, const double* m, int n, int ld, bool* out);
+int adjust_affinity(sc_handle h, const sc_config* cfg, const double* a, bool sym_a, double* out,
+                    int n, int ld);
+bool constraint_active(sc_handle h, const sc_config* cfg, bool before);
+
+#endif  // SPECTRALCLUSTER_AMD_HANDLE_H_

@@ -16,7 +16,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __global__ __launch_bounds__(256, 1) void k_gemm_wide(const double* __restrict__ A,
                                                      const double* __restrict__ B,
-                                                     double* __restrict__ C, int n) {
+                                                     double* __restrict__ C, int n,
+                                                     double* __restrict__ dbg) {
+  const long long clk0 = clock64(), wall0 = wall_clock64();
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* As = smem;                      // [NBUF][BM * BK]
   double* Bs = smem + NBUF * BM * BK;     // [NBUF][BN * BK]
@@ -120,6 +122,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_wide(const double* __restrict__
     }
     MFMA_ROWS(a1, b1, 2, 4)
   }
+  if (dbg != nullptr && tid == 0) {
+    dbg[2 * blockIdx.x] = (double)(clock64() - clk0);
+    dbg[2 * blockIdx.x + 1] = (double)(wall_clock64() - wall0);
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -153,15 +159,17 @@ int main(int argc, char** argv) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_wide),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int blocks = (n / BM) * (n / BN);
+  double* dbg;
+  hipMalloc(&dbg, sizeof(double) * 2 * blocks);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 2; ++it)
-    hipLaunchKernelGGL(k_gemm_wide, dim3(blocks), dim3(256), lds, 0, a, b, c, n);
+    hipLaunchKernelGGL(k_gemm_wide, dim3(blocks), dim3(256), lds, 0, a, b, c, n, dbg);
   hipDeviceSynchronize();
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
   hipEventRecord(e0);
   for (int it = 0; it < reps; ++it)
-    hipLaunchKernelGGL(k_gemm_wide, dim3(blocks), dim3(256), lds, 0, a, b, c, n);
+    hipLaunchKernelGGL(k_gemm_wide, dim3(blocks), dim3(256), lds, 0, a, b, c, n, dbg);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -177,6 +185,14 @@ int main(int argc, char** argv) {
     double got;
     hipMemcpy(&got, c + (size_t)i * n + j, 8, hipMemcpyDeviceToHost);
     maxerr = fmax(maxerr, fabs(got - ref) / fabs(ref));
+  }
+  {
+    std::vector<double> h(2 * blocks);
+    hipMemcpy(h.data(), dbg, sizeof(double) * 2 * blocks, hipMemcpyDeviceToHost);
+    double cc = 0, w = 0;
+    for (int i = 0; i < blocks; ++i) { cc += h[2 * i]; w += h[2 * i + 1]; }
+    printf("mode %d: shader cycles/tile %.0f (ideal %.0f), effective shader clock %.1f MHz\n", mode,
+           cc / blocks, (double)n / 4 * 32 * 64, cc / w * 100.0);
   }
   printf("wide gemm n=%d: %.3f ms  %.1f TFLOP/s  (err %.1e, hip status %s)\n", n, ms,
          2.0 * n * n * n / ms / 1e9, maxerr, hipGetErrorString(hipGetLastError()));

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   if (probe && tid == 0) {
     partial[2 * blockIdx.x] = (double)(clock64() - clk0);
     partial[2 * blockIdx.x + 1] = (double)(wall_clock64() - wall0);
+    partial[2 * gridDim.x + blockIdx.x] = (double)wall0;
   }
   // --- epilogue.  D layout of v_mfma_f64_16x16x4_f64: lane l, reg r holds
   //     D[row = (l >> 4) + 4 r][col = l & 15].
@@ -562,17 +563,26 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     // SC_GEMM_CLOCK=1: every main launch also records, per tile, the shader-clock cycles
     // (s_memtime) and the constant-rate wall ticks (s_memrealtime) between kernel entry and
     // the end of the K loop, synchronises and prints the effective shader clock -- the GEMM
-    // is power-managed, see DESIGN.md section 3.3.  Off: one pointer compare per workgroup.
+    // is power-managed, see DESIGN.md section 3.3.  SC_GEMM_CLOCK_DUMP=<file> also writes
+    // "workgroup cycles ticks start_tick" per tile (tools/gemm_tile_timeline.py reads it).
+    // Off: one pointer compare per workgroup.
     static double* dbg = nullptr;
     static const bool want_probe = getenv("SC_GEMM_CLOCK") != nullptr;
-    if (want_probe && dbg == nullptr) (void)hipMalloc(&dbg, sizeof(double) * 2 * 8192);
+    if (want_probe && dbg == nullptr) (void)hipMalloc(&dbg, sizeof(double) * 3 * 8192);
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full), dim3(256), 0, s, A, lda, B, ldb, C,
                        ldc, M, N, K, tm, tn, 0, 1, full <= 8192 ? dbg : nullptr, tilemap,
                        xcd_chunk, stats);
     if (dbg != nullptr && full <= 8192) {
       (void)hipStreamSynchronize(s);
-      std::vector<double> h(2 * full);
-      (void)hipMemcpy(h.data(), dbg, sizeof(double) * 2 * full, hipMemcpyDeviceToHost);
+      std::vector<double> h(3 * full);
+      (void)hipMemcpy(h.data(), dbg, sizeof(double) * 3 * full, hipMemcpyDeviceToHost);
+      if (const char* path = getenv("SC_GEMM_CLOCK_DUMP")) {  // workgroup, cycles, ticks, start
+        if (FILE* f = fopen(path, "w")) {
+          for (int b = 0; b < full; ++b)
+            fprintf(f, "%d %.0f %.0f %.0f\n", b, h[2 * b], h[2 * b + 1], h[2 * full + b]);
+          fclose(f);
+        }
+      }
       double c = 0, w = 0;
       for (int i = 0; i < full; ++i) { c += h[2 * i]; w += h[2 * i + 1]; }
       int rate = 0;

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "sc_internal.h"
@@ -27,6 +28,7 @@
 namespace sc {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;
 constexpr int BN = 128;
@@ -265,13 +267,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   // Raw loads only: nothing here may consume the loaded registers, or hipcc waits
   // for the loads right away and the one-tile-ahead prefetch is lost.  The K-tail
   // guard is applied when the tile is written to LDS, one iteration later.
+  // buffer_load with the K offset in an SGPR (soffset) and the row offset in one VGPR per
+  // chunk: no vector ALU work per load inside the MFMA stream.
+  const __amdgpu_buffer_rsrc_t arsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B), 0, -1, 0x00020000);
   auto gload = [&](int kt) {
-    const char* abase = reinterpret_cast<const char*>(A + kt * BK);
-    const char* bbase = reinterpret_cast<const char*>(B + kt * BK);
+    const int koff = kt * BK * (int)sizeof(double);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ra[q] = *reinterpret_cast<const double2*>(abase + aoff[q]);
-      rb[q] = *reinterpret_cast<const double2*>(bbase + boff[q]);
+      const v4i32 va = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[q], koff, 0);
+      const v4i32 vb = __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff[q], koff, 0);
+      ra[q] = __builtin_bit_cast(double2, va);
+      rb[q] = __builtin_bit_cast(double2, vb);
     }
   };
 
@@ -339,8 +348,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
         acc[m][nn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].y, b[nn].y, acc[m][nn], 0, 0, 0);
   };
   if (kt_begin < kt_end) load_frags(fa0, fb0, As[0], Bs[0], 0);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
+  // one K-tile; the LDS buffer index is a compile-time constant (the loop below is unrolled by
+  // two), so every LDS address is a precomputed register + an immediate offset
+  auto k_tile = [&](int kt, auto cur_c) {
+    constexpr int cur = decltype(cur_c)::value;
     load_frags(fa1, fb1, As[cur], Bs[cur], 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -362,7 +373,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     mfma16y(fa1, fb1);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+  };
+  int kt = kt_begin;
+  for (; kt + 1 < kt_end; kt += 2) {
+    k_tile(kt, std::integral_constant<int, 0>{});
+    k_tile(kt + 1, std::integral_constant<int, 1>{});
   }
+  if (kt < kt_end) k_tile(kt, std::integral_constant<int, 0>{});
 
   if (probe && tid == 0) {
     partial[2 * blockIdx.x] = (double)(clock64() - clk0);

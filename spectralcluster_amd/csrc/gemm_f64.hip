@@ -198,8 +198,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  double* __restrict__ partial,
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats) {
-  __shared__ __attribute__((aligned(16))) double As[2][BM * BK];
-  __shared__ __attribute__((aligned(16))) double Bs[2][BN * BK];
+  // one 64 KB block: As[2] | Bs[2] in the K loop, reduction scratch + the transposed
+  // staging of the mirror tile in the epilogue
+  __shared__ __attribute__((aligned(16))) double smem[2 * BM * BK + 2 * BN * BK];
+  double(*As)[BM * BK] = reinterpret_cast<double(*)[BM * BK]>(smem);
+  double(*Bs)[BN * BK] = reinterpret_cast<double(*)[BN * BK]>(smem + 2 * BM * BK);
 
   int ti, tj;
   const int chunk = blockIdx.x % ksplit;
@@ -400,11 +403,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     return;
   }
   const bool mirror = SYM && (ti != tj);
+  if (stats.mode != 0 || mirror) __syncthreads();  // operand tiles are dead: LDS is reused
   if (stats.mode != 0) {
-    __syncthreads();  // operand tiles are dead: their LDS serves the reductions
-    tile_row_stats<EPI, SYM>(acc, ti, tj, ntiles_n, M, N, tid, stats, &As[0][0]);
+    tile_row_stats<EPI, SYM>(acc, ti, tj, ntiles_n, M, N, tid, stats, smem);
     __builtin_amdgcn_sched_barrier(0);
   }
+  // The mirror tile is stored through a transposed copy in LDS (per wave, 16 rows of its 64 x 64
+  // sub-tile at a time: T[c][r], pitch 20 doubles = two lanes per bank pair on the writes) so
+  // that its stores are 128-byte row segments like the direct ones, not 8-byte scatters.
+  constexpr int kStagePitch = 20;
+  double* stage = smem + 1024 + wave * (64 * kStagePitch);  // after the reduction scratch
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -419,9 +427,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
         if (row < M && col < N) {
           if (EPI == kEpiAdd) v += stats.addend[(size_t)row * ldc + col];
           C[(size_t)row * ldc + col] = v;
-          if (mirror) C[(size_t)col * ldc + row] = v;
+        }
+        if (mirror) stage[(nn * 16 + li) * kStagePitch + lg + 4 * r] = v;
+      }
+    }
+    if (mirror) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * 8 + (lane >> 3);
+        const int j = 2 * (lane & 7);
+        const double2 v = *reinterpret_cast<const double2*>(stage + c * kStagePitch + j);
+        const int mrow = col0 + wc * 64 + c;            // row of the mirror tile
+        const int mcol = row0 + wr * 64 + m * 16 + j;   // its column (even)
+        if (mrow < N) {
+          double* dst = C + (size_t)mrow * ldc + mcol;
+          if (mcol + 1 < M) *reinterpret_cast<double2*>(dst) = v;
+          else if (mcol < M) dst[0] = v.x;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }

@@ -238,20 +238,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   }
 
   // --- global -> register staging: 4 chunks (16 B) of A and of B per thread.  Chunk q of a
-  // thread is row (tid >> 3) + 32 q, k-chunk tid & 7; addresses are a uniform base (SGPRs)
-  // plus a 32-bit byte offset per chunk (rows clamped for ragged edge tiles).
+  // thread is row (tid >> 3) + 32 q, k-chunk tid & 7; addresses are a per-tile base (the
+  // tile's first row: buffer resource, SGPRs) plus a 32-bit byte offset per chunk (< 128 rows,
+  // so it fits for any matrix size; rows clamped for ragged edge tiles).
   unsigned aoff[4], boff[4];
   int lds_off[4];
   const int kc0 = tid & 7;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = (tid >> 3) + 32 * q;
-    int ga = row0 + r;
-    ga = ga < M ? ga : M - 1;
-    int gb = col0 + r;
-    gb = gb < N ? gb : N - 1;
-    aoff[q] = (unsigned)(((size_t)ga * lda + 2 * kc0) * sizeof(double));
-    boff[q] = (unsigned)(((size_t)gb * ldb + 2 * kc0) * sizeof(double));
+    const int ra_ = row0 + r < M ? r : M - 1 - row0;
+    const int rb_ = col0 + r < N ? r : N - 1 - col0;
+    aoff[q] = (unsigned)(((size_t)ra_ * lda + 2 * kc0) * sizeof(double));
+    boff[q] = (unsigned)(((size_t)rb_ * ldb + 2 * kc0) * sizeof(double));
     lds_off[q] = lds_chunk_off(r, kc0);
   }
 
@@ -273,9 +272,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   // buffer_load with the K offset in an SGPR (soffset) and the row offset in one VGPR per
   // chunk: no vector ALU work per load inside the MFMA stream.
   const __amdgpu_buffer_rsrc_t arsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A), 0, -1, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A + (size_t)row0 * lda), 0, -1,
+                                        0x00020000);
   const __amdgpu_buffer_rsrc_t brsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B), 0, -1, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B + (size_t)col0 * ldb), 0, -1,
+                                        0x00020000);
   auto gload = [&](int kt) {
     const int koff = kt * BK * (int)sizeof(double);
 #pragma unroll

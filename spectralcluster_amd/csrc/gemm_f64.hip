@@ -181,12 +181,12 @@ __global__ void k_gemm_stats_reduce(const double* __restrict__ pmax,
   if (mode == 1) rowsum[i] = sm;
 }
 
-// One workgroup = one 128x128 output tile over the K range of its split:
-//   tile  = tile_offset + blockIdx.x / ksplit,  chunk = blockIdx.x % ksplit.
-// ksplit == 1: full K, epilogue + store to C (and the mirror tile when SYM).
-// ksplit  > 1: raw accumulators go to `partial` (fragment order), to be summed by
-//              k_gemm_reduce -- used for the tiles left over after the last full
-//              wave of workgroups, so the chip does not idle on a ragged tail.
+// One workgroup = one 128x128 output tile, or one K chunk of one.  One launch holds two kinds of work units.  Workgroups [0, full_tiles) each compute a whole
+// tile: full K, epilogue + store to C (and the mirror tile when SYM).  The tiles left over
+// after the last full wave of workgroups are split over K into `ksplit` chunks each: the
+// workgroups after full_tiles write raw accumulators to `partial` (fragment order), to be
+// summed by k_gemm_reduce.  Being last in dispatch order they fill the slots that free up
+// while the last whole tiles drain, so the chip does not idle on a ragged tail.
 template <int EPI, bool SYM>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A,
                                                  int lda,
@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  int ldb, double* __restrict__ C,
                                                  int ldc, int M, int N, int K,
                                                  int ntiles_m, int ntiles_n,
-                                                 int tile_offset, int ksplit,
+                                                 int full_tiles, int ksplit_tail,
                                                  double* __restrict__ partial,
+                                                 double* __restrict__ probe_out,
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats) {
   // one 64 KB block: As[2] | Bs[2] in the K loop, reduction scratch + the transposed
@@ -205,13 +206,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   double(*Bs)[BN * BK] = reinterpret_cast<double(*)[BN * BK]>(smem + 2 * BM * BK);
 
   int ti, tj;
-  const int chunk = blockIdx.x % ksplit;
-  int tile = blockIdx.x / ksplit;
+  const bool whole = (int)blockIdx.x < full_tiles;
+  const int unit = whole ? 0 : (int)blockIdx.x - full_tiles;  // index among the split-K units
+  const int ksplit = whole ? 1 : ksplit_tail;
+  const int chunk = unit % ksplit;
+  int tile = whole ? (int)blockIdx.x : full_tiles + unit / ksplit;
   // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own
   // L2), so XCD x walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the
   // patch-ordered tile list: the ~64 tiles it has in flight share 8 + 8 operand panels.
-  if (xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
-  tile += tile_offset;
+  if (whole && xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
+  if (!whole) stats.mode = 0;  // k_gemm_tail_stats covers the split tiles
   if (tilemap != nullptr) {
     const int2 t = tilemap[tile];
     ti = t.x;
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   const int lg = lane >> 4;
   // diagnostic (SC_GEMM_CLOCK=1, see launch_variant): shader cycles and wall ticks per tile
   long long clk0 = 0, wall0 = 0;
-  const bool probe = ksplit == 1 && partial != nullptr;
+  const bool probe = whole && probe_out != nullptr;
   if (probe) {
     clk0 = clock64();
     wall0 = wall_clock64();
@@ -401,14 +405,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   }
 
   if (probe && tid == 0) {
-    partial[2 * blockIdx.x] = (double)(clock64() - clk0);
-    partial[2 * blockIdx.x + 1] = (double)(wall_clock64() - wall0);
-    partial[2 * gridDim.x + blockIdx.x] = (double)wall0;
+    probe_out[2 * blockIdx.x] = (double)(clock64() - clk0);
+    probe_out[2 * blockIdx.x + 1] = (double)(wall_clock64() - wall0);
+    probe_out[2 * full_tiles + blockIdx.x] = (double)wall0;
   }
   // --- epilogue.  D layout of v_mfma_f64_16x16x4_f64: lane l, reg r holds
   //     D[row = (l >> 4) + 4 r][col = l & 15].
   if (ksplit > 1) {
-    double* out = partial + (size_t)blockIdx.x * (BM * BN);
+    double* out = partial + (size_t)unit * (BM * BN);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -598,7 +602,6 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     stats.psum = rs->partial_sum;
     stats.mode = rs->mode;
   }
-  const GemmStats no_stats{nullptr, nullptr, 0, addend};
   const int tm = (M + BM - 1) / BM;
   const int tn = (N + BN - 1) / BN;
   const int tiles = SYM ? tm * (tm + 1) / 2 : tm * tn;
@@ -618,9 +621,9 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
       ksplit = 1;
     }
   }
-  if (full > 0) {
+  {
     const int xcd_chunk = (tilemap != nullptr && full % 8 == 0 && full >= 512) ? full / 8 : 0;
-    // SC_GEMM_CLOCK=1: every main launch also records, per tile, the shader-clock cycles
+    // SC_GEMM_CLOCK=1: every launch also records, per whole tile, the shader-clock cycles
     // (s_memtime) and the constant-rate wall ticks (s_memrealtime) between kernel entry and
     // the end of the K loop, synchronises and prints the effective shader clock -- the GEMM
     // is power-managed, see DESIGN.md section 3.3.  SC_GEMM_CLOCK_DUMP=<file> also writes
@@ -629,10 +632,11 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     static double* dbg = nullptr;
     static const bool want_probe = getenv("SC_GEMM_CLOCK") != nullptr;
     if (want_probe && dbg == nullptr) (void)hipMalloc(&dbg, sizeof(double) * 3 * 8192);
-    hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full), dim3(256), 0, s, A, lda, B, ldb, C,
-                       ldc, M, N, K, tm, tn, 0, 1, full <= 8192 ? dbg : nullptr, tilemap,
+    double* probe = (full > 0 && full <= 8192) ? dbg : nullptr;
+    hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full + rem * ksplit), dim3(256), 0, s, A, lda,
+                       B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, probe, tilemap,
                        xcd_chunk, stats);
-    if (dbg != nullptr && full <= 8192) {
+    if (probe != nullptr) {
       (void)hipStreamSynchronize(s);
       std::vector<double> h(3 * full);
       (void)hipMemcpy(h.data(), dbg, sizeof(double) * 3 * full, hipMemcpyDeviceToHost);
@@ -655,9 +659,6 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     }
   }
   if (rem > 0) {
-    hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(rem * ksplit), dim3(256), 0, s, A, lda,
-                       B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, tilemap, 0,
-                       no_stats);
     hipLaunchKernelGGL((k_gemm_reduce<EPI, SYM>), dim3(rem, 16), dim3(256), 0, s, g_partial,
                        C, ldc, M, N, tm, tn, full, ksplit, tilemap, addend);
     if (stats.mode != 0)

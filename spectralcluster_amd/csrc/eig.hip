@@ -62,17 +62,20 @@ __global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
   const int r0 = blockIdx.x * 16;
   int ri = r0 + li;
   ri = ri < n ? ri : n - 1;
-  const double* srow = S + (size_t)ri * ld + 8 * lg;
+  // k-slot map inside a 32-column chunk: lane group lg, step q holds columns 8 q + 2 lg, +1 (the
+  // order of the K sum is free as long as A and B agree), so that the four lane groups of one
+  // load instruction read 64 contiguous bytes of their row -- whole sectors, not 16-byte pieces
+  const double* srow = S + (size_t)ri * ld + 2 * lg;
   v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   const int nchunks = (n + 31) / 32;
   double2 cur[4], nxt[4];
   auto load = [&](double2* dst, int ch) {
-    const int kb = ch * 32 + 8 * lg;
+    const int kb = ch * 32 + 2 * lg;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       // rows are padded to ld (multiple of 16): never read past the row's storage
-      if (kb + 2 * q + 1 < ld)
-        dst[q] = *reinterpret_cast<const double2*>(srow + ch * 32 + 2 * q);
+      if (kb + 8 * q + 1 < ld)
+        dst[q] = *reinterpret_cast<const double2*>(srow + ch * 32 + 8 * q);
       else
         dst[q] = make_double2(0.0, 0.0);
     }
@@ -81,15 +84,17 @@ __global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
   if (ch < nchunks) load(cur, ch);
   for (; ch < nchunks; ch += kMvWaves) {
     if (ch + kMvWaves < nchunks) load(nxt, ch + kMvWaves);
-    const int kb = ch * 32 + 8 * lg;
+    const int kb = ch * 32 + 2 * lg;
     double b[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)  // MFMA tile is 16 wide; columns >= B carry zeros
-      b[t] = (kb + t < n && li < B) ? Vs[(size_t)(kb + t) * B + li] : 0.0;
+    for (int t = 0; t < 8; ++t) {  // MFMA tile is 16 wide; columns >= B carry zeros
+      const int k = kb + 8 * (t >> 1) + (t & 1);
+      b[t] = (k < n && li < B) ? Vs[(size_t)k * B + li] : 0.0;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const double a0 = (kb + 2 * q < n) ? cur[q].x : 0.0;
-      const double a1 = (kb + 2 * q + 1 < n) ? cur[q].y : 0.0;
+      const double a0 = (kb + 8 * q < n) ? cur[q].x : 0.0;
+      const double a1 = (kb + 8 * q + 1 < n) ? cur[q].y : 0.0;
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[2 * q], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[2 * q + 1], acc1, 0, 0, 0);
     }

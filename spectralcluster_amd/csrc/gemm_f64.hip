@@ -612,10 +612,12 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
   int full = (tiles / g_slots) * g_slots;
   int rem = tiles - full;
   int ksplit = 1;
-  if (rem > 0 && splitk_ws != nullptr) {
-    ksplit = g_slots / rem;
-    ksplit = std::min(ksplit, std::max(1, ktiles / 8));  // >= 8 k-tiles per chunk
-    if (ksplit < 2) {  // not worth splitting
+  if (rem > 0) {
+    if (splitk_ws != nullptr) {
+      ksplit = g_slots / rem;
+      ksplit = std::min(ksplit, std::max(1, ktiles / 8));  // >= 8 k-tiles per chunk
+    }
+    if (ksplit < 2) {  // no workspace, or not worth splitting: whole tiles only
       full = tiles;
       rem = 0;
       ksplit = 1;

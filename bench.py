@@ -40,9 +40,19 @@ def blobs(n, d, k, seed, noise=0.3):
 
 
 def ari(a, b):
-  sys.path.insert(0, os.path.join(ROOT, "oracle"))
-  import spectral_oracle as so
-  return so.adjusted_rand_index(a, b)
+  """Adjusted Rand index (Hubert & Arabie 1985) from the contingency table."""
+  a = np.asarray(a).ravel()
+  b = np.asarray(b).ravel()
+  _, ai = np.unique(a, return_inverse=True)
+  _, bi = np.unique(b, return_inverse=True)
+  table = np.zeros((ai.max() + 1, bi.max() + 1), dtype=np.int64)
+  np.add.at(table, (ai, bi), 1)
+  pairs = lambda t: int((t * (t - 1) // 2).sum())
+  both, rows, cols = pairs(table), pairs(table.sum(axis=1)), pairs(table.sum(axis=0))
+  total = a.size * (a.size - 1) // 2
+  expected = rows * cols / total if total else 0.0
+  top = 0.5 * (rows + cols)
+  return 1.0 if top == expected else float((both - expected) / (top - expected))
 
 
 def cpu_baseline_leg(gpu_clusterer):

@@ -1,4 +1,4 @@
-"""Convergence probe of the general (non-symmetric) eigen path: SC_EIG_TRACE=1 python tools/gen_eig_probe.py"""
+"""Convergence probe of the general (non-symmetric) eigen path: SC_EIG_TRACE=1 python tests/probes/gen_eig_probe.py"""
 import sys, time
 import numpy as np
 sys.path.insert(0, "oracle"); sys.path.insert(0, ".")

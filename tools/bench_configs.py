@@ -13,8 +13,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import spectral_oracle as so  # noqa: E402  (input generator + ARI only)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _inputs as so  # noqa: E402  (input generator + ARI)
 import spectralcluster_amd as sca  # noqa: E402
 
 out = {}

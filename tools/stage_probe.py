@@ -27,8 +27,8 @@ elif what == "affinity":
   for _ in range(reps):
     sca.utils.compute_affinity_matrix(x)
 elif what == "predict300":
-  sys.path.insert(0, os.path.join(ROOT, "oracle"))
-  import spectral_oracle as so
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import _inputs as so
   x = so.blobs(n, 256, 4, n)
   c = sca.configs.icassp2018_clusterer
   for _ in range(reps):

@@ -323,3 +323,21 @@ def test_lpt_assignment():
   assert max(loads) / (sum(loads) / 8) < 1.02   # well balanced: >= 7.8x on 8 GPUs
   assert multigpu.lpt_assignment([5, 5, 5], 2) == [[0, 2], [1]]
   assert multigpu.first_strict_minimum(np.array([3.0, 1.0, 1.0, 2.0])) == 1
+
+
+def test_predict_validation_happens_before_the_device():
+  """Argument errors of predict() (reference spectral_clusterer.py:222-246) are raised by the
+  host mirror before any device call -- so they are checkable without a GPU."""
+  import spectralcluster_amd as sca
+  with pytest.raises(TypeError, match="embeddings must be a numpy array"):
+    sca.SpectralClusterer().predict([[1.0, 2.0]])
+  with pytest.raises(ValueError, match="embeddings must be 2-dimensional"):
+    sca.SpectralClusterer().predict(np.zeros(5))
+  with pytest.raises(ValueError, match="embeddings must be 2-dimensional"):
+    sca.SpectralClusterer().predict(np.zeros((2, 2, 2)))
+  with pytest.raises(RuntimeError, match="Cannot handle constraint_matrix"):
+    sca.SpectralClusterer(max_spectral_size=10).predict(np.zeros((20, 2)), np.zeros((20, 20)))
+  for kwargs in (dict(max_spectral_size=1), dict(max_spectral_size=5, max_clusters=5),
+                 dict(max_spectral_size=4, min_clusters=4)):
+    with pytest.raises(ValueError, match="max_spectral_size should be a relatively big"):
+      sca.SpectralClusterer(**kwargs).predict(np.zeros((20, 2)))

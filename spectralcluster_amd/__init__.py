@@ -1,45 +1,38 @@
 """MI355X-native dense hot path of SpectralClusterer.predict().
 
-Public names mirror the reference package (`spectralcluster/__init__.py:14-43`)
-for everything that touches the hot path.
+The public names are those of the reference package (`spectralcluster/__init__.py:14-43`):
+every submodule plus the classes / enums / presets it lifts to the top level, and the three
+exception types of the device boundary.
 """
 
-from spectralcluster_amd import _lib
-from spectralcluster_amd import autotune
-from spectralcluster_amd import configs
-from spectralcluster_amd import constraint
-from spectralcluster_amd import custom_distance_kmeans
-from spectralcluster_amd import fallback_clusterer
-from spectralcluster_amd import laplacian
-from spectralcluster_amd import multi_stage_clusterer
-from spectralcluster_amd import naive_clusterer
-from spectralcluster_amd import refinement
-from spectralcluster_amd import spectral_clusterer
-from spectralcluster_amd import utils
+import importlib as _importlib
 
-AutoTune = autotune.AutoTune
-AutoTuneProxy = autotune.AutoTuneProxy
-ConstraintOptions = constraint.ConstraintOptions
-ConstraintName = constraint.ConstraintName
-IntegrationType = constraint.IntegrationType
-ConstraintMatrix = constraint.ConstraintMatrix
-FallbackOptions = fallback_clusterer.FallbackOptions
-SingleClusterCondition = fallback_clusterer.SingleClusterCondition
-FallbackClustererType = fallback_clusterer.FallbackClustererType
-MultiStageClusterer = multi_stage_clusterer.MultiStageClusterer
-Deflicker = multi_stage_clusterer.Deflicker
-LaplacianType = laplacian.LaplacianType
-RefinementName = refinement.RefinementName
-RefinementOptions = refinement.RefinementOptions
-ThresholdType = refinement.ThresholdType
-SymmetrizeType = refinement.SymmetrizeType
-SpectralClusterer = spectral_clusterer.SpectralClusterer
-EigenGapType = utils.EigenGapType
-ICASSP2018_REFINEMENT_SEQUENCE = configs.ICASSP2018_REFINEMENT_SEQUENCE
-TURNTODIARIZE_REFINEMENT_SEQUENCE = configs.TURNTODIARIZE_REFINEMENT_SEQUENCE
+# submodule -> names lifted to the package level
+_PUBLIC = {
+    "autotune": ("AutoTune", "AutoTuneProxy"),
+    "configs": ("ICASSP2018_REFINEMENT_SEQUENCE", "TURNTODIARIZE_REFINEMENT_SEQUENCE"),
+    "constraint": ("ConstraintOptions", "ConstraintName", "ConstraintMatrix", "IntegrationType"),
+    "custom_distance_kmeans": (),
+    "fallback_clusterer": ("FallbackOptions", "SingleClusterCondition",
+                           "FallbackClustererType"),
+    "laplacian": ("LaplacianType",),
+    "multi_stage_clusterer": ("Deflicker", "MultiStageClusterer"),
+    "naive_clusterer": ("NaiveClusterer",),
+    "refinement": ("RefinementName", "RefinementOptions", "ThresholdType", "SymmetrizeType"),
+    "spectral_clusterer": ("SpectralClusterer",),
+    "utils": ("EigenGapType",),
+    "_lib": ("DeviceLibraryError", "UnsupportedOnDeviceError", "EigenSolverNotConverged"),
+}
 
-DeviceLibraryError = _lib.DeviceLibraryError
-UnsupportedOnDeviceError = _lib.UnsupportedOnDeviceError
-EigenSolverNotConverged = _lib.EigenSolverNotConverged
+__all__ = []
+for _module_name, _lifted in _PUBLIC.items():
+  _module = _importlib.import_module(__name__ + "." + _module_name)
+  globals()[_module_name] = _module
+  if not _module_name.startswith("_"):
+    __all__.append(_module_name)
+  for _name in _lifted:
+    globals()[_name] = getattr(_module, _name)
+    __all__.append(_name)
+del _module_name, _lifted, _module, _name
 
 __version__ = "0.1.0"

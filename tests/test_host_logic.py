@@ -141,10 +141,18 @@ def test_config_flattening():
 
 
 def test_public_surface_mirrors_reference():
-  for name in ("AutoTune", "AutoTuneProxy", "LaplacianType", "RefinementName",
-               "RefinementOptions", "ThresholdType", "SymmetrizeType",
-               "SpectralClusterer", "EigenGapType", "ICASSP2018_REFINEMENT_SEQUENCE"):
-    assert hasattr(sca, name)
+  # every public name of the reference package (dir(spectralcluster) at 2024_10_08)
+  for name in ("AutoTune", "AutoTuneProxy", "ConstraintMatrix", "ConstraintName",
+               "ConstraintOptions", "Deflicker", "EigenGapType", "FallbackClustererType",
+               "FallbackOptions", "ICASSP2018_REFINEMENT_SEQUENCE", "IntegrationType",
+               "LaplacianType", "MultiStageClusterer", "NaiveClusterer", "RefinementName",
+               "RefinementOptions", "SingleClusterCondition", "SpectralClusterer",
+               "SymmetrizeType", "TURNTODIARIZE_REFINEMENT_SEQUENCE", "ThresholdType",
+               "autotune", "configs", "constraint", "custom_distance_kmeans",
+               "fallback_clusterer", "laplacian", "multi_stage_clusterer", "naive_clusterer",
+               "refinement", "spectral_clusterer", "utils"):
+    assert hasattr(sca, name), name
+    assert name in sca.__all__, name
   assert [m.name for m in sca.RefinementName] == [
       "CropDiagonal", "GaussianBlur", "RowWiseThreshold", "Symmetrize", "Diffuse",
       "RowWiseNormalize"]

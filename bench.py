@@ -2,21 +2,32 @@
 """Benchmark of the hot path: SpectralClusterer.predict() calls/s on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
-driver launches one rank per GPU with torch.distributed.run.  One "step" = one
-predict() call on device-resident embeddings (H2D of X happens before the timed
-region; the label D2H, n*8 bytes, is inside it).  Prints ONE JSON line on rank 0.
+driver launches one rank per GPU with `python -m torch.distributed.run` (this file reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the environment; it does not import
+torch -- ranks meet over RCCL through the C ABI, `sc_comm_*`).  Prints ONE JSON line on
+rank 0.
 
-Workload (BASELINE.json configs[2], the one `metric` is quoted on): n=8192 d=256
+Headline workload (BASELINE.json configs[2], the one `metric` is quoted on): n=8192 d=256
 synthetic Gaussian blobs (8 speakers), ICASSP2018 refinement, GraphCut Laplacian,
-eigengap k in [2, 20], cosine k-means.  Multi-GPU = independent replicas
-(batched-utterance partitioning): every rank runs the same per-GPU work, no
-data-path collective, weak scaling.
+eigengap k in [2, 20], cosine k-means.  One "step" = one pass of the whole device
+pipeline over one utterance whose embeddings are already resident in HBM
+(`sc_run_resident`; the label D2H, n*8 bytes, is inside the step).  The same K steps
+are then repeated through `sc_predict` -- the call `predict()` makes, including the
+16.8 MB pageable-memory H2D of X -- and reported as `predict_incl_h2d`.
+Multi-GPU = independent replicas (every rank runs the same per-GPU work, no data-path
+collective, weak scaling).
+
+Extra keys (not the headline): `batch512` = BASELINE config 5 (512 utterances, n in
+[300, 3000], LPT-partitioned over the ranks, multi-stream batch per rank, labels
+all-gathered) in utterances/s, and `autotune16` = config 4 (16-value p_percentile sweep at
+n=4096, grid round-robin over the ranks) in ms per sweep -- the quantities the 8-GPU
+target is stated on.  `--workload batch512|autotune16` makes one of them the `value`.
 """
 
 import argparse
-import ctypes
 import json
 import os
+import platform
 import sys
 import time
 
@@ -28,6 +39,7 @@ sys.path.insert(0, ROOT)
 N_SAMPLES, N_FEATURES, N_SPEAKERS, SEED = 8192, 256, 8, 0
 MAX_CLUSTERS = 20
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak
+PEAK_HBM_TBS = 8.0            # MI355X HBM3E (MI355X_MICROARCH.md)
 GEMM_TILE = 128               # gemm_f64.hip block tile
 
 
@@ -55,66 +67,94 @@ def ari(a, b):
   return 1.0 if top == expected else float((both - expected) / (top - expected))
 
 
-def cpu_baseline_leg(gpu_clusterer):
-  """Oracle (NumPy port of the reference, np.linalg.eig) on the host cores, on a
-  bounded sample of the same workload: n=2048 instead of 8192 (the full size costs
-  ~160 s per call on 8 cores; cost is ~n^3)."""
+def host_cpu():
+  model = platform.processor() or "unknown"
+  try:
+    with open("/proc/cpuinfo") as f:
+      for line in f:
+        if line.startswith("model name"):
+          model = line.split(":", 1)[1].strip()
+          break
+  except OSError:
+    pass
+  try:
+    from threadpoolctl import threadpool_info
+    threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+  except Exception:  # pylint: disable=broad-except
+    threads = os.cpu_count() or 1
+  return model, os.cpu_count() or 1, int(threads)
+
+
+def cpu_baseline_legs(gpu_clusterer):
+  """Two CPU legs on the host cores, on a BOUNDED sample of the headline workload
+  (n=2048 instead of 8192: the full size costs ~160 s per call; cost ~ n^3):
+    port               -- oracle/spectral_oracle.predict: the reference's algorithm
+                          (np.linalg.eig on the non-symmetric n x n matrix);
+    algorithm_matched  -- oracle/spectral_oracle.predict_algorithm_matched: the DEVICE
+                          path's algorithm on the CPU (folded scaling vectors + scipy eigsh
+                          on the symmetric operator), so the hardware speed-up is not
+                          conflated with the dgeev -> Lanczos algorithmic win."""
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
   import spectral_oracle as so
   n_s = 2048
   x = so.blobs(n_s, N_FEATURES, N_SPEAKERS, SEED)
   cfg = so.icassp2018_config(laplacian_type=so.LAPLACIAN_GRAPH_CUT,
                              max_clusters=MAX_CLUSTERS)
-  reps, spent, labels = 0, 0.0, None
-  while reps < 3 and spent < 20.0:
-    t0 = time.perf_counter()
-    labels = so.predict(x, cfg)
-    spent += time.perf_counter() - t0
-    reps += 1
-  cpu_s = spent / reps
-  # same sample on the GPU, for an apples-to-apples ratio
+  model, nproc, threads = host_cpu()
+
+  def timed(fn, budget_s, max_reps):
+    reps, spent, result = 0, 0.0, None
+    while reps < max_reps and spent < budget_s:
+      t0 = time.perf_counter()
+      result = fn()
+      spent += time.perf_counter() - t0
+      reps += 1
+    return spent / reps, reps, result
+
+  port_s, port_reps, port_labels = timed(lambda: so.predict(x, cfg), 20.0, 3)
+  am_s, am_reps, (am_labels, _) = timed(lambda: so.predict_algorithm_matched(x, cfg),
+                                        10.0, 5)
   gpu_clusterer.predict(x)
   t0 = time.perf_counter()
   for _ in range(5):
     glab = gpu_clusterer.predict(x)
   gpu_s = (time.perf_counter() - t0) / 5
-  try:
-    from threadpoolctl import threadpool_info
-    threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-  except Exception:
-    threads = os.cpu_count() or 1
-  return {
-      "value": 1.0 / cpu_s, "unit": "calls/s", "cores": int(threads), "kind": "port",
-      "sample": ("oracle/spectral_oracle.predict (np.linalg.eig) on n=%d d=%d k=%d "
-                 "blobs, same config; %d reps; n=8192 extrapolates by (8192/2048)^3"
-                 % (n_s, N_FEATURES, N_SPEAKERS, reps)),
-      "seconds_per_call": cpu_s,
-      "extrapolated_n8192_calls_per_s": 1.0 / (cpu_s * (N_SAMPLES / n_s) ** 3),
-      "gpu_same_sample_calls_per_s": 1.0 / gpu_s,
-      "ari_gpu_vs_cpu_sample": ari(glab, labels),
-  }
+  scale = (N_SAMPLES / n_s) ** 3
+  common = {"unit": "calls/s", "cores": threads, "cpu_model": model, "nproc": nproc,
+            "gpu_same_sample_calls_per_s": 1.0 / gpu_s}
+  port = dict(common, value=1.0 / port_s, kind="port",
+              sample=("oracle/spectral_oracle.predict (np.linalg.eig) on n=%d d=%d k=%d blobs, "
+                      "same config; %d reps; n=8192 extrapolates by (8192/2048)^3"
+                      % (n_s, N_FEATURES, N_SPEAKERS, port_reps)),
+              seconds_per_call=port_s,
+              extrapolated_n8192_calls_per_s=1.0 / (port_s * scale),
+              ari_gpu_vs_cpu_sample=ari(glab, port_labels))
+  matched = dict(common, value=1.0 / am_s, kind="algorithm_matched",
+                 sample=("oracle/spectral_oracle.predict_algorithm_matched (NumPy refinement, "
+                         "scaling vectors folded, scipy.sparse.linalg.eigsh k=%d on the symmetric "
+                         "operator) on the same n=%d sample; %d reps"
+                         % (MAX_CLUSTERS + 1, n_s, am_reps)),
+                 seconds_per_call=am_s,
+                 ari_vs_port_labels=ari(am_labels, port_labels),
+                 ari_gpu_vs_cpu_sample=ari(glab, am_labels))
+  return port, matched
 
 
-def concurrent_leg(sca, _lib, cfg, x, steps, streams=2):
+def concurrent_leg(_lib, cfg, x, steps, streams=2):
   """Throughput of independent predict() calls issued from `streams` host threads on
   `streams` handles (HIP streams) of the same GPU: the single-workgroup phases of one
-  call (Rayleigh-Ritz, k-means) overlap the GEMM of the other.  Extra information only;
-  the headline `value` stays the single-stream number."""
+  call overlap the GEMM of the other.  Extra information only."""
   import threading
   pool = _lib.handle_pool(None, streams)
   n, d = x.shape
   per = max(1, steps // streams)
-
-  def worker(h, out):
+  ready = []
+  for h in pool:
     lab = np.empty(n, dtype=np.int64)
     diag = _lib.ScDiag()
     h.check(h.lib.sc_set_embeddings(h.raw, _lib.as_double_p(x), n, d))
     h.check(h.lib.sc_run_resident(h.raw, cfg, _lib.as_int64_p(lab), diag))  # warm-up
-    out.append((h, lab, diag))
-
-  ready = []
-  for h in pool:
-    worker(h, ready)
+    ready.append((h, lab, diag))
 
   def run(h, lab, diag):
     for _ in range(per):
@@ -133,30 +173,138 @@ def concurrent_leg(sca, _lib, cfg, x, steps, streams=2):
           "unit": "calls/s"}
 
 
+def batch512_sizes():
+  """BASELINE config 5 (same draw as oracle/make_golden.batch512_inputs)."""
+  rng = np.random.default_rng(512)
+  return rng.integers(300, 3001, 512), rng.integers(2, 8, 512)
+
+
+def batch512_leg(sca, multigpu, comm, fence, streams=8):
+  """Config 5: the 512 utterances are LPT-partitioned over the ranks by size alone, so each
+  rank only synthesises its own share; per rank a multi-stream batch; labels all-gathered."""
+  ns, ks = batch512_sizes()
+  sizes = [int(n) for n in ns]
+  owned = multigpu.lpt_assignment(sizes, comm.size)[comm.rank]
+  mine = {i: blobs(sizes[i], N_FEATURES, int(ks[i]), seed=i)[0] for i in owned}
+  clusterer = sca.configs.icassp2018_clusterer
+  clusterer.predict_batch([mine[i] for i in owned[:2 * streams]], streams=streams)  # arenas
+  fence()
+  t0 = time.perf_counter()
+  labels = multigpu.predict_batch_sharded(
+      comm, None, mine, sizes=sizes,
+      predict_many_fn=lambda share: clusterer.predict_batch(share, streams=streams))
+  fence()
+  elapsed = comm.allreduce_max(time.perf_counter() - t0)
+  out = {"value": 512 / elapsed, "unit": "utterances/s", "seconds": elapsed,
+         "streams_per_gpu": streams, "utterances": 512, "n_gpus": comm.size,
+         "scaling": "strong", "partition": "LPT on n^3 + 64 n^2"}
+  gpath = os.path.join(ROOT, "tests", "golden", "batch512.npz")
+  if comm.rank == 0 and os.path.exists(gpath):
+    g = np.load(gpath)
+    ref, pos, ok = g["labels"], 0, 0
+    for i, n in enumerate(sizes):
+      ok += ari(labels[i], ref[pos:pos + n]) == 1.0
+      pos += n
+    out["ari1_vs_reference_labels"] = int(ok)
+  return out
+
+
+def autotune16_leg(sca, multigpu, comm, fence):
+  """Config 4: one AutoTune level of 16 p_percentile values at n=4096, the grid
+  round-robin over the ranks, (ratio, n_clusters) all-gathered per level."""
+  x, _ = blobs(4096, N_FEATURES, N_SPEAKERS, 4096)
+
+  def make():
+    return sca.SpectralClusterer(
+        min_clusters=2, max_clusters=MAX_CLUSTERS, laplacian_type=sca.LaplacianType.GraphCut,
+        refinement_options=sca.RefinementOptions(
+            gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
+            refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE),
+        autotune=sca.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95,
+                              init_search_step=0.025, search_level=1))
+
+  multigpu.predict_autotune_distributed(comm, make(), x)  # warm-up
+  reps = 3
+  fence()
+  t0 = time.perf_counter()
+  for _ in range(reps):
+    c = make()
+    labels = multigpu.predict_autotune_distributed(comm, c, x)
+  fence()
+  elapsed = comm.allreduce_max(time.perf_counter() - t0) / reps
+  out = {"value": 1e3 * elapsed, "unit": "ms/sweep", "p_values": 16, "n_samples": 4096,
+         "n_gpus": comm.size, "scaling": "strong",
+         "best_p": float(c.refinement_options.p_percentile)}
+  gpath = os.path.join(ROOT, "tests", "golden", "autotune_n4096.npz")
+  if os.path.exists(gpath):
+    g = np.load(gpath)
+    out["best_p_reference"] = float(g["best_p"])
+    out["ari_vs_reference_labels"] = ari(labels, g["labels"])
+    out["reference_seconds_8vcpu"] = float(g["ref_seconds"])
+  return out
+
+
+def kernel_roofline(stage_ms, passes):
+  """Per-kernel roofline rows from the run's own hipEvent timers (sc_set_profiling(2)):
+  algorithmic bytes / flops over the measured time."""
+  n, d = N_SAMPLES, N_FEATURES
+  nt = (n + GEMM_TILE - 1) // GEMM_TILE
+  mat = n * n * 8.0
+  rows = []
+
+  def hbm(name, key, nbytes, note):
+    us = 1e3 * stage_ms[key]
+    if us > 0:
+      tbs = nbytes / (us * 1e-6) / 1e12
+      rows.append({"kernel": name, "bound": "hbm", "us": us, "bytes": nbytes,
+                   "achieved": tbs, "peak": PEAK_HBM_TBS, "unit": "TB/s",
+                   "frac": tbs / PEAK_HBM_TBS, "note": note})
+
+  def mfma(name, key, flops, note):
+    us = 1e3 * stage_ms[key]
+    if us > 0:
+      tf = flops / (us * 1e-6) / 1e12
+      rows.append({"kernel": name, "bound": "mfma", "us": us, "flops": flops,
+                   "achieved": tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                   "frac": tf / PEAK_F64_MFMA_TFLOPS, "note": note})
+
+  tri = nt * (nt + 1) // 2 * 2.0 * GEMM_TILE * GEMM_TILE
+  mfma("k_gemm_nt<EpiNone,SYM> (Diffuse)", "diffuse", tri * n, "upper-triangle tiles")
+  mfma("k_gemm_nt<EpiAffinity,SYM> (affinity)", "affinity_gemm", tri * d,
+       "K=%d: write floor %.0f us" % (d, mat / (PEAK_HBM_TBS * 1e12) * 1e6))
+  hbm("k_gaussian_blur_stream<4> (CropDiagonal+GaussianBlur)", "blur", 2 * mat,
+      "1 read + 1 write of n^2")
+  hbm("k_threshold_symmetrize (RowWiseThreshold+Symmetrize)", "threshold_sym", 2 * mat,
+      "1 read + 1 write of n^2")
+  hbm("block matvec of the eigen stage", "matvec", passes * mat,
+      "%g passes x n^2 * 8 B" % passes)
+  return rows
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--workload", default="predict8192",
+                  choices=["predict8192", "batch512", "autotune16"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-concurrent", action="store_true")
+  ap.add_argument("--no-extras", action="store_true",
+                  help="skip the batch512 / autotune16 legs")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  dist = None
-  if world > 1:
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
   import spectralcluster_amd as sca
   from spectralcluster_amd import _lib
+  from spectralcluster_amd import multigpu
 
   handle = _lib.default_handle(local_rank)
   lib = handle.lib
+  comm = multigpu.RcclComm.from_env(handle)  # RCCL (C ABI) for N > 1, identity for N = 1
   clusterer = sca.SpectralClusterer(
       min_clusters=2, max_clusters=MAX_CLUSTERS,
       refinement_options=sca.configs.icassp2018_refinement_options,
@@ -173,36 +321,66 @@ def main():
   def step():
     handle.check(lib.sc_run_resident(handle.raw, cfg, _lib.as_int64_p(labels), diag))
 
+  def step_h2d():
+    handle.check(lib.sc_predict(handle.raw, _lib.as_double_p(x), N_SAMPLES, N_FEATURES, cfg,
+                                _lib.as_int64_p(labels), diag))
+
   def fence():
-    handle.check(lib.sc_synchronize(handle.raw))
-    if dist is not None:
-      import torch
-      dist.barrier()
-      torch.cuda.synchronize()
+    handle.check(lib.sc_synchronize(handle.raw))  # this rank's stream has drained ...
+    comm.barrier()                                # ... and every rank has arrived
+
+  def timed(fn, k, collect=None):
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(k):
+      fn()
+      if collect is not None:
+        collect()
+    fence()
+    return comm.allreduce_max(time.perf_counter() - t0)
 
   for _ in range(args.warmup):
     step()
-  fence()
-  stage_sum = np.zeros(len(_lib.STAGE_NAMES))
-  passes = 0
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
+  names = _lib.STAGE_NAMES
+  stage_sum = np.zeros(len(names))
+  passes = [0]
+
+  def collect():
+    stage_sum[:] += [diag.stage_ms[i] for i in range(len(names))]
+    passes[0] += diag.eig_matvec_passes
+
+  k = args.steps
+  elapsed = timed(step, k, collect)
+  stage_ms = {name: float(stage_sum[i] / k) for i, name in enumerate(names)}
+  passes_per_call = passes[0] / k
+  eig_info = {"matvec_passes_per_call": passes_per_call, "block": int(diag.eig_block),
+              "basis": int(diag.eig_basis), "cycles": int(diag.eig_cycles),
+              "path": int(diag.eig_path)}
+  resident_labels = labels.copy()
+  n_clusters = int(diag.n_clusters)
+  eigenvalues = diag.eigenvalue_array()
+
+  step_h2d()
+  elapsed_h2d = timed(step_h2d, k)
+
+  # per-kernel timers (a few extra steps with event pairs around the hot kernels)
+  handle.check(lib.sc_set_profiling(handle.raw, 2))
+  fine_sum = np.zeros(len(names))
+  fine_k = max(3, min(k, 10))
+  for _ in range(fine_k):
     step()
-    stage_sum += [diag.stage_ms[i] for i in range(len(_lib.STAGE_NAMES))]
-    passes += diag.eig_matvec_passes
-  fence()
-  elapsed = time.perf_counter() - t0
-  if dist is not None:
-    import torch
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    fine_sum += [diag.stage_ms[i] for i in range(len(names))]
+  handle.check(lib.sc_set_profiling(handle.raw, 1))
+  fine_ms = {name: float(fine_sum[i] / fine_k) for i, name in enumerate(names)}
+
+  extras = {}
+  if not args.no_extras or args.workload != "predict8192":
+    if not args.no_extras or args.workload == "batch512":
+      extras["batch512"] = batch512_leg(sca, multigpu, comm, fence)
+    if not args.no_extras or args.workload == "autotune16":
+      extras["autotune16"] = autotune16_leg(sca, multigpu, comm, fence)
 
   if rank == 0:
-    k = args.steps
-    stage_ms = {name: float(stage_sum[i] / k) for i, name in enumerate(_lib.STAGE_NAMES)}
-    # dominant kernel: the Diffuse SYRK-style fp64 MFMA GEMM.  Algorithmic flops of
-    # the symmetric product = (upper-triangle tile pairs) * 2 * 128 * 128 * n.
     nt = (N_SAMPLES + GEMM_TILE - 1) // GEMM_TILE
     flops = nt * (nt + 1) // 2 * 2.0 * GEMM_TILE * GEMM_TILE * N_SAMPLES
     diffuse_s = stage_ms["diffuse"] * 1e-3
@@ -216,40 +394,66 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "icassp2018_graphcut_n8192_d256_k8_max20",
                    "n_samples": N_SAMPLES, "n_features": N_FEATURES,
-                   "speakers": N_SPEAKERS, "parallelism": "replicas x%d" % world},
+                   "speakers": N_SPEAKERS, "parallelism": "replicas x%d" % world,
+                   "step": "sc_run_resident: embeddings resident in HBM, labels D2H inside",
+                   "collectives": "RCCL via the C ABI (sc_comm_*)" if world > 1 else "none"},
+        "predict_incl_h2d": {
+            "value": world * k / elapsed_h2d, "unit": "calls/s",
+            "ms_per_step": 1e3 * elapsed_h2d / k,
+            "step": "sc_predict: H2D of X (16.8 MB, pageable numpy buffer, "
+                    "hipMemcpy2DAsync + sync) + the resident pipeline"},
         "roofline": {"bound": "mfma", "kernel": "k_gemm_nt<EpiNone,SYM> (Diffuse)",
                      "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                      "traffic": None, "flops_per_launch": flops,
-                     "avg_launch_ms": stage_ms["diffuse"]},
-        "stage_ms": stage_ms,
-        "eig": {"matvec_passes_per_call": passes / k, "block": int(diag.eig_block),
-                "basis": int(diag.eig_basis), "cycles": int(diag.eig_cycles)},
-        "parity": {"n_clusters": int(diag.n_clusters),
-                   "ari_vs_truth": ari(labels, truth)},
+                     "avg_launch_ms": stage_ms["diffuse"],
+                     "kernels": kernel_roofline(fine_ms, passes_per_call)},
+        "stage_ms": {kk: v for kk, v in stage_ms.items()
+                     if kk in ("affinity", "refine", "diffuse", "scaling", "eig", "kmeans",
+                               "total")},
+        "eig": eig_info,
+        "parity": {"n_clusters": n_clusters, "ari_vs_truth": ari(resident_labels, truth),
+                   "labels_equal_with_h2d_path": bool(np.array_equal(resident_labels, labels))},
     }
     gpath = os.path.join(ROOT, "tests", "golden", "e2e_n8192_lap4_max20.npz")
     if os.path.exists(gpath):
       g = np.load(gpath)
-      w = diag.eigenvalue_array()[g["consumed_index"]]
-      out["parity"]["ari_vs_reference_labels"] = ari(labels, g["labels"])
-      out["parity"]["max_rel_err_consumed_eigenvalues"] = float(np.max(
-          np.abs(w - g["consumed_eigenvalues"]) /
-          np.maximum(np.abs(g["consumed_eigenvalues"]), 1e-12)))
+      w = eigenvalues[g["consumed_index"]]
+      rel = np.abs(w - g["consumed_eigenvalues"]) / np.maximum(
+          np.abs(g["consumed_eigenvalues"]), 1e-12)
+      out["parity"]["ari_vs_reference_labels"] = ari(resident_labels, g["labels"])
+      out["parity"]["max_rel_err_consumed_eigenvalues"] = float(np.max(rel))
+      # the bulk values (~0.99999) pass 1e-5 for any Ritz value in range: the meaningful
+      # figure is the error on the informative (non-bulk) eigenvalues
+      informative = g["consumed_eigenvalues"] < 0.5
+      if informative.any():
+        out["parity"]["max_rel_err_informative_eigenvalues"] = float(np.max(rel[informative]))
       out["parity"]["reference_seconds_per_call_8vcpu"] = float(g["ref_seconds"])
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_diffuse.json")
     if os.path.exists(tpath):  # HBM bytes per Diffuse launch from a separate --pmc run
       t = json.load(open(tpath))
       out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
       out["roofline"]["traffic_source"] = t["source"]
+    out.update(extras)
+    if args.workload != "predict8192":
+      leg = extras[args.workload]
+      out["headline_predict8192"] = {"value": out["value"], "unit": out["unit"],
+                                     "ms_per_step": out["ms_per_step"]}
+      out["metric"] = ("BASELINE config 5: 512 utterances n in [300,3000] d=256, ICASSP2018"
+                       if args.workload == "batch512" else
+                       "BASELINE config 4: AutoTune 16-value sweep, n=4096 d=256, GraphCut")
+      out["value"], out["unit"] = leg["value"], leg["unit"]
+      out["scaling"] = "strong"
+      out["higher_is_better"] = args.workload == "batch512"
+      out["config"]["workload"] = args.workload
     if world == 1 and not args.no_concurrent:
-      out["concurrent_streams"] = concurrent_leg(sca, _lib, cfg, x, args.steps)
+      out["concurrent_streams"] = concurrent_leg(_lib, cfg, x, args.steps)
     if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cpu_baseline_leg(clusterer)
+      out["cpu_baseline"], out["cpu_baseline_algorithm_matched"] = cpu_baseline_legs(
+          clusterer)
     print(json.dumps(out), flush=True)
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  comm.barrier()
+  comm.close()
 
 
 if __name__ == "__main__":

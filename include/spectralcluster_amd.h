@@ -19,13 +19,14 @@
 #ifndef SPECTRALCLUSTER_AMD_H_
 #define SPECTRALCLUSTER_AMD_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 2
+#define SC_ABI_VERSION 3
 #define SC_MAX_OPS 16
 #define SC_MAX_BLUR_RADIUS 32
 #define SC_MAX_EIG 128 /* max eigenvalues reported in sc_diag */
@@ -91,7 +92,11 @@ enum {
   SC_EIG_PATH_DENSE_JACOBI = 1,   /* symmetric, n <= 128 */
   SC_EIG_PATH_BLOCK_LANCZOS = 2,  /* symmetric, larger n */
   SC_EIG_PATH_DENSE_GENERAL = 3,  /* non-symmetric, n <= 64: Hessenberg + complex QR */
-  SC_EIG_PATH_BLOCK_ARNOLDI = 4   /* non-symmetric, larger n */
+  SC_EIG_PATH_BLOCK_ARNOLDI = 4,  /* non-symmetric, larger n */
+  /* symmetric, n > 128, every eigenvalue consumed (max_clusters=None with a Laplacian,
+   * or the ascending NormalizedDiff gap's np.max): Householder tridiagonalisation +
+   * Sturm bisection for the values, block Lanczos for the few vectors k-means takes */
+  SC_EIG_PATH_DENSE_TRIDIAG = 5
 };
 
 /* Stage slots of sc_diag.stage_ms */
@@ -102,7 +107,12 @@ enum {
   SC_STAGE_SCALING = 3,   /* row stats + Laplacian/normalise scaling vectors */
   SC_STAGE_EIG = 4,
   SC_STAGE_KMEANS = 5,
-  SC_STAGE_TOTAL = 6
+  SC_STAGE_TOTAL = 6,
+  /* per-kernel slots, filled only at sc_set_profiling(h, 2) */
+  SC_STAGE_BLUR = 7,           /* CropDiagonal + GaussianBlur kernel */
+  SC_STAGE_THRESHOLD_SYM = 8,  /* RowWiseThreshold + Symmetrize kernel */
+  SC_STAGE_MATVEC = 9,         /* sum over the block matvec launches of the eigen stage */
+  SC_STAGE_AFFINITY_GEMM = 10  /* the affinity GEMM launch alone */
 };
 
 /*
@@ -182,6 +192,9 @@ int sc_destroy(sc_handle h);
 int sc_reserve(sc_handle h, int n_max, int d_max);
 const char* sc_last_error(sc_handle h);
 int sc_synchronize(sc_handle h);
+/* hipEvent timers in sc_diag.stage_ms: 1 (default) = one pair per stage, 2 = additionally
+ * around the individual hot kernels (bench.py's per-kernel roofline list) */
+int sc_set_profiling(sc_handle h, int level);
 
 /* fills cfg with the reference defaults (refinement.py:76-100,
  * spectral_clusterer.py:29-46): no ops, sigma 1 weights, p .95, mult .01 ... */
@@ -213,6 +226,11 @@ int sc_set_affinity(sc_handle h, const double* affinity, int n);
  * stay on the device; diag receives eigenvalues, n_clusters_raw, max_delta.
  */
 int sc_eig_ncluster(sc_handle h, const sc_config* cfg, sc_diag* diag);
+/* The eigenvalues the last sc_eig_ncluster / sc_predict consumed, in the order
+ * compute_sorted_eigenvectors returns them (utils.py:62-70): sc_diag.eigenvalues holds at
+ * most SC_MAX_EIG of them, these calls give all (n of them with max_clusters=None). */
+int sc_num_eigenvalues(sc_handle h);
+int sc_get_eigenvalues(sc_handle h, double* out, int count);
 /* number of eigenvector columns currently resident */
 int sc_num_eigenvectors(sc_handle h);
 /* D2H of the first ncols resident eigenvectors as an (n, ncols) matrix */
@@ -295,7 +313,9 @@ int sc_stage_laplacian(sc_handle h, int laplacian_type, const double* in, int n,
 /*
  * utils.compute_sorted_eigenvectors (utils.py:44-71) for a SYMMETRIC input:
  * the `count` largest (descend=1) or smallest (descend=0) eigenpairs.
- * values: count doubles; vectors: (n, count), unit 2-norm columns.
+ * values: count doubles; vectors: (n, count), unit 2-norm columns, or NULL for values
+ * only -- then count may be anything up to n (count > 64 at n > 128 takes the dense
+ * tridiagonalisation path: what np.linalg.eigvalsh returns).
  */
 int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, int descend,
                      double* values, double* vectors, sc_diag* diag);
@@ -330,6 +350,39 @@ int sc_stage_kmeans(sc_handle h, const double* e, int n, int k, int max_iter,
 int sc_stage_kmeans_metric(sc_handle h, const double* e, int n, int k, int max_iter,
                            int metric, int64_t* labels, double* centroids_out,
                            int* iterations);
+
+/* ---- multi-GPU: replicas of the path over the GPUs of one node ------------------------
+ * The reference has no distributed layer (a batch is a Python `for` over predict(),
+ * SURVEY.md 3.4; AutoTune evaluates its p grid serially, autotune.py:98-111).  Independent
+ * units are partitioned over GPUs by the host (spectralcluster_amd/multigpu.py); these
+ * entry points are the only communication it needs, on RCCL over xGMI.  Host buffers in
+ * and out (staged through the device on the handle's stream); every call returns after
+ * its result is on the host.  librccl is opened on first use. */
+#define SC_COMM_ID_BYTES 128
+typedef struct sc_comm_s* sc_comm;
+/* 1 when librccl could be opened */
+int sc_comm_available(void);
+/* rank 0: ncclGetUniqueId; the 128 bytes reach the other ranks out of band (file/socket) */
+int sc_comm_unique_id(unsigned char* id);
+/* one process per GPU: join a communicator of world_size ranks on the handle's device;
+ * collectives run on the handle's stream */
+int sc_comm_init_rank(sc_handle h, int world_size, int rank, const unsigned char* id,
+                      sc_comm* out);
+/* one process driving ndev GPUs (ncclCommInitAll): out[i] is bound to handles[i] */
+int sc_comm_init_all(sc_handle* handles, int ndev, sc_comm* out);
+int sc_comm_destroy(sc_comm c);
+int sc_comm_rank(sc_comm c);
+int sc_comm_size(sc_comm c);
+const char* sc_comm_last_error(sc_comm c);
+/* root's `bytes` bytes of buf reach every rank's buf (embeddings, packed sc_config) */
+int sc_comm_broadcast(sc_comm c, void* buf, size_t bytes, int root);
+/* recv (world_size * bytes) = every rank's send (bytes), in rank order (label slabs,
+ * AutoTune (ratio, n_clusters) pairs) */
+int sc_comm_allgather(sc_comm c, const void* send, void* recv, size_t bytes);
+/* element-wise max over ranks, in place (the bench's max-over-ranks time) */
+int sc_comm_allreduce_max(sc_comm c, double* values, int count);
+/* every rank's stream has drained and every rank has arrived */
+int sc_comm_barrier(sc_comm c);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,10 @@
 Run in the build container only (needs /root/reference, which does not exist
 on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general | --size-reduction | --fallback]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general | --size-reduction | --fallback | --autotune4096 | --batch512 | --dense]
+
+`--autotune4096` and `--batch512` pin BASELINE.json configs 4 and 5 at their
+full sizes (about 6 and 20 minutes of CPU).
 
 `--large` additionally runs the two n=8192 configurations (about 150-160 s of
 CPU each).  Inputs are regenerated from seeds by `spectral_oracle.blobs`; only
@@ -357,6 +360,130 @@ def kmeans_metric_goldens():
   save("kmeans_metrics.npz", **km)
 
 
+class _Spy:
+  """Captures what the reference's own eigen / eigengap calls return (they are
+  looked up through the module attribute at spectral_clusterer.py:146-167)."""
+
+  def __enter__(self):
+    self.calls = []
+    self._eig = ref_utils.compute_sorted_eigenvectors
+    self._gap = ref_utils.compute_number_of_clusters
+
+    def spy_eig(*args, **kwargs):
+      w, v = self._eig(*args, **kwargs)
+      self.calls.append({"w": w})
+      return w, v
+
+    def spy_gap(*args, **kwargs):
+      kk, delta = self._gap(*args, **kwargs)
+      self.calls[-1]["k"], self.calls[-1]["delta"] = kk, delta
+      return kk, delta
+
+    ref_utils.compute_sorted_eigenvectors = spy_eig
+    ref_utils.compute_number_of_clusters = spy_gap
+    return self
+
+  def __exit__(self, *exc):
+    ref_utils.compute_sorted_eigenvectors = self._eig
+    ref_utils.compute_number_of_clusters = self._gap
+
+
+def autotune4096_golden():
+  """11. BASELINE config 4 at full size: AutoTune over 16 p_percentile values,
+  n=4096 d=256, ICASSP2018 + GraphCut, max_clusters=20 (autotune.py:76-132,
+  spectral_clusterer.py:266-289)."""
+  n, d, k, seed, max_clusters = 4096, 256, 8, 4096, 20
+  x = so.blobs(n, d, k, seed)
+  tuner = ref_autotune.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95,
+                                init_search_step=0.025, search_level=1)
+  grid = np.array(tuner.get_percentile_range())
+  assert len(grid) == 16
+  clusterer = ref_sc.SpectralClusterer(
+      min_clusters=2, max_clusters=max_clusters,
+      refinement_options=icassp_options(), autotune=tuner,
+      laplacian_type=LAP[4])
+  idx = so.consumed_eigen_indices(n, max_clusters, False)
+  t0 = time.perf_counter()
+  with _Spy() as spy:
+    labels = clusterer.predict(x)
+  secs = time.perf_counter() - t0
+  sweep = spy.calls[:16]
+  assert len(spy.calls) == 16  # predict() re-uses the eigenvectors of the best p
+  ratios = np.array([np.sqrt(1 - p) / c["delta"] for p, c in zip(grid, sweep)])
+  save("autotune_n4096.npz",
+       params=np.array([n, d, k, seed, 4, max_clusters]), grid=grid,
+       ratios=ratios, n_clusters=np.array([c["k"] for c in sweep]),
+       max_delta=np.array([c["delta"] for c in sweep]),
+       consumed_index=idx,
+       consumed_eigenvalues=np.stack([c["w"][idx] for c in sweep]),
+       best_p=np.float64(clusterer.refinement_options.p_percentile),
+       labels=labels.astype(np.int8), ref_seconds=np.float64(secs))
+
+
+def batch512_inputs():
+  """BASELINE config 5: sizes / cluster counts of the batch."""
+  rng = np.random.default_rng(512)
+  ns = rng.integers(300, 3001, 512)
+  ks = rng.integers(2, 8, 512)
+  return ns, ks
+
+
+def batch512_golden(limit=None):
+  """12. BASELINE config 5 at full size: 512 independent predict() calls of
+  configs.icassp2018_clusterer (configs.py:37-43)."""
+  ns, ks = batch512_inputs()
+  if limit:
+    ns, ks = ns[:limit], ks[:limit]
+  labels, ncl, deltas, eig, secs = [], [], [], [], []
+  t_all = time.perf_counter()
+  for i, (n, k) in enumerate(zip(ns, ks)):
+    x = so.blobs(int(n), 256, int(k), seed=i)
+    clusterer = copy.deepcopy(ref_configs.icassp2018_clusterer)
+    t0 = time.perf_counter()
+    with _Spy() as spy:
+      lab = clusterer.predict(x)
+    secs.append(time.perf_counter() - t0)
+    c = spy.calls[-1]
+    idx = so.consumed_eigen_indices(int(n), 7, True)
+    labels.append(lab.astype(np.int8))
+    ncl.append(c["k"])
+    deltas.append(c["delta"])
+    eig.append(c["w"][idx])
+    if i % 16 == 0:
+      print("batch512 %d/%d  %.0f s" % (i, len(ns), time.perf_counter() - t_all),
+            flush=True)
+  save("batch512.npz", ns=ns, ks=ks, labels=np.concatenate(labels),
+       n_clusters_raw=np.array(ncl), max_delta=np.array(deltas),
+       consumed_eigenvalues=np.stack(eig), ref_seconds=np.array(secs))
+
+
+def dense_goldens():
+  """13. Every eigenvalue is consumed (E1 dense path): the reference's DEFAULT
+  max_clusters=None with a Laplacian (spectral_clusterer.py:32, utils.py:100-115), and the
+  ascending NormalizedDiff gap, which divides by np.max(eigenvalues) (utils.py:110)."""
+  gap = {1: ref_utils.EigenGapType.Ratio, 2: ref_utils.EigenGapType.NormalizedDiff}
+  # (n, d, k, seed, lap, max_clusters, eigengap_type)
+  cases = [(1000, 64, 5, 1000, 4, None, 1), (2048, 128, 4, 2048, 4, None, 1),
+           (1000, 64, 5, 1000, 2, None, 1), (1000, 64, 5, 1000, 3, None, 1),
+           (700, 48, 6, 700, 4, None, 2), (1000, 64, 5, 1000, 4, 20, 2),
+           (1000, 64, 5, 1000, 2, 12, 2), (600, 32, 3, 600, 0, None, 1)]
+  for n, d, k, seed, lap, maxc, gt in cases:
+    x = so.blobs(n, d, k, seed)
+    clusterer = ref_sc.SpectralClusterer(
+        min_clusters=2, max_clusters=maxc, refinement_options=icassp_options(),
+        laplacian_type=LAP[lap], eigengap_type=gap[gt])
+    t0 = time.perf_counter()
+    with _Spy() as spy:
+      labels = clusterer.predict(x)
+    secs = time.perf_counter() - t0
+    c = spy.calls[-1]
+    save("dense_n%d_lap%d_max%s_gap%d.npz" % (n, lap, maxc or "None", gt),
+         params=np.array([n, d, k, seed, lap, maxc or 0, gt]),
+         eigenvalues=c["w"], n_clusters_raw=np.int64(c["k"]),
+         max_delta=np.float64(c["delta"]), labels=labels.astype(np.int8),
+         ref_seconds=np.float64(secs))
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
@@ -374,6 +501,15 @@ def main():
     return
   if "--kmeans-metrics" in sys.argv:  # only section 4b
     kmeans_metric_goldens()
+    return
+  if "--autotune4096" in sys.argv:  # only section 11
+    autotune4096_golden()
+    return
+  if "--batch512" in sys.argv:  # only section 12
+    batch512_golden()
+    return
+  if "--dense" in sys.argv:  # only section 13
+    dense_goldens()
     return
 
   # 1. The 6x2 toy of the reference tests, sigma=0, full stage dump, all

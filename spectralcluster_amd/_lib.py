@@ -27,7 +27,7 @@ SC_ERR_UNSUPPORTED = -5
 SC_ERR_NON_FINITE = -6
 
 STAGE_NAMES = ("affinity", "refine", "diffuse", "scaling", "eig", "kmeans",
-               "total")
+               "total", "blur", "threshold_sym", "matvec", "affinity_gemm")
 
 _LIB_NAME = "libspectralcluster_amd.so"
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
@@ -45,7 +45,7 @@ class EigenSolverNotConverged(RuntimeError):
   """The block-Lanczos eigensolver did not reach its tolerance."""
 
 
-SC_ABI_VERSION = 2
+SC_ABI_VERSION = 3
 
 
 class ScConfig(ctypes.Structure):
@@ -127,6 +127,7 @@ PROTOTYPES = {
     "sc_reserve": (ctypes.c_int, [_handle_t, ctypes.c_int, ctypes.c_int]),
     "sc_last_error": (ctypes.c_char_p, [_handle_t]),
     "sc_synchronize": (ctypes.c_int, [_handle_t]),
+    "sc_set_profiling": (ctypes.c_int, [_handle_t, ctypes.c_int]),
     "sc_config_default": (ctypes.c_int, [ctypes.POINTER(ScConfig)]),
     "sc_gaussian_weights": (ctypes.c_int, [ctypes.c_double,
                                            ctypes.POINTER(ctypes.c_int32),
@@ -140,6 +141,8 @@ PROTOTYPES = {
     "sc_set_affinity": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int]),
     "sc_eig_ncluster": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig),
                                        ctypes.POINTER(ScDiag)]),
+    "sc_num_eigenvalues": (ctypes.c_int, [_handle_t]),
+    "sc_get_eigenvalues": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int]),
     "sc_num_eigenvectors": (ctypes.c_int, [_handle_t]),
     "sc_get_eigenvectors": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
                                            ctypes.c_int]),
@@ -194,6 +197,22 @@ PROTOTYPES = {
     "sc_stage_kmeans_metric": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               _c_int64_p, _c_double_p, _c_int_p]),
+    "sc_comm_available": (ctypes.c_int, []),
+    "sc_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "sc_comm_init_rank": (ctypes.c_int, [_handle_t, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_char_p, ctypes.POINTER(_handle_t)]),
+    "sc_comm_init_all": (ctypes.c_int, [ctypes.POINTER(_handle_t), ctypes.c_int,
+                                        ctypes.POINTER(_handle_t)]),
+    "sc_comm_destroy": (ctypes.c_int, [_handle_t]),
+    "sc_comm_rank": (ctypes.c_int, [_handle_t]),
+    "sc_comm_size": (ctypes.c_int, [_handle_t]),
+    "sc_comm_last_error": (ctypes.c_char_p, [_handle_t]),
+    "sc_comm_broadcast": (ctypes.c_int, [_handle_t, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.c_int]),
+    "sc_comm_allgather": (ctypes.c_int, [_handle_t, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_size_t]),
+    "sc_comm_allreduce_max": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int]),
+    "sc_comm_barrier": (ctypes.c_int, [_handle_t]),
 }
 
 # custom_dist values that run on the device (scipy cdist names)

@@ -177,6 +177,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
+                    &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
                     &h->kcent, &h->klab32, &h->klab64, &h->kinfo};
   for (DevBuf* b : bufs)
@@ -480,9 +481,12 @@ extern "C" int sc_compute_affinity(sc_handle h) {
   h->affinity_from_embeddings = true;
   // CropDiagonal's fill value (max_{j != i} A_ij, >= 0) comes out of the GEMM epilogue
   GemmRowStats rs{2, ptr<double>(h->statp), nullptr, ptr<double>(h->cropval), nullptr};
+  h->aff_ev[0] = h->aff_ev[1] = -1;
+  if (h->profile_level >= 2) ev_rec(h, &h->aff_ev[0]);
   launch_gemm_nt(h->stream, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx,
                  ptr<double>(h->A0), h->ldn, h->n, h->n, h->d, kEpiAffinity, true,
                  ptr<double>(h->splitk), ptr<int2>(h->tilemap), &rs);
+  if (h->profile_level >= 2) ev_rec(h, &h->aff_ev[1]);
   SC_TRY(check_last(h, "affinity launch"));
   h->have_affinity = true;
   h->have_cropval = true;
@@ -513,20 +517,6 @@ extern "C" int sc_set_affinity(sc_handle h, const double* a, int n) {
 // ------------------------------------------------------------------------------
 // _compute_eigenvectors_ncluster
 // ------------------------------------------------------------------------------
-static void ev_rec(sc_handle h, int* slot) {
-  if (h->nev < 48) {
-    hipEventRecord(h->ev[h->nev], h->stream);
-    *slot = h->nev++;
-  } else {
-    *slot = -1;
-  }
-}
-static float ev_ms(sc_handle h, int a, int b) {
-  if (a < 0 || b < 0) return 0.f;
-  float ms = 0.f;
-  hipEventElapsedTime(&ms, h->ev[a], h->ev[b]);
-  return ms;
-}
 
 static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   const int n = h->n, ld = h->ldn;
@@ -538,6 +528,9 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   const bool constrain_after = constraint_active(h, cfg, false);
   bool folded_rownorm = false;
   int e_begin, e_after_refine;
+  const bool fine = h->profile_level >= 2;
+  int eb0 = -1, eb1 = -1, et0 = -1, et1 = -1;  // blur / threshold+symmetrize (last of each)
+  h->n_mv_ev = 0;
   float diffuse_ms_events[SC_MAX_OPS][2];
   int n_diffuse = 0;
   ev_rec(h, &e_begin);
@@ -581,9 +574,11 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
       SC_HIP(h, hipMemcpyAsync(h->blurw.p, cfg->blur_weights,
                                (2 * cfg->blur_radius + 1) * sizeof(double),
                                hipMemcpyHostToDevice, s));
+      if (fine) ev_rec(h, &eb0);
       have_partials = launch_gaussian_blur_fused(s, cur, out, n, ld, cfg->blur_radius,
                                                  ptr<double>(h->blurw), pending_diag,
                                                  want ? ptr<double>(h->rmpart) : nullptr);
+      if (fine) ev_rec(h, &eb1);
       pending_diag = nullptr;
       SC_TRY(check_last(h, "blur launch"));
     } else if (op == SC_OP_ROW_WISE_THRESHOLD && next == SC_OP_SYMMETRIZE && thr_sym_fusable) {
@@ -597,9 +592,11 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
       else
         launch_cut_from_rows(s, cur, n, ld, cfg->p_percentile, ptr<double>(h->cut),
                              cfg->preserve_diagonal);
+      if (fine) ev_rec(h, &et0);
       launch_threshold_symmetrize(s, cur, out, n, ld, ptr<double>(h->cut),
                                   cfg->soft_multiplier, cfg->binarize, cfg->symmetrize_type,
                                   cfg->preserve_diagonal);
+      if (fine) ev_rec(h, &et1);
       SC_TRY(check_last(h, "threshold+symmetrize launch"));
       have_partials = false;
       cur = out;
@@ -714,7 +711,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   EigDecision dc;
   std::vector<double> w;
   if (symmetric) {
-    SC_TRY(sym_topk(h, cur, ld, n, rq, diag, &dc, &w));
+    SC_TRY(sym_topk(h, cur, ld, n, rq, diag, &dc, &w, bufs[which]));
   } else {
     rq.decision_aware = 1;
     SC_TRY(gen_topk(h, cur, ld, n, cfg->laplacian_type, rq, diag, &dc, &w));
@@ -722,6 +719,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   int e_after_eig;
   ev_rec(h, &e_after_eig);
   SC_HIP(h, hipStreamSynchronize(s));
+  h->last_w = w;
   if (diag) {
     diag->n = n;
     diag->n_clusters_raw = dc.n_clusters_raw;
@@ -737,6 +735,13 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
     diag->stage_ms[SC_STAGE_REFINE] = ev_ms(h, e_begin, e_after_refine) - dms;
     diag->stage_ms[SC_STAGE_SCALING] = ev_ms(h, e_after_refine, e_after_scaling);
     diag->stage_ms[SC_STAGE_EIG] = ev_ms(h, e_after_scaling, e_after_eig);
+    if (fine) {
+      diag->stage_ms[SC_STAGE_BLUR] = ev_ms(h, eb0, eb1);
+      diag->stage_ms[SC_STAGE_THRESHOLD_SYM] = ev_ms(h, et0, et1);
+      float mv = 0.f;
+      for (int i = 0; i < h->n_mv_ev; ++i) mv += ev_ms(h, h->mv_ev[i][0], h->mv_ev[i][1]);
+      diag->stage_ms[SC_STAGE_MATVEC] = mv;
+    }
   }
   return SC_OK;
 }
@@ -752,6 +757,16 @@ extern "C" int sc_eig_ncluster(sc_handle h, const sc_config* cfg, sc_diag* diag)
 }
 
 extern "C" int sc_num_eigenvectors(sc_handle h) { return h ? h->n_vec : 0; }
+
+extern "C" int sc_num_eigenvalues(sc_handle h) { return h ? (int)h->last_w.size() : 0; }
+
+extern "C" int sc_get_eigenvalues(sc_handle h, double* out, int count) {
+  if (!h || !out) return SC_ERR_INVALID;
+  if (count < 0 || count > (int)h->last_w.size())
+    return fail(h, SC_ERR_INVALID, "eigenvalue request out of range");
+  for (int i = 0; i < count; ++i) out[i] = h->last_w[i];
+  return SC_OK;
+}
 
 extern "C" int sc_get_eigenvectors(sc_handle h, double* out, int n, int ncols) {
   if (!h || !out) return SC_ERR_INVALID;
@@ -881,6 +896,14 @@ extern "C" int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* label
   SC_HIP(h, hipStreamSynchronize(h->stream));
   dg->stage_ms[SC_STAGE_AFFINITY] = ev_ms(h, e0, e1);
   dg->stage_ms[SC_STAGE_TOTAL] = ev_ms(h, e0, e2);
+  if (h->profile_level >= 2)
+    dg->stage_ms[SC_STAGE_AFFINITY_GEMM] = ev_ms(h, h->aff_ev[0], h->aff_ev[1]);
+  return SC_OK;
+}
+
+extern "C" int sc_set_profiling(sc_handle h, int level) {
+  if (!h || level < 0 || level > 2) return SC_ERR_INVALID;
+  h->profile_level = level;
   return SC_OK;
 }
 
@@ -889,7 +912,8 @@ extern "C" int sc_predict(sc_handle h, const double* x, int n, int d, const sc_c
   if (!h) return SC_ERR_INVALID;
   SC_TRY(validate_config(h, cfg));
   SC_TRY(sc_set_embeddings(h, x, n, d));
-  return sc_run_resident(h, cfg, labels, diag);
+  return sc_run_resident(h, cfg, labels, diag);  // (the upload is outside stage_ms: it is
+                                                 // host-synchronous, time it on the host)
 }
 
 extern "C" int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,
@@ -969,8 +993,8 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   if (!h) return SC_ERR_INVALID;
   if (!m || n <= 0 || count <= 0 || count > n || !values)
     return fail(h, SC_ERR_INVALID, "bad eigen request");
-  if (n > kDenseMax && count > kMaxVectors)
-    return fail(h, SC_ERR_UNSUPPORTED, "at most 64 eigenpairs for n > 128");
+  if (n > kDenseMax && count > kMaxVectors && vectors)
+    return fail(h, SC_ERR_UNSUPPORTED, "at most 64 eigenvectors for n > 128");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
   const int ld = matrix_ld(n);
@@ -979,6 +1003,31 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   h->have_affinity = h->have_cropval = false;
   h->have_x = false;
   SC_TRY(h2d_matrix(h, m, n, n, ptr<double>(h->B1), ld));
+  if (n > kDenseMax && count > kMaxVectors) {
+    // values only, more than a Krylov basis holds: the dense full-spectrum path
+    // (Householder tridiagonalisation + Sturm bisection, eig_dense.hip)
+    SC_TRY(ensure_eig(h, n));
+    SC_TRY(grow(h, h->td_d, (size_t)n * sizeof(double)));
+    SC_TRY(grow(h, h->td_e, (size_t)n * sizeof(double)));
+    SC_TRY(grow(h, h->td_theta, (size_t)n * sizeof(double)));
+    SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 16) * sizeof(double)));
+    launch_tridiagonalize(h->stream, ptr<double>(h->B1), ld, n, ptr<double>(h->td_d),
+                          ptr<double>(h->td_e), ptr<double>(h->td_work));
+    launch_tridiagonal_eigenvalues(h->stream, ptr<double>(h->td_d), ptr<double>(h->td_e), n,
+                                   ptr<double>(h->td_theta), ptr<double>(h->td_work));
+    SC_TRY(check_last(h, "dense eigenvalue launch"));
+    std::vector<double> all(n);
+    SC_HIP(h, hipMemcpyAsync(all.data(), h->td_theta.p, (size_t)n * sizeof(double),
+                             hipMemcpyDeviceToHost, h->stream));
+    SC_HIP(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < count; ++i) values[i] = descend ? all[i] : all[n - 1 - i];
+    if (diag) {
+      memset(diag, 0, sizeof(*diag));
+      diag->n = n;
+      diag->eig_path = SC_EIG_PATH_DENSE_TRIDIAG;
+    }
+    return SC_OK;
+  }
   // Op = +M (descend) or -M (ascend): c = 1, p = 0, t = 1; the sign is folded by
   // running on sigma * M through c = 1 and a negated copy when ascending.
   const int nb = (n + 255) / 256;
@@ -1010,7 +1059,8 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   h->nev = 0;
   SC_TRY(ensure_eig(h, n));
   SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 12, 0, sizeof(int), h->stream));
-  SC_TRY(sym_topk(h, S, ld, n, rq, dg, &dc, &w));
+  SC_TRY(sym_topk(h, S, ld, n, rq, dg, &dc, &w,
+                  S == ptr<double>(h->B1) ? ptr<double>(h->B2) : ptr<double>(h->B1)));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < count; ++i) values[i] = w[i];
   if (vectors) {

@@ -125,16 +125,9 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
       }
     }
   }
-  if (!rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF && rq.fixed_count == 0) {
-    // np.max(eigenvalues): the far end of the spectrum only normalises the gaps (it
-    // cannot change n_clusters) and sits on the edge of a dense bulk where Krylov
-    // methods converge like 1/degree^2: accept a 1e-4 residual bound there.
-    const double tol = std::max(std::max(rq.value_tol, 1e-4) * std::fabs(w[m - 1]), floor_abs);
-    if (!(resid[m - 1] <= tol)) {
-      if (ok) { dc.fail_kind = 2; dc.fail_index = m - 1; }
-      ok = false;
-    }
-  }
+  // (np.max(eigenvalues) of the ascending NormalizedDiff branch is the far end of the
+  //  spectrum, on the edge of a dense bulk where Krylov methods converge like 1 / degree^2:
+  //  that request never reaches this loop -- sym_topk takes it from the dense path)
   for (int i = 0; i < dc.kvec; ++i) {
     if (!(resid[i] <= std::max(rq.vector_tol * scale, floor_abs))) {
       if (ok) { dc.fail_kind = 3; dc.fail_index = i; }
@@ -234,9 +227,48 @@ static void back_transform_cols(sc_handle h, int n, int cols) {
                         ptr<double>(h->tvec));
 }
 
+// Every eigenvalue of Op = diag(p) + diag(c) S diag(c), descending, into h->spectrum
+// (eig_dense.hip: Householder tridiagonalisation + Sturm bisection).  `scratch` (n x ld)
+// receives the materialised operator and is destroyed; S is left untouched.
+static int dense_spectrum(sc_handle h, const double* S, int ld, int n, double* scratch) {
+  hipStream_t s = h->stream;
+  if (scratch == nullptr || scratch == S)
+    return fail(h, SC_ERR_UNSUPPORTED, "no scratch matrix for the dense eigenvalue path");
+  SC_TRY(grow(h, h->td_d, (size_t)n * sizeof(double)));
+  SC_TRY(grow(h, h->td_e, (size_t)n * sizeof(double)));
+  SC_TRY(grow(h, h->td_theta, (size_t)n * sizeof(double)));
+  SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 16) * sizeof(double)));
+  launch_td_materialize(s, S, ld, n, ptr<double>(h->cvec), ptr<double>(h->pvec), scratch);
+  launch_tridiagonalize(s, scratch, ld, n, ptr<double>(h->td_d), ptr<double>(h->td_e),
+                        ptr<double>(h->td_work));
+  launch_tridiagonal_eigenvalues(s, ptr<double>(h->td_d), ptr<double>(h->td_e), n,
+                                 ptr<double>(h->td_theta), ptr<double>(h->td_work));
+  SC_TRY(check_last(h, "dense eigenvalue launch"));
+  h->spectrum.resize(n);
+  SC_HIP(h, hipMemcpyAsync(h->spectrum.data(), h->td_theta.p, (size_t)n * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipMemcpyAsync(h->h_flags + 12, ptr<int>(h->flags) + 12, sizeof(int),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipStreamSynchronize(s));
+  if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+  for (int i = 0; i < n; ++i)
+    if (!std::isfinite(h->spectrum[i])) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+  return SC_OK;
+}
+
+// Does the request read the whole spectrum (or its far end) exactly?
+static bool wants_full_spectrum(const EigRequest& rq) {
+  if (rq.fixed_count > 0 || rq.descend) return false;
+  // ascending: every eigenvalue when max_clusters is None (utils.py:100-115); the
+  // NormalizedDiff gap divides by np.max(eigenvalues), the far end of the spectrum, which
+  // no Krylov method resolves to 1e-5 on a dense bulk edge
+  return rq.max_clusters == 0 || rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF;
+}
+
 // S (n x n, ld) symmetric on the device; cvec/pvec/tvec already set.
-int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
-                    sc_diag* diag, EigDecision* out_dc, std::vector<double>* out_w) {
+int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_in,
+             sc_diag* diag, EigDecision* out_dc, std::vector<double>* out_w,
+             double* scratch) {
   hipStream_t s = h->stream;
   SC_TRY(ensure_eig(h, n));
   double* theta_d = ptr<double>(h->theta);
@@ -245,6 +277,26 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
   const double* pvec = ptr<double>(h->pvec);
   EigDecision dc;
   int m = 0, passes = 0, cycles = 0;
+  EigRequest rq = rq_in;
+  // Dense full-spectrum route (n > 128): all eigenvalues from the tridiagonal form, the
+  // eigengap decision from those, then the same Lanczos loop below for just the vectors.
+  EigDecision dense_dc;
+  bool dense = false;
+  auto run_dense = [&]() -> int {
+    SC_TRY(dense_spectrum(h, S, ld, n, scratch));
+    std::vector<double> zeros(n, 0.0);
+    dense_dc = analyze(rq_in, h->spectrum.data(), zeros.data(), n, n, true);
+    if (!dense_dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
+    if (dense_dc.kvec > kMaxVectors)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "the eigengap selects more than 64 clusters; set max_clusters");
+    dense = true;
+    rq = rq_in;
+    rq.fixed_count = std::max(1, dense_dc.kvec);  // vectors only
+    rq.value_tol = std::max(rq_in.value_tol, 1e-6);
+    return SC_OK;
+  };
+  if (n > kDenseMax && wants_full_spectrum(rq_in)) SC_TRY(run_dense());
 
   if (n <= kDenseMax) {
     // ---- direct dense path: every eigenpair, one Jacobi launch
@@ -268,10 +320,9 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
     if (diag) diag->eig_path = SC_EIG_PATH_DENSE_JACOBI;
     dc.kw = n;
   } else {
-    if (rq.fixed_count == 0 && rq.max_clusters == 0 && !rq.descend)
-      return fail(h, SC_ERR_UNSUPPORTED,
-                  "max_clusters=None with a Laplacian needs every eigenvalue; only "
-                  "supported for n <= 128 on the device path");
+  restart_lanczos:
+    m = 0;
+    cycles = 0;
     uint64_t seed = 0x5eed5eedull;
     // ---- start block
     launch_random_block(s, ptr<double>(h->W), n, seed);
@@ -284,8 +335,11 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
     bool done = false;
     while (!done) {
       // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
+      const bool time_mv = h->profile_level >= 2 && h->n_mv_ev < 16;
+      if (time_mv) ev_rec(h, &h->mv_ev[h->n_mv_ev][0]);
       launch_block_matvec(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
                           ptr<double>(h->Vs), ptr<double>(h->W));
+      if (time_mv) ev_rec(h, &h->mv_ev[h->n_mv_ev++][1]);
       ++passes;
       m += kEigBlock;
       SC_TRY(orthonormalize(h, n, m, true, m - kEigBlock, m, true));
@@ -323,10 +377,13 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
                   h->h_theta[kLdq + m - 1]);
           (void)wr; (void)worst;
         }
-        if (dc.unsupported)
-          return fail(h, SC_ERR_UNSUPPORTED,
-                      "more than 64 eigenvalues are needed (max_clusters=None with a "
-                      "slowly decaying spectrum); set max_clusters");
+        if (dc.unsupported) {
+          // more than 64 eigenvalues are read (max_clusters=None with a slowly decaying
+          // spectrum): take all of them from the dense path, then come back for the vectors
+          if (dense) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
+          SC_TRY(run_dense());
+          goto restart_lanczos;
+        }
         if (dc.enough && dc.converged) {
           done = true;
           break;
@@ -339,10 +396,6 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
         int want = dc.enough ? std::max(dc.kw, dc.kvec) : cap / 4;
         int keep = round_up(want + kEigBlock, kEigBlock);
         keep = std::max(kEigBlock, std::min(keep, cap - 2 * kEigBlock));
-        if (!rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF &&
-            rq.fixed_count == 0 && keep < m)
-          // np.max(eigenvalues) is the far end of the spectrum: keep that Ritz pair too
-          launch_swap_ritz(s, ptr<double>(h->Y), kLdq, m, theta_d, keep - 1, m - 1);
         launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, keep,
                              ptr<double>(h->Q2), kLdq, n, 0);
         launch_copy_block(s, ptr<double>(h->Q) + m, kLdq, ptr<double>(h->Q2) + keep, kLdq, n,
@@ -359,9 +412,20 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq,
     back_transform_cols(h, n, cols);
     SC_TRY(check_last(h, "ritz vector launch"));
     h->n_vec = cols;
-    if (diag) diag->eig_path = SC_EIG_PATH_BLOCK_LANCZOS;
+    if (diag) diag->eig_path = dense ? SC_EIG_PATH_DENSE_TRIDIAG : SC_EIG_PATH_BLOCK_LANCZOS;
   }
-  if (out_w) {
+  if (dense) {
+    // values and the eigengap decision come from the full spectrum; the Lanczos pass above
+    // only supplied the vectors
+    const double vec_resid = dc.max_resid;
+    dc = dense_dc;
+    dc.converged = true;
+    dc.max_resid = vec_resid;
+    if (out_w) {  // the whole spectrum is known: report all of it (np.max included)
+      out_w->resize(n);
+      for (int i = 0; i < n; ++i) (*out_w)[i] = rq.descend ? h->spectrum[i] : -h->spectrum[i];
+    }
+  } else if (out_w) {
     out_w->resize(dc.kw);
     for (int i = 0; i < dc.kw; ++i) (*out_w)[i] = rq.descend ? h->h_theta[i] : -h->h_theta[i];
   }

@@ -52,6 +52,10 @@ struct sc_handle_s {
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
       flags;
   DevBuf E, Ek, Eio;      // eigenvectors (col-major), renormed copy, row-major I/O staging
+  // dense full-spectrum path (eig_dense.hip): d, e, all eigenvalues, reflector work vectors
+  DevBuf td_d, td_e, td_theta, td_work;
+  std::vector<double> spectrum;  // host copy: every eigenvalue of Op, descending
+  std::vector<double> last_w;    // eigenvalues the last eig call consumed (reference order)
   // general (non-symmetric) eigen path: right scaling, Im(theta), complex Ritz vectors
   // (column-major), residual partials, restart codes, dense Laplacian scratch
   DevBuf crvec, thetai, Vre, Vim, gpart, gsrc, genL;
@@ -65,7 +69,27 @@ struct sc_handle_s {
   int* h_flags = nullptr;
   hipEvent_t ev[48];
   int nev = 0;
+  int profile_level = 1;  // sc_set_profiling: 0 totals only, 1 stages, 2 per-kernel events
+  int mv_ev[16][2];       // event pairs around the block matvec launches (level 2)
+  int n_mv_ev = 0;
+  int aff_ev[2] = {-1, -1};  // around the affinity GEMM launch (level 2)
 };
+
+// hipEvent slots of the current call (reset by the entry points); -1 when exhausted
+inline void ev_rec(sc_handle h, int* slot) {
+  if (h->nev < 48) {
+    hipEventRecord(h->ev[h->nev], h->stream);
+    *slot = h->nev++;
+  } else {
+    *slot = -1;
+  }
+}
+inline float ev_ms(sc_handle h, int a, int b) {
+  if (a < 0 || b < 0) return 0.f;
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, h->ev[a], h->ev[b]);
+  return ms;
+}
 
 constexpr int kMaxCols = 128;  // eigenvector columns the arena can hold
 // Leading dimension of the n x n matrices.  A row stride that is a multiple of 4 KiB maps
@@ -178,8 +202,9 @@ struct EigDecision {
   int fail_index = -1;
 };
 
+// `scratch`: a free n x ld matrix (the dense full-spectrum path materialises Op there)
 int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq, sc_diag* diag,
-             EigDecision* out_dc, std::vector<double>* out_w);
+             EigDecision* out_dc, std::vector<double>* out_w, double* scratch);
 int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
              const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
              std::vector<double>* out_w);

@@ -176,6 +176,18 @@ void launch_rowmajor_to_colmajor(hipStream_t s, const double* src, int lds, int 
 void launch_colmajor_to_rowmajor(hipStream_t s, const double* src, int lds, int n, int cols,
                                  double* dst, int ldd);
 
+// ---- dense full-spectrum symmetric path, eig_dense.hip ------------------------------
+// M = diag(p) + diag(c) S diag(c), exactly symmetric
+void launch_td_materialize(hipStream_t s, const double* S, int ld, int n, const double* c,
+                           const double* p, double* M);
+// Householder tridiagonalisation of A (n x n, ld; destroyed): d[0..n), e[0..n-1).
+// work: 4 n + 8 doubles.  2 n launches.
+void launch_tridiagonalize(hipStream_t s, double* A, int ld, int n, double* d, double* e,
+                           double* work);
+// all eigenvalues of the tridiagonal (d, e) by Sturm bisection, DESCENDING; work: n + 4
+void launch_tridiagonal_eigenvalues(hipStream_t s, const double* d, const double* e, int n,
+                                    double* theta_desc, double* work);
+
 // ---- general (non-symmetric) eigen path, eig_general.hip ---------------------------
 // Dense complex-Schur eigensolver, one wavefront, order m <= kGenMax: eigenvalues of
 // sign * A sorted by real part (descending) into theta_re / theta_im, the first `nvec`

@@ -7,14 +7,21 @@ dependent.  What shards are the *units* around it:
   * batched utterances  -> `predict_batch_sharded`  (LPT by an n^3 cost model)
   * AutoTune p sweeps   -> `autotune_sharded`       (p-grid round-robin)
 
-One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI on the
-GPU box, "gloo" in the CPU tests).  Collectives are the bare minimum: broadcast of
-inputs from rank 0, all_gather of results (labels / three scalars per p).  The
-compute itself is a callable, so the plumbing is testable without a GPU.
+One process per GPU.  Communication goes through a `Comm`: on the GPU box that is
+`RcclComm` -- RCCL over xGMI behind the C ABI (`sc_comm_*` in
+include/spectralcluster_amd.h), no PyTorch.  The collectives are the bare minimum:
+broadcast of inputs from rank 0, all-gather of results (labels / two scalars per p),
+a max-reduce for timing.  Every function here takes the `Comm` and the per-unit
+compute as arguments, so the partitioning logic is testable on CPU with any
+byte-level transport (tests/ plugs in a gloo adapter for world size 2).
 """
 
 from __future__ import annotations
 
+import ctypes
+import os
+import struct
+import time
 import typing
 
 import numpy as np
@@ -40,102 +47,242 @@ def lpt_assignment(sizes: typing.Sequence[int], world: int) -> typing.List[typin
   return owned
 
 
-def _dist():
-  import torch.distributed as dist
-  if not (dist.is_available() and dist.is_initialized()):
-    raise RuntimeError("torch.distributed is not initialised")
-  return dist
+# --------------------------------------------------------------------------------
+# communicators
+# --------------------------------------------------------------------------------
+class Comm:
+  """Byte-level collectives between `size` ranks (this process is `rank`)."""
+  rank = 0
+  size = 1
+
+  def broadcast_bytes(self, data: typing.Optional[bytes], nbytes: int, root: int = 0) -> bytes:
+    """`data` (nbytes long) on `root`; returns root's bytes on every rank."""
+    raise NotImplementedError
+
+  def allgather_bytes(self, data: bytes) -> typing.List[bytes]:
+    """Every rank contributes the same number of bytes; returns them in rank order."""
+    raise NotImplementedError
+
+  def allreduce_max(self, value: float) -> float:
+    raise NotImplementedError
+
+  def barrier(self) -> None:
+    self.allreduce_max(0.0)
+
+  def close(self) -> None:
+    pass
 
 
-def _device_for_backend(dist):
-  import torch
-  if dist.get_backend() == "nccl":
-    return torch.device("cuda", torch.cuda.current_device())
-  return torch.device("cpu")
+class LocalComm(Comm):
+  """World of one: every collective is the identity."""
+
+  def broadcast_bytes(self, data, nbytes, root=0):
+    return bytes(data)
+
+  def allgather_bytes(self, data):
+    return [bytes(data)]
+
+  def allreduce_max(self, value):
+    return float(value)
 
 
-def broadcast_array(arr: typing.Optional[np.ndarray], src: int = 0) -> np.ndarray:
-  """Broadcast a float64/int64 ndarray from `src` (shape first, then data)."""
-  import torch
-  dist = _dist()
-  dev = _device_for_backend(dist)
-  rank = dist.get_rank()
-  meta = torch.zeros(9, dtype=torch.int64, device=dev)
-  if rank == src:
+def _id_file() -> str:
+  """Where rank 0 leaves the RCCL unique id for the other ranks of this launch.  All
+  ranks of one `torch.distributed.run` / mpirun launch share a parent process and a
+  MASTER_PORT, which makes the name unique per launch on the node."""
+  explicit = os.environ.get("SC_COMM_ID_FILE")
+  if explicit:
+    return explicit
+  tag = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+  return os.path.join(os.environ.get("TMPDIR", "/tmp"), "sc_comm_%s.id" % tag)
+
+
+class RcclComm(Comm):
+  """RCCL communicator behind the C ABI (`sc_comm_*`), one rank per GPU."""
+
+  def __init__(self, handle, rank: int, size: int, unique_id: bytes):
+    from spectralcluster_amd import _lib
+    self._lib = handle.lib
+    self._handle = handle  # keeps the device handle (stream) alive
+    self.rank, self.size = int(rank), int(size)
+    c = ctypes.c_void_p()
+    rc = self._lib.sc_comm_init_rank(handle.raw, self.size, self.rank, unique_id,
+                                     ctypes.byref(c))
+    if rc != _lib.SC_OK:
+      raise _lib.DeviceLibraryError("sc_comm_init_rank failed (%d): %s"
+                                    % (rc, handle.last_error()))
+    self._c = c
+
+  @staticmethod
+  def new_unique_id() -> bytes:
+    from spectralcluster_amd import _lib
+    buf = ctypes.create_string_buffer(128)
+    rc = _lib.load().sc_comm_unique_id(buf)
+    if rc != _lib.SC_OK:
+      raise _lib.DeviceLibraryError("sc_comm_unique_id failed (%d): is librccl present?" % rc)
+    return buf.raw
+
+  @classmethod
+  def from_env(cls, handle, timeout_s: float = 120.0) -> "Comm":
+    """Communicator of the launch described by RANK / WORLD_SIZE (what
+    `python -m torch.distributed.run` exports).  World size 1 needs no RCCL."""
+    size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if size == 1:
+      return LocalComm()
+    path = _id_file()
+    if rank == 0:
+      uid = cls.new_unique_id()
+      tmp = "%s.%d.tmp" % (path, os.getpid())
+      with open(tmp, "wb") as f:
+        f.write(uid)
+      os.replace(tmp, path)  # atomic: readers never see a partial id
+    else:
+      deadline = time.monotonic() + timeout_s
+      while True:
+        try:
+          with open(path, "rb") as f:
+            uid = f.read()
+          if len(uid) == 128:
+            break
+        except FileNotFoundError:
+          pass
+        if time.monotonic() > deadline:
+          raise TimeoutError("rank %d: no RCCL unique id at %s" % (rank, path))
+        time.sleep(0.01)
+    comm = cls(handle, rank, size, uid)
+    comm.barrier()  # everyone has read the id
+    if rank == 0:
+      try:
+        os.unlink(path)
+      except OSError:
+        pass
+    return comm
+
+  def _check(self, rc, what):
+    if rc != 0:
+      from spectralcluster_amd import _lib
+      msg = self._lib.sc_comm_last_error(self._c)
+      raise _lib.DeviceLibraryError("%s failed (%d): %s"
+                                    % (what, rc, msg.decode() if msg else ""))
+
+  def broadcast_bytes(self, data, nbytes, root=0):
+    buf = ctypes.create_string_buffer(int(nbytes))
+    if self.rank == root:
+      buf.raw = bytes(data)
+    self._check(self._lib.sc_comm_broadcast(self._c, buf, int(nbytes), int(root)),
+                "sc_comm_broadcast")
+    return buf.raw
+
+  def allgather_bytes(self, data):
+    data = bytes(data)
+    out = ctypes.create_string_buffer(len(data) * self.size)
+    self._check(self._lib.sc_comm_allgather(self._c, data, out, len(data)),
+                "sc_comm_allgather")
+    raw = out.raw
+    return [raw[r * len(data):(r + 1) * len(data)] for r in range(self.size)]
+
+  def allreduce_max(self, value):
+    v = (ctypes.c_double * 1)(float(value))
+    self._check(self._lib.sc_comm_allreduce_max(self._c, v, 1), "sc_comm_allreduce_max")
+    return float(v[0])
+
+  def close(self):
+    if getattr(self, "_c", None):
+      self._lib.sc_comm_destroy(self._c)
+      self._c = None
+
+
+# --------------------------------------------------------------------------------
+# collectives on arrays
+# --------------------------------------------------------------------------------
+_DTYPES = [np.float64, np.int64, np.int32, np.int8, np.uint8]
+
+
+def broadcast_array(comm: Comm, arr: typing.Optional[np.ndarray], root: int = 0) -> np.ndarray:
+  """Broadcast an ndarray from `root` (a 72-byte header -- ndim, dtype, shape -- then the
+  data).  Used for embeddings (n*d*8 bytes) and packed configs."""
+  if comm.rank == root:
     a = np.ascontiguousarray(arr)
-    meta[0] = a.ndim
-    meta[1] = 0 if a.dtype == np.float64 else 1
-    for i, s in enumerate(a.shape):
-      meta[2 + i] = s
-  dist.broadcast(meta, src)
-  m = meta.cpu().tolist()
-  shape = tuple(int(v) for v in m[2:2 + int(m[0])])
-  dtype = torch.float64 if m[1] == 0 else torch.int64
-  if rank == src:
-    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    code = [i for i, t in enumerate(_DTYPES) if a.dtype == t]
+    if not code or a.ndim > 7:
+      raise TypeError("broadcast_array: unsupported dtype/rank %s %d" % (a.dtype, a.ndim))
+    header = struct.pack("<9q", a.ndim, code[0], *(list(a.shape) + [0] * (7 - a.ndim)))
   else:
-    t = torch.empty(shape, dtype=dtype, device=dev)
-  dist.broadcast(t, src)
-  return t.cpu().numpy()
+    a, header = None, None
+  header = comm.broadcast_bytes(header, 72, root)
+  meta = struct.unpack("<9q", header)
+  shape = tuple(int(v) for v in meta[2:2 + meta[0]])
+  dtype = np.dtype(_DTYPES[meta[1]])
+  nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+  if nbytes == 0:
+    return np.empty(shape, dtype=dtype)
+  payload = comm.broadcast_bytes(a.tobytes() if comm.rank == root else None, nbytes, root)
+  return np.frombuffer(payload, dtype=dtype).reshape(shape).copy()
 
 
 def predict_batch_sharded(
+    comm: Comm,
     predict_fn: typing.Optional[typing.Callable[[np.ndarray], np.ndarray]],
-    utterances: typing.Sequence[np.ndarray],
-    predict_many_fn: typing.Optional[typing.Callable] = None) -> typing.List[np.ndarray]:
+    utterances,
+    predict_many_fn: typing.Optional[typing.Callable] = None,
+    sizes: typing.Optional[typing.Sequence[int]] = None) -> typing.List[np.ndarray]:
   """Every rank holds (or has been broadcast) the same utterance list; rank r runs
   `predict_fn` on its LPT share (or `predict_many_fn(list_of_arrays) -> list_of_labels`
-  on the whole share at once, e.g. a multi-stream batch) and the int64 labels are
-  all-gathered (padded to the longest utterance).  Every rank returns the complete,
-  input-ordered result."""
-  import torch
-  dist = _dist()
-  world, rank = dist.get_world_size(), dist.get_rank()
-  dev = _device_for_backend(dist)
-  sizes = [int(u.shape[0]) for u in utterances]
+  on the whole share at once, e.g. a multi-stream batch).  With `sizes` given (the
+  n_samples of every utterance), `utterances` only needs to hold this rank's share
+  (`utterances[i]` for the i it owns) -- the partition depends on the sizes alone.  The
+  labels travel as one ragged int32 slab per rank (the concatenation of its share, padded
+  to the longest slab: O(total samples), not O(slots x longest utterance)).  Every rank
+  returns the complete, input-ordered result."""
+  world, rank = comm.size, comm.rank
+  sizes = ([int(u.shape[0]) for u in utterances] if sizes is None
+           else [int(v) for v in sizes])
   owned = lpt_assignment(sizes, world)
-  slots = max((len(o) for o in owned), default=0)
-  longest = max(sizes, default=0)
-  mine = torch.full((slots, longest), -1, dtype=torch.int64, device=dev)
+  slab_len = max((sum(sizes[i] for i in o) for o in owned), default=0)
   if predict_many_fn is not None:
     local = predict_many_fn([utterances[idx] for idx in owned[rank]])
   else:
     local = [predict_fn(utterances[idx]) for idx in owned[rank]]
-  for s, lab in enumerate(local):
-    lab = np.asarray(lab, dtype=np.int64)
-    mine[s, :lab.shape[0]] = torch.from_numpy(lab).to(dev)
-  gathered = [torch.empty_like(mine) for _ in range(world)]
-  dist.all_gather(gathered, mine)
-  out = [None] * len(utterances)
+  mine = np.full(slab_len, -1, dtype=np.int32)
+  pos = 0
+  for idx, lab in zip(owned[rank], local):
+    lab = np.asarray(lab)
+    if lab.shape[0] != sizes[idx]:
+      raise ValueError("predict returned %d labels for an utterance of %d"
+                       % (lab.shape[0], sizes[idx]))
+    mine[pos:pos + sizes[idx]] = lab
+    pos += sizes[idx]
+  slabs = comm.allgather_bytes(mine.tobytes())
+  out = [None] * len(sizes)
   for r in range(world):
-    block = gathered[r].cpu().numpy()
-    for s, idx in enumerate(owned[r]):
-      out[idx] = block[s, :sizes[idx]].copy()
+    block = np.frombuffer(slabs[r], dtype=np.int32)
+    pos = 0
+    for idx in owned[r]:
+      out[idx] = block[pos:pos + sizes[idx]].astype(np.int64)
+      pos += sizes[idx]
   return out
 
 
 def autotune_sharded(
+    comm: Comm,
     evaluate_fn: typing.Callable[[float], typing.Tuple[float, int]],
     grid: typing.Sequence[float]) -> typing.Tuple[np.ndarray, np.ndarray]:
   """One AutoTune search level (reference autotune.py:98-111): rank r evaluates
   grid[r::world]; `evaluate_fn(p) -> (ratio, n_clusters)`.  Returns the full
-  (ratios, n_clusters) arrays on every rank (all_gather of 2 scalars per p)."""
-  import torch
-  dist = _dist()
-  world, rank = dist.get_world_size(), dist.get_rank()
-  dev = _device_for_backend(dist)
+  (ratios, n_clusters) arrays on every rank (all-gather of 2 doubles per p)."""
+  world, rank = comm.size, comm.rank
   per = (len(grid) + world - 1) // world
-  mine = torch.full((per, 2), float("nan"), dtype=torch.float64, device=dev)
+  mine = np.full((per, 2), np.nan)
   for s, i in enumerate(range(rank, len(grid), world)):
     ratio, k = evaluate_fn(float(grid[i]))
     mine[s, 0] = float(ratio)
     mine[s, 1] = float(k)
-  gathered = [torch.empty_like(mine) for _ in range(world)]
-  dist.all_gather(gathered, mine)
+  blocks = comm.allgather_bytes(mine.tobytes())
   ratios = np.full(len(grid), np.nan)
   ks = np.zeros(len(grid), dtype=np.int64)
   for r in range(world):
-    block = gathered[r].cpu().numpy()
+    block = np.frombuffer(blocks[r], dtype=np.float64).reshape(per, 2)
     for s, i in enumerate(range(r, len(grid), world)):
       ratios[i] = block[s, 0]
       ks[i] = int(block[s, 1])
@@ -155,43 +302,59 @@ def first_strict_minimum(ratios: np.ndarray) -> int:
 # --------------------------------------------------------------------------------
 # thin wrappers around a SpectralClusterer (device compute on this rank's GPU)
 # --------------------------------------------------------------------------------
-def predict_batch_distributed(clusterer, utterances: typing.Sequence[np.ndarray],
+def predict_batch_distributed(comm: Comm, clusterer,
+                              utterances: typing.Sequence[np.ndarray],
                               streams: int = 4) -> typing.List[np.ndarray]:
   """BASELINE config 5: utterances partitioned over the ranks (LPT), each rank runs its
   share as a multi-stream batch on its own GPU, labels all-gathered."""
   return predict_batch_sharded(
-      None, utterances,
+      comm, None, utterances,
       predict_many_fn=lambda share: clusterer.predict_batch(share, streams=streams))
 
 
-def predict_autotune_distributed(clusterer, embeddings: np.ndarray) -> np.ndarray:
+def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
+                                 constraint_matrix=None) -> np.ndarray:
   """BASELINE config 4: every rank holds the embeddings (broadcast them first if only
   rank 0 has them), recomputes the affinity locally (cheaper than shipping n^2 doubles),
   evaluates its share of each AutoTune search level, all-gathers (ratio, n_clusters),
   and every rank finishes with the winner's eigenvectors + k-means: identical labels
-  everywhere, no n x n or n x k matrix ever crosses xGMI."""
-  import ctypes
+  everywhere, no n x n or n x k matrix ever crosses xGMI.  Constraints are handled as in
+  predict() (reference spectral_clusterer.py:259-264, 137-142)."""
   from spectralcluster_amd import _lib
   tuner = clusterer.autotune
   if tuner is None:
     raise ValueError("clusterer.autotune is not set")
   handle = clusterer._handle()
-  clusterer._scope_check()
+  n = embeddings.shape[0]
+  constrained = clusterer._set_constraint(handle, n, constraint_matrix)
   clusterer._upload(handle, embeddings)
+  if constrained and clusterer.constraint_options.apply_before_refinement:
+    handle.check(handle.lib.sc_apply_constraint(handle.raw, clusterer.build_config()))
 
   def evaluate(p):
-    diag = clusterer._eig_resident(handle, p)
-    return tuner.ratio(p, diag.max_delta), int(diag.n_clusters_raw)
+    # a rank that fails mid-sweep must still reach the all-gather, or the others hang:
+    # report NaN and raise after the level
+    try:
+      diag = clusterer._eig_resident(handle, p)
+      return tuner.ratio(p, diag.max_delta), int(diag.n_clusters_raw)
+    except Exception as exc:  # pylint: disable=broad-except
+      evaluate.error = exc
+      return float("nan"), 0
+
+  evaluate.error = None
 
   def evaluate_many(ps):
-    ratios, ks = autotune_sharded(evaluate, ps)
+    ratios, ks = autotune_sharded(comm, evaluate, ps)
+    if evaluate.error is not None:
+      raise evaluate.error
+    if np.isnan(ratios).any():
+      raise RuntimeError("an AutoTune evaluation failed on another rank")
     return [(float(r), p, int(k)) for r, p, k in zip(ratios, ps, ks)]
 
   _, n_clusters, best_p = tuner.tune(None, evaluate_many=evaluate_many)
   diag = clusterer._eig_resident(handle, best_p)
   if clusterer.min_clusters is not None:
     n_clusters = max(n_clusters, clusterer.min_clusters)
-  n = embeddings.shape[0]
   labels = np.empty(n, dtype=np.int64)
   handle.check(handle.lib.sc_cluster(handle.raw, clusterer.build_config(best_p), n_clusters,
                                      _lib.as_int64_p(labels), diag))

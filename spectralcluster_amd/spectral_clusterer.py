@@ -83,11 +83,6 @@ class SpectralClusterer:
   def _handle(self) -> _lib.Handle:
     return _lib.default_handle(self.device)
 
-  def _scope_check(self, constraint_matrix=None):
-    """Nothing of the constructor surface is out of the device scope any more, except
-    non-cosine k-means (checked in predict)."""
-    del constraint_matrix
-
   def build_config(self, p_percentile: typing.Optional[float] = None) -> _lib.ScConfig:
     """Flatten the constructor arguments into an `sc_config`."""
     cfg = _lib.ScConfig()
@@ -123,9 +118,9 @@ class SpectralClusterer:
       handle.check(handle.lib.sc_clear_constraint(handle.raw))
       return False
     con = np.asarray(constraint_matrix)
-    # ConstraintOperation.check_input against the (n, n) affinity
-    self.constraint_options.constraint_operator.check_input(np.empty((n, n), dtype=bool),
-                                                            con)
+    # ConstraintOperation.check_input against the (n, n) affinity: only its shape is read
+    self.constraint_options.constraint_operator.check_input(
+        np.lib.stride_tricks.as_strided(np.zeros(1, dtype=bool), (n, n), (0, 0)), con)
     con = np.ascontiguousarray(con, dtype=np.float64)
     handle.check(handle.lib.sc_set_constraint(handle.raw, _lib.as_double_p(con), n))
     return True
@@ -149,6 +144,16 @@ class SpectralClusterer:
     self.last_diag = diag
     return diag
 
+  def consumed_eigenvalues(self) -> np.ndarray:
+    """Every eigenvalue the last eigen call consumed, in the reference's order
+    (`compute_sorted_eigenvectors`, utils.py:62-70): max_clusters + 1 of them, or all n
+    with max_clusters=None and a Laplacian (`last_diag.eigenvalues` holds at most 128)."""
+    handle = self._handle()
+    count = handle.lib.sc_num_eigenvalues(handle.raw)
+    out = np.empty(count, dtype=np.float64)
+    handle.check(handle.lib.sc_get_eigenvalues(handle.raw, _lib.as_double_p(out), count))
+    return out
+
   def _download_eigenvectors(self, handle: _lib.Handle, n: int,
                              cols: typing.Optional[int] = None) -> np.ndarray:
     have = handle.lib.sc_num_eigenvectors(handle.raw)
@@ -167,9 +172,10 @@ class SpectralClusterer:
 
     Returns (eigenvectors, n_clusters, max_delta_norm).  For n <= 128 the
     eigenvector matrix is (n, n) like the reference's; above that it has only the
-    columns the eigengap search can select (max_clusters + 1, at most 64).
+    columns the eigengap search can select (max_clusters + 1, at most 64; with
+    max_clusters=None and a Laplacian -- where every eigenvalue is read, from the dense
+    tridiagonalisation path -- the max(n_clusters, min_clusters) columns predict() uses).
     """
-    self._scope_check(constraint_matrix)
     a = np.ascontiguousarray(affinity, dtype=np.float64)
     if a.ndim != 2 or a.shape[0] != a.shape[1]:
       raise ValueError("affinity must be a square matrix")
@@ -197,7 +203,6 @@ class SpectralClusterer:
       raise TypeError("embeddings must be a numpy array")
     if len(embeddings.shape) != 2:
       raise ValueError("embeddings must be 2-dimensional")
-    self._scope_check(constraint_matrix)
     n = embeddings.shape[0]
     if n < self.fallback_options.spectral_min_embeddings:
       # too few embeddings for spectral clustering (reference :229-233)
@@ -317,9 +322,14 @@ class SpectralClusterer:
     thread per handle (ctypes releases the GIL during the calls).
     """
     if (self.autotune is not None or self.max_spectral_size is not None or
-        self.min_clusters == 1 or self.fallback_options.spectral_min_embeddings > 1):
+        self.min_clusters == 1 or self.fallback_options.spectral_min_embeddings > 1 or
+        self.affinity_function is not utils.compute_affinity_matrix or
+        self.post_eigen_cluster_function is not custom_distance_kmeans.run_kmeans):
+      # anything sc_predict_batch does not cover (user-supplied affinity / clustering
+      # functions, AutoTune, size reduction, fallback decisions) goes through predict().
+      # A batch never carries a constraint matrix -- same as predict(u) without one.
       return [self.predict(u) for u in utterances]
-    self._scope_check()
+    _lib.kmeans_metric_code(self.custom_dist)  # raises for metrics that are not on the device
     if not utterances:
       return []
     for u in utterances:

@@ -1,7 +1,8 @@
-"""CPU, world_size 2, backend gloo: the multi-GPU partitioning layer
-(`spectralcluster_amd/multigpu.py`).  The per-unit compute is injected (here the
-CPU oracle on tiny problems) so that sharding, broadcast and gather are exercised
-exactly as they run over RCCL on the GPU box."""
+"""CPU, world_size 2: the multi-GPU partitioning layer (`spectralcluster_amd/multigpu.py`).
+The per-unit compute is injected (here the CPU oracle on tiny problems) and the byte
+transport is a gloo adapter (tests/_gloo_comm.py), so that sharding, broadcast and gather
+run exactly the code that sits on RCCL (`multigpu.RcclComm`, C ABI `sc_comm_*`) on the GPU
+box."""
 
 import os
 import socket
@@ -24,17 +25,21 @@ def _free_port():
 def _worker(rank, world, port, out_dir):
   sys.path.insert(0, ROOT)
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   import torch.distributed as dist
   import spectral_oracle as so
   from spectralcluster_amd import multigpu
+  import _gloo_comm
   dist.init_process_group("gloo", rank=rank, world_size=world)
   try:
+    comm = _gloo_comm.GlooComm()
+    assert comm.allreduce_max(float(rank)) == world - 1
     cfg = so.icassp2018_config()
     # --- broadcast: only rank 0 has the data
     x0 = so.blobs(90, 8, 3, seed=1) if rank == 0 else None
-    x = multigpu.broadcast_array(x0)
+    x = multigpu.broadcast_array(comm, x0)
     assert x.shape == (90, 8) and np.array_equal(x, so.blobs(90, 8, 3, seed=1))
     # --- batched utterances: LPT shard + all_gather of ragged labels
     sizes = [60, 35, 80, 50, 45]
@@ -45,7 +50,7 @@ def _worker(rank, world, port, out_dir):
       ran.append(u.shape[0])
       return so.predict(u, cfg)
 
-    got = multigpu.predict_batch_sharded(predict_fn, utts)
+    got = multigpu.predict_batch_sharded(comm, predict_fn, utts)
     want = [so.predict(u, cfg) for u in utts]
     for g, w in zip(got, want):
       assert g.dtype == np.int64 and np.array_equal(g, w)
@@ -61,7 +66,7 @@ def _worker(rank, world, port, out_dir):
       _, k, delta = so.eig_ncluster(a, dataclasses.replace(gcfg, p_percentile=p))
       return np.sqrt(1 - p) / delta, k
 
-    ratios, ks = multigpu.autotune_sharded(evaluate, grid)
+    ratios, ks = multigpu.autotune_sharded(comm, evaluate, grid)
     _, _, best_p, seen = so.autotune_search(a, gcfg, 0.55, 0.95, 0.05)
     np.testing.assert_allclose(ratios, [seen[p] for p in grid], rtol=1e-12)
     assert grid[multigpu.first_strict_minimum(ratios)] == best_p
@@ -77,3 +82,33 @@ def test_world_size_2_gloo(tmp_path):
   r0 = np.load(tmp_path / "ok_0.npy")
   r1 = np.load(tmp_path / "ok_1.npy")
   assert np.array_equal(r0, r1)  # every rank ends with the same, complete answer
+
+
+def test_local_comm_is_identity():
+  """World of one (what bench.py --gpus 1 and single-GPU users get): no transport."""
+  sys.path.insert(0, ROOT)
+  from spectralcluster_amd import multigpu
+  comm = multigpu.LocalComm()
+  a = np.arange(12, dtype=np.float64).reshape(3, 4)
+  assert np.array_equal(multigpu.broadcast_array(comm, a), a)
+  labs = multigpu.predict_batch_sharded(
+      comm, lambda u: np.arange(u.shape[0]) % 3, [np.zeros((5, 2)), np.zeros((9, 2))])
+  assert [l.tolist() for l in labs] == [[0, 1, 2, 0, 1], [0, 1, 2, 0, 1, 2, 0, 1, 2]]
+  assert labs[0].dtype == np.int64
+  ratios, ks = multigpu.autotune_sharded(comm, lambda p: (1.0 - p, 3), [0.5, 0.7])
+  assert ratios.tolist() == [0.5, 1.0 - 0.7] and ks.tolist() == [3, 3]
+
+
+def test_product_code_never_imports_torch():
+  """north_star: Python host + C ABI, no PyTorch -- neither the package nor bench.py."""
+  import re
+  offenders = []
+  files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+  for dirpath, _, names in os.walk(os.path.join(ROOT, "spectralcluster_amd")):
+    files += [os.path.join(dirpath, f) for f in names if f.endswith(".py")]
+  for path in files:
+    with open(path) as f:
+      for line in f:
+        if re.match(r"\s*(import|from)\s+torch\b", line):
+          offenders.append(path)
+  assert not offenders, offenders

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), name
   assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-  assert lib.sc_abi_version() == 2
+  assert lib.sc_abi_version() == 3
 
 
 def test_graft_entry_build_runs():
@@ -349,3 +349,39 @@ def test_predict_validation_happens_before_the_device():
                  dict(max_spectral_size=4, min_clusters=4)):
     with pytest.raises(ValueError, match="max_spectral_size should be a relatively big"):
       sca.SpectralClusterer(**kwargs).predict(np.zeros((20, 2)))
+
+
+def test_predict_batch_falls_back_to_predict_for_custom_functions(monkeypatch):
+  """sc_predict_batch runs the device cosine affinity + device k-means; a clusterer built
+  with a user affinity_function / post_eigen_cluster_function (or a k-means metric that is
+  not on the device) must not be routed there silently."""
+  seen = []
+
+  def fake_predict(self, u, constraint_matrix=None):
+    seen.append(u.shape[0])
+    return np.zeros(u.shape[0], dtype=np.int64)
+
+  monkeypatch.setattr(sca.SpectralClusterer, "predict", fake_predict)
+  utts = [np.ones((5, 3)), np.ones((7, 3))]
+  for kwargs in ({"affinity_function": lambda x: np.ones((x.shape[0], x.shape[0]))},
+                 {"post_eigen_cluster_function": lambda **kw: np.zeros(3)}):
+    del seen[:]
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=4, **kwargs)
+    out = c.predict_batch(utts, streams=2)
+    assert seen == [5, 7] and [o.shape[0] for o in out] == [5, 7]
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=4, custom_dist="mahalanobis")
+  with pytest.raises(sca.UnsupportedOnDeviceError):
+    c.predict_batch(utts)
+
+
+def test_comm_header_and_id_file(monkeypatch, tmp_path):
+  """Rendezvous plumbing of RcclComm.from_env that needs no GPU: the id file name is
+  unique per launch (MASTER_PORT + parent pid) and can be overridden."""
+  monkeypatch.delenv("SC_COMM_ID_FILE", raising=False)
+  monkeypatch.setenv("MASTER_PORT", "29517")
+  monkeypatch.setenv("TMPDIR", str(tmp_path))
+  path = multigpu._id_file()
+  assert path == os.path.join(str(tmp_path), "sc_comm_29517_%d.id" % os.getppid())
+  monkeypatch.setenv("SC_COMM_ID_FILE", str(tmp_path / "x.id"))
+  assert multigpu._id_file() == str(tmp_path / "x.id")
+  assert _lib.load().sc_comm_rank(None) == -1 and _lib.load().sc_comm_size(None) == 0

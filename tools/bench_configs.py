@@ -74,4 +74,14 @@ for n in (300, 1000, 3000):
     c.predict(x)
   out["single_n%d_ms" % n] = 1e3 * (time.perf_counter() - t) / 10
   out["single_n%d_stage_ms" % n] = c.last_diag.stage_times_ms()
+# E1 dense path: the reference's default max_clusters=None with a Laplacian
+for n in (1000, 2048, 4096, 8192):
+  x = so.blobs(n, 256 if n > 2048 else 128, 4, n)
+  c = sca.SpectralClusterer(min_clusters=2, refinement_options=opts,
+                            laplacian_type=sca.LaplacianType.GraphCut)
+  c.predict(x)
+  t = time.perf_counter()
+  c.predict(x)
+  out["dense_default_max_clusters_n%d_ms" % n] = 1e3 * (time.perf_counter() - t)
+  out["dense_default_max_clusters_n%d_eig_ms" % n] = c.last_diag.stage_times_ms()["eig"]
 print(json.dumps(out, indent=1))

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""profiles/pmc_traffic_diffuse.json from rocprofv3 --pmc passes of bench.py:
+   python tools/make_pmc_traffic.py <pmc_FETCH_dir> <pmc_WRITE_dir> <label> > profiles/pmc_traffic_diffuse.json
+HBM-side bytes per Diffuse launch = FETCH_SIZE [KiB] x 1024 x 2 (gfx950: the counter reports
+half the bytes of 16 B/lane streaming loads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE [KiB]
+x 1024, averaged over the dispatches of k_gemm_nt<0, true> (+ its split-K reduce kernel)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_dispatch(d, counter):
+  tot = collections.defaultdict(float)
+  disp = collections.defaultdict(set)
+  for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+      if r["Counter_Name"] != counter:
+        continue
+      k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+      tot[k] += float(r["Counter_Value"])
+      disp[k].add(r["Dispatch_Id"])
+  return {k: (tot[k] / len(disp[k]), len(disp[k])) for k in tot}
+
+
+fetch = per_dispatch(sys.argv[1], "FETCH_SIZE")
+write = per_dispatch(sys.argv[2], "WRITE_SIZE")
+label = sys.argv[3] if len(sys.argv) > 3 else ""
+main, red = "sc::k_gemm_nt<0, true>", "sc::k_gemm_reduce<0, true>"
+f = fetch[main][0] + (fetch[red][0] if red in fetch else 0.0)
+w = write[main][0] + (write[red][0] if red in write else 0.0)
+n = 8192
+print(json.dumps({
+    "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024),
+    "source": "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3 "
+              "--no-extras`, per-dispatch average over %d launches of k_gemm_nt<EpiNone,SYM> at n=8192 "
+              "(+ split-K reduce): FETCH_SIZE %.4g KiB x 2 (gfx950 16 B/lane correction) + WRITE_SIZE "
+              "%.4g KiB" % (label, fetch[main][1], f, w),
+    "algorithmic_bytes_per_launch": 2 * n * n * 8,
+}, indent=1))

@@ -64,7 +64,8 @@ int ensure_eig(sc_handle h, int n) {
   SC_TRY(grow(h, h->Q2, nq));
   SC_TRY(grow(h, h->Vs, (size_t)n * kEigBlock * sizeof(double)));
   SC_TRY(grow(h, h->W, (size_t)n * kEigBlock * sizeof(double)));
-  SC_TRY(grow(h, h->partial, (size_t)kProjBlocks * kLdq * kEigBlock * sizeof(double)));
+  SC_TRY(grow(h, h->partial, std::max((size_t)kProjBlocks * kLdq * kEigBlock,
+                                       lz_partial_doubles(n)) * sizeof(double)));
   SC_TRY(grow(h, h->T, (size_t)kLdq * kLdq * sizeof(double)));
   SC_TRY(grow(h, h->Y, (size_t)kLdq * kLdq * sizeof(double)));
   SC_TRY(grow(h, h->Yt, (size_t)kLdq * kLdq * sizeof(double)));
@@ -75,7 +76,10 @@ int ensure_eig(sc_handle h, int n) {
   SC_TRY(grow(h, h->Hbuf, (size_t)kLdq * kEigBlock * sizeof(double)));
   SC_TRY(grow(h, h->hsq, 16 * sizeof(double)));
   SC_TRY(grow(h, h->colnorm, (size_t)kProjBlocks * kMaxVectors * sizeof(double)));
-  SC_TRY(grow(h, h->flags, 16 * sizeof(int)));
+  if (h->flags.bytes < 16 * sizeof(int)) {
+    SC_TRY(grow(h, h->flags, 16 * sizeof(int)));
+    SC_HIP(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), h->stream));
+  }
   SC_TRY(grow(h, h->E, (size_t)round_up(n, 16) * kMaxCols * sizeof(double)));
   SC_TRY(grow(h, h->Eio, (size_t)n * kMaxCols * sizeof(double)));
   return SC_OK;

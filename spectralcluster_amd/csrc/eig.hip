@@ -9,6 +9,7 @@
 // The only O(n^2) kernel is k_block_matvec (one HBM pass over S per 16 vectors);
 // everything else is tall-skinny (n x <=144) and L2-resident.
 #include <algorithm>
+#include <mutex>
 
 #include "sc_internal.h"
 
@@ -227,6 +228,12 @@ __global__ __launch_bounds__(256) void k_update_block(
   }
 }
 
+__device__ __forceinline__ void chol8_wave(const double* G, double* __restrict__ Rinv,
+                                           const double* __restrict__ hsq,
+                                           int* __restrict__ flags,
+                                           int* __restrict__ defect_flag, int flag_mode,
+                                           int* __restrict__ sticky_flag = nullptr);
+
 // Gram reduce + Cholesky G = R^T R (right-looking, 256 threads), Rinv = R^-1 (upper).
 // A column whose pivot is <= 1e-22 * (its own squared norm + what projection removed,
 // hsq) is linearly dependent at working precision: it is zeroed and flagged for a
@@ -253,9 +260,19 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
   }
   __syncthreads();
   if (tid >= 64) return;
-  // ---- wave 0: lane (i, j) = (tid / 8, tid % 8) owns entry (i, j); the right-looking
-  // Cholesky and the triangular inverse exchange rows / columns through shuffles, so the
-  // whole factorisation runs without a barrier
+  chol8_wave(G, Rinv, hsq, flags, defect_flag, flag_mode);
+}
+
+// 8 x 8 Cholesky G = R^T R + Rinv = R^-1 on ONE wavefront (the first 64 threads of the
+// workgroup): lane (i, j) = (tid / 8, tid % 8) owns entry (i, j); the right-looking
+// factorisation and the triangular inverse exchange rows / columns through shuffles, so the
+// whole thing runs without a barrier.  G in LDS (or global), Rinv to global.
+__device__ __forceinline__ void chol8_wave(const double* G, double* __restrict__ Rinv,
+                                           const double* __restrict__ hsq,
+                                           int* __restrict__ flags,
+                                           int* __restrict__ defect_flag, int flag_mode,
+                                           int* __restrict__ sticky_flag) {
+  const int tid = threadIdx.x;
   const int i = tid >> 3, j = tid & 7;
   double g = G[tid];
   const double gii = __shfl(g, i * 9), gjj = __shfl(g, j * 9);  // original diagonal
@@ -308,6 +325,10 @@ __global__ __launch_bounds__(256) void k_reduce_chol(
     // (second CholQR pass): a Gram matrix far from I means the first pass met a block of
     // condition > 1e8.
     if (defect_flag != nullptr) *defect_flag = (defect > 0.1 || pmax > 1e3 * pmin) ? 1 : 0;
+    // fused step chain (k_lz_step): nobody reads the flags between the blocks, so anything
+    // that needs the careful host-driven path (a dependent column, a first CholQR pass that
+    // met a block of condition > 1e8) is latched
+    if (sticky_flag != nullptr && (mask != 0 || defect > 0.1)) *sticky_flag = 1;
   }
 }
 
@@ -334,6 +355,184 @@ __global__ __launch_bounds__(256) void k_apply_rinv(
     if (Qdst) Qdst[(size_t)r * ldq + col0 + jj] = v;
     if (Vs) Vs[(size_t)r * B + jj] = cvec[r] * v;
   }
+}
+
+// ---------------------------------------------------------------- fused block step
+// One link of the orthonormalisation chain of a Lanczos block.  Row-parallel part (64 rows
+// per workgroup):   W <- (W - Q[:, 0:m] Hc) Rc   (coefficients left by the previous link),
+// optional store of the finished block (Q[:, store_col ..], Vs = c .* W), then this
+// workgroup's share of the next link's reductions:  Q[:, 0:m]^T W  and  W^T W.
+// The LAST workgroup to finish (atomic ticket; partial sums are published with a
+// device-scope fence first) adds the partials in fixed order -- deterministic, whichever
+// workgroup it is -- and prepares the next link's coefficients:
+//   mode 1  Hout = Q^T W; T[:, col0 ..] = Hout; hsq = its column energies          (CGS 1)
+//   mode 2  Hout = Q^T W (accumulated into T), G' = W^T W - Hout^T Hout = Gram of the
+//           projected block without another pass (Pythagoras; Hout is rounding-level on a
+//           second projection), Cholesky of G' -> Rout = R^-1                    (CGS 2 + QR)
+//   mode 3  like 2 on the block the first Cholesky normalised; T is not touched: a third
+//           projection on a well-conditioned block, what the host-driven path does when a
+//           block was ill-conditioned (pivot ratio > 1e3), at no extra pass here
+//   mode 4  Cholesky of W^T W only                                         (start block)
+// So a block costs matvec + 4 launches and no host synchronisation; rank deficiency or a
+// hopeless first Cholesky is latched in flags[13] and the caller falls back to the
+// host-driven chain (orthonormalize / finish_block in eig_driver.hip).
+constexpr int kLzRows = 64;
+constexpr int kLzThreads = 512;
+constexpr int kLzPartStride = (kLdq + B) * B;  // proj rows [0, kLdq), Gram rows after
+struct LzStep {
+  double* W;
+  int n;
+  const double* Q;
+  int ldq, m;
+  const double* Hc;   // m x B or nullptr
+  const double* Rc;   // B x B or nullptr
+  double* Qdst;       // store target (same buffer as Q, other columns) or nullptr
+  int store_col;
+  const double* vs_scale;
+  double* Vs;
+  int init_random;
+  uint64_t seed;
+  int want_proj, want_gram;
+  double* partial;
+  int* ticket;
+  int mode;           // 0: no reduction
+  double* Hout;
+  double* Rout;
+  double* T;
+  int ldt, col0;
+  double* Gsave;
+  double* hsq;
+  int* flags;
+  double* Tzero;      // start block: the last workgroup clears T (kLdq x kLdq)
+};
+
+__global__ __launch_bounds__(kLzThreads) void k_lz_step(const LzStep a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int m = a.m;
+  const int mq = m + 1;                       // row pitch of the basis rows in LDS
+  double* Ql = smem;                          // kLzRows x mq
+  double* Hl = Ql + kLzRows * mq;             // m x B   (later: reduced projections)
+  double* Rl = Hl + kLdq * B;                 // B x B
+  double* Wl = Rl + B * B;                    // kLzRows x B
+  double* Gs = Wl + kLzRows * B;              // B x B reduced Gram
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int rl = tid / B, j = tid % B;
+  const int r0 = blockIdx.x * kLzRows;
+  const int r = r0 + rl;
+  const bool use_q = m > 0 && (a.Hc != nullptr || a.want_proj);
+  if (tid < B * B) Rl[tid] = a.Rc ? a.Rc[tid] : ((tid / B == tid % B) ? 1.0 : 0.0);
+  if (a.Hc)
+    for (int e = tid; e < m * B; e += kLzThreads) Hl[e] = a.Hc[e];
+  if (use_q)
+    for (int e = tid; e < kLzRows * m; e += kLzThreads) {
+      const int rr = e / m, i = e - rr * m;
+      Ql[rr * mq + i] = (r0 + rr < a.n) ? a.Q[(size_t)(r0 + rr) * a.ldq + i] : 0.0;
+    }
+  double w = 0.0;
+  if (r < a.n)
+    w = a.init_random ? hash_uniform(a.seed, (uint64_t)r * B + j) : a.W[(size_t)r * B + j];
+  __syncthreads();
+  if (a.Hc)
+    for (int i = 0; i < m; ++i) w = __builtin_fma(-Ql[rl * mq + i], Hl[i * B + j], w);
+  double v = w;
+  if (a.Rc) {
+    v = 0.0;
+#pragma unroll
+    for (int k = 0; k < B; ++k) v = __builtin_fma(__shfl(w, k, B), Rl[k * B + j], v);
+  }
+  if (r < a.n) {
+    a.W[(size_t)r * B + j] = v;
+    if (a.Qdst) a.Qdst[(size_t)r * a.ldq + a.store_col + j] = v;
+    if (a.Vs) a.Vs[(size_t)r * B + j] = a.vs_scale[r] * v;
+  }
+  if (a.mode == 0) return;
+  Wl[rl * B + j] = (r < a.n) ? v : 0.0;
+  __syncthreads();
+  double* mine = a.partial + (size_t)blockIdx.x * kLzPartStride;
+  if (a.want_proj)
+    for (int e = tid; e < m * B; e += kLzThreads) {
+      const int i = e / B, jj = e % B;
+      double acc = 0.0;
+#pragma unroll 8
+      for (int rr = 0; rr < kLzRows; ++rr)
+        acc = __builtin_fma(Ql[rr * mq + i], Wl[rr * B + jj], acc);
+      mine[e] = acc;
+    }
+  if (a.want_gram && tid < B * B) {
+    const int a1 = tid / B, b1 = tid % B;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int rr = 0; rr < kLzRows; ++rr)
+      acc = __builtin_fma(Wl[rr * B + a1], Wl[rr * B + b1], acc);
+    mine[kLdq * B + tid] = acc;
+  }
+  // ---- publish, take a ticket; only the last workgroup goes on
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(a.ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int nparts = gridDim.x;
+  // projections: 4 lanes per entry, each every 4th partial, fixed-order butterfly
+  if (a.want_proj) {
+    for (int base = 0; base < m * B; base += kLzThreads / 4) {
+      const int e = base + (tid >> 2), sub = tid & 3;
+      double h = 0.0;
+      if (e < m * B)
+        for (int p = sub; p < nparts; p += 4) h += a.partial[(size_t)p * kLzPartStride + e];
+      h += __shfl_xor(h, 1);
+      h += __shfl_xor(h, 2);
+      if (e < m * B && sub == 0) Hl[e] = h;
+    }
+  }
+  if (a.want_gram) {  // 64 entries x 8 lanes
+    const int e = tid >> 3, sub = tid & 7;
+    double g = 0.0;
+    for (int p = sub; p < nparts; p += 8)
+      g += a.partial[(size_t)p * kLzPartStride + kLdq * B + e];
+    g += __shfl_xor(g, 1);
+    g += __shfl_xor(g, 2);
+    g += __shfl_xor(g, 4);
+    if (sub == 0) Gs[e] = g;
+  }
+  __syncthreads();
+  if (a.want_proj) {
+    for (int e = tid; e < m * B; e += kLzThreads) {
+      const double h = Hl[e];
+      a.Hout[e] = h;
+      if (a.T != nullptr && a.mode != 3) {
+        const int i = e / B, jc = a.col0 + (e % B);
+        if (i <= jc) {
+          const double t = a.mode == 2 ? a.T[(size_t)i * a.ldt + jc] + h : h;
+          a.T[(size_t)i * a.ldt + jc] = t;
+          a.T[(size_t)jc * a.ldt + i] = t;
+        }
+      }
+    }
+    if (tid < B && a.mode != 3) {  // column energies removed by projection
+      double sq = 0.0;
+      for (int i = 0; i < m; ++i) sq = __builtin_fma(Hl[i * B + tid], Hl[i * B + tid], sq);
+      a.hsq[tid] = a.mode == 2 ? a.hsq[tid] + sq : sq;
+    }
+  }
+  if (a.Tzero != nullptr)
+    for (int e = tid; e < kLdq * kLdq; e += kLzThreads) a.Tzero[e] = 0.0;
+  if (a.mode >= 2) {
+    if (a.want_proj && tid < B * B) {  // Gram of the projected block (Pythagoras)
+      const int a1 = tid / B, b1 = tid % B;
+      double g = Gs[tid];
+      for (int i = 0; i < m; ++i) g = __builtin_fma(-Hl[i * B + a1], Hl[i * B + b1], g);
+      Gs[tid] = g;
+    }
+    __syncthreads();
+    if (a.mode == 2 && a.Gsave != nullptr && tid < B * B) a.Gsave[tid] = Gs[tid];
+    if (tid < 64)
+      chol8_wave(Gs, a.Rout, a.mode == 2 ? a.hsq : nullptr, a.flags,
+                 a.flags + (a.mode == 3 ? 10 : 11), a.mode == 3 ? 2 : 1, a.flags + 13);
+  }
+  if (tid == 0) *a.ticket = 0;  // ready for the next link (stream order: it starts after us)
 }
 
 // fp64 reciprocal / reciprocal-sqrt from the hardware seeds (v_rcp_f64 / v_rsq_f64)
@@ -742,6 +941,54 @@ void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
                        double* Vs) {
   hipLaunchKernelGGL(k_apply_rinv, dim3((n + RB - 1) / RB), dim3(256), 0, s, W, n, Rinv,
                      Qdst, ldq, col0, cvec, Vs);
+}
+size_t lz_partial_doubles(int n) {
+  return (size_t)((n + kLzRows - 1) / kLzRows) * kLzPartStride;
+}
+
+// One link of the fused chain (see k_lz_step).  `what`: 0 apply only, 1 CGS-1 reduction,
+// 2 CGS-2 + Cholesky, 3 re-projection + Cholesky on the normalised block, 4 Gram + Cholesky.
+void launch_lz_step(hipStream_t s, const EigWorkspace& ws, int n, int m, int what,
+                    bool apply_h, bool apply_r, int store_col, const double* vs_scale,
+                    int col0, bool init_random, uint64_t seed, bool zero_T, int* ticket) {
+  LzStep a;
+  a.W = ws.W;
+  a.n = n;
+  a.Q = ws.Q;
+  a.ldq = kLdq;
+  a.m = m;
+  a.Hc = apply_h ? ws.Hbuf : nullptr;
+  a.Rc = apply_r ? ws.Rinv : nullptr;
+  a.Qdst = store_col >= 0 ? ws.Q : nullptr;
+  a.store_col = store_col >= 0 ? store_col : 0;
+  a.vs_scale = vs_scale;
+  a.Vs = store_col >= 0 ? ws.Vs : nullptr;
+  a.init_random = init_random ? 1 : 0;
+  a.seed = seed;
+  a.want_proj = (what >= 1 && what <= 3 && m > 0) ? 1 : 0;
+  a.want_gram = what >= 2 ? 1 : 0;
+  a.partial = ws.partial;
+  a.ticket = ticket;
+  a.mode = what;
+  a.Hout = ws.Hbuf;
+  a.Rout = ws.Rinv;
+  a.T = ws.T;
+  a.ldt = kLdq;
+  a.col0 = col0;
+  a.Gsave = ws.G;
+  a.hsq = ws.hsq;
+  a.flags = ws.flags;
+  a.Tzero = zero_T ? ws.T : nullptr;
+  const size_t lds = sizeof(double) * ((size_t)kLzRows * (m + 1) + (size_t)kLdq * B + B * B +
+                                       (size_t)kLzRows * B + B * B);
+  static std::once_flag once[16];
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::call_once(once[dev & 15], [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz_step),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  });
+  hipLaunchKernelGGL(k_lz_step, dim3((n + kLzRows - 1) / kLzRows), dim3(kLzThreads), lds, s, a);
 }
 void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
                    const double* cvec, const double* pvec, const double* G,

@@ -24,7 +24,13 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
     // max_clusters None: everything >= stop_eigenvalue, plus the first one below
     int c = 0;
     while (c < m && !(w[c] < rq.stop_eigenvalue)) ++c;
-    if (c >= m && m < n) return dc;  // have not reached the stop value yet
+    if (c >= m && m < n) {  // have not reached the stop value yet
+      // Ritz values never exceed the eigenvalues they approximate: m of them above the stop
+      // value mean more than m are read -- beyond half the basis cap that is a job for the
+      // dense full-spectrum path
+      if (m >= kEigBasisCap / 2 && !exact) dc.unsupported = true;
+      return dc;
+    }
     kw = std::min(c + 1, n);
   } else {
     kw = n;  // ascending without max_clusters reads every eigenvalue
@@ -185,7 +191,7 @@ static int orthonormalize(sc_handle h, int n, int m, bool record, int col0, int 
 }
 
 static int read_flags(sc_handle h, int* mask) {
-  SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, 13 * sizeof(int), hipMemcpyDeviceToHost,
+  SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, 16 * sizeof(int), hipMemcpyDeviceToHost,
                            h->stream));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   *mask = h->h_flags[0];
@@ -265,6 +271,27 @@ static bool wants_full_spectrum(const EigRequest& rq) {
   return rq.max_clusters == 0 || rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF;
 }
 
+static EigWorkspace eig_workspace(sc_handle h) {
+  EigWorkspace ws;
+  ws.Q = ptr<double>(h->Q);
+  ws.Q2 = ptr<double>(h->Q2);
+  ws.Vs = ptr<double>(h->Vs);
+  ws.W = ptr<double>(h->W);
+  ws.partial = ptr<double>(h->partial);
+  ws.T = ptr<double>(h->T);
+  ws.Y = ptr<double>(h->Y);
+  ws.theta = ptr<double>(h->theta);
+  ws.resid = ptr<double>(h->resid);
+  ws.G = ptr<double>(h->G);
+  ws.Rinv = ptr<double>(h->Rinv);
+  ws.Hbuf = ptr<double>(h->Hbuf);
+  ws.hsq = ptr<double>(h->hsq);
+  ws.Yt = ptr<double>(h->Yt);
+  ws.colnorm = ptr<double>(h->colnorm);
+  ws.flags = ptr<int>(h->flags);
+  return ws;
+}
+
 // S (n x n, ld) symmetric on the device; cvec/pvec/tvec already set.
 int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_in,
              sc_diag* diag, EigDecision* out_dc, std::vector<double>* out_w,
@@ -278,6 +305,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
   EigDecision dc;
   int m = 0, passes = 0, cycles = 0;
   EigRequest rq = rq_in;
+  bool fused = getenv("SC_EIG_HOST_CHAIN") == nullptr;
   // Dense full-spectrum route (n > 128): all eigenvalues from the tridiagonal form, the
   // eigengap decision from those, then the same Lanczos loop below for just the vectors.
   EigDecision dense_dc;
@@ -324,11 +352,23 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     m = 0;
     cycles = 0;
     uint64_t seed = 0x5eed5eedull;
+    const double* vscale = h->vs_scale ? h->vs_scale : cvec;
+    int* ticket = ptr<int>(h->flags) + 14;
     // ---- start block
-    launch_random_block(s, ptr<double>(h->W), n, seed);
-    SC_TRY(orthonormalize(h, n, 0, false, 0, 0, false));
-    SC_TRY(finish_block(h, n, 0, 0, &seed));
-    SC_HIP(h, hipMemsetAsync(h->T.p, 0, (size_t)kLdq * kLdq * sizeof(double), s));
+    if (fused) {
+      // fused chain (k_lz_step): no host synchronisation until the first Rayleigh-Ritz
+      SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
+      const EigWorkspace ws = eig_workspace(h);
+      launch_lz_step(s, ws, n, 0, 4, false, false, -1, vscale, 0, true, seed, true, ticket);
+      launch_lz_step(s, ws, n, 0, 3, false, true, -1, vscale, 0, false, 0, false, ticket);
+      launch_lz_step(s, ws, n, 0, 0, false, true, 0, vscale, 0, false, 0, false, ticket);
+      SC_TRY(check_last(h, "start block launch"));
+    } else {
+      launch_random_block(s, ptr<double>(h->W), n, seed);
+      SC_TRY(orthonormalize(h, n, 0, false, 0, 0, false));
+      SC_TRY(finish_block(h, n, 0, 0, &seed));
+      SC_HIP(h, hipMemsetAsync(h->T.p, 0, (size_t)kLdq * kLdq * sizeof(double), s));
+    }
     // basis cap: LDS Jacobi limit, and basis + next block must fit in R^n
     const int cap = std::min(kEigBasisCap, ((n - kEigBlock) / kEigBlock) * kEigBlock);
     const int first_check = std::min(3 * kEigBlock, cap);
@@ -342,7 +382,19 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       if (time_mv) ev_rec(h, &h->mv_ev[h->n_mv_ev++][1]);
       ++passes;
       m += kEigBlock;
-      SC_TRY(orthonormalize(h, n, m, true, m - kEigBlock, m, true));
+      if (fused) {
+        // CGS-1 | CGS-2 + CholQR | re-projection + CholQR on the normalised block | store
+        const EigWorkspace ws = eig_workspace(h);
+        launch_lz_step(s, ws, n, m, 1, false, false, -1, vscale, m - kEigBlock, false, 0, false,
+                       ticket);
+        launch_lz_step(s, ws, n, m, 2, true, false, -1, vscale, m - kEigBlock, false, 0, false,
+                       ticket);
+        launch_lz_step(s, ws, n, m, 3, true, true, -1, vscale, 0, false, 0, false, ticket);
+        launch_lz_step(s, ws, n, m, 0, true, true, m, vscale, 0, false, 0, false, ticket);
+        SC_TRY(check_last(h, "block step launch"));
+      } else {
+        SC_TRY(orthonormalize(h, n, m, true, m - kEigBlock, m, true));
+      }
       // Rayleigh-Ritz is the expensive serial step: every block early on (where
       // convergence is expected), then sparser, then once per restart cycle.
       const bool check = cycles == 0 ? (m >= first_check && (m <= 4 * kEigBlock ||
@@ -359,7 +411,20 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
         SC_HIP(h, hipMemcpyAsync(h->h_theta + kLdq, resid_d, m * sizeof(double),
                                  hipMemcpyDeviceToHost, s));
       }
-      SC_TRY(finish_block(h, n, m, m, &seed));  // syncs the stream
+      if (!fused) {
+        SC_TRY(finish_block(h, n, m, m, &seed));  // syncs the stream
+      } else if (check) {
+        int mask = 0;
+        SC_TRY(read_flags(h, &mask));  // the one synchronisation of the fused chain
+        if (h->h_flags[13] != 0) {
+          // a dependent column or a hopeless first Cholesky somewhere in the chain: redo the
+          // solve with the host-driven chain, which repairs blocks one by one
+          if (getenv("SC_EIG_TRACE")) fprintf(stderr, "[sc] fused chain flagged: host chain\n");
+          fused = false;
+          passes = 0;
+          goto restart_lanczos;
+        }
+      }
       if (check) {
         dc = analyze(rq, h->h_theta, h->h_theta + kLdq, m, n, false);
         if (getenv("SC_EIG_TRACE")) {

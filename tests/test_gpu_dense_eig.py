@@ -141,16 +141,17 @@ def test_descending_without_max_clusters_many_values(handle):
   stop_eigenvalue (utils.py:117-128).  With a slowly decaying spectrum that is more than a
   Krylov basis holds -> dense path for the values."""
   n = 400
-  rng = np.random.default_rng(3)
-  x = rng.standard_normal((n, 200))   # no cluster structure: ~n significant eigenvalues
+  x = so.blobs(n, 200, 3, seed=11)   # unrefined affinity: ~200 eigenvalues above 1e-2
   cfg = so.OracleConfig(sequence=(), stop_eigenvalue=1e-2)
   dump = {}
   want = so.predict(x, cfg, dump)
+  ref = dump["eigenvalues"]
+  idx = so.consumed_eigen_indices(n, None, True, ref, 1e-2)
+  assert idx.size > 64
   clusterer = sca.SpectralClusterer(min_clusters=2, max_clusters=None)
-  try:
-    got = clusterer.predict(x)
-  except sca.UnsupportedOnDeviceError as exc:
-    # the eigengap picked > 64 clusters: outside the k-means capacity, and said so
-    assert "64" in str(exc) and dump["n_clusters"] > 64
-    return
+  got = clusterer.predict(x)
+  assert clusterer.last_diag.eig_path == 5
+  w = clusterer.consumed_eigenvalues()
+  assert np.max(np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-12)) < 1e-5
+  assert max(clusterer.last_diag.n_clusters_raw, 2) == dump["n_clusters"]
   assert so.adjusted_rand_index(got, want) == 1.0

@@ -172,6 +172,9 @@ typedef struct sc_diag {
   double eig_max_residual;       /* max residual norm over accepted Ritz pairs */
   int32_t kmeans_iterations;     /* cosine k-means distance passes */
   int32_t symmetry_state;        /* 1 SYM, 2 DIAG*SYM (after RowWiseNormalize), 3 GENERAL */
+  int32_t eig_host_chain;        /* 1: the fused Lanczos chain met a rank-deficient block and
+                                    the host-driven repair chain redid the solve */
+  int32_t reserved0;
   float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */
 } sc_diag;
 

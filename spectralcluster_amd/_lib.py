@@ -98,6 +98,8 @@ class ScDiag(ctypes.Structure):
       ("eig_max_residual", ctypes.c_double),
       ("kmeans_iterations", ctypes.c_int32),
       ("symmetry_state", ctypes.c_int32),
+      ("eig_host_chain", ctypes.c_int32),
+      ("reserved0", ctypes.c_int32),
       ("stage_ms", ctypes.c_float * SC_MAX_STAGES),
   ]
 

@@ -33,9 +33,15 @@ Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names) {
-      r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    // The ROCm installation's RCCL by absolute path first: a bare soname would resolve to
+    // whatever librccl.so.1 the process already holds (PyTorch wheels bundle their own,
+    // bound to their own HIP runtime -- its communicators cannot use this library's
+    // streams and buffers).
+    std::string root = getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm";
+    const std::string names[] = {root + "/lib/librccl.so.1", "/opt/rocm/lib/librccl.so.1",
+                                 "librccl.so.1", "librccl.so"};
+    for (const std::string& nm : names) {
+      r.lib = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (r.lib) break;
     }
     if (!r.lib) {

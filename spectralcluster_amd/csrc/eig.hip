@@ -475,26 +475,37 @@ __global__ __launch_bounds__(kLzThreads) void k_lz_step(const LzStep a) {
   if (!s_last) return;
   __threadfence();
   const int nparts = gridDim.x;
-  // projections: 4 lanes per entry, each every 4th partial, fixed-order butterfly
+  // The partials were written by workgroups on other XCDs: every load below is an L2 miss
+  // (~1 us).  So the loads of a lane are issued in independent batches of 16 before they
+  // are added (in fixed order): the reduction costs a few miss latencies, not one per
+  // partial.  Lanes of an entry take every 8th partial; fixed-order butterfly at the end.
+  auto sum_partials = [&](const double* src, int sub, bool live) -> double {
+    double acc = 0.0;
+    for (int p0 = sub; p0 < nparts; p0 += 8 * 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int p = p0 + 8 * u;
+        v[u] = (live && p < nparts) ? src[(size_t)p * kLzPartStride] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    return acc;
+  };
   if (a.want_proj) {
-    for (int base = 0; base < m * B; base += kLzThreads / 4) {
-      const int e = base + (tid >> 2), sub = tid & 3;
-      double h = 0.0;
-      if (e < m * B)
-        for (int p = sub; p < nparts; p += 4) h += a.partial[(size_t)p * kLzPartStride + e];
-      h += __shfl_xor(h, 1);
-      h += __shfl_xor(h, 2);
+    for (int base = 0; base < m * B; base += kLzThreads / 8) {
+      const int e = base + (tid >> 3), sub = tid & 7;
+      const double h = sum_partials(a.partial + e, sub, e < m * B);
       if (e < m * B && sub == 0) Hl[e] = h;
     }
   }
   if (a.want_gram) {  // 64 entries x 8 lanes
     const int e = tid >> 3, sub = tid & 7;
-    double g = 0.0;
-    for (int p = sub; p < nparts; p += 8)
-      g += a.partial[(size_t)p * kLzPartStride + kLdq * B + e];
-    g += __shfl_xor(g, 1);
-    g += __shfl_xor(g, 2);
-    g += __shfl_xor(g, 4);
+    const double g = sum_partials(a.partial + kLdq * B + e, sub, true);
     if (sub == 0) Gs[e] = g;
   }
   __syncthreads();

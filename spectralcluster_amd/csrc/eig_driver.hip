@@ -500,6 +500,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     diag->eig_basis = m;
     diag->eig_cycles = cycles;
     diag->eig_max_residual = dc.max_resid;
+    diag->eig_host_chain = (n > kDenseMax && !fused) ? 1 : 0;
   }
   *out_dc = dc;
   return SC_OK;

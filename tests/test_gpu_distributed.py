@@ -71,35 +71,66 @@ def test_two_ranks_one_gpu_gloo(tmp_path):
   assert np.array_equal(np.load(tmp_path / "labels_0.npy"), np.load(tmp_path / "labels_1.npy"))
 
 
-def test_rccl_comm_world_1(handle):
+_RCCL_WORLD1 = r"""
+import os, sys
+import numpy as np
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import spectral_oracle as so
+import spectralcluster_amd as sca
+from spectralcluster_amd import _lib, multigpu
+assert "torch" not in sys.modules
+handle = _lib.default_handle()
+assert handle.lib.sc_comm_available() == 1
+uid = multigpu.RcclComm.new_unique_id()
+assert len(uid) == 128 and uid != bytes(128)
+comm = multigpu.RcclComm(handle, 0, 1, uid)
+assert (comm.rank, comm.size) == (0, 1)
+rng = np.random.default_rng(0)
+x = rng.standard_normal((300, 17))
+assert np.array_equal(multigpu.broadcast_array(comm, x), x)
+lab = rng.integers(0, 7, 1000).astype(np.int32)
+assert comm.allgather_bytes(lab.tobytes()) == [lab.tobytes()]
+assert comm.allreduce_max(3.25) == 3.25
+comm.barrier()
+big = rng.integers(0, 255, 5 << 20, dtype=np.uint8)  # staging buffer regrowth
+assert comm.broadcast_bytes(big.tobytes(), big.size, 0) == big.tobytes()
+utts = [so.blobs(n, 16, 3, seed=n) for n in (150, 260, 200)]
+c = sca.configs.icassp2018_clusterer
+got = multigpu.predict_batch_distributed(comm, c, utts, streams=1)
+for u, g in zip(utts, got):
+  assert np.array_equal(g, c.predict(u))
+# config 4 through the same communicator
+x4 = so.blobs(512, 64, 6, 512)
+def make():
+  return sca.SpectralClusterer(
+      min_clusters=2, max_clusters=20, laplacian_type=sca.LaplacianType.GraphCut,
+      refinement_options=sca.RefinementOptions(
+          refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE),
+      autotune=sca.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95,
+                            init_search_step=0.025, search_level=1))
+assert np.array_equal(multigpu.predict_autotune_distributed(comm, make(), x4), make().predict(x4))
+comm.close()
+# the launch-environment path: rank 0 of a world of 1 needs no RCCL; a world of 2 with only
+# this rank present times out on the id file instead of hanging
+os.environ.update(WORLD_SIZE="1", RANK="0")
+assert isinstance(multigpu.RcclComm.from_env(handle), multigpu.LocalComm)
+print("RCCL_WORLD1_OK")
+"""
+
+
+def test_rccl_comm_world_1(tmp_path):
   """RCCL behind the C ABI: unique id, ncclCommInitRank, broadcast / all-gather /
-  max-reduce staged through the device, destroy."""
-  from spectralcluster_amd import multigpu
-  assert handle.lib.sc_comm_available() == 1
-  uid = multigpu.RcclComm.new_unique_id()
-  assert len(uid) == 128 and uid != bytes(128)
-  comm = multigpu.RcclComm(handle, 0, 1, uid)
-  try:
-    assert (comm.rank, comm.size) == (0, 1)
-    rng = np.random.default_rng(0)
-    x = rng.standard_normal((300, 17))
-    assert np.array_equal(multigpu.broadcast_array(comm, x), x)
-    lab = rng.integers(0, 7, 1000).astype(np.int32)
-    assert comm.allgather_bytes(lab.tobytes()) == [lab.tobytes()]
-    assert comm.allreduce_max(3.25) == 3.25
-    comm.barrier()
-    big = rng.integers(0, 255, 5 << 20, dtype=np.uint8)  # staging buffer regrowth
-    assert comm.broadcast_bytes(big.tobytes(), big.size, 0) == big.tobytes()
-    import spectralcluster_amd as sca
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import spectral_oracle as so
-    utts = [so.blobs(n, 16, 3, seed=n) for n in (150, 260, 200)]
-    c = sca.configs.icassp2018_clusterer
-    got = multigpu.predict_batch_distributed(comm, c, utts, streams=1)
-    for u, g in zip(utts, got):
-      assert np.array_equal(g, c.predict(u))
-  finally:
-    comm.close()
+  max-reduce staged through the device, the two sharded drivers, destroy.  Runs in a fresh
+  interpreter, the way the product runs: no PyTorch in the process (its wheel carries a
+  second RCCL + HIP runtime)."""
+  import subprocess
+  script = tmp_path / "rccl_world1.py"
+  script.write_text(_RCCL_WORLD1)
+  r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True,
+                     timeout=300)
+  assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_rccl_comm_from_env_world_1(handle, monkeypatch):

@@ -357,26 +357,29 @@ __global__ __launch_bounds__(256) void k_apply_rinv(
   }
 }
 
-// ---------------------------------------------------------------- fused block step
-// One link of the orthonormalisation chain of a Lanczos block.  Row-parallel part (64 rows
-// per workgroup):   W <- (W - Q[:, 0:m] Hc) Rc   (coefficients left by the previous link),
-// optional store of the finished block (Q[:, store_col ..], Vs = c .* W), then this
-// workgroup's share of the next link's reductions:  Q[:, 0:m]^T W  and  W^T W.
-// The LAST workgroup to finish (atomic ticket; partial sums are published with a
-// device-scope fence first) adds the partials in fixed order -- deterministic, whichever
-// workgroup it is -- and prepares the next link's coefficients:
-//   mode 1  Hout = Q^T W; T[:, col0 ..] = Hout; hsq = its column energies          (CGS 1)
-//   mode 2  Hout = Q^T W (accumulated into T), G' = W^T W - Hout^T Hout = Gram of the
-//           projected block without another pass (Pythagoras; Hout is rounding-level on a
-//           second projection), Cholesky of G' -> Rout = R^-1                    (CGS 2 + QR)
-//   mode 3  like 2 on the block the first Cholesky normalised; T is not touched: a third
-//           projection on a well-conditioned block, what the host-driven path does when a
-//           block was ill-conditioned (pivot ratio > 1e3), at no extra pass here
-//   mode 4  Cholesky of W^T W only                                         (start block)
-// So a block costs matvec + 4 launches and no host synchronisation; rank deficiency or a
+// ---------------------------------------------------------------- block step chain
+// The orthonormalisation of a Lanczos block as a chain of SHORT kernels, each one global
+// load round trip long (the tall-skinny work is latency-bound: a dependent kernel boundary
+// costs ~1.5 us, a dependent miss ~1 us, an in-kernel cross-workgroup hand-off 5 us and
+// more -- so links are separate launches and every link issues all its loads at once).
+//
+//   k_lz_rows   row-parallel, ROWS rows per workgroup:  W <- (W - Q[:, 0:m] Hc) Rc  with the
+//               coefficients the previous reduce left, optional store of the finished
+//               block (Q[:, store_col ..], Vs = c .* W), then this workgroup's share of the
+//               next reductions:  Q[:, 0:m]^T W  and  W^T W  -> partial[workgroup].
+//   k_lz_reduce one workgroup: adds the partials in fixed order (deterministic) and
+//               prepares the next link's coefficients:
+//     mode 1  Hout = Q^T W; T[:, col0 ..] = Hout; hsq = its column energies          (CGS 1)
+//     mode 2  Hout = Q^T W (accumulated into T), G' = W^T W - Hout^T Hout = Gram of the
+//             projected block without another pass (Pythagoras; Hout is rounding-level on
+//             a second projection), Cholesky of G' -> Rout = R^-1               (CGS 2 + QR)
+//     mode 3  like 2 on the block the first Cholesky normalised; T is not touched: a third
+//             projection on a well-conditioned block -- what the host-driven path does when
+//             a block was ill-conditioned (pivot ratio > 1e3) -- at no extra pass here
+//     mode 4  Cholesky of W^T W only                                       (start block)
+// A block costs matvec + 7 short launches and no host synchronisation; rank deficiency or a
 // hopeless first Cholesky is latched in flags[13] and the caller falls back to the
 // host-driven chain (orthonormalize / finish_block in eig_driver.hip).
-constexpr int kLzRows = 64;
 constexpr int kLzThreads = 512;
 constexpr int kLzPartStride = (kLdq + B) * B;  // proj rows [0, kLdq), Gram rows after
 struct LzStep {
@@ -394,8 +397,8 @@ struct LzStep {
   uint64_t seed;
   int want_proj, want_gram;
   double* partial;
-  int* ticket;
-  int mode;           // 0: no reduction
+  int nparts;
+  int mode;           // reduce mode
   double* Hout;
   double* Rout;
   double* T;
@@ -403,133 +406,170 @@ struct LzStep {
   double* Gsave;
   double* hsq;
   int* flags;
-  double* Tzero;      // start block: the last workgroup clears T (kLdq x kLdq)
+  double* Tzero;      // start block: the reduce clears T (kLdq x kLdq)
 };
 
-__global__ __launch_bounds__(kLzThreads) void k_lz_step(const LzStep a) {
+template <int ROWS>
+__global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int kPass = kLzThreads / B;        // rows handled per sweep of the workgroup
   const int m = a.m;
-  const int mq = m + 1;                       // row pitch of the basis rows in LDS
-  double* Ql = smem;                          // kLzRows x mq
-  double* Hl = Ql + kLzRows * mq;             // m x B   (later: reduced projections)
-  double* Rl = Hl + kLdq * B;                 // B x B
-  double* Wl = Rl + B * B;                    // kLzRows x B
-  double* Gs = Wl + kLzRows * B;              // B x B reduced Gram
-  __shared__ int s_last;
+  const int mq = m + 1;                        // row pitch of the basis rows in LDS
+  double* Ql = smem;                           // ROWS x mq
+  double* Hl = Ql + ROWS * mq;                 // m x B
+  double* Rl = Hl + kLdq * B;                  // B x B
+  double* Wl = Rl + B * B;                     // ROWS x B
   const int tid = threadIdx.x;
-  const int rl = tid / B, j = tid % B;
-  const int r0 = blockIdx.x * kLzRows;
-  const int r = r0 + rl;
+  const int j = tid % B;
+  const int r0 = blockIdx.x * ROWS;
   const bool use_q = m > 0 && (a.Hc != nullptr || a.want_proj);
+  // ---- everything this workgroup reads, issued together
   if (tid < B * B) Rl[tid] = a.Rc ? a.Rc[tid] : ((tid / B == tid % B) ? 1.0 : 0.0);
   if (a.Hc)
     for (int e = tid; e < m * B; e += kLzThreads) Hl[e] = a.Hc[e];
   if (use_q)
-    for (int e = tid; e < kLzRows * m; e += kLzThreads) {
+    for (int e = tid; e < ROWS * m; e += kLzThreads) {
       const int rr = e / m, i = e - rr * m;
       Ql[rr * mq + i] = (r0 + rr < a.n) ? a.Q[(size_t)(r0 + rr) * a.ldq + i] : 0.0;
     }
-  double w = 0.0;
-  if (r < a.n)
-    w = a.init_random ? hash_uniform(a.seed, (uint64_t)r * B + j) : a.W[(size_t)r * B + j];
-  __syncthreads();
-  if (a.Hc)
-    for (int i = 0; i < m; ++i) w = __builtin_fma(-Ql[rl * mq + i], Hl[i * B + j], w);
-  double v = w;
-  if (a.Rc) {
-    v = 0.0;
+  double w[ROWS / kPass];
 #pragma unroll
-    for (int k = 0; k < B; ++k) v = __builtin_fma(__shfl(w, k, B), Rl[k * B + j], v);
+  for (int q = 0; q < ROWS / kPass; ++q) {
+    const int r = r0 + q * kPass + tid / B;
+    w[q] = 0.0;
+    if (r < a.n)
+      w[q] = a.init_random ? hash_uniform(a.seed, (uint64_t)r * B + j) : a.W[(size_t)r * B + j];
   }
-  if (r < a.n) {
-    a.W[(size_t)r * B + j] = v;
-    if (a.Qdst) a.Qdst[(size_t)r * a.ldq + a.store_col + j] = v;
-    if (a.Vs) a.Vs[(size_t)r * B + j] = a.vs_scale[r] * v;
-  }
-  if (a.mode == 0) return;
-  Wl[rl * B + j] = (r < a.n) ? v : 0.0;
   __syncthreads();
+#pragma unroll
+  for (int q = 0; q < ROWS / kPass; ++q) {
+    const int rl = q * kPass + tid / B;
+    const int r = r0 + rl;
+    double x = w[q];
+    if (a.Hc)
+      for (int i = 0; i < m; ++i) x = __builtin_fma(-Ql[rl * mq + i], Hl[i * B + j], x);
+    double v = x;
+    if (a.Rc) {
+      v = 0.0;
+#pragma unroll
+      for (int k = 0; k < B; ++k) v = __builtin_fma(__shfl(x, k, B), Rl[k * B + j], v);
+    }
+    if (r < a.n) {
+      a.W[(size_t)r * B + j] = v;
+      if (a.Qdst) a.Qdst[(size_t)r * a.ldq + a.store_col + j] = v;
+      if (a.Vs) a.Vs[(size_t)r * B + j] = a.vs_scale[r] * v;
+    }
+    Wl[rl * B + j] = (r < a.n) ? v : 0.0;
+  }
+  if (!a.want_proj && !a.want_gram) return;
+  __syncthreads();
+  // ---- partial sums over this workgroup's rows.  Every entry is split over two threads
+  //      (lower / upper half of the rows) that are added lower + upper: fixed order.
+  const int nproj = a.want_proj ? m * B : 0;
+  const int nent = nproj + (a.want_gram ? B * B : 0);
   double* mine = a.partial + (size_t)blockIdx.x * kLzPartStride;
-  if (a.want_proj)
-    for (int e = tid; e < m * B; e += kLzThreads) {
-      const int i = e / B, jj = e % B;
-      double acc = 0.0;
-#pragma unroll 8
-      for (int rr = 0; rr < kLzRows; ++rr)
-        acc = __builtin_fma(Ql[rr * mq + i], Wl[rr * B + jj], acc);
-      mine[e] = acc;
-    }
-  if (a.want_gram && tid < B * B) {
-    const int a1 = tid / B, b1 = tid % B;
+  for (int base = 0; base < nent; base += kLzThreads / 2) {
+    const int e = base + (tid >> 1), half = tid & 1;
     double acc = 0.0;
+    if (e < nent) {
+      const int rbeg = half * (ROWS / 2);
+      if (e < nproj) {
+        const int i = e / B, jj = e % B;
 #pragma unroll 8
-    for (int rr = 0; rr < kLzRows; ++rr)
-      acc = __builtin_fma(Wl[rr * B + a1], Wl[rr * B + b1], acc);
-    mine[kLdq * B + tid] = acc;
-  }
-  // ---- publish, take a ticket; only the last workgroup goes on
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) s_last = (atomicAdd(a.ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  const int nparts = gridDim.x;
-  // The partials were written by workgroups on other XCDs: every load below is an L2 miss
-  // (~1 us).  So the loads of a lane are issued in independent batches of 16 before they
-  // are added (in fixed order): the reduction costs a few miss latencies, not one per
-  // partial.  Lanes of an entry take every 8th partial; fixed-order butterfly at the end.
-  auto sum_partials = [&](const double* src, int sub, bool live) -> double {
-    double acc = 0.0;
-    for (int p0 = sub; p0 < nparts; p0 += 8 * 16) {
-      double v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int p = p0 + 8 * u;
-        v[u] = (live && p < nparts) ? src[(size_t)p * kLzPartStride] : 0.0;
+        for (int rr = 0; rr < ROWS / 2; ++rr)
+          acc = __builtin_fma(Ql[(rbeg + rr) * mq + i], Wl[(rbeg + rr) * B + jj], acc);
+      } else {
+        const int g = e - nproj, a1 = g / B, b1 = g % B;
+#pragma unroll 8
+        for (int rr = 0; rr < ROWS / 2; ++rr)
+          acc = __builtin_fma(Wl[(rbeg + rr) * B + a1], Wl[(rbeg + rr) * B + b1], acc);
       }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc += v[u];
     }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 4);
-    return acc;
-  };
-  if (a.want_proj) {
-    for (int base = 0; base < m * B; base += kLzThreads / 8) {
-      const int e = base + (tid >> 3), sub = tid & 7;
-      const double h = sum_partials(a.partial + e, sub, e < m * B);
-      if (e < m * B && sub == 0) Hl[e] = h;
+    const double other = __shfl_xor(acc, 1);
+    if (e < nent && half == 0)
+      mine[e < nproj ? e : kLdq * B + (e - nproj)] = acc + other;
+  }
+}
+
+// One workgroup (1024 threads).  The partials arrive in chunks through LDS: all the loads of
+// a chunk are in flight together (one miss latency per chunk), then every entry adds its
+// column of the chunk in partial order.
+constexpr int kLzRedThreads = 1024;
+constexpr int kLzRedChunk = 15360;  // doubles of LDS staging per chunk (dynamic, 120 KB)
+__global__ __launch_bounds__(kLzRedThreads) void k_lz_reduce(const LzStep a) {
+  extern __shared__ __attribute__((aligned(16))) double stage[];
+  __shared__ double Hl[kLdq * B];
+  __shared__ double Gs[B * B];
+  __shared__ double hs[B];
+  const int tid = threadIdx.x;
+  const int m = a.m;
+  const int nproj = a.want_proj ? m * B : 0;
+  const int nent = nproj + (a.want_gram ? B * B : 0);  // entries, proj first
+  // what the epilogue will read-modify-write: loads issued now, with the partials
+  double told[2] = {0.0, 0.0};
+  if (a.mode == 2 && a.T != nullptr) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * kLzRedThreads;
+      if (e < nproj) told[u] = a.T[(size_t)(e / B) * a.ldt + a.col0 + (e % B)];
     }
   }
-  if (a.want_gram) {  // 64 entries x 8 lanes
-    const int e = tid >> 3, sub = tid & 7;
-    const double g = sum_partials(a.partial + kLdq * B + e, sub, true);
-    if (sub == 0) Gs[e] = g;
+  double hsq_old = 0.0;
+  if (a.mode == 2 && tid < B) hsq_old = a.hsq[tid];
+  double acc[2] = {0.0, 0.0};
+  const int per_chunk = max(1, kLzRedChunk / max(nent, 1));  // partials per chunk
+  for (int p0 = 0; p0 < a.nparts; p0 += per_chunk) {
+    const int np = min(per_chunk, a.nparts - p0);
+    __syncthreads();
+    for (int idx = tid; idx < np * nent; idx += kLzRedThreads) {
+      const int p = idx / nent, e = idx - p * nent;
+      stage[idx] = a.partial[(size_t)(p0 + p) * kLzPartStride +
+                             (e < nproj ? e : kLdq * B + (e - nproj))];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * kLzRedThreads;
+      if (e < nent)
+        for (int p = 0; p < np; ++p) acc[u] += stage[p * nent + e];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * kLzRedThreads;
+    if (e < nproj) Hl[e] = acc[u];
+    else if (e < nent) Gs[e - nproj] = acc[u];
   }
   __syncthreads();
   if (a.want_proj) {
-    for (int e = tid; e < m * B; e += kLzThreads) {
-      const double h = Hl[e];
-      a.Hout[e] = h;
-      if (a.T != nullptr && a.mode != 3) {
-        const int i = e / B, jc = a.col0 + (e % B);
-        if (i <= jc) {
-          const double t = a.mode == 2 ? a.T[(size_t)i * a.ldt + jc] + h : h;
-          a.T[(size_t)i * a.ldt + jc] = t;
-          a.T[(size_t)jc * a.ldt + i] = t;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * kLzRedThreads;
+      if (e < nproj) {
+        const double h = Hl[e];
+        a.Hout[e] = h;
+        if (a.T != nullptr && a.mode != 3) {
+          const int i = e / B, jc = a.col0 + (e % B);
+          if (i <= jc) {
+            const double t = a.mode == 2 ? told[u] + h : h;
+            a.T[(size_t)i * a.ldt + jc] = t;
+            a.T[(size_t)jc * a.ldt + i] = t;
+          }
         }
       }
     }
     if (tid < B && a.mode != 3) {  // column energies removed by projection
       double sq = 0.0;
       for (int i = 0; i < m; ++i) sq = __builtin_fma(Hl[i * B + tid], Hl[i * B + tid], sq);
-      a.hsq[tid] = a.mode == 2 ? a.hsq[tid] + sq : sq;
+      sq = a.mode == 2 ? hsq_old + sq : sq;
+      a.hsq[tid] = sq;
+      hs[tid] = sq;
     }
+  } else if (tid < B) {
+    hs[tid] = 0.0;
   }
   if (a.Tzero != nullptr)
-    for (int e = tid; e < kLdq * kLdq; e += kLzThreads) a.Tzero[e] = 0.0;
+    for (int e = tid; e < kLdq * kLdq; e += kLzRedThreads) a.Tzero[e] = 0.0;
   if (a.mode >= 2) {
     if (a.want_proj && tid < B * B) {  // Gram of the projected block (Pythagoras)
       const int a1 = tid / B, b1 = tid % B;
@@ -540,10 +580,9 @@ __global__ __launch_bounds__(kLzThreads) void k_lz_step(const LzStep a) {
     __syncthreads();
     if (a.mode == 2 && a.Gsave != nullptr && tid < B * B) a.Gsave[tid] = Gs[tid];
     if (tid < 64)
-      chol8_wave(Gs, a.Rout, a.mode == 2 ? a.hsq : nullptr, a.flags,
+      chol8_wave(Gs, a.Rout, a.mode == 2 ? hs : nullptr, a.flags,
                  a.flags + (a.mode == 3 ? 10 : 11), a.mode == 3 ? 2 : 1, a.flags + 13);
   }
-  if (tid == 0) *a.ticket = 0;  // ready for the next link (stream order: it starts after us)
 }
 
 // fp64 reciprocal / reciprocal-sqrt from the hardware seeds (v_rcp_f64 / v_rsq_f64)
@@ -953,15 +992,35 @@ void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
   hipLaunchKernelGGL(k_apply_rinv, dim3((n + RB - 1) / RB), dim3(256), 0, s, W, n, Rinv,
                      Qdst, ldq, col0, cvec, Vs);
 }
-size_t lz_partial_doubles(int n) {
-  return (size_t)((n + kLzRows - 1) / kLzRows) * kLzPartStride;
+// rows per workgroup of k_lz_rows: as many as the basis rows leave room for in LDS (fewer,
+// fatter workgroups = fewer partials for the reduce kernel to add)
+static int lz_rows_for(int m) {
+  if ((size_t)256 * (m + 1) * sizeof(double) <= 96 * 1024) return 256;
+  if ((size_t)128 * (m + 1) * sizeof(double) <= 112 * 1024) return 128;
+  return 64;
+}
+size_t lz_partial_doubles(int n) { return (size_t)((n + 63) / 64) * kLzPartStride; }
+
+template <int ROWS>
+static void launch_rows(hipStream_t s, const LzStep& a) {
+  const size_t lds = sizeof(double) * ((size_t)ROWS * (a.m + 1) + (size_t)kLdq * B + B * B +
+                                       (size_t)ROWS * B);
+  static std::once_flag once[16];
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::call_once(once[dev & 15], [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz_rows<ROWS>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  });
+  hipLaunchKernelGGL(k_lz_rows<ROWS>, dim3(a.nparts), dim3(kLzThreads), lds, s, a);
 }
 
-// One link of the fused chain (see k_lz_step).  `what`: 0 apply only, 1 CGS-1 reduction,
-// 2 CGS-2 + Cholesky, 3 re-projection + Cholesky on the normalised block, 4 Gram + Cholesky.
+// One link of the chain (see k_lz_rows / k_lz_reduce).  `what`: 0 apply (+ store) only,
+// 1 CGS-1 reduction, 2 CGS-2 + Cholesky, 3 re-projection + Cholesky on the normalised
+// block, 4 Gram + Cholesky.
 void launch_lz_step(hipStream_t s, const EigWorkspace& ws, int n, int m, int what,
                     bool apply_h, bool apply_r, int store_col, const double* vs_scale,
-                    int col0, bool init_random, uint64_t seed, bool zero_T, int* ticket) {
+                    int col0, bool init_random, uint64_t seed, bool zero_T) {
   LzStep a;
   a.W = ws.W;
   a.n = n;
@@ -979,7 +1038,6 @@ void launch_lz_step(hipStream_t s, const EigWorkspace& ws, int n, int m, int wha
   a.want_proj = (what >= 1 && what <= 3 && m > 0) ? 1 : 0;
   a.want_gram = what >= 2 ? 1 : 0;
   a.partial = ws.partial;
-  a.ticket = ticket;
   a.mode = what;
   a.Hout = ws.Hbuf;
   a.Rout = ws.Rinv;
@@ -990,16 +1048,23 @@ void launch_lz_step(hipStream_t s, const EigWorkspace& ws, int n, int m, int wha
   a.hsq = ws.hsq;
   a.flags = ws.flags;
   a.Tzero = zero_T ? ws.T : nullptr;
-  const size_t lds = sizeof(double) * ((size_t)kLzRows * (m + 1) + (size_t)kLdq * B + B * B +
-                                       (size_t)kLzRows * B + B * B);
-  static std::once_flag once[16];
-  int dev = 0;
-  hipGetDevice(&dev);
-  std::call_once(once[dev & 15], [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz_step),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  });
-  hipLaunchKernelGGL(k_lz_step, dim3((n + kLzRows - 1) / kLzRows), dim3(kLzThreads), lds, s, a);
+  const int rows = lz_rows_for(m);
+  a.nparts = (n + rows - 1) / rows;
+  if (rows == 256) launch_rows<256>(s, a);
+  else if (rows == 128) launch_rows<128>(s, a);
+  else launch_rows<64>(s, a);
+  if (what != 0) {
+    static std::once_flag once[16];
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::call_once(once[dev & 15], [] {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz_reduce),
+                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(kLzRedChunk * sizeof(double)));
+    });
+    hipLaunchKernelGGL(k_lz_reduce, dim3(1), dim3(kLzRedThreads), kLzRedChunk * sizeof(double),
+                       s, a);
+  }
 }
 void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
                    const double* cvec, const double* pvec, const double* G,

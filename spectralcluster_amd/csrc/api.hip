@@ -111,6 +111,7 @@ int ensure_kmeans(sc_handle h, int n) {
   SC_TRY(grow(h, h->klab32, (size_t)n * sizeof(int)));
   SC_TRY(grow(h, h->klab64, (size_t)n * sizeof(long long)));
   SC_TRY(grow(h, h->kinfo, 16 * sizeof(int)));
+  SC_TRY(grow(h, h->kchain, kmeans_chain_workspace_doubles(n) * sizeof(double)));
   return SC_OK;
 }
 
@@ -183,7 +184,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
                     &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
-                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo};
+                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);
@@ -820,12 +821,37 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   ws.labels32 = ptr<int>(h->klab32);
   ws.labels64 = ptr<long long>(h->klab64);
   ws.info = ptr<int>(h->kinfo);
+  ws.chain = ptr<double>(h->kchain);
+  int info[16] = {0};
+  if (metric == kKmeansCosine && kmeans_chain_supported(n, k, trials) &&
+      !getenv("SC_KMEANS_SINGLE")) {
+    // chain of short multi-workgroup kernels; cosine iterations four launches at a time
+    // (the typical run stops after two or three), `done` comes back with the labels
+    for (int it = 0;; it += 4) {
+      launch_kmeans_chain(h->stream, E, lde, n, k, max_iter, first, trials, ws, it, 4);
+      SC_TRY(check_last(h, "kmeans launch"));
+      SC_HIP(h, hipMemcpyAsync(labels, h->klab64.p, (size_t)n * sizeof(int64_t),
+                               hipMemcpyDeviceToHost, h->stream));
+      SC_HIP(h, hipMemcpyAsync(info, h->kinfo.p, 9 * sizeof(int), hipMemcpyDeviceToHost,
+                               h->stream));
+      SC_HIP(h, hipStreamSynchronize(h->stream));
+      if (info[8] != 0) break;
+      if (it > max_iter + 4)
+        return fail(h, SC_ERR_HIP, "k-means chain did not reach its stop rule");
+    }
+    if (centroids_out) {
+      SC_HIP(h, hipMemcpyAsync(centroids_out, h->kcent.p, (size_t)k * k * sizeof(double),
+                               hipMemcpyDeviceToHost, h->stream));
+      SC_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    if (iterations) *iterations = info[0];
+    return SC_OK;
+  }
   SC_HIP(h, hipMemsetAsync(h->kinfo.p, 0, 8 * sizeof(int), h->stream));
   launch_kmeans(h->stream, E, lde, n, k, max_iter, first, trials, ws, metric);
   SC_TRY(check_last(h, "kmeans launch"));
   SC_HIP(h, hipMemcpyAsync(labels, h->klab64.p, (size_t)n * sizeof(int64_t),
                            hipMemcpyDeviceToHost, h->stream));
-  int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   SC_HIP(h, hipMemcpyAsync(info, h->kinfo.p, 6 * sizeof(int), hipMemcpyDeviceToHost,
                            h->stream));
   if (centroids_out)

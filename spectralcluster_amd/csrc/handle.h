@@ -63,7 +63,7 @@ struct sc_handle_s {
   DevBuf ahc_size, ahc_chain, ahc_Z, ahc_lab, ahc_cent;  // size reduction (AHC) scratch
   DevBuf fb_part, fb_small, fb_x, fb_cent, fb_int;      // fallback decisions scratch
   // k-means workspace
-  DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo;
+  DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo, kchain;
   // pinned host scratch
   double* h_theta = nullptr;  // 3 * kLdq doubles (theta, resid, Im theta)
   int* h_flags = nullptr;

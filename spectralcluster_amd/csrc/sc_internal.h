@@ -253,8 +253,15 @@ struct KmeansWorkspace {
   double* centroids = nullptr;  // kMaxVectors x kMaxVectors
   int* labels32 = nullptr;    // n
   long long* labels64 = nullptr;  // n
-  int* info = nullptr;        // [0] iterations
+  int* info = nullptr;        // [0] iterations, [8] chain: stop rule met
+  double* chain = nullptr;    // kmeans_chain_workspace_doubles(n): partials of the kernel chain
 };
+// k-means as a chain of short multi-workgroup kernels (kmeans_chain.hip), cosine metric
+size_t kmeans_chain_workspace_doubles(int n);
+bool kmeans_chain_supported(int n, int k, int trials);
+void launch_kmeans_chain(hipStream_t s, const double* ET, int lde, int n, int k, int max_iter,
+                         int first_center, int trials, const KmeansWorkspace& ws, int it_begin,
+                         int it_count);
 void launch_row_renorm(hipStream_t s, double* ET, int lde, int n, int k);
 void launch_to_colmajor(hipStream_t s, const double* src, int n, int k, double* dst,
                         int ldt);

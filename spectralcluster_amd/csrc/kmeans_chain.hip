@@ -33,6 +33,7 @@ namespace sc {
 
 constexpr int kKmT = 256;  // threads per workgroup = rows per workgroup
 constexpr int kKmW = kKmT / 64;
+constexpr int kKmMaxG = 1024;  // workgroups (n <= 262144) the chain is used for
 
 struct KmChain {
   const double* ET;
@@ -44,6 +45,7 @@ struct KmChain {
   long long* labels64;
   double* centroids_out;
   double* pm;     // [G][64] column sums
+  double* meang;  // [64] column means (km_meanreduce)
   double* ppot;   // [G]
   double* pT;     // [G][8]
   double* pS[2];  // [G][k*k + 2k]
@@ -72,13 +74,30 @@ __device__ __forceinline__ double km_bsum(double v, double* sm) {
   return t;
 }
 
-// mean[j] = (sum over workgroups, in order, of the column sums) / n
-__device__ __forceinline__ void km_mean(const KmChain& a, double* mean) {
-  if ((int)threadIdx.x < a.k) {
-    double t = 0.0;
-    for (int g = 0; g < a.G; ++g) t += a.pm[(size_t)g * 64 + threadIdx.x];
-    mean[threadIdx.x] = t / (double)a.n;
+// Sum of src[g * stride], g = 0 .. G-1, in that order.  The partials were written by
+// workgroups on other XCDs, so every load is a miss (~1 us): they are issued in independent
+// batches of 16 and then added in order -- a few miss latencies instead of G.
+__device__ __forceinline__ double km_ordered_sum(const double* src, int stride, int G) {
+  double acc = 0.0;
+  for (int g0 = 0; g0 < G; g0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (g0 + u < G) ? src[(size_t)(g0 + u) * stride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
   }
+  return acc;
+}
+
+// every thread gets the column means km_meanreduce left
+__device__ __forceinline__ void km_mean(const KmChain& a, double* mean) {
+  if ((int)threadIdx.x < a.k) mean[threadIdx.x] = a.meang[threadIdx.x];
+}
+
+// mean[j] = (sum over workgroups, in order, of the column sums) / n; one workgroup
+__global__ __launch_bounds__(64) void km_meanreduce(const KmChain a) {
+  if ((int)threadIdx.x < a.k)
+    a.meang[threadIdx.x] = km_ordered_sum(a.pm + threadIdx.x, 64, a.G) / (double)a.n;
 }
 
 template <int KC>
@@ -166,11 +185,7 @@ __global__ __launch_bounds__(kKmT) void km_first(const KmChain a) {
 
 // first index of the minimum of pots[0..trials) (np.argmin)
 __device__ __forceinline__ int km_best_trial(const KmChain& a, double* pots) {
-  if ((int)threadIdx.x < a.trials) {
-    double t = 0.0;
-    for (int g = 0; g < a.G; ++g) t += a.pT[(size_t)g * 8 + threadIdx.x];
-    pots[threadIdx.x] = t;
-  }
+  if ((int)threadIdx.x < a.trials) pots[threadIdx.x] = km_ordered_sum(a.pT + threadIdx.x, 8, a.G);
   __syncthreads();
   int best = 0;
   double bp = pots[0];
@@ -182,12 +197,33 @@ __device__ __forceinline__ int km_best_trial(const KmChain& a, double* pots) {
   return best;
 }
 
+// offset = sum of src[g * stride] over the workgroups before this one, total = over all of
+// them, both added in workgroup order (all loads in flight together, staged through LDS)
+__device__ __forceinline__ void km_prefix(const double* src, int stride, int G, double* part,
+                                          double* offset, double* total) {
+  for (int g = threadIdx.x; g < G; g += kKmT) part[g] = src[(size_t)g * stride];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double off = 0.0, tot = 0.0;
+    for (int g = 0; g < G; ++g) {
+      if (g == (int)blockIdx.x) off = tot;
+      tot += part[g];
+    }
+    part[kKmMaxG] = off;
+    part[kKmMaxG + 1] = tot;
+  }
+  __syncthreads();
+  *offset = part[kKmMaxG];
+  *total = part[kKmMaxG + 1];
+}
+
 // k-means++ round c (1 <= c < k): sample `trials` candidate rows with probability
 // proportional to `closest` (sklearn _kmeans_plusplus: searchsorted(stable_cumsum(closest),
 // rand * pot)).
 template <int KC>
 __global__ __launch_bounds__(kKmT) void km_select(const KmChain a, int c) {
   __shared__ double mean[KC], crow[KC], sm[kKmW], pots[8], rvals[8], scan[kKmT];
+  __shared__ double part[kKmMaxG + 2];
   __shared__ double csq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = blockIdx.x * kKmT + tid;
@@ -216,17 +252,9 @@ __global__ __launch_bounds__(kKmT) void km_select(const KmChain a, int c) {
       a.closest[r] = cl;
     }
     // per-workgroup sums of the new `closest` are what km_trials left for this trial
-    for (int g = 0; g < a.G; ++g) {
-      const double t = a.pT[(size_t)g * 8 + best];
-      if (g < (int)blockIdx.x) offset += t;
-      pot += t;
-    }
+    km_prefix(a.pT + best, 8, a.G, part, &offset, &pot);
   } else {
-    for (int g = 0; g < a.G; ++g) {
-      const double t = a.ppot[g];
-      if (g < (int)blockIdx.x) offset += t;
-      pot += t;
-    }
+    km_prefix(a.ppot, 1, a.G, part, &offset, &pot);
   }
   if (tid < a.trials) rvals[tid] = a.rnd[(c - 1) * a.trials + tid] * pot;
   // ---- cumulative sum in row order: scan inside the wave, wave totals, workgroup offset
@@ -297,21 +325,32 @@ __device__ __forceinline__ void km_cluster_partials(const KmChain& a, const doub
   for (int j = 0; j < KC; ++j)
     if (j < k) vals[tid * KC + j] = v[j] - shift[j];
   __syncthreads();
+  // entry e of the (k*k + 2k) sums, split over 4 row segments of 64 rows each; a segment
+  // adds its members in row order and the segments are added 0 + 1 + 2 + 3: fixed order
   const int r0 = blockIdx.x * kKmT;
-  for (int e = tid; e < k * k + 2 * k; e += kKmT) {
+  const int nsum = k * k + 2 * k;
+  for (int base = 0; base < nsum; base += kKmT / 4) {
+    const int e = base + (tid >> 2), seg = tid & 3;
     double acc = 0.0;
-    if (e < k * k) {
-      const int c2 = e / k, j = e - c2 * k;
-      for (int t = 0; t < kKmT; ++t)
-        if (labs[t] == c2) acc += vals[t * KC + j];
-    } else if (e < k * k + k) {
-      const int c2 = e - k * k;
-      for (int t = 0; t < kKmT; ++t) acc += labs[t] == c2 ? 1.0 : 0.0;
-    } else {
-      const int c2 = e - k * k - k;
-      for (int t = 0; t < kKmT; ++t) acc += (labs[t] == c2 && r0 + t > 0) ? 1.0 : 0.0;
+    if (e < nsum) {
+      const int t0 = seg * (kKmT / 4);
+      if (e < k * k) {
+        const int c2 = e / k, j = e - c2 * k;
+#pragma unroll 8
+        for (int t = t0; t < t0 + kKmT / 4; ++t) acc += labs[t] == c2 ? vals[t * KC + j] : 0.0;
+      } else if (e < k * k + k) {
+        const int c2 = e - k * k;
+#pragma unroll 8
+        for (int t = t0; t < t0 + kKmT / 4; ++t) acc += labs[t] == c2 ? 1.0 : 0.0;
+      } else {
+        const int c2 = e - k * k - k;
+#pragma unroll 8
+        for (int t = t0; t < t0 + kKmT / 4; ++t)
+          acc += (labs[t] == c2 && r0 + t > 0) ? 1.0 : 0.0;
+      }
     }
-    out[e] = acc;
+    const double a1 = __shfl_down(acc, 1), a2 = __shfl_down(acc, 2), a3 = __shfl_down(acc, 3);
+    if (e < nsum && seg == 0) out[e] = ((acc + a1) + a2) + a3;
   }
 }
 
@@ -383,9 +422,7 @@ __global__ __launch_bounds__(kKmT) void km_cosine(const KmChain a, int it) {
   // ---- the stop rule of iteration it - 1
   if (it > 0) {
     if (tid == 0) {
-      double t = 0.0;
-      for (int g = 0; g < a.G; ++g) t += a.pD[it & 1][g];
-      const double mean_d = t / (double)a.n;
+      const double mean_d = km_ordered_sum(a.pD[it & 1], 1, a.G) / (double)a.n;
       const double prev = it >= 2 ? a.meand[it - 2] : 0.0;
       s_done = ((mean_d <= prev && mean_d >= (1.0 - 0.001) * prev) || it - 1 == a.max_iter)
                    ? 1 : 0;
@@ -406,11 +443,7 @@ __global__ __launch_bounds__(kKmT) void km_cosine(const KmChain a, int it) {
     }
   }
   // ---- centroid update from the previous assignment's partial sums
-  for (int e = tid; e < nsum; e += kKmT) {
-    double t = 0.0;
-    for (int g = 0; g < a.G; ++g) t += a.pS[it & 1][(size_t)g * nsum + e];
-    tot[e] = t;
-  }
+  for (int e = tid; e < nsum; e += kKmT) tot[e] = km_ordered_sum(a.pS[it & 1] + e, nsum, a.G);
   if (it == 0) {
     km_mean(a, mean);
     if (tid < k) seeds[tid] = a.seeds[tid];
@@ -472,13 +505,14 @@ __global__ __launch_bounds__(kKmT) void km_cosine(const KmChain a, int it) {
 size_t kmeans_chain_workspace_doubles(int n) {
   const size_t G = (size_t)(n + kKmT - 1) / kKmT;
   // pm, ppot, pT, 2 x pS (k <= 32), 2 x pD, meand, 2 x cent, ints (seeds, cand, as doubles)
-  return G * 64 + G + G * 8 + 2 * G * (32 * 32 + 64) + 2 * G + 512 + 2 * 32 * 32 + 256;
+  return G * 64 + 64 + G + G * 8 + 2 * G * (32 * 32 + 64) + 2 * G + 512 + 2 * 32 * 32 + 256;
 }
 
 bool kmeans_chain_supported(int n, int k, int trials) {
   if (k < 1 || k > 32 || trials > 8 || n < 1) return false;
   const size_t G = (size_t)(n + kKmT - 1) / kKmT;
-  return G * (size_t)(k * k + 2 * k) <= 65536;  // every launch adds G partials in its prologue
+  // every launch adds the G partials of its predecessor in its prologue
+  return G <= (size_t)kKmMaxG && G * (size_t)(k * k + 2 * k) <= 65536;
 }
 
 static KmChain km_args(const double* ET, int lde, int n, int k, int max_iter, int first_center,
@@ -500,6 +534,7 @@ static KmChain km_args(const double* ET, int lde, int n, int k, int max_iter, in
   const size_t G = a.G;
   double* p = ws.chain;
   a.pm = p;          p += G * 64;
+  a.meang = p;       p += 64;
   a.ppot = p;        p += G;
   a.pT = p;          p += G * 8;
   a.pS[0] = p;       p += G * (32 * 32 + 64);
@@ -532,6 +567,7 @@ static void km_enqueue(hipStream_t s, const KmChain& a, int it_begin, int it_cou
   });
   if (it_begin == 0) {
     hipLaunchKernelGGL(km_colsum<KC>, grid, block, 0, s, a);
+    hipLaunchKernelGGL(km_meanreduce, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL(km_first<KC>, grid, block, 0, s, a);
     for (int c = 1; c < a.k; ++c) {
       hipLaunchKernelGGL(km_select<KC>, grid, block, 0, s, a, c);

@@ -370,7 +370,19 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     }
     // basis cap: LDS Jacobi limit, and basis + next block must fit in R^n
     const int cap = std::min(kEigBasisCap, ((n - kEigBlock) / kEigBlock) * kEigBlock);
-    const int first_check = std::min(3 * kEigBlock, cap);
+    // first Rayleigh-Ritz check after 3 blocks -- or where the previous solve of the same
+    // kind converged (re-probed from 3 blocks every 16th call, so the hint can also shrink)
+    const long long sig = ((long long)rq.descend << 40) ^ ((long long)rq.max_clusters << 20) ^
+                          ((long long)rq.fixed_count << 8) ^ rq.eigengap_type ^
+                          ((long long)(n > 4096) << 50);
+    int first_check = std::min(3 * kEigBlock, cap);
+    if (h->eig_hint_sig == sig && h->eig_hint_m > first_check && h->eig_hint_age < 16 &&
+        !getenv("SC_EIG_NO_HINT")) {
+      first_check = std::min(h->eig_hint_m, cap);
+      ++h->eig_hint_age;
+    } else {
+      h->eig_hint_age = 0;
+    }
     bool done = false;
     while (!done) {
       // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
@@ -447,6 +459,10 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
           goto restart_lanczos;
         }
         if (dc.enough && dc.converged) {
+          if (cycles == 0) {
+            h->eig_hint_sig = sig;
+            h->eig_hint_m = m;
+          }
           done = true;
           break;
         }

@@ -33,6 +33,8 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 16;
+constexpr int kSyncWin = 8;        // K-tiles per throttle window
+constexpr int kSyncWindows = 1024;  // windows per group the counter array holds (K <= 131072)
 
 // 16-byte chunk kc (k = 2kc, 2kc+1) of row `row` sits at chunk position kc ^ ((row >> 1) & 7)
 // of the row's 128 bytes: the 16 lanes of a ds_read_b128 group (rows li = 0..15, one kc)
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  double* __restrict__ partial,
                                                  double* __restrict__ probe_out,
                                                  const int2* __restrict__ tilemap,
-                                                 int xcd_chunk, GemmStats stats) {
+                                                 int xcd_chunk, GemmStats stats,
+                                                 int* __restrict__ ksync) {
   // one 64 KB block: As[2] | Bs[2] in the K loop, reduction scratch + the transposed
   // staging of the mirror tile in the epilogue
   __shared__ __attribute__((aligned(16))) double smem[2 * BM * BK + 2 * BN * BK];
@@ -214,6 +217,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own
   // L2), so XCD x walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the
   // patch-ordered tile list: the ~64 tiles it has in flight share 8 + 8 operand panels.
+  // K-window throttle (optional, ksync != nullptr): the <= 64 tiles an XCD has in flight
+  // come from one 8 x 8 patch and share 16 operand panels; they reuse each other's panel
+  // lines in the XCD's 4 MB L2 only while they are at about the same K.  Each workgroup
+  // counts the K windows (kSyncWin K-tiles) it has finished in cnt[group][window] and does not
+  // start window w before every member of its group has finished window w - 2, which bounds
+  // the K spread of a group to two windows = 2 x 16 x 128 rows x kSyncWin x 16 x 8 B.
+  int* sync_cnt = nullptr;
+  int sync_size = 0;
+  if (whole && xcd_chunk > 0 && ksync != nullptr) {
+    const int slot = tile >> 3;                 // index inside this XCD's run
+    const int grp = slot >> 6;                  // generation of 64 co-dispatched tiles
+    const int ngrp = (xcd_chunk + 63) >> 6;
+    sync_size = min(64, xcd_chunk - (grp << 6));
+    sync_cnt = ksync + ((size_t)(tile & 7) * ngrp + grp) * kSyncWindows;
+  }
   if (whole && xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
   if (!whole) stats.mode = 0;  // k_gemm_tail_stats covers the split tiles
   if (tilemap != nullptr) {
@@ -361,9 +379,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   if (kt_begin < kt_end) load_frags(fa0, fb0, As[first_buf], Bs[first_buf], 0);
   // one K-tile; the LDS buffer index is a compile-time constant (the loop below is unrolled by
   // two), so every LDS address is a precomputed register + an immediate offset
+  int sync_seen = 0;  // count of cnt[w - 1] as loaded one window ago
   auto k_tile = [&](int kt, auto cur_c, auto prio_c) {
     constexpr int cur = decltype(cur_c)::value;
     constexpr int prio = decltype(prio_c)::value;
+    if (sync_cnt != nullptr && (kt & (kSyncWin - 1)) == 0 && kt > kt_begin) {
+      const int w = (kt - kt_begin) / kSyncWin;  // window about to start; w - 1 just finished
+      if (tid == 0) {
+        __hip_atomic_fetch_add(sync_cnt + (w - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w >= 2) {
+          // sync_seen holds cnt[w - 2] as it was one window ago: normally already complete
+          int seen = sync_seen;
+          while (seen < sync_size) {
+            __builtin_amdgcn_s_sleep(8);
+            seen = __hip_atomic_load(sync_cnt + (w - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        sync_seen = __hip_atomic_load(sync_cnt + (w - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // (the other waves meet wave 0 at this K-tile's barrier)
+    }
     load_frags(fa1, fb1, As[cur], Bs[cur], 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(prio);
@@ -635,9 +670,28 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     static const bool want_probe = getenv("SC_GEMM_CLOCK") != nullptr;
     if (want_probe && dbg == nullptr) (void)hipMalloc(&dbg, sizeof(double) * 3 * 8192);
     double* probe = (full > 0 && full <= 8192) ? dbg : nullptr;
+    // SC_GEMM_KSYNC=1: K-window throttle (see k_gemm_nt); counters zeroed per launch
+    static const bool want_ksync = getenv("SC_GEMM_KSYNC") != nullptr;
+    static int* ksync_buf[16] = {nullptr};
+    int* ksync = nullptr;
+    if (want_ksync && xcd_chunk > 0 && ktiles / kSyncWin < kSyncWindows) {
+      int dev = 0;
+      hipGetDevice(&dev);
+      dev &= 15;
+      const int ngrp = (xcd_chunk + 63) / 64;
+      const size_t bytes = sizeof(int) * 8 * (size_t)ngrp * kSyncWindows;
+      static size_t ksync_bytes[16] = {0};
+      if (ksync_bytes[dev] < bytes) {
+        if (ksync_buf[dev]) (void)hipFree(ksync_buf[dev]);
+        (void)hipMalloc(&ksync_buf[dev], bytes);
+        ksync_bytes[dev] = bytes;
+      }
+      ksync = ksync_buf[dev];
+      (void)hipMemsetAsync(ksync, 0, bytes, s);
+    }
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full + rem * ksplit), dim3(256), 0, s, A, lda,
                        B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, probe, tilemap,
-                       xcd_chunk, stats);
+                       xcd_chunk, stats, ksync);
     if (probe != nullptr) {
       (void)hipStreamSynchronize(s);
       std::vector<double> h(3 * full);

@@ -73,6 +73,12 @@ struct sc_handle_s {
   int mv_ev[16][2];       // event pairs around the block matvec launches (level 2)
   int n_mv_ev = 0;
   int aff_ev[2] = {-1, -1};  // around the affinity GEMM launch (level 2)
+  // Rayleigh-Ritz scheduling hint: basis size at which the previous solve with the same
+  // request signature converged (a check costs a ~0.2 ms Jacobi + a host sync; consecutive
+  // calls of one workload converge at the same size)
+  int eig_hint_m = 0;
+  long long eig_hint_sig = -1;
+  int eig_hint_age = 0;
 };
 
 // hipEvent slots of the current call (reset by the entry points); -1 when exhausted

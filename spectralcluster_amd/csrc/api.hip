@@ -411,6 +411,19 @@ int validate_config(sc_handle h, const sc_config* cfg) {
   return SC_OK;
 }
 
+// device copy of the blur weights; the upload is skipped while they do not change
+static int upload_blur_weights(sc_handle h, const sc_config* cfg) {
+  const int count = 2 * cfg->blur_radius + 1;
+  if (h->blurw_radius == cfg->blur_radius &&
+      memcmp(h->blurw_host, cfg->blur_weights, count * sizeof(double)) == 0)
+    return SC_OK;
+  memcpy(h->blurw_host, cfg->blur_weights, count * sizeof(double));
+  h->blurw_radius = cfg->blur_radius;
+  SC_HIP(h, hipMemcpyAsync(h->blurw.p, h->blurw_host, count * sizeof(double),
+                           hipMemcpyHostToDevice, h->stream));
+  return SC_OK;
+}
+
 // run one refinement op `in` -> `out` (distinct buffers)
 static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double* in,
                          double* out, int n, int ld) {
@@ -420,10 +433,7 @@ static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double
       launch_crop_diagonal(s, in, out, n, ld);
       break;
     case SC_OP_GAUSSIAN_BLUR:
-      if (cfg->blur_radius > 0)
-        SC_HIP(h, hipMemcpyAsync(h->blurw.p, cfg->blur_weights,
-                                 (2 * cfg->blur_radius + 1) * sizeof(double),
-                                 hipMemcpyHostToDevice, s));
+      if (cfg->blur_radius > 0) SC_TRY(upload_blur_weights(h, cfg));
       launch_gaussian_blur(s, in, out, n, ld, cfg->blur_radius, ptr<double>(h->blurw));
       break;
     case SC_OP_ROW_WISE_THRESHOLD:
@@ -576,9 +586,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
     if (op == SC_OP_GAUSSIAN_BLUR && blur_fast) {
       const bool want = next == SC_OP_ROW_WISE_THRESHOLD && next2 == SC_OP_SYMMETRIZE &&
                         partials_usable;
-      SC_HIP(h, hipMemcpyAsync(h->blurw.p, cfg->blur_weights,
-                               (2 * cfg->blur_radius + 1) * sizeof(double),
-                               hipMemcpyHostToDevice, s));
+      SC_TRY(upload_blur_weights(h, cfg));
       if (fine) ev_rec(h, &eb0);
       have_partials = launch_gaussian_blur_fused(s, cur, out, n, ld, cfg->blur_radius,
                                                  ptr<double>(h->blurw), pending_diag,
@@ -805,11 +813,17 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   const double u = rng.next_double();
   const int first = sc_uniform_choice(n, u);
   const int trials = 2 + (int)std::log((double)k);
-  std::vector<double> rnd((size_t)std::max(1, (k - 1) * trials));
-  for (size_t i = 0; i < rnd.size(); ++i) rnd[i] = rng.next_double();
-  if (rnd.size() > 1024) return fail(h, SC_ERR_UNSUPPORTED, "too many k-means++ trials");
-  SC_HIP(h, hipMemcpyAsync(h->krnd.p, rnd.data(), rnd.size() * sizeof(double),
-                           hipMemcpyHostToDevice, h->stream));
+  const size_t nrnd = (size_t)std::max(1, (k - 1) * trials);
+  if (nrnd > 1024) return fail(h, SC_ERR_UNSUPPORTED, "too many k-means++ trials");
+  if (h->krnd_k != k || h->krnd_trials != trials) {  // RandomState(0) doubles: a function of k
+    std::vector<double> rnd(nrnd);
+    for (size_t i = 0; i < nrnd; ++i) rnd[i] = rng.next_double();
+    SC_HIP(h, hipMemcpyAsync(h->krnd.p, rnd.data(), nrnd * sizeof(double),
+                             hipMemcpyHostToDevice, h->stream));
+    SC_HIP(h, hipStreamSynchronize(h->stream));  // rnd is a local
+    h->krnd_k = k;
+    h->krnd_trials = trials;
+  }
   KmeansWorkspace ws;
   ws.Xc = ptr<double>(h->kXc);
   ws.xsq = ptr<double>(h->kxsq);

@@ -316,7 +316,7 @@ __device__ __forceinline__ void chol8_wave(const double* G, double* __restrict__
       ri = i == j ? 1.0 / rii : v / rii;
   }
   Rinv[tid] = ri;
-  if (tid == 0) {
+  if (tid == 0 && flags != nullptr) {
     flags[0] = mask;
     // An ill-conditioned block (pivot ratio > 1e3: the operator is numerically low-rank)
     // gets its small columns from R^-1 entries of that size, which amplify the absolute
@@ -358,26 +358,29 @@ __global__ __launch_bounds__(256) void k_apply_rinv(
 }
 
 // ---------------------------------------------------------------- block step chain
-// The orthonormalisation of a Lanczos block as a chain of SHORT kernels, each one global
-// load round trip long (the tall-skinny work is latency-bound: a dependent kernel boundary
-// costs ~1.5 us, a dependent miss ~1 us, an in-kernel cross-workgroup hand-off 5 us and
-// more -- so links are separate launches and every link issues all its loads at once).
+// The orthonormalisation of a Lanczos block as a chain of SHORT kernels, each about one
+// global load round trip long (the tall-skinny work is latency-bound: a dependent kernel
+// boundary costs ~1.5 us, a dependent miss ~1 us, an in-kernel cross-workgroup hand-off 5 us
+// and more -- so links are separate launches and every link issues its loads in batches).
 //
-//   k_lz_rows   row-parallel, ROWS rows per workgroup:  W <- (W - Q[:, 0:m] Hc) Rc  with the
-//               coefficients the previous reduce left, optional store of the finished
-//               block (Q[:, store_col ..], Vs = c .* W), then this workgroup's share of the
-//               next reductions:  Q[:, 0:m]^T W  and  W^T W  -> partial[workgroup].
-//   k_lz_reduce one workgroup: adds the partials in fixed order (deterministic) and
-//               prepares the next link's coefficients:
-//     mode 1  Hout = Q^T W; T[:, col0 ..] = Hout; hsq = its column energies          (CGS 1)
-//     mode 2  Hout = Q^T W (accumulated into T), G' = W^T W - Hout^T Hout = Gram of the
-//             projected block without another pass (Pythagoras; Hout is rounding-level on
-//             a second projection), Cholesky of G' -> Rout = R^-1               (CGS 2 + QR)
-//     mode 3  like 2 on the block the first Cholesky normalised; T is not touched: a third
-//             projection on a well-conditioned block -- what the host-driven path does when
-//             a block was ill-conditioned (pivot ratio > 1e3) -- at no extra pass here
-//     mode 4  Cholesky of W^T W only                                       (start block)
-// A block costs matvec + 7 short launches and no host synchronisation; rank deficiency or a
+// One link = k_lz_rows, ROWS rows per workgroup:
+//   prologue   every workgroup adds the partial sums the PREVIOUS link left (all workgroups,
+//              fixed order: deterministic and identical everywhere) and turns them into this
+//              link's coefficients -- the launch-boundary reduce, no separate kernel:
+//     pre 1  Hc = Q^T W                                                          (CGS 1)
+//     pre 2  Hc = Q^T W, G' = W^T W - Hc^T Hc = Gram of the projected block without another
+//            pass (Pythagoras; Hc is rounding-level on a second projection), Rc = chol(G')^-1
+//     pre 3  like 2 on the block the first Cholesky normalised: a third projection on a
+//            well-conditioned block -- what the host-driven path does when a block was
+//            ill-conditioned (pivot ratio > 1e3) -- at no extra pass here
+//     pre 4  Rc = chol(W^T W)^-1                                           (start block)
+//            workgroup 0 also records what the host side needs: T[:, col0 ..] (pre 1: set,
+//            pre 2: accumulated), the column energies hsq, the residual Gram (pre 2), the
+//            rank / conditioning flags.
+//   body       W <- (W - Q[:, 0:m] Hc) Rc, optional store of the finished block
+//              (Q[:, store_col ..], Vs = c .* W)
+//   epilogue   this workgroup's share of the next link's sums, Q[:, 0:m]^T W and W^T W.
+// A block costs matvec + 4 short launches and no host synchronisation; rank deficiency or a
 // hopeless first Cholesky is latched in flags[13] and the caller falls back to the
 // host-driven chain (orthonormalize / finish_block in eig_driver.hip).
 constexpr int kLzThreads = 512;
@@ -387,27 +390,41 @@ struct LzStep {
   int n;
   const double* Q;
   int ldq, m;
-  const double* Hc;   // m x B or nullptr
-  const double* Rc;   // B x B or nullptr
-  double* Qdst;       // store target (same buffer as Q, other columns) or nullptr
-  int store_col;
-  const double* vs_scale;
-  double* Vs;
-  int init_random;
-  uint64_t seed;
-  int want_proj, want_gram;
-  double* partial;
-  int nparts;
-  int mode;           // reduce mode
-  double* Hout;
-  double* Rout;
+  // ---- prologue: reduce the previous link's partials
+  int pre;                  // 0 none, else the mode above
+  const double* pre_partial;
+  int pre_nparts;
   double* T;
   int ldt, col0;
   double* Gsave;
   double* hsq;
   int* flags;
-  double* Tzero;      // start block: the reduce clears T (kLdq x kLdq)
+  double* Tzero;            // start block: workgroup 0 clears T (kLdq x kLdq)
+  // ---- body
+  double* Qdst;             // store target (same buffer as Q, other columns) or nullptr
+  int store_col;
+  const double* vs_scale;
+  double* Vs;
+  int init_random;
+  uint64_t seed;
+  // ---- epilogue
+  int want_proj, want_gram;
+  double* partial;
 };
+
+// ordered sum of src[p * kLzPartStride], p < nparts; loads in independent batches of 16
+__device__ __forceinline__ double lz_ordered_sum(const double* src, int nparts) {
+  double acc = 0.0;
+  for (int p0 = 0; p0 < nparts; p0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      v[u] = (p0 + u < nparts) ? src[(size_t)(p0 + u) * kLzPartStride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  return acc;
+}
 
 template <int ROWS>
 __global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
@@ -419,14 +436,39 @@ __global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
   double* Hl = Ql + ROWS * mq;                 // m x B
   double* Rl = Hl + kLdq * B;                  // B x B
   double* Wl = Rl + B * B;                     // ROWS x B
+  double* Gs = Wl + ROWS * B;                  // B x B
+  double* hs = Gs + B * B;                     // B
   const int tid = threadIdx.x;
   const int j = tid % B;
   const int r0 = blockIdx.x * ROWS;
-  const bool use_q = m > 0 && (a.Hc != nullptr || a.want_proj);
-  // ---- everything this workgroup reads, issued together
-  if (tid < B * B) Rl[tid] = a.Rc ? a.Rc[tid] : ((tid / B == tid % B) ? 1.0 : 0.0);
-  if (a.Hc)
-    for (int e = tid; e < m * B; e += kLzThreads) Hl[e] = a.Hc[e];
+  const bool first_wg = blockIdx.x == 0;
+  const bool pre_proj = (a.pre >= 1 && a.pre <= 3) && m > 0;
+  const bool pre_gram = a.pre >= 2;
+  const bool use_h = pre_proj;                 // apply Hc
+  const bool use_r = pre_gram;                 // apply Rc
+  const bool use_q = m > 0 && (use_h || a.want_proj);
+  // ---- everything this workgroup reads, issued together: the previous link's partials,
+  //      what workgroup 0 will read-modify-write, the basis rows, the block rows
+  const int nproj = pre_proj ? m * B : 0;
+  double hsum[3] = {0.0, 0.0, 0.0};            // up to (kLdq * B + 64) / 512 entries per thread
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int e = tid + u * kLzThreads;
+    if (e < nproj) hsum[u] = lz_ordered_sum(a.pre_partial + e, a.pre_nparts);
+    else if (pre_gram && e < nproj + B * B)
+      hsum[u] = lz_ordered_sum(a.pre_partial + kLdq * B + (e - nproj), a.pre_nparts);
+  }
+  double told[3] = {0.0, 0.0, 0.0};
+  double hsq_old = 0.0;
+  if (first_wg && a.pre == 2) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int e = tid + u * kLzThreads;
+      if (e < nproj) told[u] = a.T[(size_t)(e / B) * a.ldt + a.col0 + (e % B)];
+    }
+    if (tid < B) hsq_old = a.hsq[tid];
+  }
+  if (!first_wg && a.pre == 2 && tid < B) hsq_old = a.hsq[tid];  // every Cholesky needs it
   if (use_q)
     for (int e = tid; e < ROWS * m; e += kLzThreads) {
       const int rr = e / m, i = e - rr * m;
@@ -440,16 +482,69 @@ __global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
     if (r < a.n)
       w[q] = a.init_random ? hash_uniform(a.seed, (uint64_t)r * B + j) : a.W[(size_t)r * B + j];
   }
+  // ---- coefficients of this link
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int e = tid + u * kLzThreads;
+    if (e < nproj) Hl[e] = hsum[u];
+    else if (pre_gram && e < nproj + B * B) Gs[e - nproj] = hsum[u];
+  }
+  if (tid < B * B) Rl[tid] = (tid / B == tid % B) ? 1.0 : 0.0;
   __syncthreads();
+  if (pre_proj && a.pre != 3) {
+    if (first_wg && a.T != nullptr) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int e = tid + u * kLzThreads;
+        if (e < nproj) {
+          const int i = e / B, jc = a.col0 + (e % B);
+          if (i <= jc) {
+            const double t = a.pre == 2 ? told[u] + hsum[u] : hsum[u];
+            a.T[(size_t)i * a.ldt + jc] = t;
+            a.T[(size_t)jc * a.ldt + i] = t;
+          }
+        }
+      }
+    }
+    if (tid < B) {  // column energies removed by projection
+      double sq = 0.0;
+      for (int i = 0; i < m; ++i) sq = __builtin_fma(Hl[i * B + tid], Hl[i * B + tid], sq);
+      sq = a.pre == 2 ? hsq_old + sq : sq;
+      // (global copy only from the CGS-1 link: in the CGS-2 link the other workgroups are
+      //  still reading it)
+      if (first_wg && a.pre == 1) a.hsq[tid] = sq;
+      hs[tid] = sq;
+    }
+  } else if (tid < B) {
+    hs[tid] = 0.0;
+  }
+  if (first_wg && a.Tzero != nullptr)
+    for (int e = tid; e < kLdq * kLdq; e += kLzThreads) a.Tzero[e] = 0.0;
+  if (pre_gram) {
+    if (pre_proj && tid < B * B) {  // Gram of the projected block (Pythagoras)
+      const int a1 = tid / B, b1 = tid % B;
+      double g = Gs[tid];
+      for (int i = 0; i < m; ++i) g = __builtin_fma(-Hl[i * B + a1], Hl[i * B + b1], g);
+      Gs[tid] = g;
+    }
+    __syncthreads();
+    if (first_wg && a.pre == 2 && a.Gsave != nullptr && tid < B * B) a.Gsave[tid] = Gs[tid];
+    if (tid < 64)
+      chol8_wave(Gs, Rl, a.pre == 2 ? hs : nullptr, first_wg ? a.flags : nullptr,
+                 first_wg ? a.flags + (a.pre == 3 ? 10 : 11) : nullptr, a.pre == 3 ? 2 : 1,
+                 first_wg ? a.flags + 13 : nullptr);
+    __syncthreads();
+  }
+  // ---- body
 #pragma unroll
   for (int q = 0; q < ROWS / kPass; ++q) {
     const int rl = q * kPass + tid / B;
     const int r = r0 + rl;
     double x = w[q];
-    if (a.Hc)
+    if (use_h)
       for (int i = 0; i < m; ++i) x = __builtin_fma(-Ql[rl * mq + i], Hl[i * B + j], x);
     double v = x;
-    if (a.Rc) {
+    if (use_r) {
       v = 0.0;
 #pragma unroll
       for (int k = 0; k < B; ++k) v = __builtin_fma(__shfl(x, k, B), Rl[k * B + j], v);
@@ -463,23 +558,23 @@ __global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
   }
   if (!a.want_proj && !a.want_gram) return;
   __syncthreads();
-  // ---- partial sums over this workgroup's rows.  Every entry is split over two threads
-  //      (lower / upper half of the rows) that are added lower + upper: fixed order.
-  const int nproj = a.want_proj ? m * B : 0;
-  const int nent = nproj + (a.want_gram ? B * B : 0);
+  // ---- epilogue: partial sums over this workgroup's rows.  Every entry is split over two
+  //      threads (lower / upper half of the rows) that are added lower + upper: fixed order.
+  const int oproj = a.want_proj ? m * B : 0;
+  const int nent = oproj + (a.want_gram ? B * B : 0);
   double* mine = a.partial + (size_t)blockIdx.x * kLzPartStride;
   for (int base = 0; base < nent; base += kLzThreads / 2) {
     const int e = base + (tid >> 1), half = tid & 1;
     double acc = 0.0;
     if (e < nent) {
       const int rbeg = half * (ROWS / 2);
-      if (e < nproj) {
+      if (e < oproj) {
         const int i = e / B, jj = e % B;
 #pragma unroll 8
         for (int rr = 0; rr < ROWS / 2; ++rr)
           acc = __builtin_fma(Ql[(rbeg + rr) * mq + i], Wl[(rbeg + rr) * B + jj], acc);
       } else {
-        const int g = e - nproj, a1 = g / B, b1 = g % B;
+        const int g = e - oproj, a1 = g / B, b1 = g % B;
 #pragma unroll 8
         for (int rr = 0; rr < ROWS / 2; ++rr)
           acc = __builtin_fma(Wl[(rbeg + rr) * B + a1], Wl[(rbeg + rr) * B + b1], acc);
@@ -487,101 +582,7 @@ __global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
     }
     const double other = __shfl_xor(acc, 1);
     if (e < nent && half == 0)
-      mine[e < nproj ? e : kLdq * B + (e - nproj)] = acc + other;
-  }
-}
-
-// One workgroup (1024 threads).  The partials arrive in chunks through LDS: all the loads of
-// a chunk are in flight together (one miss latency per chunk), then every entry adds its
-// column of the chunk in partial order.
-constexpr int kLzRedThreads = 1024;
-constexpr int kLzRedChunk = 15360;  // doubles of LDS staging per chunk (dynamic, 120 KB)
-__global__ __launch_bounds__(kLzRedThreads) void k_lz_reduce(const LzStep a) {
-  extern __shared__ __attribute__((aligned(16))) double stage[];
-  __shared__ double Hl[kLdq * B];
-  __shared__ double Gs[B * B];
-  __shared__ double hs[B];
-  const int tid = threadIdx.x;
-  const int m = a.m;
-  const int nproj = a.want_proj ? m * B : 0;
-  const int nent = nproj + (a.want_gram ? B * B : 0);  // entries, proj first
-  // what the epilogue will read-modify-write: loads issued now, with the partials
-  double told[2] = {0.0, 0.0};
-  if (a.mode == 2 && a.T != nullptr) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = tid + u * kLzRedThreads;
-      if (e < nproj) told[u] = a.T[(size_t)(e / B) * a.ldt + a.col0 + (e % B)];
-    }
-  }
-  double hsq_old = 0.0;
-  if (a.mode == 2 && tid < B) hsq_old = a.hsq[tid];
-  double acc[2] = {0.0, 0.0};
-  const int per_chunk = max(1, kLzRedChunk / max(nent, 1));  // partials per chunk
-  for (int p0 = 0; p0 < a.nparts; p0 += per_chunk) {
-    const int np = min(per_chunk, a.nparts - p0);
-    __syncthreads();
-    for (int idx = tid; idx < np * nent; idx += kLzRedThreads) {
-      const int p = idx / nent, e = idx - p * nent;
-      stage[idx] = a.partial[(size_t)(p0 + p) * kLzPartStride +
-                             (e < nproj ? e : kLdq * B + (e - nproj))];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = tid + u * kLzRedThreads;
-      if (e < nent)
-        for (int p = 0; p < np; ++p) acc[u] += stage[p * nent + e];
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int e = tid + u * kLzRedThreads;
-    if (e < nproj) Hl[e] = acc[u];
-    else if (e < nent) Gs[e - nproj] = acc[u];
-  }
-  __syncthreads();
-  if (a.want_proj) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = tid + u * kLzRedThreads;
-      if (e < nproj) {
-        const double h = Hl[e];
-        a.Hout[e] = h;
-        if (a.T != nullptr && a.mode != 3) {
-          const int i = e / B, jc = a.col0 + (e % B);
-          if (i <= jc) {
-            const double t = a.mode == 2 ? told[u] + h : h;
-            a.T[(size_t)i * a.ldt + jc] = t;
-            a.T[(size_t)jc * a.ldt + i] = t;
-          }
-        }
-      }
-    }
-    if (tid < B && a.mode != 3) {  // column energies removed by projection
-      double sq = 0.0;
-      for (int i = 0; i < m; ++i) sq = __builtin_fma(Hl[i * B + tid], Hl[i * B + tid], sq);
-      sq = a.mode == 2 ? hsq_old + sq : sq;
-      a.hsq[tid] = sq;
-      hs[tid] = sq;
-    }
-  } else if (tid < B) {
-    hs[tid] = 0.0;
-  }
-  if (a.Tzero != nullptr)
-    for (int e = tid; e < kLdq * kLdq; e += kLzRedThreads) a.Tzero[e] = 0.0;
-  if (a.mode >= 2) {
-    if (a.want_proj && tid < B * B) {  // Gram of the projected block (Pythagoras)
-      const int a1 = tid / B, b1 = tid % B;
-      double g = Gs[tid];
-      for (int i = 0; i < m; ++i) g = __builtin_fma(-Hl[i * B + a1], Hl[i * B + b1], g);
-      Gs[tid] = g;
-    }
-    __syncthreads();
-    if (a.mode == 2 && a.Gsave != nullptr && tid < B * B) a.Gsave[tid] = Gs[tid];
-    if (tid < 64)
-      chol8_wave(Gs, a.Rout, a.mode == 2 ? hs : nullptr, a.flags,
-                 a.flags + (a.mode == 3 ? 10 : 11), a.mode == 3 ? 2 : 1, a.flags + 13);
+      mine[e < oproj ? e : kLdq * B + (e - oproj)] = acc + other;
   }
 }
 
@@ -993,18 +994,19 @@ void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
                      Qdst, ldq, col0, cvec, Vs);
 }
 // rows per workgroup of k_lz_rows: as many as the basis rows leave room for in LDS (fewer,
-// fatter workgroups = fewer partials for the reduce kernel to add)
+// fatter workgroups = fewer partials for the next link to add)
 static int lz_rows_for(int m) {
   if ((size_t)256 * (m + 1) * sizeof(double) <= 96 * 1024) return 256;
   if ((size_t)128 * (m + 1) * sizeof(double) <= 112 * 1024) return 128;
   return 64;
 }
-size_t lz_partial_doubles(int n) { return (size_t)((n + 63) / 64) * kLzPartStride; }
+// two partial buffers: a link reads its predecessor's sums while it writes its own
+size_t lz_partial_doubles(int n) { return 2 * (size_t)((n + 63) / 64) * kLzPartStride; }
 
 template <int ROWS>
-static void launch_rows(hipStream_t s, const LzStep& a) {
+static void launch_rows(hipStream_t s, const LzStep& a, int nwg) {
   const size_t lds = sizeof(double) * ((size_t)ROWS * (a.m + 1) + (size_t)kLdq * B + B * B +
-                                       (size_t)ROWS * B);
+                                       (size_t)ROWS * B + B * B + B);
   static std::once_flag once[16];
   int dev = 0;
   hipGetDevice(&dev);
@@ -1012,35 +1014,26 @@ static void launch_rows(hipStream_t s, const LzStep& a) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz_rows<ROWS>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   });
-  hipLaunchKernelGGL(k_lz_rows<ROWS>, dim3(a.nparts), dim3(kLzThreads), lds, s, a);
+  hipLaunchKernelGGL(k_lz_rows<ROWS>, dim3(nwg), dim3(kLzThreads), lds, s, a);
 }
 
-// One link of the chain (see k_lz_rows / k_lz_reduce).  `what`: 0 apply (+ store) only,
-// 1 CGS-1 reduction, 2 CGS-2 + Cholesky, 3 re-projection + Cholesky on the normalised
-// block, 4 Gram + Cholesky.
-void launch_lz_step(hipStream_t s, const EigWorkspace& ws, int n, int m, int what,
-                    bool apply_h, bool apply_r, int store_col, const double* vs_scale,
-                    int col0, bool init_random, uint64_t seed, bool zero_T) {
+// One link of the chain (see k_lz_rows).  `pre`: what to make of the previous link's partial
+// sums (0 nothing, 1 CGS-1, 2 CGS-2 + Cholesky, 3 re-projection + Cholesky, 4 Gram +
+// Cholesky); `next`: which sums to leave for the next link (same codes, 0 = none).
+// chain->parity / chain->nparts carry the partial buffer in use from link to link.
+void launch_lz_link(hipStream_t s, const EigWorkspace& ws, LzChain* chain, int n, int m,
+                    int pre, int next, int store_col, const double* vs_scale, int col0,
+                    bool init_random, uint64_t seed, bool zero_T) {
   LzStep a;
   a.W = ws.W;
   a.n = n;
   a.Q = ws.Q;
   a.ldq = kLdq;
   a.m = m;
-  a.Hc = apply_h ? ws.Hbuf : nullptr;
-  a.Rc = apply_r ? ws.Rinv : nullptr;
-  a.Qdst = store_col >= 0 ? ws.Q : nullptr;
-  a.store_col = store_col >= 0 ? store_col : 0;
-  a.vs_scale = vs_scale;
-  a.Vs = store_col >= 0 ? ws.Vs : nullptr;
-  a.init_random = init_random ? 1 : 0;
-  a.seed = seed;
-  a.want_proj = (what >= 1 && what <= 3 && m > 0) ? 1 : 0;
-  a.want_gram = what >= 2 ? 1 : 0;
-  a.partial = ws.partial;
-  a.mode = what;
-  a.Hout = ws.Hbuf;
-  a.Rout = ws.Rinv;
+  a.pre = pre;
+  const size_t half = lz_partial_doubles(n) / 2;
+  a.pre_partial = ws.partial + (size_t)chain->parity * half;
+  a.pre_nparts = chain->nparts;
   a.T = ws.T;
   a.ldt = kLdq;
   a.col0 = col0;
@@ -1048,23 +1041,22 @@ void launch_lz_step(hipStream_t s, const EigWorkspace& ws, int n, int m, int wha
   a.hsq = ws.hsq;
   a.flags = ws.flags;
   a.Tzero = zero_T ? ws.T : nullptr;
+  a.Qdst = store_col >= 0 ? ws.Q : nullptr;
+  a.store_col = store_col >= 0 ? store_col : 0;
+  a.vs_scale = vs_scale;
+  a.Vs = store_col >= 0 ? ws.Vs : nullptr;
+  a.init_random = init_random ? 1 : 0;
+  a.seed = seed;
+  a.want_proj = (next >= 1 && next <= 3 && m > 0) ? 1 : 0;
+  a.want_gram = next >= 2 ? 1 : 0;
+  chain->parity ^= 1;
+  a.partial = ws.partial + (size_t)chain->parity * half;
   const int rows = lz_rows_for(m);
-  a.nparts = (n + rows - 1) / rows;
-  if (rows == 256) launch_rows<256>(s, a);
-  else if (rows == 128) launch_rows<128>(s, a);
-  else launch_rows<64>(s, a);
-  if (what != 0) {
-    static std::once_flag once[16];
-    int dev = 0;
-    hipGetDevice(&dev);
-    std::call_once(once[dev & 15], [] {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_lz_reduce),
-                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)(kLzRedChunk * sizeof(double)));
-    });
-    hipLaunchKernelGGL(k_lz_reduce, dim3(1), dim3(kLzRedThreads), kLzRedChunk * sizeof(double),
-                       s, a);
-  }
+  const int nwg = (n + rows - 1) / rows;
+  chain->nparts = nwg;
+  if (rows == 256) launch_rows<256>(s, a, nwg);
+  else if (rows == 128) launch_rows<128>(s, a, nwg);
+  else launch_rows<64>(s, a, nwg);
 }
 void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
                    const double* cvec, const double* pvec, const double* G,

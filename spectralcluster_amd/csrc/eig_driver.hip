@@ -353,14 +353,17 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     cycles = 0;
     uint64_t seed = 0x5eed5eedull;
     const double* vscale = h->vs_scale ? h->vs_scale : cvec;
+    LzChain chain;
     // ---- start block
     if (fused) {
       // fused chain (k_lz_step): no host synchronisation until the first Rayleigh-Ritz
       SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
       const EigWorkspace ws = eig_workspace(h);
-      launch_lz_step(s, ws, n, 0, 4, false, false, -1, vscale, 0, true, seed, true);
-      launch_lz_step(s, ws, n, 0, 3, false, true, -1, vscale, 0, false, 0, false);
-      launch_lz_step(s, ws, n, 0, 0, false, true, 0, vscale, 0, false, 0, false);
+      chain = LzChain();
+      // random block + its Gram | CholQR | CholQR again (Gram checked against I) + store
+      launch_lz_link(s, ws, &chain, n, 0, 0, 4, -1, vscale, 0, true, seed, false);
+      launch_lz_link(s, ws, &chain, n, 0, 4, 3, -1, vscale, 0, false, 0, true);
+      launch_lz_link(s, ws, &chain, n, 0, 3, 0, 0, vscale, 0, false, 0, false);
       SC_TRY(check_last(h, "start block launch"));
     } else {
       launch_random_block(s, ptr<double>(h->W), n, seed);
@@ -396,10 +399,10 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       if (fused) {
         // CGS-1 | CGS-2 + CholQR | re-projection + CholQR on the normalised block | store
         const EigWorkspace ws = eig_workspace(h);
-        launch_lz_step(s, ws, n, m, 1, false, false, -1, vscale, m - kEigBlock, false, 0, false);
-        launch_lz_step(s, ws, n, m, 2, true, false, -1, vscale, m - kEigBlock, false, 0, false);
-        launch_lz_step(s, ws, n, m, 3, true, true, -1, vscale, 0, false, 0, false);
-        launch_lz_step(s, ws, n, m, 0, true, true, m, vscale, 0, false, 0, false);
+        launch_lz_link(s, ws, &chain, n, m, 0, 1, -1, vscale, m - kEigBlock, false, 0, false);
+        launch_lz_link(s, ws, &chain, n, m, 1, 2, -1, vscale, m - kEigBlock, false, 0, false);
+        launch_lz_link(s, ws, &chain, n, m, 2, 3, -1, vscale, m - kEigBlock, false, 0, false);
+        launch_lz_link(s, ws, &chain, n, m, 3, 0, m, vscale, 0, false, 0, false);
         SC_TRY(check_last(h, "block step launch"));
       } else {
         SC_TRY(orthonormalize(h, n, m, true, m - kEigBlock, m, true));

@@ -76,6 +76,10 @@ struct sc_handle_s {
   // Rayleigh-Ritz scheduling hint: basis size at which the previous solve with the same
   // request signature converged (a check costs a ~0.2 ms Jacobi + a host sync; consecutive
   // calls of one workload converge at the same size)
+  // what the small per-call uploads last carried (skipped when unchanged)
+  int blurw_radius = -1;
+  double blurw_host[2 * SC_MAX_BLUR_RADIUS + 1];
+  int krnd_k = -1, krnd_trials = -1;
   int eig_hint_m = 0;
   long long eig_hint_sig = -1;
   int eig_hint_age = 0;

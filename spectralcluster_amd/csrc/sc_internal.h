@@ -152,12 +152,16 @@ void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
                        double* Vs);
 void launch_refill_deficient(hipStream_t s, double* W, int n, const int* flags,
                              uint64_t seed);
-// Orthonormalisation chain of short kernels (k_lz_rows / k_lz_reduce in eig.hip): no host
-// sync.  ws.partial must hold lz_partial_doubles(n) doubles.
+// Orthonormalisation chain of short kernels (k_lz_rows in eig.hip): no host sync.
+// ws.partial must hold lz_partial_doubles(n) doubles (two buffers, used alternately).
+struct LzChain {
+  int parity = 0;   // partial buffer the last link wrote
+  int nparts = 0;   // workgroups of the last link
+};
 size_t lz_partial_doubles(int n);
-void launch_lz_step(hipStream_t s, const EigWorkspace& ws, int n, int m, int what,
-                    bool apply_h, bool apply_r, int store_col, const double* vs_scale,
-                    int col0, bool init_random, uint64_t seed, bool zero_T);
+void launch_lz_link(hipStream_t s, const EigWorkspace& ws, LzChain* chain, int n, int m,
+                    int pre, int next, int store_col, const double* vs_scale, int col0,
+                    bool init_random, uint64_t seed, bool zero_T);
 // Dense symmetric eigensolver (one workgroup, cyclic Jacobi, matrix in LDS).
 // mode 0: A = T (m x m, ldt).  mode 1: A_ij = c_i c_j S_ij + delta_ij p_i.
 void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,

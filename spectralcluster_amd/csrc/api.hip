@@ -721,6 +721,11 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   rq.vector_tol = cfg->eig_vector_tol > 0 ? cfg->eig_vector_tol : 1e-10;
   rq.max_cycles = cfg->eig_max_cycles > 0 ? cfg->eig_max_cycles : 40;
   rq.fixed_count = 0;
+  {  // p_percentile and the Laplacian shape the spectrum: part of the hint's signature
+    long long pbits;
+    memcpy(&pbits, &cfg->p_percentile, sizeof(pbits));
+    rq.hint_key = pbits ^ ((long long)cfg->laplacian_type << 3) ^ ((long long)cfg->n_ops << 7);
+  }
   EigDecision dc;
   std::vector<double> w;
   if (symmetric) {

@@ -377,11 +377,13 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     // kind converged (re-probed from 3 blocks every 16th call, so the hint can also shrink)
     const long long sig = ((long long)rq.descend << 40) ^ ((long long)rq.max_clusters << 20) ^
                           ((long long)rq.fixed_count << 8) ^ rq.eigengap_type ^
-                          ((long long)(n > 4096) << 50);
+                          ((long long)(n > 4096) << 50) ^ rq.hint_key;
     int first_check = std::min(3 * kEigBlock, cap);
     if (h->eig_hint_sig == sig && h->eig_hint_m > first_check && h->eig_hint_age < 16 &&
         !getenv("SC_EIG_NO_HINT")) {
-      first_check = std::min(h->eig_hint_m, cap);
+      // (one block at most: a later check costs a pass per block if this problem would have
+      //  converged earlier -- an AutoTune sweep changes the spectrum from call to call)
+      first_check = std::min(std::min(h->eig_hint_m, 4 * kEigBlock), cap);
       ++h->eig_hint_age;
     } else {
       h->eig_hint_age = 0;

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  double* __restrict__ probe_out,
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats,
-                                                 int* __restrict__ ksync) {
+                                                 int* __restrict__ ksync,
+                                                 int* __restrict__ queue) {
   // one 64 KB block: As[2] | Bs[2] in the K loop, reduction scratch + the transposed
   // staging of the mirror tile in the epilogue
   __shared__ __attribute__((aligned(16))) double smem[2 * BM * BK + 2 * BN * BK];
@@ -209,11 +210,64 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   double(*Bs)[BN * BK] = reinterpret_cast<double(*)[BN * BK]>(smem + 2 * BM * BK);
 
   int ti, tj;
-  const bool whole = (int)blockIdx.x < full_tiles;
-  const int unit = whole ? 0 : (int)blockIdx.x - full_tiles;  // index among the split-K units
+  // Work item of this workgroup.  Static (queue == nullptr): by block index.  Dynamic: the grid
+  // still has exactly one workgroup per item, but each workgroup DRAWS its item when it
+  // starts -- whole tiles from its XCD's run of the tile list, in order, and the split-K
+  // units of the leftover tiles from one global counter -- with one twist: the workgroups
+  // that start as the SECOND resident of their CU (LDS allocation not at 0: the first
+  // generation's other half) take a split-K unit first.  That shifts the two workgroups of
+  // every CU by a fraction of a tile for the rest of the launch, so that the ~86 us between
+  // one tile's K loop and the next one's (epilogue at low issue priority, teardown, dispatch,
+  // prologue) overlaps the partner's K loop instead of the partner's own gap (measured with
+  // SC_GEMM_CLOCK_DUMP: both gaps coincided at every generation boundary, ~4 % of the launch
+  // with the MFMA pipe idle).  Which workgroup computes which item does not change any result.
+  int item_blk = (int)blockIdx.x;
+  if (queue != nullptr) {
+    int* s_item = reinterpret_cast<int*>(smem);  // (one LDS object per kernel: no second array)
+    if (threadIdx.x == 0) {
+      const int nunits = (int)gridDim.x - full_tiles;
+      const int x = (int)blockIdx.x & 7;
+      const bool second = (__builtin_amdgcn_s_getreg(6 | (31 << 11)) & 0xfff) != 0;
+      auto draw = [&](int* counter, int limit) -> int {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= limit)
+          return -1;
+        const int v = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        return v < limit ? v : -1;
+      };
+      int got = -1;
+      // (a) the stagger: second residents of the first generation start with a split unit
+      if (second && nunits > 0 && draw(&queue[8], min(nunits, queue[10])) >= 0) {
+        const int u = draw(&queue[9], nunits);
+        if (u >= 0) got = full_tiles + u;
+      }
+      // (b) the next tile of this XCD's run (block id = what the static map gives it)
+      if (got < 0) {
+        const int k = draw(&queue[x], xcd_chunk);
+        if (k >= 0) got = x + 8 * k;
+      }
+      // (c) a split unit, (d) a tile of another XCD's run
+      if (got < 0) {
+        const int u = draw(&queue[9], nunits);
+        if (u >= 0) got = full_tiles + u;
+      }
+      for (int dx = 1; got < 0 && dx < 8; ++dx) {
+        const int xx = (x + dx) & 7;
+        const int k = draw(&queue[xx], xcd_chunk);
+        if (k >= 0) got = xx + 8 * k;
+      }
+      *s_item = got;
+    }
+    __syncthreads();
+    item_blk = *s_item;
+    __syncthreads();  // smem is about to become the operand tiles
+    if (item_blk < 0) return;  // cannot happen: as many items as workgroups
+  }
+  const bool whole = item_blk < full_tiles;
+  const int unit = whole ? 0 : item_blk - full_tiles;  // index among the split-K units
   const int ksplit = whole ? 1 : ksplit_tail;
   const int chunk = unit % ksplit;
-  int tile = whole ? (int)blockIdx.x : full_tiles + unit / ksplit;
+  int tile = whole ? item_blk : full_tiles + unit / ksplit;
   // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own
   // L2), so XCD x walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the
   // patch-ordered tile list: the ~64 tiles it has in flight share 8 + 8 operand panels.
@@ -440,9 +494,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   }
 
   if (probe && tid == 0) {
-    probe_out[2 * blockIdx.x] = (double)(clock64() - clk0);
-    probe_out[2 * blockIdx.x + 1] = (double)(wall_clock64() - wall0);
-    probe_out[2 * full_tiles + blockIdx.x] = (double)wall0;
+    probe_out[2 * item_blk] = (double)(clock64() - clk0);
+    probe_out[2 * item_blk + 1] = (double)(wall_clock64() - wall0);
+    probe_out[2 * full_tiles + item_blk] = (double)wall0;
   }
   // --- epilogue.  D layout of v_mfma_f64_16x16x4_f64: lane l, reg r holds
   //     D[row = (l >> 4) + 4 r][col = l & 15].
@@ -605,6 +659,10 @@ __global__ __launch_bounds__(256) void k_gemm_tail_stats(const double* __restric
   }
 }
 
+__global__ void k_gemm_queue_init(int* queue, int front) {
+  queue[threadIdx.x] = threadIdx.x == 10 ? front : 0;
+}
+
 // co-resident k_gemm_nt workgroups on the current device (occupancy x CUs)
 int gemm_resident_slots() {
   static int slots_dev[16] = {0};
@@ -650,6 +708,7 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
   if (rem > 0) {
     if (splitk_ws != nullptr) {
       ksplit = g_slots / rem;
+      if (const char* e = getenv("SC_GEMM_TAIL_SPLIT")) ksplit = std::max(2, atoi(e));
       ksplit = std::min(ksplit, std::max(1, ktiles / 8));  // >= 8 k-tiles per chunk
     }
     if (ksplit < 2) {  // no workspace, or not worth splitting: whole tiles only
@@ -689,9 +748,23 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
       ksync = ksync_buf[dev];
       (void)hipMemsetAsync(ksync, 0, bytes, s);
     }
+    // dynamic work draw with staggered CU partners (see k_gemm_nt); SC_GEMM_STATIC=1 keeps
+    // the block-index map.  queue: [0..7] next tile per XCD, [8] stagger claims, [9] next
+    // split unit, [10] units reserved for the stagger (one per CU)
+    static const bool want_static = getenv("SC_GEMM_STATIC") != nullptr;
+    static int* queue_buf[16] = {nullptr};
+    int* queue = nullptr;
+    if (!want_static && xcd_chunk > 0 && rem > 0 && SYM) {
+      int dev = 0;
+      hipGetDevice(&dev);
+      dev &= 15;
+      if (queue_buf[dev] == nullptr) (void)hipMalloc(&queue_buf[dev], 16 * sizeof(int));
+      queue = queue_buf[dev];
+      hipLaunchKernelGGL(k_gemm_queue_init, dim3(1), dim3(16), 0, s, queue, g_slots / 2);
+    }
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full + rem * ksplit), dim3(256), 0, s, A, lda,
                        B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, probe, tilemap,
-                       xcd_chunk, stats, ksync);
+                       xcd_chunk, stats, ksync, queue);
     if (probe != nullptr) {
       (void)hipStreamSynchronize(s);
       std::vector<double> h(3 * full);

@@ -197,6 +197,7 @@ struct EigRequest {
   // the others must be accurate enough that, with their residual intervals, no other gap
   // can reach the maximum and no comparison with stop_eigenvalue can flip.
   int decision_aware = 0;
+  long long hint_key = 0;  // distinguishes workloads for the Rayleigh-Ritz scheduling hint
 };
 
 struct EigDecision {

@@ -202,13 +202,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats,
                                                  int* __restrict__ ksync,
-                                                 int* __restrict__ queue) {
+                                                 int* __restrict__ queue, int edge_prio) {
   // one 64 KB block: As[2] | Bs[2] in the K loop, reduction scratch + the transposed
   // staging of the mirror tile in the epilogue
   __shared__ __attribute__((aligned(16))) double smem[2 * BM * BK + 2 * BN * BK];
   double(*As)[BM * BK] = reinterpret_cast<double(*)[BM * BK]>(smem);
   double(*Bs)[BN * BK] = reinterpret_cast<double(*)[BN * BK]>(smem + 2 * BM * BK);
 
+  // Prologue and epilogue at the TOP issue priority: the partner workgroup of this CU is in
+  // its K loop at priority 1-2, and at priority 0 the ~2000 scalar / vector / store
+  // instructions of an epilogue only get the issue slots its MFMA stream leaves -- the tile
+  // timeline shows 86 us between one tile's K loop and the next one's on the same slot,
+  // during which this half of the CU's MFMA capacity is lost (one workgroup cannot use
+  // more than its own share: staggering the partners did not help, profiles/r02_i).
+  if (edge_prio) __builtin_amdgcn_s_setprio(3);
   int ti, tj;
   // Work item of this workgroup.  Static (queue == nullptr): by block index.  Dynamic: the grid
   // still has exactly one workgroup per item, but each workgroup DRAWS its item when it
@@ -493,6 +500,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     if (kt < kt_end) k_tile(kt, std::integral_constant<int, 0>{}, P0{});
   }
 
+  if (edge_prio) __builtin_amdgcn_s_setprio(3);
   if (probe && tid == 0) {
     probe_out[2 * item_blk] = (double)(clock64() - clk0);
     probe_out[2 * item_blk + 1] = (double)(wall_clock64() - wall0);
@@ -748,10 +756,10 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
       ksync = ksync_buf[dev];
       (void)hipMemsetAsync(ksync, 0, bytes, s);
     }
-    // dynamic work draw with staggered CU partners (see k_gemm_nt); SC_GEMM_STATIC=1 keeps
-    // the block-index map.  queue: [0..7] next tile per XCD, [8] stagger claims, [9] next
+    // dynamic work draw with staggered CU partners (see k_gemm_nt), SC_GEMM_DYNAMIC=1: an
+    // experiment that did not pay (profiles/r02_i); the block-index map is the default.  queue: [0..7] next tile per XCD, [8] stagger claims, [9] next
     // split unit, [10] units reserved for the stagger (one per CU)
-    static const bool want_static = getenv("SC_GEMM_STATIC") != nullptr;
+    static const bool want_static = getenv("SC_GEMM_DYNAMIC") == nullptr;  // opt-in: no gain
     static int* queue_buf[16] = {nullptr};
     int* queue = nullptr;
     if (!want_static && xcd_chunk > 0 && rem > 0 && SYM) {
@@ -762,9 +770,10 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
       queue = queue_buf[dev];
       hipLaunchKernelGGL(k_gemm_queue_init, dim3(1), dim3(16), 0, s, queue, g_slots / 2);
     }
+    static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 1;
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full + rem * ksplit), dim3(256), 0, s, A, lda,
                        B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, probe, tilemap,
-                       xcd_chunk, stats, ksync, queue);
+                       xcd_chunk, stats, ksync, queue, edge_prio);
     if (probe != nullptr) {
       (void)hipStreamSynchronize(s);
       std::vector<double> h(3 * full);

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   // timeline shows 86 us between one tile's K loop and the next one's on the same slot,
   // during which this half of the CU's MFMA capacity is lost (one workgroup cannot use
   // more than its own share: staggering the partners did not help, profiles/r02_i).
-  if (edge_prio) __builtin_amdgcn_s_setprio(3);
+  if (edge_prio & 1) __builtin_amdgcn_s_setprio(3);
   int ti, tj;
   // Work item of this workgroup.  Static (queue == nullptr): by block index.  Dynamic: the grid
   // still has exactly one workgroup per item, but each workgroup DRAWS its item when it
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     if (kt < kt_end) k_tile(kt, std::integral_constant<int, 0>{}, P0{});
   }
 
-  if (edge_prio) __builtin_amdgcn_s_setprio(3);
+  if (edge_prio & 1) __builtin_amdgcn_s_setprio(3);
   if (probe && tid == 0) {
     probe_out[2 * item_blk] = (double)(clock64() - clk0);
     probe_out[2 * item_blk + 1] = (double)(wall_clock64() - wall0);
@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     return;
   }
   const bool mirror = SYM && (ti != tj);
+  const bool nt_store = (edge_prio & 2) != 0;
   if (stats.mode != 0 || mirror) __syncthreads();  // operand tiles are dead: LDS is reused
   if (stats.mode != 0) {
     tile_row_stats<EPI, SYM>(acc, ti, tj, ntiles_n, M, N, tid, stats, smem);
@@ -543,7 +544,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
         if (EPI == kEpiAffinity) v = __builtin_fma(v, 0.5, 0.5);
         if (row < M && col < N) {
           if (EPI == kEpiAdd) v += stats.addend[(size_t)row * ldc + col];
-          C[(size_t)row * ldc + col] = v;
+          if (nt_store) __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
+          else C[(size_t)row * ldc + col] = v;
         }
         if (mirror) stage[(nn * 16 + li) * kStagePitch + lg + 4 * r] = v;
       }
@@ -560,8 +562,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
         const int mcol = row0 + wr * 64 + m * 16 + j;   // its column (even)
         if (mrow < N) {
           double* dst = C + (size_t)mrow * ldc + mcol;
-          if (mcol + 1 < M) *reinterpret_cast<double2*>(dst) = v;
-          else if (mcol < M) dst[0] = v.x;
+          if (mcol + 1 < M) {
+            if (nt_store) {
+              __builtin_nontemporal_store(v.x, dst);
+              __builtin_nontemporal_store(v.y, dst + 1);
+            } else {
+              *reinterpret_cast<double2*>(dst) = v;
+            }
+          } else if (mcol < M) {
+            dst[0] = v.x;
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -770,7 +780,7 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
       queue = queue_buf[dev];
       hipLaunchKernelGGL(k_gemm_queue_init, dim3(1), dim3(16), 0, s, queue, g_slots / 2);
     }
-    static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 1;
+    static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 3;
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full + rem * ksplit), dim3(256), 0, s, A, lda,
                        B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, probe, tilemap,
                        xcd_chunk, stats, ksync, queue, edge_prio);

@@ -122,6 +122,33 @@ class RcclComm(Comm):
       raise _lib.DeviceLibraryError("sc_comm_unique_id failed (%d): is librccl present?" % rc)
     return buf.raw
 
+  @staticmethod
+  def exchange_id(rank: int, make_id: typing.Callable[[], bytes],
+                  timeout_s: float = 120.0) -> bytes:
+    """Out-of-band hand-over of the 128-byte RCCL unique id on one node: rank 0 creates it
+    and leaves it in `_id_file()` (written to a temporary name and renamed: readers never
+    see a partial id); the other ranks poll for the file."""
+    path = _id_file()
+    if rank == 0:
+      uid = make_id()
+      tmp = "%s.%d.tmp" % (path, os.getpid())
+      with open(tmp, "wb") as f:
+        f.write(uid)
+      os.replace(tmp, path)
+      return uid
+    deadline = time.monotonic() + timeout_s
+    while True:
+      try:
+        with open(path, "rb") as f:
+          uid = f.read()
+        if len(uid) == 128:
+          return uid
+      except FileNotFoundError:
+        pass
+      if time.monotonic() > deadline:
+        raise TimeoutError("rank %d: no RCCL unique id at %s" % (rank, path))
+      time.sleep(0.01)
+
   @classmethod
   def from_env(cls, handle, timeout_s: float = 120.0) -> "Comm":
     """Communicator of the launch described by RANK / WORLD_SIZE (what
@@ -130,31 +157,12 @@ class RcclComm(Comm):
     rank = int(os.environ.get("RANK", "0"))
     if size == 1:
       return LocalComm()
-    path = _id_file()
-    if rank == 0:
-      uid = cls.new_unique_id()
-      tmp = "%s.%d.tmp" % (path, os.getpid())
-      with open(tmp, "wb") as f:
-        f.write(uid)
-      os.replace(tmp, path)  # atomic: readers never see a partial id
-    else:
-      deadline = time.monotonic() + timeout_s
-      while True:
-        try:
-          with open(path, "rb") as f:
-            uid = f.read()
-          if len(uid) == 128:
-            break
-        except FileNotFoundError:
-          pass
-        if time.monotonic() > deadline:
-          raise TimeoutError("rank %d: no RCCL unique id at %s" % (rank, path))
-        time.sleep(0.01)
+    uid = cls.exchange_id(rank, cls.new_unique_id, timeout_s)
     comm = cls(handle, rank, size, uid)
     comm.barrier()  # everyone has read the id
     if rank == 0:
       try:
-        os.unlink(path)
+        os.unlink(_id_file())
       except OSError:
         pass
     return comm

@@ -112,3 +112,38 @@ def test_product_code_never_imports_torch():
         if re.match(r"\s*(import|from)\s+torch\b", line):
           offenders.append(path)
   assert not offenders, offenders
+
+
+def _id_worker(rank, path, out):
+  sys.path.insert(0, ROOT)
+  os.environ["SC_COMM_ID_FILE"] = path
+  from spectralcluster_amd import multigpu
+  uid = multigpu.RcclComm.exchange_id(rank, lambda: bytes(range(128)), timeout_s=30.0)
+  with open("%s.%d" % (out, rank), "wb") as f:
+    f.write(uid)
+
+
+def test_unique_id_rendezvous_between_processes(tmp_path):
+  """The out-of-band half of RcclComm.from_env (no GPU needed): rank 0 publishes the id
+  atomically, late and early readers all get the same 128 bytes."""
+  import multiprocessing as mp
+  ctx = mp.get_context("spawn")
+  path, out = str(tmp_path / "id"), str(tmp_path / "got")
+  readers = [ctx.Process(target=_id_worker, args=(r, path, out)) for r in (1, 2)]
+  for p in readers:
+    p.start()          # readers first: they must wait for the file
+  writer = ctx.Process(target=_id_worker, args=(0, path, out))
+  writer.start()
+  for p in readers + [writer]:
+    p.join(60)
+    assert p.exitcode == 0
+  for r in (0, 1, 2):
+    assert open("%s.%d" % (out, r), "rb").read() == bytes(range(128))
+  sys.path.insert(0, ROOT)
+  from spectralcluster_amd import multigpu
+  os.environ["SC_COMM_ID_FILE"] = str(tmp_path / "never")
+  try:
+    with pytest.raises(TimeoutError):
+      multigpu.RcclComm.exchange_id(1, lambda: b"", timeout_s=0.2)
+  finally:
+    del os.environ["SC_COMM_ID_FILE"]

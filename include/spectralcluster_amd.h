@@ -339,6 +339,11 @@ int sc_random_state_doubles(uint32_t seed, int count, double* out);
 /* index RandomState.choice(n, p=uniform) returns for the uniform draw u:
  * cumsum(1/n) / cdf[-1], searchsorted(u, side="right") (first k-means++ centre) */
 int sc_uniform_choice(int n, double u);
+/* The host routine that solves the small (<= 64 x 64) Rayleigh-Ritz problems of the block
+ * Lanczos solver: symmetric a (m x m, row-major) -> eigenvalues ascending, eigenvectors in
+ * the columns of `vectors` (Householder tridiagonalisation + implicit QL).  Host-only;
+ * exported so it can be pinned without a GPU. */
+int sc_host_symmetric_eig(const double* a, int m, double* values, double* vectors);
 /* utils.compute_number_of_clusters (utils.py:74-130) -- host scalar loop */
 int sc_eigengap(const double* eigenvalues, int count, int max_clusters,
                 double stop_eigenvalue, int eigengap_type, int descend,

@@ -190,6 +190,8 @@ PROTOTYPES = {
     "sc_random_state_doubles": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_int,
                                                _c_double_p]),
     "sc_uniform_choice": (ctypes.c_int, [ctypes.c_int, ctypes.c_double]),
+    "sc_host_symmetric_eig": (ctypes.c_int, [_c_double_p, ctypes.c_int, _c_double_p,
+                                             _c_double_p]),
     "sc_eigengap": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                    _c_int_p, _c_double_p]),

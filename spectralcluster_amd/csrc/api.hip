@@ -165,7 +165,9 @@ extern "C" int sc_create(int device, sc_handle* out) {
   if (hipHostMalloc(reinterpret_cast<void**>(&h->h_theta), 3 * kLdq * sizeof(double)) !=
           hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&h->h_flags), 16 * sizeof(int)) !=
-          hipSuccess) {
+          hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->h_rr),
+                    (2 * kHostRR * kHostRR + 64) * sizeof(double)) != hipSuccess) {
     delete h;
     return SC_ERR_HIP;
   }
@@ -190,6 +192,7 @@ extern "C" int sc_destroy(sc_handle h) {
   for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);
   if (h->h_theta) hipHostFree(h->h_theta);
   if (h->h_flags) hipHostFree(h->h_flags);
+  if (h->h_rr) hipHostFree(h->h_rr);
   hipStreamDestroy(h->stream);
   delete h;
   return SC_OK;

@@ -145,6 +145,158 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
   return dc;
 }
 
+// ------------------------------------------------------------------------------
+// Rayleigh-Ritz on the host for small projected problems (m <= kHostRR)
+// ------------------------------------------------------------------------------
+// The projected matrix T = Q^T Op Q of the first checks is 24 x 24 .. 48 x 48: 4.6-18 KB that
+// come back with the flags the host reads anyway.  A one-workgroup Jacobi takes 170-330 us
+// for it on the device (a chain of ~160 barrier-separated rounds); Householder
+// tridiagonalisation + implicit QL (the textbook tred2 / tql2 recurrences) on one host core
+// takes ~20-60 us.  Larger bases (after restarts) stay on the device (k_jacobi).
+//
+// a: m x m symmetric (row-major, lda), overwritten with the eigenvectors (columns);
+// d: eigenvalues ascending.  Returns false if QL did not converge (30 iterations).
+static bool host_symmetric_eig(double* a, int lda, int m, double* d, double* e) {
+  auto A = [&](int i, int j) -> double& { return a[(size_t)i * lda + j]; };
+  // ---- tred2: Householder reduction to tridiagonal form, accumulating the transformation
+  for (int i = m - 1; i >= 1; --i) {
+    const int l = i - 1;
+    double h = 0.0, scale = 0.0;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale += std::fabs(A(i, k));
+      if (scale == 0.0) {
+        e[i] = A(i, l);
+      } else {
+        for (int k = 0; k <= l; ++k) {
+          A(i, k) /= scale;
+          h += A(i, k) * A(i, k);
+        }
+        double f = A(i, l);
+        double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+        e[i] = scale * g;
+        h -= f * g;
+        A(i, l) = f - g;
+        f = 0.0;
+        for (int j = 0; j <= l; ++j) {
+          A(j, i) = A(i, j) / h;
+          g = 0.0;
+          for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
+          for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
+          e[j] = g / h;
+          f += e[j] * A(i, j);
+        }
+        const double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) {
+          f = A(i, j);
+          e[j] = g = e[j] - hh * f;
+          for (int k = 0; k <= j; ++k) A(j, k) -= (f * e[k] + g * A(i, k));
+        }
+      }
+    } else {
+      e[i] = A(i, l);
+    }
+    d[i] = h;
+  }
+  d[0] = 0.0;
+  e[0] = 0.0;
+  for (int i = 0; i < m; ++i) {
+    const int l = i - 1;
+    if (d[i] != 0.0) {
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= l; ++k) g += A(i, k) * A(k, j);
+        for (int k = 0; k <= l; ++k) A(k, j) -= g * A(k, i);
+      }
+    }
+    d[i] = A(i, i);
+    A(i, i) = 1.0;
+    for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
+  }
+  // ---- tql2: implicit QL with eigenvector accumulation
+  for (int i = 1; i < m; ++i) e[i - 1] = e[i];
+  e[m - 1] = 0.0;
+  for (int l = 0; l < m; ++l) {
+    int iter = 0, mm;
+    do {
+      for (mm = l; mm < m - 1; ++mm) {
+        const double dd = std::fabs(d[mm]) + std::fabs(d[mm + 1]);
+        if (std::fabs(e[mm]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (mm != l) {
+        if (iter++ == 60) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[mm] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = mm - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          e[i + 1] = r = std::hypot(f, g);
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[mm] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          d[i + 1] = g + (p = s * r);
+          g = c * r - b;
+          for (int k = 0; k < m; ++k) {
+            f = A(k, i + 1);
+            A(k, i + 1) = s * A(k, i) + c * f;
+            A(k, i) = c * A(k, i) - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[mm] = 0.0;
+      }
+    } while (mm != l);
+  }
+  return true;
+}
+
+// host-only export: lets the CPU tests pin the routine without a GPU
+extern "C" int sc_host_symmetric_eig(const double* a, int m, double* values, double* vectors) {
+  if (!a || !values || !vectors || m < 1) return SC_ERR_INVALID;
+  std::vector<double> e(m);
+  for (size_t i = 0; i < (size_t)m * m; ++i) vectors[i] = a[i];
+  return host_symmetric_eig(vectors, m, m, values, e.data()) ? SC_OK : SC_ERR_NOT_CONVERGED;
+}
+
+// T (m x m, from the device, row-major ld) and the residual block's Gram G (B x B) ->
+// theta descending, resid estimates sqrt(y_last^T G y_last), Y (m x m, row-major ldy,
+// column `rank` = Ritz vector of theta[rank]).  Same outputs as k_jacobi.
+static bool host_rayleigh_ritz(const double* T, int ld, const double* G, int m, double* theta,
+                               double* resid, double* Y, int ldy) {
+  std::vector<double> a((size_t)m * m), d(m), e(m);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j)  // the mirrored upper triangle is what the chain wrote
+      a[(size_t)i * m + j] = i <= j ? T[(size_t)i * ld + j] : T[(size_t)j * ld + i];
+  if (!host_symmetric_eig(a.data(), m, m, d.data(), e.data())) return false;
+  std::vector<int> order(m);
+  for (int i = 0; i < m; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d[x] > d[y]; });
+  for (int rank = 0; rank < m; ++rank) {
+    const int c = order[rank];
+    theta[rank] = d[c];
+    double r2 = 0.0;
+    for (int p = 0; p < kEigBlock; ++p) {
+      double t = 0.0;
+      for (int q = 0; q < kEigBlock; ++q)
+        t += G[p * kEigBlock + q] * a[(size_t)(m - kEigBlock + q) * m + c];
+      r2 += a[(size_t)(m - kEigBlock + p) * m + c] * t;
+    }
+    resid[rank] = std::sqrt(std::max(r2, 0.0));
+    for (int r = 0; r < m; ++r) Y[(size_t)r * ldy + rank] = a[(size_t)r * m + c];
+  }
+  return true;
+}
+
 // One CholQR pass on W (n x 8) with the orthonormality-defect flag of its input armed
 // (flags[10]); stores the result into Q[:, store_col ...] and Vs when store_col >= 0.
 static int cholqr_pass(sc_handle h, int n, int store_col) {
@@ -415,7 +567,16 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
                                                                m % (2 * kEigBlock) == 0 ||
                                                                m + kEigBlock > cap))
                                      : (m + kEigBlock > cap);
-      if (check) {
+      const bool host_rr = check && m <= kHostRR && !getenv("SC_EIG_DEVICE_RR");
+      if (host_rr) {
+        // small projected problem: T and G come back with the flags; solved on the host
+        SC_HIP(h, hipMemcpy2DAsync(h->h_rr, (size_t)m * sizeof(double), h->T.p,
+                                   (size_t)kLdq * sizeof(double), (size_t)m * sizeof(double), m,
+                                   hipMemcpyDeviceToHost, s));
+        SC_HIP(h, hipMemcpyAsync(h->h_rr + kHostRR * kHostRR, h->G.p,
+                                 kEigBlock * kEigBlock * sizeof(double), hipMemcpyDeviceToHost,
+                                 s));
+      } else if (check) {
         launch_jacobi(s, ptr<double>(h->T), kLdq, m, 0, nullptr, nullptr, ptr<double>(h->G),
                       theta_d, ptr<double>(h->Y), kLdq, resid_d, ptr<double>(h->Yt),
                       ptr<int>(h->flags));
@@ -438,6 +599,20 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
           passes = 0;
           goto restart_lanczos;
         }
+      }
+      if (host_rr) {
+        double* hy = h->h_rr + kHostRR * kHostRR + 64;
+        if (!host_rayleigh_ritz(h->h_rr, m, h->h_rr + kHostRR * kHostRR, m, h->h_theta,
+                                h->h_theta + kLdq, hy, m))
+          return fail(h, SC_ERR_NOT_CONVERGED, "Rayleigh-Ritz (QL) did not converge");
+        for (int i = 0; i < m; ++i)
+          if (!std::isfinite(h->h_theta[i])) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+        // the Ritz vectors (and values, for a restart) go back to where k_jacobi leaves them
+        SC_HIP(h, hipMemcpy2DAsync(h->Y.p, (size_t)kLdq * sizeof(double), hy,
+                                   (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
+                                   hipMemcpyHostToDevice, s));
+        SC_HIP(h, hipMemcpyAsync(theta_d, h->h_theta, m * sizeof(double),
+                                 hipMemcpyHostToDevice, s));
       }
       if (check) {
         dc = analyze(rq, h->h_theta, h->h_theta + kLdq, m, n, false);

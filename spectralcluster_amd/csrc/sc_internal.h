@@ -17,6 +17,8 @@ constexpr int kEigBlock = 8;         // Lanczos block width (half an MFMA tile c
 constexpr int kEigBasisCap = 128;    // Rayleigh-Ritz size limit (LDS Jacobi)
 constexpr int kLdq = kEigBasisCap + kEigBlock;  // row stride of the Krylov basis
 constexpr int kDenseMax = 128;       // n <= this: direct dense Jacobi
+constexpr int kHostRR = 64;          // Rayleigh-Ritz problems up to this order are solved on
+                                     // the host (O(m^3) scalars, like the eigengap loop)
 constexpr int kGenMax = 64;          // general eigen path: dense limit and Arnoldi basis cap
 constexpr int kMaxVectors = 64;      // eigenvector columns kept resident
 constexpr int kProjBlocks = 128;     // partial-sum blocks for tall-skinny products

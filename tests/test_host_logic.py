@@ -385,3 +385,26 @@ def test_comm_header_and_id_file(monkeypatch, tmp_path):
   monkeypatch.setenv("SC_COMM_ID_FILE", str(tmp_path / "x.id"))
   assert multigpu._id_file() == str(tmp_path / "x.id")
   assert _lib.load().sc_comm_rank(None) == -1 and _lib.load().sc_comm_size(None) == 0
+
+
+def test_host_rayleigh_ritz_solver_vs_numpy():
+  """The host routine behind the small Rayleigh-Ritz problems (tred2 / tql2)."""
+  lib = _lib.load()
+  rng = np.random.default_rng(0)
+  for m in (1, 2, 3, 8, 24, 32, 48, 64):
+    a = rng.standard_normal((m, m))
+    a = 0.5 * (a + a.T)
+    if m == 24:  # the shape of a projected Laplacian: a few informative values + a tight bulk
+      q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+      lam = np.concatenate([[0.0, -0.07, -0.073, -0.075], -1 + 1e-6 * rng.standard_normal(m - 4)])
+      a = (q * lam) @ q.T
+      a = 0.5 * (a + a.T)
+    a = np.ascontiguousarray(a)
+    w = np.empty(m)
+    v = np.empty((m, m))
+    assert lib.sc_host_symmetric_eig(_lib.as_double_p(a), m, _lib.as_double_p(w),
+                                     _lib.as_double_p(v)) == 0
+    scale = max(1.0, np.abs(a).max())
+    np.testing.assert_allclose(np.sort(w), np.linalg.eigvalsh(a), rtol=0, atol=1e-13 * scale)
+    assert np.abs(a @ v - v * w).max() < 1e-13 * scale * m
+    assert np.abs(v.T @ v - np.eye(m)).max() < 1e-13 * m

@@ -269,6 +269,12 @@ int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* labels,
 int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,
                      int count, const sc_config* cfg, int64_t* const* labels,
                      sc_diag* diags);
+/* the same over `streams` HIP streams of the handle's device (pooled arenas, one host
+ * thread per stream inside the call, longest utterances first): small utterances cannot
+ * fill the GPU and their pipeline is latency-bound, several in flight overlap */
+int sc_predict_batch_streams(sc_handle h, const double* const* xs, const int* ns, int d,
+                             int count, const sc_config* cfg, int64_t* const* labels,
+                             sc_diag* diags, int streams);
 
 /*
  * Size reduction before the spectral path (spectral_clusterer.py:170-199,

@@ -174,6 +174,11 @@ PROTOTYPES = {
                                         ctypes.POINTER(ScConfig),
                                         ctypes.POINTER(_c_int64_p),
                                         ctypes.POINTER(ScDiag)]),
+    "sc_predict_batch_streams": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),
+                                                _c_int_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(ScConfig),
+                                                ctypes.POINTER(_c_int64_p),
+                                                ctypes.POINTER(ScDiag), ctypes.c_int]),
     "sc_stage_affinity": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
                                          ctypes.c_int, _c_double_p]),
     "sc_stage_refine": (ctypes.c_int, [_handle_t, ctypes.c_int,
@@ -356,11 +361,33 @@ class Handle:
 
 
 _default_handles = {}
+_scope = threading.local()
+
+
+class use_device:
+  """`with use_device(k):` -- module-level helpers called inside (which take no device
+  argument, like the reference's functions) run on device k in this thread.  A
+  `SpectralClusterer(device=k)` wraps its predict() in it, so its pre-clustering, fallback
+  and single-cluster helpers share its GPU and arena."""
+
+  def __init__(self, device: typing.Optional[int]):
+    self.device = device
+
+  def __enter__(self):
+    self.previous = getattr(_scope, "device", None)
+    if self.device is not None:
+      _scope.device = self.device
+    return self
+
+  def __exit__(self, *exc):
+    _scope.device = self.previous
 
 
 def default_handle(device: typing.Optional[int] = None) -> Handle:
-  """Process-wide handle per device (device from SPECTRALCLUSTER_AMD_DEVICE,
-  else LOCAL_RANK, else 0)."""
+  """Process-wide handle per device (the enclosing `use_device`, else
+  SPECTRALCLUSTER_AMD_DEVICE, else LOCAL_RANK, else 0)."""
+  if device is None:
+    device = getattr(_scope, "device", None)
   if device is None:
     device = int(os.environ.get("SPECTRALCLUSTER_AMD_DEVICE",
                                 os.environ.get("LOCAL_RANK", "0")))

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <vector>
 
+#include <thread>
+
 #include "handle.h"
 
 // ------------------------------------------------------------------------------
@@ -177,6 +179,8 @@ extern "C" int sc_create(int device, sc_handle* out) {
 
 extern "C" int sc_destroy(sc_handle h) {
   if (!h) return SC_OK;
+  for (sc_handle sub : h->pool) sc_destroy(sub);
+  h->pool.clear();
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
@@ -978,6 +982,64 @@ extern "C" int sc_predict_batch(sc_handle h, const double* const* xs, const int*
   if (nmax > 0) SC_TRY(sc_reserve(h, nmax, d));  // one arena sized for the largest member
   for (int i = 0; i < count; ++i)
     SC_TRY(sc_predict(h, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr));
+  return SC_OK;
+}
+
+// The batch over `streams` HIP streams of the handle's device: handle h plus streams - 1
+// pooled handles (one arena + one stream each), one host thread per stream inside this call.
+// Small utterances cannot fill 256 CUs and their pipeline is a chain of short, dependent
+// launches with two host synchronisations: several in flight hide each other's latencies.
+// Utterances are dealt longest-processing-time first (cost n^3 + 64 n^2).
+extern "C" int sc_predict_batch_streams(sc_handle h, const double* const* xs, const int* ns,
+                                        int d, int count, const sc_config* cfg,
+                                        int64_t* const* labels, sc_diag* diags, int streams) {
+  if (!h) return SC_ERR_INVALID;
+  if (!xs || !ns || !labels || count < 0) return fail(h, SC_ERR_INVALID, "NULL argument");
+  streams = std::max(1, std::min(streams, std::min(count, 32)));
+  if (streams == 1) return sc_predict_batch(h, xs, ns, d, count, cfg, labels, diags);
+  while ((int)h->pool.size() < streams - 1) {
+    sc_handle sub = nullptr;
+    const int rc = sc_create(h->device, &sub);
+    if (rc != SC_OK) return fail(h, rc, "could not create a stream handle for the batch");
+    sub->profile_level = h->profile_level;
+    h->pool.push_back(sub);
+  }
+  // longest-processing-time-first assignment (ties: lower index, lower stream)
+  std::vector<int> order(count);
+  for (int i = 0; i < count; ++i) order[i] = i;
+  auto cost = [&](int i) { const double n = ns[i]; return n * n * n + 64.0 * n * n; };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+  std::vector<std::vector<int>> share(streams);
+  std::vector<double> load(streams, 0.0);
+  for (int i : order) {
+    int best = 0;
+    for (int q = 1; q < streams; ++q)
+      if (load[q] < load[best]) best = q;
+    share[best].push_back(i);
+    load[best] += cost(i);
+  }
+  std::vector<int> rcs(streams, SC_OK);
+  auto work = [&](int q) {
+    sc_handle hq = q == 0 ? h : h->pool[q - 1];
+    int nmax = 0;
+    for (int i : share[q]) nmax = std::max(nmax, ns[i]);
+    int rc = nmax > 0 ? sc_reserve(hq, nmax, d) : SC_OK;
+    if (rc == SC_OK) rc = sc_clear_constraint(hq);
+    for (size_t k = 0; rc == SC_OK && k < share[q].size(); ++k) {
+      const int i = share[q][k];
+      rc = sc_predict(hq, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr);
+    }
+    rcs[q] = rc;
+  };
+  std::vector<std::thread> threads;
+  for (int q = 1; q < streams; ++q) threads.emplace_back(work, q);
+  work(0);
+  for (std::thread& t : threads) t.join();
+  for (int q = 0; q < streams; ++q)
+    if (rcs[q] != SC_OK) {
+      if (q > 0) h->err = h->pool[q - 1]->err;
+      return rcs[q];
+    }
   return SC_OK;
 }
 

@@ -318,12 +318,7 @@ bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, in
   }
   const int HW = TW + 2 * radius, HH = TH + 2 * radius;
   const size_t lds = sizeof(double) * ((size_t)HH * HW + (size_t)TH * HW + radius + 1);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gaussian_blur),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
+  SC_OPT_IN_LDS(k_gaussian_blur, 150 * 1024);
   hipLaunchKernelGGL(k_gaussian_blur, grid, dim3(256), lds, s, in, out, n, ld, radius,
                      weights_dev);
   return false;

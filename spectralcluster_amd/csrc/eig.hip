@@ -1066,14 +1066,8 @@ void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
   const size_t with_yt = base + sizeof(double) * (size_t)mp * mp;
   const int yt_in_lds = with_yt <= 150 * 1024;
   const size_t lds = yt_in_lds ? with_yt : base;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_jacobi<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    attr_set = true;
-  }
+  SC_OPT_IN_LDS(k_jacobi<true>, 160 * 1024 - 256);
+  SC_OPT_IN_LDS(k_jacobi<false>, 160 * 1024 - 256);
   // always 16 waves: each round is a chain of dependent LDS round trips, so the time
   // per round is set by how many work items a wave handles one after the other
   const int threads = 1024;
@@ -1093,12 +1087,7 @@ void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
                           const double* Y, int ldy, int cols, double* dst,
                           int lddst, int n, int colmajor) {
   const size_t lds = sizeof(double) * ((size_t)m * cols + 16 * (size_t)(m + 1));
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_basis_times_Y),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
+  SC_OPT_IN_LDS(k_basis_times_Y, 128 * 1024);
   hipLaunchKernelGGL(k_basis_times_Y, dim3((n + 15) / 16), dim3(256), lds, s, Q, ldq,
                      m, Y, ldy, cols, dst, lddst, n, colmajor);
 }

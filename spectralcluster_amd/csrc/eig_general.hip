@@ -527,12 +527,7 @@ void launch_gen_eig(hipStream_t s, const double* A, int lda, int m, double sign,
                     double* theta_re, double* theta_im, double* Yre, double* Yim, int ldy,
                     int* info) {
   const size_t lds = sizeof(double) * (4 * (size_t)GM * GLD + 6 * GM) + sizeof(int) * GM + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_gen_eig),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    attr_set = true;
-  }
+  SC_OPT_IN_LDS(k_gen_eig, 160 * 1024 - 256);
   hipLaunchKernelGGL(k_gen_eig, dim3(1), dim3(64), lds, s, A, lda, m, sign, nvec, theta_re,
                      theta_im, Yre, Yim, ldy, info);
 }

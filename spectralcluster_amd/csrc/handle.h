@@ -68,6 +68,7 @@ struct sc_handle_s {
   double* h_theta = nullptr;  // 3 * kLdq doubles (theta, resid, Im theta)
   int* h_flags = nullptr;
   double* h_rr = nullptr;     // pinned: T (kHostRR^2) | G (64) | Y (kHostRR^2): host Rayleigh-Ritz
+  std::vector<sc_handle_s*> pool;  // extra handles (streams) of sc_predict_batch_streams
   hipEvent_t ev[48];
   int nev = 0;
   int profile_level = 1;  // sc_set_profiling: 0 totals only, 1 stages, 2 per-kernel events

@@ -534,12 +534,7 @@ void launch_cut_percentile(hipStream_t s, const double* in, int n, int ld, doubl
   if (vi < 0.0) { prev = 0; next = 0; gamma = 0.0; }
   const size_t bytes = (size_t)n * sizeof(unsigned long long);
   const int in_lds = bytes <= 128 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_row_percentile_cut),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
+  SC_OPT_IN_LDS(k_row_percentile_cut, 128 * 1024);
   hipLaunchKernelGGL(k_row_percentile_cut, dim3(n), dim3(256), in_lds ? bytes : 0, s, in, n,
                      ld, zero_diag, prev, next, gamma, cut, in_lds);
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,19 @@ constexpr int kMaxVectors = 64;      // eigenvector columns kept resident
 constexpr int kProjBlocks = 128;     // partial-sum blocks for tall-skinny products
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device, per-function attribute: set it
+// once per device (thread-safe; handles of several devices / threads share the process)
+#define SC_OPT_IN_LDS(kernel, bytes)                                                      \
+  do {                                                                                    \
+    static std::once_flag sc_once_[16];                                                   \
+    int sc_dev_ = 0;                                                                      \
+    (void)hipGetDevice(&sc_dev_);                                                         \
+    std::call_once(sc_once_[sc_dev_ & 15], [] {                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+    });                                                                                   \
+  } while (0)
 
 // GEMM epilogues
 enum { kEpiNone = 0, kEpiAffinity = 1, kEpiAdd = 2 };

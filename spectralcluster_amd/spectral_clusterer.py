@@ -199,6 +199,10 @@ class SpectralClusterer:
   def predict(self, embeddings: np.ndarray, constraint_matrix=None) -> np.ndarray:
     """Cluster `embeddings` (n_samples, n_features); returns int64 labels
     (reference spectral_clusterer.py:201-314)."""
+    with _lib.use_device(self.device):  # helpers without a device argument follow self.device
+      return self._predict(embeddings, constraint_matrix)
+
+  def _predict(self, embeddings: np.ndarray, constraint_matrix=None) -> np.ndarray:
     if not isinstance(embeddings, np.ndarray):
       raise TypeError("embeddings must be a numpy array")
     if len(embeddings.shape) != 2:
@@ -294,32 +298,16 @@ class SpectralClusterer:
         custom_dist=self.custom_dist, max_iter=self.max_iter)
 
   # -------------------------------------------------------------- batch (new)
-  def _predict_batch_on(self, handle, xs, labels, diags_out, indices):
-    """Run utterances `indices` back to back on one handle (one HIP stream)."""
-    count = len(indices)
-    if count == 0:
-      return
-    handle.check(handle.lib.sc_clear_constraint(handle.raw))  # a batch carries none
-    xp = (ctypes.POINTER(ctypes.c_double) * count)(
-        *[_lib.as_double_p(xs[i]) for i in indices])
-    lp = (ctypes.POINTER(ctypes.c_int64) * count)(
-        *[_lib.as_int64_p(labels[i]) for i in indices])
-    ns = (ctypes.c_int * count)(*[xs[i].shape[0] for i in indices])
-    diags = (_lib.ScDiag * count)()
-    handle.check(handle.lib.sc_predict_batch(handle.raw, xp, ns, xs[0].shape[1], count,
-                                             self.build_config(), lp, diags), TypeError)
-    for slot, i in enumerate(indices):
-      diags_out[i] = diags[slot]
-
   def predict_batch(self, utterances: typing.Sequence[np.ndarray],
                     streams: int = 4) -> typing.List[np.ndarray]:
     """Independent predict() calls (the reference has no batch API: a batch is a
     Python loop).
 
-    Small utterances cannot fill 256 CUs, and their eigen stage is a chain of short
-    launches, so the batch is spread (longest-processing-time first) over `streams`
-    independent handles -- one HIP stream and one arena each -- driven by one host
-    thread per handle (ctypes releases the GIL during the calls).
+    Small utterances cannot fill 256 CUs, and their pipeline is a chain of short dependent
+    launches, so the batch is spread (longest-processing-time first) over `streams` HIP
+    streams of this clusterer's device inside ONE library call
+    (`sc_predict_batch_streams`: pooled arenas, one host thread per stream in the C++
+    library; the GIL is released for the whole batch).
     """
     if (self.autotune is not None or self.max_spectral_size is not None or
         self.min_clusters == 1 or self.fallback_options.spectral_min_embeddings > 1 or
@@ -340,20 +328,16 @@ class SpectralClusterer:
     for x in xs:
       if x.ndim != 2 or x.shape[1] != d:
         raise ValueError("all utterances must be (n_i, d) with the same d")
+    count = len(xs)
     labels = [np.empty(x.shape[0], dtype=np.int64) for x in xs]
-    diags = [None] * len(xs)
-    streams = max(1, min(int(streams), len(xs)))
-    if streams == 1:
-      self._predict_batch_on(self._handle(), xs, labels, diags, list(range(len(xs))))
-    else:
-      from spectralcluster_amd import multigpu
-      import concurrent.futures
-      shares = multigpu.lpt_assignment([x.shape[0] for x in xs], streams)
-      pool = _lib.handle_pool(self.device, streams)
-      with concurrent.futures.ThreadPoolExecutor(max_workers=streams) as ex:
-        futures = [ex.submit(self._predict_batch_on, h, xs, labels, diags, share)
-                   for h, share in zip(pool, shares)]
-        for f in futures:
-          f.result()
-    self.last_batch_diags = diags
+    handle = self._handle()
+    handle.check(handle.lib.sc_clear_constraint(handle.raw))  # a batch carries none
+    xp = (ctypes.POINTER(ctypes.c_double) * count)(*[_lib.as_double_p(x) for x in xs])
+    lp = (ctypes.POINTER(ctypes.c_int64) * count)(*[_lib.as_int64_p(l) for l in labels])
+    ns = (ctypes.c_int * count)(*[x.shape[0] for x in xs])
+    diags = (_lib.ScDiag * count)()
+    handle.check(handle.lib.sc_predict_batch_streams(
+        handle.raw, xp, ns, d, count, self.build_config(), lp, diags,
+        max(1, int(streams))), TypeError)
+    self.last_batch_diags = list(diags)
     return labels

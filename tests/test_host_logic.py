@@ -408,3 +408,15 @@ def test_host_rayleigh_ritz_solver_vs_numpy():
     np.testing.assert_allclose(np.sort(w), np.linalg.eigvalsh(a), rtol=0, atol=1e-13 * scale)
     assert np.abs(a @ v - v * w).max() < 1e-13 * scale * m
     assert np.abs(v.T @ v - np.eye(m)).max() < 1e-13 * m
+
+
+def test_use_device_scope_is_thread_local_and_nested():
+  assert getattr(_lib._scope, "device", None) is None
+  with _lib.use_device(3):
+    assert _lib._scope.device == 3
+    with _lib.use_device(None):      # None does not override
+      assert _lib._scope.device == 3
+    with _lib.use_device(1):
+      assert _lib._scope.device == 1
+    assert _lib._scope.device == 3
+  assert _lib._scope.device is None

@@ -1,0 +1,70 @@
+"""GPU: the paths that the default configuration does not take must stay correct --
+they are the repair / large-problem routes of the default ones:
+
+  SC_EIG_HOST_CHAIN=1   host-driven orthonormalisation chain (what the fused k_lz_rows chain
+                        falls back to when a block is rank deficient)
+  SC_EIG_DEVICE_RR=1    one-workgroup Jacobi for the Rayleigh-Ritz problem (used above 64
+                        basis vectors; the host solves the smaller ones)
+  SC_KMEANS_SINGLE=1    single-workgroup k-means (k > 32, other metrics, very large n)
+  SC_EIG_NO_HINT=1      no Rayleigh-Ritz scheduling hint
+
+Each runs in a fresh interpreter (the switches are read once per process) over reference
+goldens of both Laplacian branches."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r"""
+import os, sys
+import numpy as np
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import spectral_oracle as so
+import spectralcluster_amd as sca
+LAP = {0: None, 2: sca.LaplacianType.Unnormalized, 3: sca.LaplacianType.RandomWalk,
+       4: sca.LaplacianType.GraphCut}
+opts = sca.configs.icassp2018_refinement_options
+for name in ("e2e_n1000_lap0_max7", "e2e_n1000_lap4_max20", "e2e_n1000_lap3_max20",
+             "e2e_n2048_lap0_max7", "e2e_n2048_lap4_max20"):
+  g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+  n, d, k, seed, lap, maxc = (int(v) for v in g["params"])
+  x = so.blobs(n, d, k, seed)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=maxc, refinement_options=opts,
+                            laplacian_type=LAP[lap])
+  for rep in range(2):   # twice: the second call runs with whatever state the first left
+    labels = c.predict(x)
+    dg = c.last_diag
+    idx, ref = g["consumed_index"], g["consumed_eigenvalues"]
+    if lap == 0:  # the descending loop stops reading after the first value < 1e-2
+      keep = so.consumed_eigen_indices(n, maxc, True, ref, 1e-2)
+      idx, ref = idx[keep], ref[keep]
+    w = dg.eigenvalue_array()[idx]
+    assert np.max(np.abs(w - ref) / np.maximum(np.abs(ref), 1e-12)) < 1e-6, name
+    assert dg.n_clusters_raw == int(g["n_clusters_raw"]), name
+    assert so.adjusted_rand_index(labels, g["labels"]) == 1.0, name
+  if os.environ.get("SC_EIG_HOST_CHAIN"):
+    assert dg.eig_host_chain == 1
+km = np.load(os.path.join(ROOT, "tests", "golden", "kmeans.npz"))
+for tag, k in (("a", 4), ("b", 8), ("c", 2), ("d", 20)):
+  got = sca.custom_distance_kmeans.run_kmeans(km["e_" + tag], k, "cosine", 300)
+  assert np.array_equal(got, km["labels_" + tag]), tag
+print("ALTERNATE_PATH_OK")
+"""
+
+
+@pytest.mark.parametrize("switch", ["SC_EIG_HOST_CHAIN", "SC_EIG_DEVICE_RR", "SC_KMEANS_SINGLE",
+                                    "SC_EIG_NO_HINT"])
+def test_alternate_path(tmp_path, switch):
+  script = tmp_path / "alt.py"
+  script.write_text(_SCRIPT)
+  env = dict(os.environ)
+  env[switch] = "1"
+  r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True,
+                     timeout=600, env=env)
+  assert r.returncode == 0 and "ALTERNATE_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,13 +1,19 @@
 // Symmetric top-k eigensolver kernels (reference utils.py:44-71 calls LAPACK
-// dgeev on a matrix that is diagonally similar to a symmetric one; see DESIGN.md).
+// dgeev on a matrix that is diagonally similar to a symmetric one; see DESIGN.md 3.4-3.5).
 //
 // Operator:  Op = diag(p) + diag(c) S diag(c),  S = refined (symmetric) matrix.
-// Method:    block Lanczos, block = 16 vectors (one v_mfma_f64_16x16x4_f64 tile
-//            column), full re-orthogonalisation (CGS2 + CholQR2), explicit
-//            Rayleigh-Ritz T = Q^T Op Q, thick restart; the small dense
-//            eigenproblem is a one-workgroup cyclic Jacobi with T in LDS.
-// The only O(n^2) kernel is k_block_matvec (one HBM pass over S per 16 vectors);
-// everything else is tall-skinny (n x <=144) and L2-resident.
+// Method:    block Lanczos, 8 vectors per block (half a v_mfma_f64_16x16x4_f64 tile column),
+//            full re-orthogonalisation, explicit Rayleigh-Ritz T = Q^T Op Q, thick restart.
+//   k_block_matvec   the only O(n^2) kernel: one HBM pass over S per block
+//   k_lz_rows        the orthonormalisation as a chain of short launches (4 per block) whose
+//                    prologues add the previous link's partial sums: no host sync per block
+//   k_proj_partial / k_reduce_H / k_update_block / k_reduce_chol / k_apply_rinv
+//                    the host-driven form of the same chain (one step per launch, flags read
+//                    after every block): the repair path for rank-deficient blocks
+//   k_jacobi         one-workgroup cyclic Jacobi, matrix in LDS: the dense solver for n <= 128
+//                    and the Rayleigh-Ritz problems above 64 (smaller ones are solved on the
+//                    host, eig_driver.hip)
+// Everything except the matvec is tall-skinny (n x <= 136), L2-resident and latency-bound.
 #include <algorithm>
 #include <mutex>
 
@@ -886,22 +892,6 @@ __global__ __launch_bounds__(256) void k_basis_times_Y(
   }
 }
 
-// swap Ritz pairs a <-> b (columns of Y, entries of theta): lets a thick restart keep
-// the far end of the spectrum (needed by the NormalizedDiff eigengap when ascending)
-__global__ void k_swap_ritz(double* Y, int ldy, int m, double* theta, int a, int b) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < m) {
-    const double t = Y[(size_t)r * ldy + a];
-    Y[(size_t)r * ldy + a] = Y[(size_t)r * ldy + b];
-    Y[(size_t)r * ldy + b] = t;
-  }
-  if (r == 0) {
-    const double t = theta[a];
-    theta[a] = theta[b];
-    theta[b] = t;
-  }
-}
-
 __global__ void k_copy_block(const double* __restrict__ src, int ldsrc,
                              double* __restrict__ dst, int lddst, int n, int cols) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1090,9 +1080,6 @@ void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
   SC_OPT_IN_LDS(k_basis_times_Y, 128 * 1024);
   hipLaunchKernelGGL(k_basis_times_Y, dim3((n + 15) / 16), dim3(256), lds, s, Q, ldq,
                      m, Y, ldy, cols, dst, lddst, n, colmajor);
-}
-void launch_swap_ritz(hipStream_t s, double* Y, int ldy, int m, double* theta, int a, int b) {
-  hipLaunchKernelGGL(k_swap_ritz, dim3((m + 255) / 256), dim3(256), 0, s, Y, ldy, m, theta, a, b);
 }
 void launch_copy_block(hipStream_t s, const double* src, int ldsrc, double* dst,
                        int lddst, int n, int cols) {

@@ -190,7 +190,6 @@ void launch_set_diag_T(hipStream_t s, double* T, int ldt, int mtot,
 void launch_basis_times_Y(hipStream_t s, const double* Q, int ldq, int m,
                           const double* Y, int ldy, int cols, double* dst,
                           int lddst, int n, int colmajor);
-void launch_swap_ritz(hipStream_t s, double* Y, int ldy, int m, double* theta, int a, int b);
 void launch_copy_block(hipStream_t s, const double* src, int ldsrc, double* dst,
                        int lddst, int n, int cols);
 // Eigenvectors live COLUMN-major on the device: ET[j * ld + r].

@@ -82,6 +82,7 @@ int ensure_eig(sc_handle h, int n) {
     SC_TRY(grow(h, h->flags, 16 * sizeof(int)));
     SC_HIP(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), h->stream));
   }
+  SC_TRY(grow(h, h->mvsym, matvec_sym_workspace_doubles(n) * sizeof(double)));
   SC_TRY(grow(h, h->E, (size_t)round_up(n, 16) * kMaxCols * sizeof(double)));
   SC_TRY(grow(h, h->Eio, (size_t)n * kMaxCols * sizeof(double)));
   return SC_OK;
@@ -188,7 +189,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
-                    &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work,
+                    &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
                     &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain};
   for (DevBuf* b : bufs)

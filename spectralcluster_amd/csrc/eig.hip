@@ -125,6 +125,184 @@ __global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
   }
 }
 
+// ---------------------------------------------------------------- symmetric block matvec
+// The same product from the UPPER TRIANGLE of S only: half the HBM bytes per pass.
+// One workgroup = one 128 x 128 tile (I, J), J >= I, of S.  It contributes
+//   direct :  U[I rows]  += S_IJ   * Vs[J rows]
+//   mirror :  U[J rows]  += S_IJ^T * Vs[I rows]        (J > I only)
+// Each wave owns 32 rows of the tile.  It loads them in the direct product's MFMA layout
+// (lane (li, lg): row li, 16-byte column chunks -- the same sector-aligned k-slot map as
+// k_block_matvec), feeds the direct MFMAs, then turns ITS OWN 32 x 32 sub-block around
+// through a wave-private LDS patch (row-major write, column-wise read: lane (i, g) reads
+// S[4t + g][i], the A operand of the transposed product) -- no workgroup barrier in the loop.
+// The two 128 x 8 results of a tile go to per-tile partial slabs; k_matvec_sym_reduce adds,
+// for every block row R, the direct slabs (R, R..) and the mirror slabs (0..R-1, R) in that
+// fixed order and applies  W = p .* V + c .* U.  Extra traffic: 2 x 8 KB per 128 KB tile,
+// written and read once (+25 % of the halved matrix traffic).
+constexpr int kSymTile = 128;
+constexpr int kSymPitch = 34;  // doubles per row of a wave's 32 x 32 LDS patch
+__device__ __forceinline__ int sym_item_id(int I, int J, int nt) {
+  return I * nt - I * (I - 1) / 2 + (J - I);
+}
+__global__ __launch_bounds__(256) void k_block_matvec_sym(
+    const double* __restrict__ S, int ld, int n, const double* __restrict__ Vs,
+    double* __restrict__ pdirect, double* __restrict__ pmirror, int nt) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * 32 * kSymPitch];
+  // block -> (I, J): row-major over the upper triangle
+  int I = 0, rem = blockIdx.x, rowlen = nt;
+  while (rem >= rowlen) {
+    rem -= rowlen;
+    --rowlen;
+    ++I;
+  }
+  const int J = I + rem;
+  const bool diag = I == J;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int r0 = I * kSymTile + 32 * wave;   // this wave's 32 rows
+  const int c0 = J * kSymTile;
+  double* patch = smem + wave * (32 * kSymPitch);
+  // B operand of the mirror product: Vs rows of this wave, k-step t carries rows 4t + g
+  double bm[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int row = r0 + 4 * t + lg;
+    bm[t] = (row < n && li < B) ? Vs[(size_t)row * B + li] : 0.0;
+  }
+  v4f64 accd[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  v4f64 accm[4][2];
+#pragma unroll
+  for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) accm[cs][ct] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  double2 a[2][2][4];  // [buffer][row tile][q]
+  auto load = [&](int buf, int cs) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      int row = r0 + 16 * rt + li;
+      row = row < n ? row : n - 1;
+      const double* src = S + (size_t)row * ld + c0 + 32 * cs + 2 * lg;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // rows are padded to ld (multiple of 16): never read past the row's storage
+        if (c0 + 32 * cs + 8 * q + 2 * lg + 1 < ld)
+          a[buf][rt][q] = *reinterpret_cast<const double2*>(src + 8 * q);
+        else
+          a[buf][rt][q] = make_double2(0.0, 0.0);
+      }
+    }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int cs = 0; cs < 4; ++cs) {
+    const int cur = cs & 1;
+    if (cs + 1 < 4) load(cur ^ 1, cs + 1);
+    const int kb = c0 + 32 * cs + 2 * lg;
+    // zero what lies outside the matrix (rows >= n were clamped, columns >= n are padding)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const bool rok = r0 + 16 * rt + li < n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!rok || kb + 8 * q >= n) a[cur][rt][q].x = 0.0;
+        if (!rok || kb + 8 * q + 1 >= n) a[cur][rt][q].y = 0.0;
+      }
+    }
+    // ---- direct product
+    double b[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = kb + 8 * (t >> 1) + (t & 1);
+      b[t] = (k < n && li < B) ? Vs[(size_t)k * B + li] : 0.0;
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        accd[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][rt][q].x, b[2 * q], accd[rt], 0, 0, 0);
+        accd[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][rt][q].y, b[2 * q + 1], accd[rt], 0, 0, 0);
+      }
+    if (!diag) {
+      // ---- mirror product: this wave's 32 x 32 sub-block, turned around through LDS
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<double2*>(patch + (16 * rt + li) * kSymPitch + 8 * q + 2 * lg) =
+              a[cur][rt][q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const double at = patch[(4 * t + lg) * kSymPitch + 16 * ct + li];
+          accm[cs][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, bm[t], accm[cs][ct], 0, 0, 0);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // ---- slabs.  D layout: lane l, reg r holds D[row = (l >> 4) + 4 r][col = l & 15]
+  const size_t item = blockIdx.x;
+  if (li < B) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pdirect[(item * kSymTile + 32 * wave + 16 * rt + lg + 4 * r) * B + li] = accd[rt][r];
+  }
+  if (diag) return;
+  // mirror: the four waves' contributions to the tile's 128 columns, added wave 0..3
+  __syncthreads();  // the patches are dead: LDS becomes the reduction buffer [4][128][B]
+  double* red = smem;
+  if (li < B) {
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[(wave * kSymTile + 32 * cs + 16 * ct + lg + 4 * r) * B + li] = accm[cs][ct][r];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kSymTile * B; e += 256)
+    pmirror[item * (kSymTile * B) + e] =
+        ((red[e] + red[kSymTile * B + e]) + red[2 * kSymTile * B + e]) + red[3 * kSymTile * B + e];
+}
+
+// W[r, :] = p[r] V[r, :] + c[r] * (sum of the slabs of block row R = r / 128, fixed order)
+__global__ __launch_bounds__(256) void k_matvec_sym_reduce(
+    const double* __restrict__ pdirect, const double* __restrict__ pmirror, int nt, int n,
+    const double* __restrict__ cvec, const double* __restrict__ pvec,
+    const double* __restrict__ V, int ldv, double* __restrict__ W) {
+  const int R = blockIdx.x / 4;                       // 4 workgroups per block row
+  const int e = (blockIdx.x & 3) * 256 + threadIdx.x;  // entry of the 128 x B slab
+  const int rl = e / B, v = e % B;
+  const int row = R * kSymTile + rl;
+  double acc = 0.0;
+  // direct slabs (R, J), J = R .. nt-1, then mirror slabs (I, R), I = 0 .. R-1; loads in
+  // independent batches of 8
+  const int total = nt;  // (nt - R) + R
+  for (int s0 = 0; s0 < total; s0 += 8) {
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int sidx = s0 + u;
+      x[u] = 0.0;
+      if (sidx < nt - R) {
+        x[u] = pdirect[(size_t)sym_item_id(R, R + sidx, nt) * (kSymTile * B) + e];
+      } else if (sidx < total) {
+        x[u] = pmirror[(size_t)sym_item_id(sidx - (nt - R), R, nt) * (kSymTile * B) + e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += x[u];
+  }
+  if (row < n) W[(size_t)row * B + v] =
+      __builtin_fma(cvec[row], acc, pvec[row] * V[(size_t)row * ldv + v]);
+}
+
 // ---------------------------------------------------------------- projections
 // partial[blk][i * B + j] = sum over the block's rows of Q[r][i] * W[r][j]
 constexpr int kProjGroups = 256 / B;                          // i-groups per workgroup
@@ -955,6 +1133,24 @@ void launch_block_matvec(hipStream_t s, const double* S, int ld, int n,
                          int ldv, const double* Vs, double* W) {
   hipLaunchKernelGGL(k_block_matvec, dim3((n + 15) / 16), dim3(64 * kMvWaves), 0, s, S,
                      ld, n, cvec, pvec, V, ldv, Vs, W);
+}
+// slabs of the symmetric form: 2 x (tiles of the upper triangle) x 128 x B doubles
+size_t matvec_sym_workspace_doubles(int n) {
+  const size_t nt = (size_t)(n + kSymTile - 1) / kSymTile;
+  return 2 * (nt * (nt + 1) / 2) * kSymTile * B;
+}
+// Same result from the upper triangle of a SYMMETRIC S (tiles with column block >= row block;
+// the strictly lower tiles are never read).  ws: matvec_sym_workspace_doubles(n).
+void launch_block_matvec_sym(hipStream_t s, const double* S, int ld, int n, const double* cvec,
+                             const double* pvec, const double* V, int ldv, const double* Vs,
+                             double* W, double* ws) {
+  const int nt = (n + kSymTile - 1) / kSymTile;
+  const int items = nt * (nt + 1) / 2;
+  double* pd = ws;
+  double* pm = ws + (size_t)items * kSymTile * B;
+  hipLaunchKernelGGL(k_block_matvec_sym, dim3(items), dim3(256), 0, s, S, ld, n, Vs, pd, pm, nt);
+  hipLaunchKernelGGL(k_matvec_sym_reduce, dim3(nt * 4), dim3(256), 0, s, pd, pm, nt, n, cvec,
+                     pvec, V, ldv, W);
 }
 void launch_proj_partial(hipStream_t s, const double* Q, int ldq, int m,
                          const double* W, int n, double* partial) {

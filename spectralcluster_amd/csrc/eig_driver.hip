@@ -458,6 +458,11 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
   int m = 0, passes = 0, cycles = 0;
   EigRequest rq = rq_in;
   bool fused = getenv("SC_EIG_HOST_CHAIN") == nullptr;
+  // upper-triangle matvec once the matrix no longer fits the caches (below that the full
+  // read is served on-die and the second launch costs more than it saves)
+  static const int sym_min_n = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N"))
+                                                            : 4096;
+  const bool sym_mv = n >= sym_min_n;
   // Dense full-spectrum route (n > 128): all eigenvalues from the tridiagonal form, the
   // eigengap decision from those, then the same Lanczos loop below for just the vectors.
   EigDecision dense_dc;
@@ -545,8 +550,12 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
       const bool time_mv = h->profile_level >= 2 && h->n_mv_ev < 16;
       if (time_mv) ev_rec(h, &h->mv_ev[h->n_mv_ev][0]);
-      launch_block_matvec(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
-                          ptr<double>(h->Vs), ptr<double>(h->W));
+      if (sym_mv)
+        launch_block_matvec_sym(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
+                                ptr<double>(h->Vs), ptr<double>(h->W), ptr<double>(h->mvsym));
+      else
+        launch_block_matvec(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
+                            ptr<double>(h->Vs), ptr<double>(h->W));
       if (time_mv) ev_rec(h, &h->mv_ev[h->n_mv_ev++][1]);
       ++passes;
       m += kEigBlock;

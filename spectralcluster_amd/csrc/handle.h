@@ -52,6 +52,7 @@ struct sc_handle_s {
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
       flags;
   DevBuf E, Ek, Eio;      // eigenvectors (col-major), renormed copy, row-major I/O staging
+  DevBuf mvsym;           // slabs of the symmetric block matvec
   // dense full-spectrum path (eig_dense.hip): d, e, all eigenvalues, reflector work vectors
   DevBuf td_d, td_e, td_theta, td_work;
   std::vector<double> spectrum;  // host copy: every eigenvalue of Op, descending

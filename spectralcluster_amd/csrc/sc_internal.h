@@ -147,6 +147,12 @@ void launch_random_block(hipStream_t s, double* W, int n, uint64_t seed);
 void launch_block_matvec(hipStream_t s, const double* S, int ld, int n,
                          const double* cvec, const double* pvec, const double* V,
                          int ldv, const double* Vs, double* W);
+// the same from the upper triangle of a symmetric S (half the HBM bytes); ws:
+// matvec_sym_workspace_doubles(n) doubles of slabs
+size_t matvec_sym_workspace_doubles(int n);
+void launch_block_matvec_sym(hipStream_t s, const double* S, int ld, int n, const double* cvec,
+                             const double* pvec, const double* V, int ldv, const double* Vs,
+                             double* W, double* ws);
 void launch_proj_partial(hipStream_t s, const double* Q, int ldq, int m,
                          const double* W, int n, double* partial);
 // H = sum of partials (m x 16) -> Hbuf; if T != nullptr also (accumulated) into

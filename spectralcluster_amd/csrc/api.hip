@@ -552,18 +552,6 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   bool folded_rownorm = false;
   int e_begin, e_after_refine;
   const bool fine = h->profile_level >= 2;
-  bool upper_only = false;
-  bool full_spectrum_request;
-  {
-    EigRequest probe;
-    probe.descend = (cfg->laplacian_type == SC_LAPLACIAN_NONE ||
-                     cfg->laplacian_type == SC_LAPLACIAN_AFFINITY);
-    probe.max_clusters = cfg->max_clusters;
-    probe.eigengap_type = cfg->eigengap_type;
-    probe.fixed_count = 0;
-    full_spectrum_request = eig_wants_full_spectrum(probe);
-  }
-  h->s_upper_only = false;
   int eb0 = -1, eb1 = -1, et0 = -1, et1 = -1;  // blur / threshold+symmetrize (last of each)
   h->n_mv_ev = 0;
   float diffuse_ms_events[SC_MAX_OPS][2];
@@ -644,13 +632,8 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
       GemmRowStats rs{1, ptr<double>(h->statp), ptr<double>(h->statp) + (size_t)n * gemm_tile_dim(n),
                       ptr<double>(h->rowmax), ptr<double>(h->rowsum)};
       SC_TRY(ensure_tilemap(h, n));
-      // the last Diffuse of a symmetric fast-path call is consumed only by the upper-triangle
-      // block matvec (and by its own epilogue statistics): the mirror tiles are not stored
-      upper_only = last && symmetric && !constrain_after && n >= matvec_sym_min_n() &&
-                   n > kDenseMax && !full_spectrum_request && !getenv("SC_GEMM_FULL_STORE");
       launch_gemm_nt(s, cur, ld, cur, ld, out, ld, n, n, n, kEpiNone, true,
-                     ptr<double>(h->splitk), ptr<int2>(h->tilemap), last ? &rs : nullptr, nullptr,
-                     upper_only);
+                     ptr<double>(h->splitk), ptr<int2>(h->tilemap), last ? &rs : nullptr);
       SC_TRY(check_last(h, "diffuse launch"));
       have_row_stats = last;
       have_partials = false;
@@ -753,7 +736,6 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   }
   EigDecision dc;
   std::vector<double> w;
-  h->s_upper_only = upper_only && symmetric;
   if (symmetric) {
     SC_TRY(sym_topk(h, cur, ld, n, rq, diag, &dc, &w, bufs[which]));
   } else {

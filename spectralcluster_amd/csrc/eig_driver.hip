@@ -423,12 +423,6 @@ static bool wants_full_spectrum(const EigRequest& rq) {
   return rq.max_clusters == 0 || rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF;
 }
 
-int matvec_sym_min_n() {
-  static const int v = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N")) : 4096;
-  return v;
-}
-bool eig_wants_full_spectrum(const EigRequest& rq) { return wants_full_spectrum(rq); }
-
 static EigWorkspace eig_workspace(sc_handle h) {
   EigWorkspace ws;
   ws.Q = ptr<double>(h->Q);
@@ -466,16 +460,14 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
   bool fused = getenv("SC_EIG_HOST_CHAIN") == nullptr;
   // upper-triangle matvec once the matrix no longer fits the caches (below that the full
   // read is served on-die and the second launch costs more than it saves)
-  const bool sym_mv = n >= matvec_sym_min_n();
+  static const int sym_min_n = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N"))
+                                                            : 4096;
+  const bool sym_mv = n >= sym_min_n;
   // Dense full-spectrum route (n > 128): all eigenvalues from the tridiagonal form, the
   // eigengap decision from those, then the same Lanczos loop below for just the vectors.
   EigDecision dense_dc;
   bool dense = false;
   auto run_dense = [&]() -> int {
-    if (h->s_upper_only) {  // the Diffuse GEMM skipped the mirror tiles: restore them
-      launch_mirror_fill(s, const_cast<double*>(S), ld, n);
-      h->s_upper_only = false;
-    }
     SC_TRY(dense_spectrum(h, S, ld, n, scratch));
     std::vector<double> zeros(n, 0.0);
     dense_dc = analyze(rq_in, h->spectrum.data(), zeros.data(), n, n, true);

@@ -77,8 +77,6 @@ struct GemmStats {
   double* psum;   // n x ntiles (mode 1 only)
   int mode;       // 0 = off
   const double* addend;  // kEpiAdd: C = A B^T + addend (same ld as C; may not alias C)
-  int upper_only;        // SYM: do not store the mirror tiles (the consumer reads tiles
-                         // with column block >= row block only: k_block_matvec_sym)
 };
 
 template <int EPI, bool SYM>
@@ -521,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
           out[((m * 4 + nn) * 4 + r) * 256 + tid] = acc[m][nn][r];
     return;
   }
-  const bool mirror = SYM && (ti != tj) && !stats.upper_only;
+  const bool mirror = SYM && (ti != tj);
   const bool nt_store = (edge_prio & 2) != 0;
   if (stats.mode != 0 || mirror) __syncthreads();  // operand tiles are dead: LDS is reused
   if (stats.mode != 0) {
@@ -683,28 +681,6 @@ __global__ void k_gemm_queue_init(int* queue, int front) {
   queue[threadIdx.x] = threadIdx.x == 10 ? front : 0;
 }
 
-// C[j][i] = C[i][j] for every element of the tiles strictly below the tile diagonal
-// (32 x 32 sub-tiles through LDS: coalesced on both sides)
-__global__ __launch_bounds__(256) void k_mirror_fill(double* __restrict__ C, int ld, int n) {
-  __shared__ double t[32][33];
-  const int bi = blockIdx.y, bj = blockIdx.x;  // destination sub-tile (row block bi, col bj)
-  if (bi / 4 <= bj / 4) return;                // only 128-tiles strictly below the diagonal
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) {
-    const int srow = bj * 32 + r, scol = bi * 32 + tx;  // source = transposed position
-    t[r][tx] = (srow < n && scol < n) ? C[(size_t)srow * ld + scol] : 0.0;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int drow = bi * 32 + r, dcol = bj * 32 + tx;
-    if (drow < n && dcol < n) C[(size_t)drow * ld + dcol] = t[tx][r];
-  }
-}
-void launch_mirror_fill(hipStream_t s, double* C, int ld, int n) {
-  const int nb = (n + 31) / 32;
-  hipLaunchKernelGGL(k_mirror_fill, dim3(nb, nb), dim3(256), 0, s, C, ld, n);
-}
-
 // co-resident k_gemm_nt workgroups on the current device (occupancy x CUs)
 int gemm_resident_slots() {
   static int slots_dev[16] = {0};
@@ -730,8 +706,8 @@ template <int EPI, bool SYM>
 static void launch_variant(hipStream_t s, const double* A, int lda, const double* B,
                            int ldb, double* C, int ldc, int M, int N, int K,
                            double* splitk_ws, const int2* tilemap, const GemmRowStats* rs,
-                           const double* addend, bool upper_only) {
-  GemmStats stats{nullptr, nullptr, 0, addend, (SYM && upper_only) ? 1 : 0};
+                           const double* addend) {
+  GemmStats stats{nullptr, nullptr, 0, addend};
   if (rs != nullptr && rs->mode != 0) {
     stats.pmax = rs->partial_max;
     stats.psum = rs->partial_sum;
@@ -858,12 +834,11 @@ int gemm_tile_dim(int n) { return (n + BM - 1) / BM; }
 void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
                     int epilogue, bool symmetric, double* splitk_ws,
-                    const int2* tilemap, const GemmRowStats* rs, const double* addend,
-                    bool upper_only) {
+                    const int2* tilemap, const GemmRowStats* rs, const double* addend) {
   if (M <= 0 || N <= 0) return;
 #define SC_GEMM_CASE(E, S)                                                                \
   launch_variant<E, S>(s, A, lda, B, ldb, C, ldc, M, N, K, splitk_ws, S ? tilemap : nullptr, \
-                       rs, addend, upper_only)
+                       rs, addend)
   if (symmetric) {
     if (epilogue == kEpiAffinity) SC_GEMM_CASE(kEpiAffinity, true);
     else if (epilogue == kEpiAdd) SC_GEMM_CASE(kEpiAdd, true);

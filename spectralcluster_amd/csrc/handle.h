@@ -35,7 +35,6 @@ struct sc_handle_s {
   bool have_x = false, have_affinity = false;
   bool have_cropval = false;  // cropval = CropDiagonal fill values of A0 (affinity GEMM epilogue)
   int n_vec = 0;          // eigenvector columns resident in E
-  bool s_upper_only = false;  // the matrix handed to the eigen stage has no mirror tiles
   // matrices
   DevBuf X, Xn, A0, B1, B2;
   // n-vectors
@@ -220,10 +219,6 @@ struct EigDecision {
 // `scratch`: a free n x ld matrix (the dense full-spectrum path materialises Op there)
 int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq, sc_diag* diag,
              EigDecision* out_dc, std::vector<double>* out_w, double* scratch);
-// n from which the block matvec reads only the upper triangle (SC_MATVEC_SYM_MIN_N)
-int matvec_sym_min_n();
-// does this request take the dense full-spectrum path from the start?
-bool eig_wants_full_spectrum(const EigRequest& rq);
 int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
              const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
              std::vector<double>* out_w);

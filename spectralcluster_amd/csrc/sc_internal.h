@@ -63,10 +63,7 @@ void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc, int M, int N, int K,
                     int epilogue, bool symmetric, double* splitk_ws,
                     const int2* tilemap, const GemmRowStats* rs = nullptr,
-                    const double* addend = nullptr, bool upper_only = false);
-// symmetric launches with upper_only leave the tiles strictly below the diagonal unwritten
-// (their consumer is launch_block_matvec_sym); this restores them from the upper ones
-void launch_mirror_fill(hipStream_t s, double* C, int ld, int n);
+                    const double* addend = nullptr);
 // patch-ordered (ti, tj) list of the upper triangle, for `tilemap` (symmetric launches)
 void gemm_build_sym_tilemap(int nt, std::vector<int2>* out);
 int gemm_tile_dim(int n);

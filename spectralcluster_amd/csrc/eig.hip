@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void k_block_matvec_sym(
   for (int cs = 0; cs < 4; ++cs)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) accm[cs][ct] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  double2 a[2][2][4];  // [buffer][row tile][q]
+  // (no register double-buffering of the strip: at ~120 VGPRs four workgroups share a CU and
+  //  cover each other's load latency -- measured faster than 2 workgroups with prefetch)
+  double2 a[1][2][4];  // [buffer][row tile][q]
   auto load = [&](int buf, int cs) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -192,11 +194,10 @@ __global__ __launch_bounds__(256) void k_block_matvec_sym(
       }
     }
   };
-  load(0, 0);
 #pragma unroll
   for (int cs = 0; cs < 4; ++cs) {
-    const int cur = cs & 1;
-    if (cs + 1 < 4) load(cur ^ 1, cs + 1);
+    constexpr int cur = 0;
+    load(cur, cs);
     const int kb = c0 + 32 * cs + 2 * lg;
     // zero what lies outside the matrix (rows >= n were clamped, columns >= n are padding)
 #pragma unroll

@@ -7,6 +7,8 @@ they are the repair / large-problem routes of the default ones:
                         basis vectors; the host solves the smaller ones)
   SC_KMEANS_SINGLE=1    single-workgroup k-means (k > 32, other metrics, very large n)
   SC_EIG_NO_HINT=1      no Rayleigh-Ritz scheduling hint
+  SC_MATVEC_SYM_MIN_N=129  upper-triangle block matvec on every Krylov solve, not only for
+                        n >= 4096 (edge tiles, restarts, the repair chain all go through it)
 
 Each runs in a fresh interpreter (the switches are read once per process) over reference
 goldens of both Laplacian branches."""
@@ -54,17 +56,33 @@ km = np.load(os.path.join(ROOT, "tests", "golden", "kmeans.npz"))
 for tag, k in (("a", 4), ("b", 8), ("c", 2), ("d", 20)):
   got = sca.custom_distance_kmeans.run_kmeans(km["e_" + tag], k, "cosine", 300)
   assert np.array_equal(got, km["labels_" + tag]), tag
+# a long run: 76 consumed eigenvalues, basis at its cap, thick restarts (every path above
+# must survive it)
+n = 400
+x = so.blobs(n, 200, 3, seed=11)
+cfg = so.OracleConfig(sequence=(so.OP_DIFFUSE,), stop_eigenvalue=1e-2)
+dump = {}
+want = so.predict(x, cfg, dump)
+ref = dump["eigenvalues"]
+idx = so.consumed_eigen_indices(n, None, True, ref, 1e-2)
+assert idx.size > 64
+c = sca.SpectralClusterer(min_clusters=2, refinement_options=sca.RefinementOptions(
+    refinement_sequence=[sca.RefinementName.Diffuse]))
+got = c.predict(x)
+w = c.consumed_eigenvalues()
+assert np.max(np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-12)) < 1e-5
+assert so.adjusted_rand_index(got, want) == 1.0
 print("ALTERNATE_PATH_OK")
 """
 
 
 @pytest.mark.parametrize("switch", ["SC_EIG_HOST_CHAIN", "SC_EIG_DEVICE_RR", "SC_KMEANS_SINGLE",
-                                    "SC_EIG_NO_HINT"])
+                                    "SC_EIG_NO_HINT", "SC_MATVEC_SYM_MIN_N"])
 def test_alternate_path(tmp_path, switch):
   script = tmp_path / "alt.py"
   script.write_text(_SCRIPT)
   env = dict(os.environ)
-  env[switch] = "1"
+  env[switch] = "129" if switch == "SC_MATVEC_SYM_MIN_N" else "1"
   r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True,
                      timeout=600, env=env)
   assert r.returncode == 0 and "ALTERNATE_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -79,6 +79,13 @@ struct GemmStats {
   const double* addend;  // kEpiAdd: C = A B^T + addend (same ld as C; may not alias C)
 };
 
+// No cross-lane shuffles: every lane combines what it holds in registers (its 4 column blocks
+// of a row / its 16 rows of a column), drops one (max, sum) pair into LDS, and 128 threads
+// finish each row / column from LDS in a fixed order.  The first version reduced over the
+// 16 / 4 lanes with 144 dependent ds_bpermute round trips per tile behind scheduling barriers,
+// competing with the partner workgroup's operand reads: 30 us per tile (measured with the
+// in-kernel clock probe), a third of the gap between two K loops on a slot.
+// `scratch`: 8192 doubles (the 64 KB of operand tiles, dead by now).
 template <int EPI, bool SYM>
 __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti, int tj,
                                                int ntiles, int M, int N, int tid,
@@ -86,12 +93,9 @@ __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti,
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
-  double* rmax = scratch;            // [2][128]  (wc, row)
-  double* rsum = scratch + 256;      // [2][128]
-  double* cmax = scratch + 512;      // [2][128]  (wr, col)
-  double* csum = scratch + 768;      // [2][128]
+  double2* pairs = reinterpret_cast<double2*>(scratch);  // (max, sum)
   const bool diag_tile = ti == tj;
-  // --- per-row partials over this wave's 64 columns
+  // --- rows: pairs[row][wc * 16 + li] = this lane's 4 column blocks of the row
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -108,20 +112,28 @@ __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti,
         if (inside && !skip) mx = fmax(mx, x);
         if (inside) sm += x;
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        mx = fmax(mx, __shfl_xor(mx, o));
-        sm += __shfl_xor(sm, o);
-      }
-      if (li == 0) {
-        rmax[wc * 128 + lrow] = mx;
-        rsum[wc * 128 + lrow] = sm;
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep the live range of each reduction short
+      pairs[lrow * 32 + wc * 16 + li] = make_double2(mx, sm);
     }
   }
-  // --- per-column partials over this wave's 64 rows (the mirror tile's rows)
+  __syncthreads();
+  if (tid < 128) {
+    double mx = -INFINITY, sm = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {  // column order: wc 0 (li 0..15), wc 1 (li 0..15)
+      const double2 v = pairs[tid * 32 + q];
+      mx = fmax(mx, v.x);
+      sm += v.y;
+    }
+    const int row = ti * BM + tid;
+    if (row < M) {
+      st.pmax[(size_t)row * ntiles + tj] = mx;
+      if (st.mode == 1) st.psum[(size_t)row * ntiles + tj] = sm;
+    }
+  }
+  // --- columns (the mirror tile's rows): pairs[(wr * 4 + lg) * 128 + col] = this lane's
+  //     16 rows of the column
   if (SYM && !diag_tile) {
+    __syncthreads();
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
       const int lcol = wc * 64 + nn * 16 + li;
@@ -138,32 +150,25 @@ __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti,
             sm += x;
           }
         }
-      mx = fmax(mx, __shfl_xor(mx, 16));
-      sm += __shfl_xor(sm, 16);
-      mx = fmax(mx, __shfl_xor(mx, 32));
-      sm += __shfl_xor(sm, 32);
-      if (lg == 0) {
-        cmax[wr * 128 + lcol] = mx;
-        csum[wr * 128 + lcol] = sm;
+      pairs[(wr * 4 + lg) * 128 + lcol] = make_double2(mx, sm);
+    }
+    __syncthreads();
+    if (tid < 128) {
+      double mx = -INFINITY, sm = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {  // row order: wr 0 (lg 0..3), wr 1 (lg 0..3)
+        const double2 v = pairs[q * 128 + tid];
+        mx = fmax(mx, v.x);
+        sm += v.y;
       }
-      __builtin_amdgcn_sched_barrier(0);
+      const int row = tj * BN + tid;
+      if (row < N) {
+        st.pmax[(size_t)row * ntiles + ti] = mx;
+        if (st.mode == 1) st.psum[(size_t)row * ntiles + ti] = sm;
+      }
     }
   }
-  __syncthreads();
-  if (tid < 128) {
-    const int row = ti * BM + tid;
-    if (row < M) {
-      st.pmax[(size_t)row * ntiles + tj] = fmax(rmax[tid], rmax[128 + tid]);
-      if (st.mode == 1) st.psum[(size_t)row * ntiles + tj] = rsum[tid] + rsum[128 + tid];
-    }
-  } else if (SYM && !diag_tile) {
-    const int c = tid - 128;
-    const int row = tj * BN + c;
-    if (row < N) {
-      st.pmax[(size_t)row * ntiles + ti] = fmax(cmax[c], cmax[128 + c]);
-      if (st.mode == 1) st.psum[(size_t)row * ntiles + ti] = csum[c] + csum[128 + c];
-    }
-  }
+  __syncthreads();  // the staging of the mirror tile reuses this LDS
 }
 
 // rowmax[i] / rowsum[i] from the per-tile partials (fixed slot order)
@@ -202,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats,
                                                  int* __restrict__ ksync,
-                                                 int* __restrict__ queue, int edge_prio) {
+                                                 int* __restrict__ queue, int edge_prio,
+                                                 int nunits, int persist) {
   // one 64 KB block: As[2] | Bs[2] in the K loop, reduction scratch + the transposed
   // staging of the mirror tile in the epilogue
   __shared__ __attribute__((aligned(16))) double smem[2 * BM * BK + 2 * BN * BK];
@@ -215,6 +221,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   // timeline shows 86 us between one tile's K loop and the next one's on the same slot,
   // during which this half of the CU's MFMA capacity is lost (one workgroup cannot use
   // more than its own share: staggering the partners did not help, profiles/r02_i).
+  // Persistent form (persist != 0, with a queue): the launch has one workgroup per resident
+  // slot and every workgroup keeps drawing items until none is left -- no teardown / dispatch
+  // between tiles (~30 us of the 86 us gap on a slot), and the split-K units of the leftover
+  // tiles are taken by whoever finishes first.
+  for (int iter = 0;; ++iter) {
+  if (iter > 0) {
+    if (!persist || queue == nullptr) break;
+    __syncthreads();  // the previous item's epilogue is done with the LDS
+  }
   if (edge_prio & 1) __builtin_amdgcn_s_setprio(3);
   int ti, tj;
   // Work item of this workgroup.  Static (queue == nullptr): by block index.  Dynamic: the grid
@@ -232,7 +247,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   if (queue != nullptr) {
     int* s_item = reinterpret_cast<int*>(smem);  // (one LDS object per kernel: no second array)
     if (threadIdx.x == 0) {
-      const int nunits = (int)gridDim.x - full_tiles;
       const int x = (int)blockIdx.x & 7;
       const bool second = (__builtin_amdgcn_s_getreg(6 | (31 << 11)) & 0xfff) != 0;
       auto draw = [&](int* counter, int limit) -> int {
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     __syncthreads();
     item_blk = *s_item;
     __syncthreads();  // smem is about to become the operand tiles
-    if (item_blk < 0) return;  // cannot happen: as many items as workgroups
+    if (item_blk < 0) break;  // nothing left
   }
   const bool whole = item_blk < full_tiles;
   const int unit = whole ? 0 : item_blk - full_tiles;  // index among the split-K units
@@ -482,6 +496,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
+  long long wall_k0 = 0;
+  if (probe) wall_k0 = wall_clock64();  // prologue done: K loop starts
   // The two workgroups of a CU take turns at the higher MFMA priority, one K-tile each: the
   // second one runs one peeled K-tile first (starting in LDS buffer 1), which shifts its
   // even / odd phase by one (measured: Diffuse -0.8 %).
@@ -501,10 +517,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   }
 
   if (edge_prio & 1) __builtin_amdgcn_s_setprio(3);
+  long long wall_k1 = 0;
+  if (probe) wall_k1 = wall_clock64();
   if (probe && tid == 0) {
     probe_out[2 * item_blk] = (double)(clock64() - clk0);
-    probe_out[2 * item_blk + 1] = (double)(wall_clock64() - wall0);
+    probe_out[2 * item_blk + 1] = (double)(wall_k1 - wall0);
     probe_out[2 * full_tiles + item_blk] = (double)wall0;
+    probe_out[3 * full_tiles + item_blk] = (double)(wall_k0 - wall0);  // prologue ticks
   }
   // --- epilogue.  D layout of v_mfma_f64_16x16x4_f64: lane l, reg r holds
   //     D[row = (l >> 4) + 4 r][col = l & 15].
@@ -517,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           out[((m * 4 + nn) * 4 + r) * 256 + tid] = acc[m][nn][r];
-    return;
+    continue;
   }
   const bool mirror = SYM && (ti != tj);
   const bool nt_store = (edge_prio & 2) != 0;
@@ -526,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
     tile_row_stats<EPI, SYM>(acc, ti, tj, ntiles_n, M, N, tid, stats, smem);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (probe && tid == 0) probe_out[4 * full_tiles + item_blk] = (double)(wall_clock64() - wall_k1);
   // The mirror tile is stored through a transposed copy in LDS (per wave, 16 rows of its 64 x 64
   // sub-tile at a time: T[c][r], pitch 20 doubles = two lanes per bank pair on the writes) so
   // that its stores are 128-byte row segments like the direct ones, not 8-byte scatters.
@@ -578,6 +598,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
       __builtin_amdgcn_wave_barrier();
     }
   }
+  if (probe) {  // stores issued | stores drained (ticks since the end of the K loop)
+    const long long t_issued = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      probe_out[5 * full_tiles + item_blk] = (double)(t_issued - wall_k1);
+      probe_out[6 * full_tiles + item_blk] = (double)(wall_clock64() - wall_k1);
+    }
+  }
+  }  // item loop
 }
 
 // Sums the ksplit partial tiles of k_gemm_nt (fixed order: deterministic), applies
@@ -745,7 +774,7 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     // Off: one pointer compare per workgroup.
     static double* dbg = nullptr;
     static const bool want_probe = getenv("SC_GEMM_CLOCK") != nullptr;
-    if (want_probe && dbg == nullptr) (void)hipMalloc(&dbg, sizeof(double) * 3 * 8192);
+    if (want_probe && dbg == nullptr) (void)hipMalloc(&dbg, sizeof(double) * 7 * 8192);
     double* probe = (full > 0 && full <= 8192) ? dbg : nullptr;
     // SC_GEMM_KSYNC=1: K-window throttle (see k_gemm_nt); counters zeroed per launch
     static const bool want_ksync = getenv("SC_GEMM_KSYNC") != nullptr;
@@ -769,7 +798,9 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     // dynamic work draw with staggered CU partners (see k_gemm_nt), SC_GEMM_DYNAMIC=1: an
     // experiment that did not pay (profiles/r02_i); the block-index map is the default.  queue: [0..7] next tile per XCD, [8] stagger claims, [9] next
     // split unit, [10] units reserved for the stagger (one per CU)
-    static const bool want_static = getenv("SC_GEMM_DYNAMIC") == nullptr;  // opt-in: no gain
+    // SC_GEMM_PERSIST=0: one workgroup per item by block index (round 1's form)
+    static const int want_persist = getenv("SC_GEMM_PERSIST") ? atoi(getenv("SC_GEMM_PERSIST")) : 1;
+    static const bool want_static = getenv("SC_GEMM_DYNAMIC") == nullptr && !want_persist;
     static int* queue_buf[16] = {nullptr};
     int* queue = nullptr;
     if (!want_static && xcd_chunk > 0 && rem > 0 && SYM) {
@@ -778,20 +809,27 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
       dev &= 15;
       if (queue_buf[dev] == nullptr) (void)hipMalloc(&queue_buf[dev], 16 * sizeof(int));
       queue = queue_buf[dev];
-      hipLaunchKernelGGL(k_gemm_queue_init, dim3(1), dim3(16), 0, s, queue, g_slots / 2);
+      hipLaunchKernelGGL(k_gemm_queue_init, dim3(1), dim3(16), 0, s, queue,
+                         want_persist ? 0 : g_slots / 2);
     }
+    const int persist = (queue != nullptr && want_persist) ? 1 : 0;
+    const int grid = persist ? std::min(g_slots, full + rem * ksplit) : full + rem * ksplit;
     static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 3;
-    hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(full + rem * ksplit), dim3(256), 0, s, A, lda,
+    hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(grid), dim3(256), 0, s, A, lda,
                        B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, probe, tilemap,
-                       xcd_chunk, stats, ksync, queue, edge_prio);
+                       xcd_chunk, stats, ksync, queue, edge_prio, rem * ksplit, persist);
     if (probe != nullptr) {
       (void)hipStreamSynchronize(s);
-      std::vector<double> h(3 * full);
-      (void)hipMemcpy(h.data(), dbg, sizeof(double) * 3 * full, hipMemcpyDeviceToHost);
-      if (const char* path = getenv("SC_GEMM_CLOCK_DUMP")) {  // workgroup, cycles, ticks, start
+      std::vector<double> h(7 * full);
+      (void)hipMemcpy(h.data(), dbg, sizeof(double) * 7 * full, hipMemcpyDeviceToHost);
+      if (const char* path = getenv("SC_GEMM_CLOCK_DUMP")) {
+        // workgroup, cycles, ticks entry..K-loop end, start tick, prologue ticks, then ticks
+        // since the end of the K loop: after the row statistics, stores issued, stores drained
         if (FILE* f = fopen(path, "w")) {
           for (int b = 0; b < full; ++b)
-            fprintf(f, "%d %.0f %.0f %.0f\n", b, h[2 * b], h[2 * b + 1], h[2 * full + b]);
+            fprintf(f, "%d %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", b, h[2 * b], h[2 * b + 1],
+                    h[2 * full + b], h[3 * full + b], h[4 * full + b], h[5 * full + b],
+                    h[6 * full + b]);
           fclose(f);
         }
       }

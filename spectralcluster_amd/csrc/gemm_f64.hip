@@ -79,13 +79,6 @@ struct GemmStats {
   const double* addend;  // kEpiAdd: C = A B^T + addend (same ld as C; may not alias C)
 };
 
-// No cross-lane shuffles: every lane combines what it holds in registers (its 4 column blocks
-// of a row / its 16 rows of a column), drops one (max, sum) pair into LDS, and 128 threads
-// finish each row / column from LDS in a fixed order.  The first version reduced over the
-// 16 / 4 lanes with 144 dependent ds_bpermute round trips per tile behind scheduling barriers,
-// competing with the partner workgroup's operand reads: 30 us per tile (measured with the
-// in-kernel clock probe), a third of the gap between two K loops on a slot.
-// `scratch`: 8192 doubles (the 64 KB of operand tiles, dead by now).
 template <int EPI, bool SYM>
 __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti, int tj,
                                                int ntiles, int M, int N, int tid,
@@ -93,9 +86,12 @@ __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti,
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 15, lg = lane >> 4;
-  double2* pairs = reinterpret_cast<double2*>(scratch);  // (max, sum)
+  double* rmax = scratch;            // [2][128]  (wc, row)
+  double* rsum = scratch + 256;      // [2][128]
+  double* cmax = scratch + 512;      // [2][128]  (wr, col)
+  double* csum = scratch + 768;      // [2][128]
   const bool diag_tile = ti == tj;
-  // --- rows: pairs[row][wc * 16 + li] = this lane's 4 column blocks of the row
+  // --- per-row partials over this wave's 64 columns
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -112,28 +108,20 @@ __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti,
         if (inside && !skip) mx = fmax(mx, x);
         if (inside) sm += x;
       }
-      pairs[lrow * 32 + wc * 16 + li] = make_double2(mx, sm);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        mx = fmax(mx, __shfl_xor(mx, o));
+        sm += __shfl_xor(sm, o);
+      }
+      if (li == 0) {
+        rmax[wc * 128 + lrow] = mx;
+        rsum[wc * 128 + lrow] = sm;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the live range of each reduction short
     }
   }
-  __syncthreads();
-  if (tid < 128) {
-    double mx = -INFINITY, sm = 0.0;
-#pragma unroll 8
-    for (int q = 0; q < 32; ++q) {  // column order: wc 0 (li 0..15), wc 1 (li 0..15)
-      const double2 v = pairs[tid * 32 + q];
-      mx = fmax(mx, v.x);
-      sm += v.y;
-    }
-    const int row = ti * BM + tid;
-    if (row < M) {
-      st.pmax[(size_t)row * ntiles + tj] = mx;
-      if (st.mode == 1) st.psum[(size_t)row * ntiles + tj] = sm;
-    }
-  }
-  // --- columns (the mirror tile's rows): pairs[(wr * 4 + lg) * 128 + col] = this lane's
-  //     16 rows of the column
+  // --- per-column partials over this wave's 64 rows (the mirror tile's rows)
   if (SYM && !diag_tile) {
-    __syncthreads();
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) {
       const int lcol = wc * 64 + nn * 16 + li;
@@ -150,25 +138,32 @@ __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti,
             sm += x;
           }
         }
-      pairs[(wr * 4 + lg) * 128 + lcol] = make_double2(mx, sm);
-    }
-    __syncthreads();
-    if (tid < 128) {
-      double mx = -INFINITY, sm = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {  // row order: wr 0 (lg 0..3), wr 1 (lg 0..3)
-        const double2 v = pairs[q * 128 + tid];
-        mx = fmax(mx, v.x);
-        sm += v.y;
+      mx = fmax(mx, __shfl_xor(mx, 16));
+      sm += __shfl_xor(sm, 16);
+      mx = fmax(mx, __shfl_xor(mx, 32));
+      sm += __shfl_xor(sm, 32);
+      if (lg == 0) {
+        cmax[wr * 128 + lcol] = mx;
+        csum[wr * 128 + lcol] = sm;
       }
-      const int row = tj * BN + tid;
-      if (row < N) {
-        st.pmax[(size_t)row * ntiles + ti] = mx;
-        if (st.mode == 1) st.psum[(size_t)row * ntiles + ti] = sm;
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();  // the staging of the mirror tile reuses this LDS
+  __syncthreads();
+  if (tid < 128) {
+    const int row = ti * BM + tid;
+    if (row < M) {
+      st.pmax[(size_t)row * ntiles + tj] = fmax(rmax[tid], rmax[128 + tid]);
+      if (st.mode == 1) st.psum[(size_t)row * ntiles + tj] = rsum[tid] + rsum[128 + tid];
+    }
+  } else if (SYM && !diag_tile) {
+    const int c = tid - 128;
+    const int row = tj * BN + c;
+    if (row < N) {
+      st.pmax[(size_t)row * ntiles + ti] = fmax(cmax[c], cmax[128 + c]);
+      if (st.mode == 1) st.psum[(size_t)row * ntiles + ti] = csum[c] + csum[128 + c];
+    }
+  }
 }
 
 // rowmax[i] / rowsum[i] from the per-tile partials (fixed slot order)
@@ -319,7 +314,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   const int row0 = ti * BM;
   const int col0 = tj * BN;
 
-  const int tid = threadIdx.x;
+  // (opaque to the optimiser: otherwise every tid-derived address of the item body is hoisted
+  //  out of the item loop and kept alive across the epilogue -- spills)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wr = wave >> 1;
@@ -800,7 +799,9 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     // split unit, [10] units reserved for the stagger (one per CU)
     // SC_GEMM_PERSIST=0: one workgroup per item by block index (round 1's form)
     static const int want_persist = getenv("SC_GEMM_PERSIST") ? atoi(getenv("SC_GEMM_PERSIST")) : 1;
-    static const bool want_static = getenv("SC_GEMM_DYNAMIC") == nullptr && !want_persist;
+    // (persistent only for long K: with K = 256 a tile is 16 K-tiles and the draw costs more
+    //  than the dispatch it saves -- affinity GEMM 0.395 -> 0.417 ms)
+    const bool want_static = getenv("SC_GEMM_DYNAMIC") == nullptr && !(want_persist && K >= 1024);
     static int* queue_buf[16] = {nullptr};
     int* queue = nullptr;
     if (!want_static && xcd_chunk > 0 && rem > 0 && SYM) {
@@ -810,9 +811,9 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
       if (queue_buf[dev] == nullptr) (void)hipMalloc(&queue_buf[dev], 16 * sizeof(int));
       queue = queue_buf[dev];
       hipLaunchKernelGGL(k_gemm_queue_init, dim3(1), dim3(16), 0, s, queue,
-                         want_persist ? 0 : g_slots / 2);
+                         (want_persist && K >= 1024) ? 0 : g_slots / 2);
     }
-    const int persist = (queue != nullptr && want_persist) ? 1 : 0;
+    const int persist = (queue != nullptr && want_persist && K >= 1024) ? 1 : 0;
     const int grid = persist ? std::min(g_slots, full + rem * ksplit) : full + rem * ksplit;
     static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 3;
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(grid), dim3(256), 0, s, A, lda,

@@ -211,3 +211,26 @@ def test_non_finite_input_raises_like_numpy():
     assert so.adjusted_rand_index(labels, so.predict(good, so.icassp2018_config())) == 1.0
   w, _ = sca.utils.compute_sorted_eigenvectors(np.diag([3.0, 2.0, 1.0]))
   np.testing.assert_allclose(w, [3.0, 2.0, 1.0])
+
+
+@pytest.mark.parametrize("n,lap", [(4100, 4), (4233, 0)])
+def test_ragged_size_above_the_symmetric_matvec_threshold(n, lap):
+  """n >= 4096 takes the upper-triangle block matvec (128 x 128 tiles) and the persistent
+  GEMM loop; an n that is not a multiple of 128 exercises their edge tiles.  Checked against
+  the algorithm-matched CPU path (NumPy refinement + scipy eigsh on the symmetric operator,
+  itself checked against the reference-shaped oracle in test_oracle_vs_golden.py), which
+  finishes in seconds at this size."""
+  x = so.blobs(n, 48, 5, seed=n)
+  maxc = 20 if lap else 7
+  cfg = so.icassp2018_config(laplacian_type=lap, max_clusters=maxc)
+  want, w_ref = so.predict_algorithm_matched(x, cfg)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=maxc,
+                            refinement_options=sca.configs.icassp2018_refinement_options,
+                            laplacian_type=sca.LaplacianType.GraphCut if lap else None)
+  got = c.predict(x)
+  assert c.last_diag.eig_path == 2 and c.last_diag.eig_host_chain == 0
+  idx = so.consumed_eigen_indices(n, maxc, lap == 0, w_ref, 1e-2)
+  w = c.last_diag.eigenvalue_array()
+  floor = 1e-9  # the Laplacian's null eigenvalue is not in idx; eigsh's tolerance is 1e-10
+  assert np.max(np.abs(w[idx] - w_ref[idx]) / np.maximum(np.abs(w_ref[idx]), floor)) < 1e-6
+  assert so.adjusted_rand_index(got, want) == 1.0

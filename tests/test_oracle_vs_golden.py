@@ -302,3 +302,24 @@ def test_adjusted_rand_index():
     b = rng.integers(0, 5, 200)
     assert abs(so.adjusted_rand_index(a, b) - adjusted_rand_score(a, b)) < 1e-12
   assert so.adjusted_rand_index(a, (a + 1) % 4) == 1.0
+
+
+@pytest.mark.parametrize("name", ["e2e_n200_lap0_max7", "e2e_n200_lap4_max7",
+                                  "e2e_n1000_lap0_max7", "e2e_n1000_lap4_max20",
+                                  "e2e_n1000_lap3_max20", "e2e_n1000_lap2_max20"])
+def test_algorithm_matched_cpu_path_vs_reference_golden(name):
+  """`predict_algorithm_matched` (bench.py's second CPU leg and the checker of the large
+  ragged GPU cases): the device's algorithm -- folded scaling vectors + a symmetric Krylov
+  solver -- reproduces the real reference's consumed eigenvalues and labels."""
+  g = golden(name + ".npz")
+  n, d, k, seed, lap, maxc = (int(v) for v in g["params"])
+  x = so.blobs(n, d, k, seed)
+  cfg = so.icassp2018_config(laplacian_type=lap, max_clusters=maxc)
+  labels, w = so.predict_algorithm_matched(x, cfg)
+  idx, ref = g["consumed_index"], g["consumed_eigenvalues"]
+  if lap == 0:
+    keep = so.consumed_eigen_indices(n, maxc, True, ref, 1e-2)
+    idx, ref = idx[keep], ref[keep]
+  rel = np.abs(w[idx] - ref) / np.maximum(np.abs(ref), 1e-12)
+  assert rel.max() < 1e-8, rel.max()
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0

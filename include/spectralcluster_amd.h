@@ -275,6 +275,15 @@ int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,
 int sc_predict_batch_streams(sc_handle h, const double* const* xs, const int* ns, int d,
                              int count, const sc_config* cfg, int64_t* const* labels,
                              sc_diag* diags, int streams);
+/* the same on ONE stream with ONE host thread, `group` (<= 16) utterances per launch: the
+ * stages before the eigensolver are enqueued member after member, the block Lanczos chain
+ * and the k-means chain of the members advance in lockstep (one launch per step and one
+ * host synchronisation per check for the whole group).  Per-utterance results are those of
+ * sc_predict; utterances outside the grouped path's range (n <= 128, n >= 4096, a
+ * full-spectrum request, non-cosine k-means, constraints) take the single-call path. */
+int sc_predict_batch_grouped(sc_handle h, const double* const* xs, const int* ns, int d,
+                             int count, const sc_config* cfg, int64_t* const* labels,
+                             sc_diag* diags, int group);
 
 /*
  * Size reduction before the spectral path (spectral_clusterer.py:170-199,

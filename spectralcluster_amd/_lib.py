@@ -179,6 +179,11 @@ PROTOTYPES = {
                                                 ctypes.POINTER(ScConfig),
                                                 ctypes.POINTER(_c_int64_p),
                                                 ctypes.POINTER(ScDiag), ctypes.c_int]),
+    "sc_predict_batch_grouped": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),
+                                                _c_int_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(ScConfig),
+                                                ctypes.POINTER(_c_int64_p),
+                                                ctypes.POINTER(ScDiag), ctypes.c_int]),
     "sc_stage_affinity": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
                                          ctypes.c_int, _c_double_p]),
     "sc_stage_refine": (ctypes.c_int, [_handle_t, ctypes.c_int,

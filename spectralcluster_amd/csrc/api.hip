@@ -47,16 +47,37 @@ int ensure_matrices(sc_handle h, int n, int d) {
   return SC_OK;
 }
 
+// Tile orders of the symmetric GEMM for every tile-grid size up to kTilemapTableMax live in
+// one device table built once per handle: a change of n between calls costs no upload and no
+// synchronisation (batches of short utterances change it with every call).
 int ensure_tilemap(sc_handle h, int n) {
   const int nt = gemm_tile_dim(n);
-  if (h->tilemap_nt == nt) return SC_OK;
-  std::vector<int2> map;
-  gemm_build_sym_tilemap(nt, &map);
-  SC_TRY(grow(h, h->tilemap, map.size() * sizeof(int2)));
-  SC_HIP(h, hipMemcpyAsync(h->tilemap.p, map.data(), map.size() * sizeof(int2),
-                           hipMemcpyHostToDevice, h->stream));
-  SC_HIP(h, hipStreamSynchronize(h->stream));  // `map` is a local
-  h->tilemap_nt = nt;
+  if (nt <= kTilemapTableMax) {
+    if (!h->tilemap_table.p) {
+      std::vector<int2> all, one;
+      for (int t = 1; t <= kTilemapTableMax; ++t) {
+        h->tilemap_off[t] = (int)all.size();
+        gemm_build_sym_tilemap(t, &one);
+        all.insert(all.end(), one.begin(), one.end());
+      }
+      SC_TRY(grow(h, h->tilemap_table, all.size() * sizeof(int2)));
+      SC_HIP(h, hipMemcpyAsync(h->tilemap_table.p, all.data(), all.size() * sizeof(int2),
+                               hipMemcpyHostToDevice, h->stream));
+      SC_HIP(h, hipStreamSynchronize(h->stream));  // `all` is a local
+    }
+    h->tilemap_cur = ptr<int2>(h->tilemap_table) + h->tilemap_off[nt];
+    return SC_OK;
+  }
+  if (h->tilemap_nt != nt) {
+    std::vector<int2> map;
+    gemm_build_sym_tilemap(nt, &map);
+    SC_TRY(grow(h, h->tilemap, map.size() * sizeof(int2)));
+    SC_HIP(h, hipMemcpyAsync(h->tilemap.p, map.data(), map.size() * sizeof(int2),
+                             hipMemcpyHostToDevice, h->stream));
+    SC_HIP(h, hipStreamSynchronize(h->stream));  // `map` is a local
+    h->tilemap_nt = nt;
+  }
+  h->tilemap_cur = ptr<int2>(h->tilemap);
   return SC_OK;
 }
 
@@ -182,22 +203,25 @@ extern "C" int sc_destroy(sc_handle h) {
   if (!h) return SC_OK;
   for (sc_handle sub : h->pool) sc_destroy(sub);
   h->pool.clear();
+  for (sc_handle sub : h->gslots) sc_destroy(sub);
+  h->gslots.clear();
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->ahc_size, &h->ahc_chain, &h->ahc_Z, &h->ahc_lab, &h->ahc_cent, &h->fb_part, &h->fb_small, &h->fb_x, &h->fb_cent, &h->fb_int, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->tilemap_table, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->ahc_size, &h->ahc_chain, &h->ahc_Z, &h->ahc_lab, &h->ahc_cent, &h->fb_part, &h->fb_small, &h->fb_x, &h->fb_cent, &h->fb_int, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
                     &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
-                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain};
+                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);
   if (h->h_theta) hipHostFree(h->h_theta);
   if (h->h_flags) hipHostFree(h->h_flags);
   if (h->h_rr) hipHostFree(h->h_rr);
+  if (h->sync_ev) hipEventDestroy(h->sync_ev);
   hipStreamDestroy(h->stream);
   delete h;
   return SC_OK;
@@ -364,16 +388,16 @@ extern "C" int sc_random_state_doubles(uint32_t seed, int count, double* out) {
 
 extern "C" int sc_uniform_choice(int n, double u) {
   if (n <= 0) return SC_ERR_INVALID;
+  // cdf = cumsum(p) in order, normalised by its last entry: the same running sums twice
+  // instead of an n-element array
   const double p = 1.0 / (double)n;
-  std::vector<double> cdf(n);
+  double last = 0.0;
+  for (int i = 0; i < n; ++i) last += p;
   double run = 0.0;
   for (int i = 0; i < n; ++i) {
     run += p;
-    cdf[i] = run;
+    if (run / last > u) return i;  // searchsorted(..., side="right")
   }
-  const double last = cdf[n - 1];
-  for (int i = 0; i < n; ++i)
-    if (cdf[i] / last > u) return i;  // searchsorted(..., side="right")
   return n - 1;
 }
 
@@ -461,7 +485,7 @@ static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double
     case SC_OP_DIFFUSE:
       SC_TRY(ensure_tilemap(h, n));
       launch_gemm_nt(s, in, ld, in, ld, out, ld, n, n, n, kEpiNone, true, ptr<double>(h->splitk),
-                     ptr<int2>(h->tilemap));
+                     h->tilemap_cur);
       break;
     case SC_OP_ROW_WISE_NORMALIZE:
       launch_row_normalize(s, in, out, n, ld);
@@ -508,7 +532,7 @@ extern "C" int sc_compute_affinity(sc_handle h) {
   if (h->profile_level >= 2) ev_rec(h, &h->aff_ev[0]);
   launch_gemm_nt(h->stream, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx,
                  ptr<double>(h->A0), h->ldn, h->n, h->n, h->d, kEpiAffinity, true,
-                 ptr<double>(h->splitk), ptr<int2>(h->tilemap), &rs);
+                 ptr<double>(h->splitk), h->tilemap_cur, &rs);
   if (h->profile_level >= 2) ev_rec(h, &h->aff_ev[1]);
   SC_TRY(check_last(h, "affinity launch"));
   h->have_affinity = true;
@@ -541,7 +565,32 @@ extern "C" int sc_set_affinity(sc_handle h, const double* a, int n) {
 // _compute_eigenvectors_ncluster
 // ------------------------------------------------------------------------------
 
-static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
+EigRequest make_eig_request(const sc_config* cfg) {
+  EigRequest rq;
+  rq.descend = (cfg->laplacian_type == SC_LAPLACIAN_NONE ||
+                cfg->laplacian_type == SC_LAPLACIAN_AFFINITY);
+  rq.max_clusters = cfg->max_clusters;
+  rq.min_clusters = cfg->min_clusters;
+  rq.stop_eigenvalue = cfg->stop_eigenvalue;
+  rq.eigengap_type = cfg->eigengap_type;
+  rq.use_stop = rq.descend;  // spectral_clusterer.py:163-167: not passed when ascending
+  rq.value_tol = cfg->eig_value_tol > 0 ? cfg->eig_value_tol : 1e-6;
+  rq.vector_tol = cfg->eig_vector_tol > 0 ? cfg->eig_vector_tol : 1e-10;
+  rq.max_cycles = cfg->eig_max_cycles > 0 ? cfg->eig_max_cycles : 40;
+  rq.fixed_count = 0;
+  {  // p_percentile and the Laplacian shape the spectrum: part of the hint's signature
+    long long pbits;
+    memcpy(&pbits, &cfg->p_percentile, sizeof(pbits));
+    rq.hint_key = pbits ^ ((long long)cfg->laplacian_type << 3) ^ ((long long)cfg->n_ops << 7);
+  }
+  return rq;
+}
+
+// `front_only`: stop after the refinement and the scaling vectors (everything before the
+// eigensolver, no host synchronisation) and say where the refined matrix is -- the grouped
+// batch (batch_group.hip) solves several such problems in lockstep from there.
+int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontResult* front_only,
+                      const FrontResult* resume) {
   const int n = h->n, ld = h->ldn;
   hipStream_t s = h->stream;
   const double* cur = ptr<double>(h->A0);
@@ -565,7 +614,13 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   const double* pending_diag = nullptr;
   bool have_partials = false;
   bool have_row_stats = false;
-  for (int i = 0; i < cfg->n_ops; ++i) {
+  if (resume) {
+    cur = resume->matrix;
+    symmetric = resume->symmetric;
+    folded_rownorm = resume->folded_rownorm;
+    which = resume->scratch == bufs[0] ? 0 : 1;
+  }
+  for (int i = 0; i < (resume ? 0 : cfg->n_ops); ++i) {
     const int op = cfg->ops[i];
     const int next = i + 1 < cfg->n_ops ? cfg->ops[i + 1] : 0;
     const int next2 = i + 2 < cfg->n_ops ? cfg->ops[i + 2] : 0;
@@ -633,7 +688,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
                       ptr<double>(h->rowmax), ptr<double>(h->rowsum)};
       SC_TRY(ensure_tilemap(h, n));
       launch_gemm_nt(s, cur, ld, cur, ld, out, ld, n, n, n, kEpiNone, true,
-                     ptr<double>(h->splitk), ptr<int2>(h->tilemap), last ? &rs : nullptr);
+                     ptr<double>(h->splitk), h->tilemap_cur, last ? &rs : nullptr);
       SC_TRY(check_last(h, "diffuse launch"));
       have_row_stats = last;
       have_partials = false;
@@ -662,7 +717,7 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
         break;
     }
   }
-  if (constrain_after) {  // spectral_clusterer.py:137-142
+  if (constrain_after && !resume) {  // spectral_clusterer.py:137-142
     if (h->qn != n)
       return fail(h, SC_ERR_INVALID,
                   "affinity and constraint matrix must have the same shape");
@@ -675,7 +730,9 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   }
   ev_rec(h, &e_after_refine);
   // ---- scaling vectors (RowWiseNormalize fold + Laplacian)
-  if (!symmetric) {
+  if (resume) {
+    SC_TRY(ensure_eig(h, n));  // (scaling vectors and the finite-ness flag are resident)
+  } else if (!symmetric) {
     // general matrix (e.g. RowWiseThreshold without a later Symmetrize / Diffuse):
     // Op x = p .* x + cl .* (M (cr .* x)), no similarity transform
     SC_TRY(ensure_gen(h, n));
@@ -716,24 +773,16 @@ static int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag) {
   }
   int e_after_scaling;
   ev_rec(h, &e_after_scaling);
-  // ---- eigen + eigengap
-  EigRequest rq;
-  rq.descend = (cfg->laplacian_type == SC_LAPLACIAN_NONE ||
-                cfg->laplacian_type == SC_LAPLACIAN_AFFINITY);
-  rq.max_clusters = cfg->max_clusters;
-  rq.min_clusters = cfg->min_clusters;
-  rq.stop_eigenvalue = cfg->stop_eigenvalue;
-  rq.eigengap_type = cfg->eigengap_type;
-  rq.use_stop = rq.descend;  // spectral_clusterer.py:163-167: not passed when ascending
-  rq.value_tol = cfg->eig_value_tol > 0 ? cfg->eig_value_tol : 1e-6;
-  rq.vector_tol = cfg->eig_vector_tol > 0 ? cfg->eig_vector_tol : 1e-10;
-  rq.max_cycles = cfg->eig_max_cycles > 0 ? cfg->eig_max_cycles : 40;
-  rq.fixed_count = 0;
-  {  // p_percentile and the Laplacian shape the spectrum: part of the hint's signature
-    long long pbits;
-    memcpy(&pbits, &cfg->p_percentile, sizeof(pbits));
-    rq.hint_key = pbits ^ ((long long)cfg->laplacian_type << 3) ^ ((long long)cfg->n_ops << 7);
+  if (front_only) {
+    front_only->matrix = cur;
+    front_only->scratch = bufs[which];
+    front_only->ld = ld;
+    front_only->symmetric = symmetric;
+    front_only->folded_rownorm = folded_rownorm;
+    return SC_OK;
   }
+  // ---- eigen + eigengap
+  EigRequest rq = make_eig_request(cfg);
   EigDecision dc;
   std::vector<double> w;
   if (symmetric) {
@@ -779,7 +828,7 @@ extern "C" int sc_eig_ncluster(sc_handle h, const sc_config* cfg, sc_diag* diag)
   SC_HIP(h, hipSetDevice(h->device));
   h->nev = 0;
   if (diag) memset(diag, 0, sizeof(*diag));
-  return eig_ncluster_impl(h, cfg, diag);
+  return eig_ncluster_impl(h, cfg, diag, nullptr);
 }
 
 extern "C" int sc_num_eigenvectors(sc_handle h) { return h ? h->n_vec : 0; }
@@ -807,6 +856,31 @@ extern "C" int sc_get_eigenvectors(sc_handle h, double* out, int n, int ncols) {
 // ------------------------------------------------------------------------------
 // k-means tail
 // ------------------------------------------------------------------------------
+void kmeans_seed_constants(int k, double* u_first, int* trials, std::vector<double>* rnd) {
+  Mt19937 rng(0);
+  *u_first = rng.next_double();
+  *trials = 2 + (int)std::log((double)k);
+  const size_t nrnd = (size_t)std::max(1, (k - 1) * *trials);
+  rnd->resize(nrnd);
+  for (size_t i = 0; i < nrnd; ++i) (*rnd)[i] = rng.next_double();
+}
+
+KmeansWorkspace kmeans_workspace(sc_handle h) {
+  KmeansWorkspace ws;
+  ws.Xc = ptr<double>(h->kXc);
+  ws.xsq = ptr<double>(h->kxsq);
+  ws.closest = ptr<double>(h->kclosest);
+  ws.cand = ptr<double>(h->kcand);
+  ws.enorm = ptr<double>(h->kenorm);
+  ws.rnd = ptr<double>(h->krnd);
+  ws.centroids = ptr<double>(h->kcent);
+  ws.labels32 = ptr<int>(h->klab32);
+  ws.labels64 = ptr<long long>(h->klab64);
+  ws.info = ptr<int>(h->kinfo);
+  ws.chain = ptr<double>(h->kchain);
+  return ws;
+}
+
 static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k, int max_iter,
                             int64_t* labels, double* centroids_out, int* iterations,
                             int metric = kKmeansCosine) {
@@ -837,18 +911,7 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
     h->krnd_k = k;
     h->krnd_trials = trials;
   }
-  KmeansWorkspace ws;
-  ws.Xc = ptr<double>(h->kXc);
-  ws.xsq = ptr<double>(h->kxsq);
-  ws.closest = ptr<double>(h->kclosest);
-  ws.cand = ptr<double>(h->kcand);
-  ws.enorm = ptr<double>(h->kenorm);
-  ws.rnd = ptr<double>(h->krnd);
-  ws.centroids = ptr<double>(h->kcent);
-  ws.labels32 = ptr<int>(h->klab32);
-  ws.labels64 = ptr<long long>(h->klab64);
-  ws.info = ptr<int>(h->kinfo);
-  ws.chain = ptr<double>(h->kchain);
+  const KmeansWorkspace ws = kmeans_workspace(h);
   int info[16] = {0};
   if (metric == kKmeansCosine && kmeans_chain_supported(n, k, trials) &&
       !getenv("SC_KMEANS_SINGLE")) {
@@ -945,7 +1008,7 @@ extern "C" int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* label
   SC_TRY(sc_compute_affinity(h));
   if (constraint_active(h, cfg, true)) SC_TRY(sc_apply_constraint(h, cfg));  // :259-264
   ev_rec(h, &e1);
-  SC_TRY(eig_ncluster_impl(h, cfg, dg));
+  SC_TRY(eig_ncluster_impl(h, cfg, dg, nullptr));
   int k = dg->n_clusters_raw;
   if (cfg->min_clusters > 0 && k < cfg->min_clusters) k = cfg->min_clusters;  // :295-296
   SC_TRY(sc_cluster(h, cfg, k, labels, dg));

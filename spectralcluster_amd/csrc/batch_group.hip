@@ -1,0 +1,316 @@
+// Grouped execution of a batch of SHORT utterances (512 independent
+// predict() calls, n = 300..3000) on ONE stream with ONE host thread.
+//
+// A short utterance cannot fill 256 CUs, and after its three GEMM-shaped stages its pipeline
+// is ~50 tiny dependent launches (block Lanczos chain, k-means chain) with three host
+// synchronisations: 0.45-0.6 ms of latency that does not shrink with n.  Running utterances
+// on several streams from several host threads hides that latency (sc_predict_batch_streams);
+// this file removes it instead:
+//   front   upload, affinity GEMM, refinement, Diffuse GEMM, scaling vectors of every member
+//           of a group of up to kGroupMax utterances are enqueued back to back, each on the
+//           member's own stream (no host synchronisation; one utterance's GEMM tiles cannot
+//           fill the chip, several members' do); an event per member hands over to the
+//           owner's stream,
+//   eigen   ONE lockstep block Lanczos for the group (eig_driver.hip: sym_topk_group): every
+//           launch carries one link of every member (blockIdx.y = member, descriptors in the
+//           kernel arguments), one synchronisation per Rayleigh-Ritz check for all of them,
+//   k-means ONE lockstep chain for the group (kmeans_chain.hip: launch_kmeans_chain_group).
+// Each member runs the same kernel bodies with the same arguments as a single call; members
+// that leave the common path (rare branches of the eigensolver, k > 32, a non-symmetric
+// refinement, n <= 128 or n >= 4096) go through the single-call path, so results are those of
+// sc_predict for every utterance.
+#include <ctime>
+
+#include "handle.h"
+
+namespace {
+
+double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+constexpr int kRndStride = 256;  // doubles per k in the RandomState(0) table (k <= 32)
+
+int group_slot(sc_handle lead, int z, sc_handle* out) {
+  while ((int)lead->gslots.size() <= z) {
+    sc_handle sub = nullptr;
+    const int rc = sc_create(lead->device, &sub);
+    if (rc != SC_OK) return fail(lead, rc, "could not create a member arena for the group");
+    // the member's stages before the eigensolver run on its own stream (several members'
+    // GEMMs and refinement passes share the chip); `sync_ev` hands the result to the
+    // owner's stream, where the lockstep chains run
+    if (hipEventCreateWithFlags(&sub->sync_ev, hipEventDisableTiming) != hipSuccess) {
+      sc_destroy(sub);
+      return fail(lead, SC_ERR_HIP, "could not create a member event");
+    }
+    sub->profile_level = 1;
+    lead->gslots.push_back(sub);
+  }
+  *out = lead->gslots[z];
+  return SC_OK;
+}
+
+int ensure_seed_table(sc_handle lead) {
+  if (lead->gkrnd_ready) return SC_OK;
+  std::vector<double> table((size_t)33 * kRndStride, 0.0), rnd;
+  for (int k = 1; k <= 32; ++k) {
+    double u;
+    int trials;
+    kmeans_seed_constants(k, &u, &trials, &rnd);
+    if (rnd.size() > (size_t)kRndStride) return fail(lead, SC_ERR_UNSUPPORTED, "seed table");
+    std::copy(rnd.begin(), rnd.end(), table.begin() + (size_t)k * kRndStride);
+  }
+  SC_TRY(grow(lead, lead->gkrnd, table.size() * sizeof(double)));
+  SC_HIP(lead, hipMemcpyAsync(lead->gkrnd.p, table.data(), table.size() * sizeof(double),
+                              hipMemcpyHostToDevice, lead->stream));
+  SC_HIP(lead, hipStreamSynchronize(lead->stream));  // `table` is a local
+  lead->gkrnd_ready = true;
+  return SC_OK;
+}
+
+// sc_set_embeddings without its synchronisation: the caller's arrays stay valid for the whole
+// batch call
+int upload_embeddings(sc_handle h, const double* x, int n, int d) {
+  if (!x || n <= 0 || d <= 0) return fail(h, SC_ERR_INVALID, "embeddings must be (n, d)");
+  SC_TRY(ensure_matrices(h, n, d));
+  h->n = n;
+  h->d = d;
+  h->ldn = matrix_ld(n);
+  h->ldx = round_up(d, 16);
+  h->have_affinity = h->have_cropval = false;
+  h->n_vec = 0;
+  SC_HIP(h, hipMemcpy2DAsync(h->X.p, (size_t)h->ldx * sizeof(double), x,
+                             (size_t)d * sizeof(double), (size_t)d * sizeof(double), n,
+                             hipMemcpyHostToDevice, h->stream));
+  h->have_x = true;
+  return SC_OK;
+}
+
+struct Member {
+  int index = -1;        // utterance
+  sc_handle h = nullptr;
+  FrontResult front;
+  int state = 0;         // 0 in the group, 1 single-call path, 2 done
+  int k = 0;
+};
+
+// Stages before the eigensolver of one group, member after member, each on its member's
+// stream: no synchronisation.  `slot0`: first member arena of the bank the group uses.
+int enqueue_front(sc_handle lead, const double* const* xs, const int* ns, int d,
+                  const sc_config* cfg, sc_diag* diags, const int* idx, int count, int slot0,
+                  Member* mb) {
+  for (int z = 0; z < count; ++z) {
+    Member& m = mb[z];
+    m = Member();
+    m.index = idx[z];
+    SC_TRY(group_slot(lead, slot0 + z, &m.h));
+    sc_handle h = m.h;
+    h->err.clear();
+    int rc = upload_embeddings(h, xs[m.index], ns[m.index], d);
+    h->nev = 0;
+    sc_diag local;
+    sc_diag* dg = diags ? diags + m.index : &local;
+    memset(dg, 0, sizeof(*dg));
+    if (rc == SC_OK) rc = sc_compute_affinity(h);
+    if (rc == SC_OK) rc = eig_ncluster_impl(h, cfg, dg, &m.front);
+    if (rc != SC_OK) {
+      lead->err = h->err;
+      return rc;
+    }
+    if (!m.front.symmetric) m.state = 1;
+    SC_HIP(lead, hipEventRecord(h->sync_ev, h->stream));
+  }
+  return SC_OK;
+}
+
+// Eigensolver and k-means of a group whose stages before are enqueued (enqueue_front), in
+// lockstep on the owner's stream; then the members that left the common path.
+int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* const* labels,
+                 sc_diag* diags, Member* mb, int count, const EigRequest& rq) {
+  hipStream_t s = lead->stream;
+  const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
+  for (int z = 0; z < count; ++z) SC_HIP(lead, hipStreamWaitEvent(s, mb[z].h->sync_ev, 0));
+  const double t1 = trace ? now_us() : 0.0;
+  // ---- eigen: lockstep over the symmetric members
+  GroupEigMember em[kGroupMax];
+  int emz[kGroupMax], ne = 0;
+  for (int z = 0; z < count; ++z) {
+    if (mb[z].state != 0) continue;
+    em[ne].h = mb[z].h;
+    em[ne].S = mb[z].front.matrix;
+    em[ne].ld = mb[z].front.ld;
+    em[ne].n = ns[mb[z].index];
+    em[ne].rq = rq;
+    emz[ne++] = z;
+  }
+  if (ne > 0) SC_TRY(sym_topk_group(lead, em, ne));
+  const double t2 = trace ? now_us() : 0.0;
+  // ---- k-means: lockstep over the solved members
+  KmGroupItem km[kGroupMax];
+  int kmz[kGroupMax];
+  int info[kGroupMax][16];
+  int nk = 0;
+  for (int e = 0; e < ne; ++e) {
+    Member& m = mb[emz[e]];
+    if (em[e].status != 0) {
+      m.state = 1;
+      continue;
+    }
+    sc_handle h = m.h;
+    const int n = em[e].n;
+    int k = em[e].dc.n_clusters_raw;
+    if (cfg->min_clusters > 0 && k < cfg->min_clusters) k = cfg->min_clusters;  // :295-296
+    m.k = k;
+    double u = 0.0;
+    int trials = 0;
+    std::vector<double> unused;
+    if (k >= 1 && k <= 32) kmeans_seed_constants(k, &u, &trials, &unused);
+    if (k < 1 || k > 32 || k > h->n_vec || n < k || cfg->max_iter <= 0 ||
+        !kmeans_chain_supported(n, k, trials) || getenv("SC_KMEANS_SINGLE")) {
+      m.state = 1;  // the single-call path states the error or takes the other kernel
+      continue;
+    }
+    if (diags) {
+      sc_diag* dg = diags + m.index;
+      dg->n = n;
+      dg->n_clusters_raw = em[e].dc.n_clusters_raw;
+      dg->max_delta = em[e].dc.max_delta;
+      dg->eig_descending = rq.descend;
+      dg->n_eigenvalues = std::min((int)em[e].w.size(), SC_MAX_EIG);
+      for (int i = 0; i < dg->n_eigenvalues; ++i) dg->eigenvalues[i] = em[e].w[i];
+      dg->symmetry_state = m.front.folded_rownorm ? 2 : 1;
+      dg->eig_path = SC_EIG_PATH_BLOCK_LANCZOS;
+      dg->eig_matvec_passes = em[e].passes;
+      dg->eig_block = kEigBlock;
+      dg->eig_basis = em[e].basis;
+      dg->eig_max_residual = em[e].dc.max_resid;
+      dg->n_clusters = k;
+    }
+    SC_TRY(ensure_kmeans(h, n));
+    const int lde = round_up(n, 16);
+    const double* E = ptr<double>(h->E);
+    if (cfg->row_wise_renorm) {
+      SC_HIP(lead, hipMemcpyAsync(h->Ek.p, h->E.p, (size_t)lde * k * sizeof(double),
+                                  hipMemcpyDeviceToDevice, s));
+      launch_row_renorm(s, ptr<double>(h->Ek), lde, n, k);
+      E = ptr<double>(h->Ek);
+    }
+    KmGroupItem& it = km[nk];
+    it = KmGroupItem();
+    it.ET = E;
+    it.lde = lde;
+    it.n = n;
+    it.k = k;
+    it.max_iter = cfg->max_iter;
+    it.first_center = sc_uniform_choice(n, u);
+    it.trials = trials;
+    it.ws = kmeans_workspace(h);
+    it.ws.rnd = ptr<double>(lead->gkrnd) + (size_t)k * kRndStride;
+    kmz[nk++] = emz[e];
+  }
+  int running = nk;
+  for (int it = 0; running > 0; it += 4) {
+    launch_kmeans_chain_group(s, km, nk, it, 4);
+    SC_TRY(check_last(lead, "group kmeans launch"));
+    for (int q = 0; q < nk; ++q) {
+      if (km[q].n <= 0) continue;
+      Member& m = mb[kmz[q]];
+      SC_HIP(lead, hipMemcpyAsync(labels[m.index], m.h->klab64.p,
+                                  (size_t)km[q].n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      SC_HIP(lead, hipMemcpyAsync(info[q], m.h->kinfo.p, 9 * sizeof(int),
+                                  hipMemcpyDeviceToHost, s));
+    }
+    SC_HIP(lead, hipStreamSynchronize(s));
+    for (int q = 0; q < nk; ++q) {
+      if (km[q].n <= 0 || info[q][8] == 0) continue;
+      Member& m = mb[kmz[q]];
+      if (diags) diags[m.index].kmeans_iterations = info[q][0];
+      m.state = 2;
+      km[q].n = 0;  // idle from here on
+      --running;
+    }
+    if (running > 0 && it > cfg->max_iter + 4)
+      return fail(lead, SC_ERR_HIP, "k-means chain did not reach its stop rule");
+  }
+  if (trace)
+    fprintf(stderr, "[sc] group of %d (n %d..%d): eigen %.0f us, k-means %.0f us (%d members)\n",
+            count, ns[mb[count - 1].index], ns[mb[0].index], t2 - t1, now_us() - t2, nk);
+  // ---- members that left the common path: the single-call pipeline on their own arena
+  for (int z = 0; z < count; ++z) {
+    Member& m = mb[z];
+    if (m.state != 1) continue;
+    // (from the refined matrix the member's front left: only the solver and k-means again)
+    sc_diag local;
+    sc_diag* dg = diags ? diags + m.index : &local;
+    memset(dg, 0, sizeof(*dg));
+    m.h->nev = 0;
+    int rc = eig_ncluster_impl(m.h, cfg, dg, nullptr, &m.front);
+    if (rc == SC_OK) {
+      int k = dg->n_clusters_raw;
+      if (cfg->min_clusters > 0 && k < cfg->min_clusters) k = cfg->min_clusters;  // :295-296
+      rc = sc_cluster(m.h, cfg, k, labels[m.index], dg);
+    }
+    if (rc != SC_OK) {
+      lead->err = m.h->err;
+      return rc;
+    }
+  }
+  return SC_OK;
+}
+
+}  // namespace
+
+extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, const int* ns,
+                                        int d, int count, const sc_config* cfg,
+                                        int64_t* const* labels, sc_diag* diags, int group) {
+  if (!h) return SC_ERR_INVALID;
+  if (!xs || !ns || !labels || count < 0) return fail(h, SC_ERR_INVALID, "NULL argument");
+  SC_TRY(validate_config(h, cfg));
+  SC_HIP(h, hipSetDevice(h->device));
+  group = std::max(1, std::min(group, kGroupMax));
+  const EigRequest rq = make_eig_request(cfg);
+  const bool cfg_ok = group > 1 && cfg->kmeans_metric == kKmeansCosine &&
+                      !constraint_active(h, cfg, true) && !constraint_active(h, cfg, false);
+  std::vector<int> grouped, single;
+  for (int i = 0; i < count; ++i) {
+    if (cfg_ok && xs[i] && ns[i] > 0 && sym_group_eligible(ns[i], rq)) grouped.push_back(i);
+    else single.push_back(i);
+  }
+  if (!grouped.empty()) {
+    SC_TRY(ensure_seed_table(h));
+    // similar sizes together: a group's launches are sized by its largest member
+    std::stable_sort(grouped.begin(), grouped.end(), [&](int a, int b) { return ns[a] > ns[b]; });
+    const int width = std::min(group, (int)grouped.size());
+    const int ngroups = ((int)grouped.size() + width - 1) / width;
+    // Two banks of member arenas: while the eigensolver and k-means chains of group g run
+    // (short launches, host synchronisations, Rayleigh-Ritz on the host), the GEMMs and
+    // refinement passes of group g + 1 keep the chip busy on the other bank's streams.
+    const int nslots = std::min(2 * width, (int)grouped.size());
+    for (int z = 0; z < nslots; ++z) {  // arenas once, for the largest member each will see
+      sc_handle hz = nullptr;
+      SC_TRY(group_slot(h, z, &hz));
+      const int rc = sc_reserve(hz, ns[grouped[z]], d);
+      if (rc != SC_OK) return fail(h, rc, hz->err);
+      hz->have_constraint = false;
+    }
+    Member mbs[2][kGroupMax];
+    auto group_count = [&](int g) {
+      return (int)std::min<size_t>(width, grouped.size() - (size_t)g * width);
+    };
+    const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
+    SC_TRY(enqueue_front(h, xs, ns, d, cfg, diags, grouped.data(), group_count(0), 0, mbs[0]));
+    for (int g = 0; g < ngroups; ++g) {
+      const double t0 = trace ? now_us() : 0.0;
+      if (g + 1 < ngroups)
+        SC_TRY(enqueue_front(h, xs, ns, d, cfg, diags, grouped.data() + (size_t)(g + 1) * width,
+                             group_count(g + 1), ((g + 1) & 1) * width, mbs[(g + 1) & 1]));
+      if (trace) fprintf(stderr, "[sc] next group's front enqueued in %.0f us\n", now_us() - t0);
+      SC_TRY(finish_group(h, ns, cfg, labels, diags, mbs[g & 1], group_count(g), rq));
+    }
+  }
+  for (int i : single)
+    SC_TRY(sc_predict(h, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr));
+  return SC_OK;
+}

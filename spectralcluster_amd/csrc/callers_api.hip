@@ -71,7 +71,7 @@ extern "C" int sc_ahc(sc_handle h, const double* x, int n, int d, int linkage, i
   const int ld = h->ldn;
   launch_normalize_rows(s, ptr<double>(h->X), h->ldx, n, d, ptr<double>(h->Xn));
   launch_gemm_nt(s, ptr<double>(h->Xn), h->ldx, ptr<double>(h->Xn), h->ldx, ptr<double>(h->B1),
-                 ld, n, n, d, kEpiNone, true, ptr<double>(h->splitk), ptr<int2>(h->tilemap));
+                 ld, n, n, d, kEpiNone, true, ptr<double>(h->splitk), h->tilemap_cur);
   launch_cosine_distance(s, ptr<double>(h->B1), n, ld);
   SC_TRY(grow(h, h->ahc_size, (size_t)n * sizeof(int)));
   SC_TRY(grow(h, h->ahc_chain, (size_t)n * sizeof(int)));

@@ -54,7 +54,7 @@ static int constraint_propagation(sc_handle h, const double* a, bool sym_a, cons
   double* Tn = ptr<double>(h->cp[3]);
   double* X = ptr<double>(h->cp[4]);  // transposes (general A), then T Q^T
   double* ws = ptr<double>(h->splitk);
-  const int2* tm = ptr<int2>(h->tilemap);
+  const int2* tm = h->tilemap_cur;
   launch_row_stats(s, a, n, ld, ptr<double>(h->cut), ptr<double>(h->deg));  // deg = rowsum
   launch_cp_prepare(s, a, ptr<double>(h->deg), alpha, P, T, n, ld);          // T = I + P
   for (int j = 1; j < steps; ++j) {

@@ -15,6 +15,7 @@
 //                    host, eig_driver.hip)
 // Everything except the matvec is tall-skinny (n x <= 136), L2-resident and latency-bound.
 #include <algorithm>
+#include <cstring>
 #include <mutex>
 
 #include "sc_internal.h"
@@ -58,7 +59,7 @@ __global__ void k_refill_deficient(double* W, int n, const int* flags,
 // carries k = kb + 8 g + t; two accumulators break the MFMA dependency chain.
 // HBM-bound: one pass over S (n^2 * 8 bytes) per 16 vectors.
 constexpr int kMvWaves = 8;
-__global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
+__device__ __forceinline__ void block_matvec_body(
     const double* __restrict__ S, int ld, int n, const double* __restrict__ cvec,
     const double* __restrict__ pvec, const double* __restrict__ V, int ldv,
     const double* __restrict__ Vs, double* __restrict__ W) {
@@ -123,6 +124,19 @@ __global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
             __builtin_fma(cvec[row], sum, pvec[row] * V[(size_t)row * ldv + li]);
     }
   }
+}
+__global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec(
+    const double* __restrict__ S, int ld, int n, const double* __restrict__ cvec,
+    const double* __restrict__ pvec, const double* __restrict__ V, int ldv,
+    const double* __restrict__ Vs, double* __restrict__ W) {
+  block_matvec_body(S, ld, n, cvec, pvec, V, ldv, Vs, W);
+}
+// Grouped form (batch_group.hip): blockIdx.y picks one of up to kGroupMax independent
+// problems whose descriptors travel in the kernel arguments; a problem with n = 0 is idle.
+__global__ __launch_bounds__(64 * kMvWaves) void k_block_matvec_g(const GroupOf<MatvecItem> g) {
+  const MatvecItem& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x * 16 >= a.n) return;
+  block_matvec_body(a.S, a.ld, a.n, a.cvec, a.pvec, a.V, a.ldv, a.Vs, a.W);
 }
 
 // ---------------------------------------------------------------- symmetric block matvec
@@ -417,7 +431,8 @@ __device__ __forceinline__ void chol8_wave(const double* G, double* __restrict__
                                            const double* __restrict__ hsq,
                                            int* __restrict__ flags,
                                            int* __restrict__ defect_flag, int flag_mode,
-                                           int* __restrict__ sticky_flag = nullptr);
+                                           int* __restrict__ sticky_flag = nullptr,
+                                           int sticky_m = 0, bool sticky_on_defect = true);
 
 // Gram reduce + Cholesky G = R^T R (right-looking, 256 threads), Rinv = R^-1 (upper).
 // A column whose pivot is <= 1e-22 * (its own squared norm + what projection removed,
@@ -456,7 +471,8 @@ __device__ __forceinline__ void chol8_wave(const double* G, double* __restrict__
                                            const double* __restrict__ hsq,
                                            int* __restrict__ flags,
                                            int* __restrict__ defect_flag, int flag_mode,
-                                           int* __restrict__ sticky_flag) {
+                                           int* __restrict__ sticky_flag, int sticky_m,
+                                           bool sticky_on_defect) {
   const int tid = threadIdx.x;
   const int i = tid >> 3, j = tid & 7;
   double g = G[tid];
@@ -513,7 +529,15 @@ __device__ __forceinline__ void chol8_wave(const double* G, double* __restrict__
     // fused step chain (k_lz_step): nobody reads the flags between the blocks, so anything
     // that needs the careful host-driven path (a dependent column, a first CholQR pass that
     // met a block of condition > 1e8) is latched
-    if (sticky_flag != nullptr && (mask != 0 || defect > 0.1)) *sticky_flag = 1;
+    // ([1]: the basis size m of the first link that latched -- T[0:m, 0:m], the residual
+    //  Gram and Q[:, 0:m] do not depend on this Cholesky and are still good; [2]: why)
+    if (sticky_flag != nullptr && (mask != 0 || (sticky_on_defect && defect > 0.1))) {
+      if (*sticky_flag == 0) {
+        sticky_flag[1] = sticky_m;
+        sticky_flag[2] = flag_mode * 1000 + mask;
+      }
+      *sticky_flag = 1;
+    }
   }
 }
 
@@ -584,6 +608,7 @@ struct LzStep {
   double* Gsave;
   double* hsq;
   int* flags;
+  int arm_defect;           // a Gram matrix far from I at this link's Cholesky latches flags[13]
   double* Tzero;            // start block: workgroup 0 clears T (kLdq x kLdq)
   // ---- body
   double* Qdst;             // store target (same buffer as Q, other columns) or nullptr
@@ -612,7 +637,7 @@ __device__ __forceinline__ double lz_ordered_sum(const double* src, int nparts) 
 }
 
 template <int ROWS>
-__global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
+__device__ __forceinline__ void lz_rows_body(const LzStep& a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int kPass = kLzThreads / B;        // rows handled per sweep of the workgroup
   const int m = a.m;
@@ -717,7 +742,7 @@ __global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
     if (tid < 64)
       chol8_wave(Gs, Rl, a.pre == 2 ? hs : nullptr, first_wg ? a.flags : nullptr,
                  first_wg ? a.flags + (a.pre == 3 ? 10 : 11) : nullptr, a.pre == 3 ? 2 : 1,
-                 first_wg ? a.flags + 13 : nullptr);
+                 first_wg ? a.flags + 13 : nullptr, m, a.arm_defect != 0);
     __syncthreads();
   }
   // ---- body
@@ -769,6 +794,16 @@ __global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
     if (e < nent && half == 0)
       mine[e < oproj ? e : kLdq * B + (e - oproj)] = acc + other;
   }
+}
+template <int ROWS>
+__global__ __launch_bounds__(kLzThreads) void k_lz_rows(const LzStep a) {
+  lz_rows_body<ROWS>(a);
+}
+template <int ROWS>
+__global__ __launch_bounds__(kLzThreads) void k_lz_rows_g(const GroupOf<LzStep> g) {
+  const LzStep& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x * ROWS >= a.n) return;
+  lz_rows_body<ROWS>(a);
 }
 
 // fp64 reciprocal / reciprocal-sqrt from the hardware seeds (v_rcp_f64 / v_rsq_f64)
@@ -1040,7 +1075,7 @@ __global__ void k_set_diag_T(double* T, int ldt, int mtot, const double* theta,
 }
 
 // dst[r, 0:cols] = Q[r, 0:m] * Y[0:m, 0:cols]
-__global__ __launch_bounds__(256) void k_basis_times_Y(
+__device__ __forceinline__ void basis_times_Y_body(
     const double* __restrict__ Q, int ldq, int m, const double* __restrict__ Y,
     int ldy, int cols, double* __restrict__ dst, int lddst, int n, int colmajor) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1070,6 +1105,16 @@ __global__ __launch_bounds__(256) void k_basis_times_Y(
       dst[(size_t)r * lddst + j] = acc;
   }
 }
+__global__ __launch_bounds__(256) void k_basis_times_Y(
+    const double* __restrict__ Q, int ldq, int m, const double* __restrict__ Y,
+    int ldy, int cols, double* __restrict__ dst, int lddst, int n, int colmajor) {
+  basis_times_Y_body(Q, ldq, m, Y, ldy, cols, dst, lddst, n, colmajor);
+}
+__global__ __launch_bounds__(256) void k_basis_times_Y_g(const GroupOf<RitzItem> g) {
+  const RitzItem& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x * 16 >= a.n) return;
+  basis_times_Y_body(a.Q, a.ldq, a.m, a.Y, a.ldy, a.cols, a.E, a.lde, a.n, 1);
+}
 
 __global__ void k_copy_block(const double* __restrict__ src, int ldsrc,
                              double* __restrict__ dst, int lddst, int n, int cols) {
@@ -1081,9 +1126,8 @@ __global__ void k_copy_block(const double* __restrict__ src, int ldsrc,
 
 // Column-major eigenvectors: ET[j * ld + r].  One workgroup per column:
 // v = t .* u, then v / ||v||_2  (LAPACK dgeev returns unit 2-norm columns).
-__global__ __launch_bounds__(256) void k_back_transform(double* __restrict__ ET, int ld,
-                                                        int n,
-                                                        const double* __restrict__ tvec) {
+__device__ __forceinline__ void back_transform_body(double* __restrict__ ET, int ld, int n,
+                                                    const double* __restrict__ tvec) {
   __shared__ double sm[4];
   double* col = ET + (size_t)blockIdx.x * ld;
   double acc = 0.0;
@@ -1098,6 +1142,16 @@ __global__ __launch_bounds__(256) void k_back_transform(double* __restrict__ ET,
   __syncthreads();
   const double inv = 1.0 / sqrt((sm[0] + sm[1]) + (sm[2] + sm[3]));
   for (int r = threadIdx.x; r < n; r += 256) col[r] *= inv;
+}
+__global__ __launch_bounds__(256) void k_back_transform(double* __restrict__ ET, int ld,
+                                                        int n,
+                                                        const double* __restrict__ tvec) {
+  back_transform_body(ET, ld, n, tvec);
+}
+__global__ __launch_bounds__(256) void k_back_transform_g(const GroupOf<RitzItem> g) {
+  const RitzItem& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.cols || a.n <= 0) return;
+  back_transform_body(a.E, a.lde, a.n, a.tvec);
 }
 
 // dst (column-major, ldd) <- src (row-major, lds), n rows x cols
@@ -1208,10 +1262,13 @@ static void launch_rows(hipStream_t s, const LzStep& a, int nwg) {
 // sums (0 nothing, 1 CGS-1, 2 CGS-2 + Cholesky, 3 re-projection + Cholesky, 4 Gram +
 // Cholesky); `next`: which sums to leave for the next link (same codes, 0 = none).
 // chain->parity / chain->nparts carry the partial buffer in use from link to link.
-void launch_lz_link(hipStream_t s, const EigWorkspace& ws, LzChain* chain, int n, int m,
-                    int pre, int next, int store_col, const double* vs_scale, int col0,
-                    bool init_random, uint64_t seed, bool zero_T) {
+static LzStep lz_make_step(const EigWorkspace& ws, LzChain* chain, int n, int m, int pre,
+                           int next, int store_col, const double* vs_scale, int col0,
+                           bool init_random, uint64_t seed, bool zero_T) {
   LzStep a;
+  // the three-pass form (chain->three_pass) re-orthonormalises once more: only its LAST
+  // Cholesky (the link that stores the block) may still latch on a Gram matrix far from I
+  a.arm_defect = (!chain->three_pass || store_col >= 0) ? 1 : 0;
   a.W = ws.W;
   a.n = n;
   a.Q = ws.Q;
@@ -1239,11 +1296,79 @@ void launch_lz_link(hipStream_t s, const EigWorkspace& ws, LzChain* chain, int n
   chain->parity ^= 1;
   a.partial = ws.partial + (size_t)chain->parity * half;
   const int rows = lz_rows_for(m);
-  const int nwg = (n + rows - 1) / rows;
-  chain->nparts = nwg;
+  chain->nparts = (n + rows - 1) / rows;
+  return a;
+}
+void launch_lz_link(hipStream_t s, const EigWorkspace& ws, LzChain* chain, int n, int m,
+                    int pre, int next, int store_col, const double* vs_scale, int col0,
+                    bool init_random, uint64_t seed, bool zero_T) {
+  const LzStep a = lz_make_step(ws, chain, n, m, pre, next, store_col, vs_scale, col0,
+                                init_random, seed, zero_T);
+  const int rows = lz_rows_for(m);
+  const int nwg = chain->nparts;
   if (rows == 256) launch_rows<256>(s, a, nwg);
   else if (rows == 128) launch_rows<128>(s, a, nwg);
   else launch_rows<64>(s, a, nwg);
+}
+
+// ---- grouped launches: one link / matvec / Ritz-vector product for up to kGroupMax
+//      independent problems that advance in lockstep (same m); idle members carry n = 0
+template <int ROWS>
+static void launch_rows_group(hipStream_t s, const GroupOf<LzStep>& g, int m, int nwg,
+                              int count) {
+  const size_t lds = sizeof(double) * ((size_t)ROWS * (m + 1) + (size_t)kLdq * B + B * B +
+                                       (size_t)ROWS * B + B * B + B);
+  SC_OPT_IN_LDS(k_lz_rows_g<ROWS>, 150 * 1024);
+  hipLaunchKernelGGL(k_lz_rows_g<ROWS>, dim3(nwg, count), dim3(kLzThreads), lds, s, g);
+}
+void launch_lz_link_group(hipStream_t s, LzGroupMember* mem, int count, int m, int pre,
+                          int next, int store_col, int col0, bool init_random, uint64_t seed,
+                          bool zero_T) {
+  GroupOf<LzStep> g;
+  memset(&g, 0, sizeof(g));
+  const int rows = lz_rows_for(m);
+  int nwg = 0;
+  for (int z = 0; z < count; ++z) {
+    if (!mem[z].active) continue;  // n stays 0: every workgroup of the member returns
+    g.s[z] = lz_make_step(mem[z].ws, &mem[z].chain, mem[z].n, m, pre, next, store_col,
+                          mem[z].vs_scale, col0, init_random, seed, zero_T);
+    nwg = std::max(nwg, mem[z].chain.nparts);
+  }
+  if (nwg == 0) return;
+  if (rows == 256) launch_rows_group<256>(s, g, m, nwg, count);
+  else if (rows == 128) launch_rows_group<128>(s, g, m, nwg, count);
+  else launch_rows_group<64>(s, g, m, nwg, count);
+}
+void launch_block_matvec_group(hipStream_t s, const MatvecItem* items, int count) {
+  GroupOf<MatvecItem> g;
+  memset(&g, 0, sizeof(g));
+  int nmax = 0;
+  for (int z = 0; z < count; ++z) {
+    g.s[z] = items[z];
+    nmax = std::max(nmax, items[z].n);
+  }
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_block_matvec_g, dim3((nmax + 15) / 16, count), dim3(64 * kMvWaves), 0,
+                     s, g);
+}
+// E[:, 0:cols] = normalise(t .* (Q[:, 0:m] Y[0:m, 0:cols])) for every member (n = 0: idle)
+void launch_ritz_vectors_group(hipStream_t s, const RitzItem* items, int count) {
+  GroupOf<RitzItem> g;
+  memset(&g, 0, sizeof(g));
+  int nmax = 0, cmax = 0;
+  size_t lds = 0;
+  for (int z = 0; z < count; ++z) {
+    g.s[z] = items[z];
+    if (items[z].n <= 0) continue;
+    nmax = std::max(nmax, items[z].n);
+    cmax = std::max(cmax, items[z].cols);
+    lds = std::max(lds, sizeof(double) * ((size_t)items[z].m * items[z].cols +
+                                          16 * (size_t)(items[z].m + 1)));
+  }
+  if (nmax == 0) return;
+  SC_OPT_IN_LDS(k_basis_times_Y_g, 128 * 1024);
+  hipLaunchKernelGGL(k_basis_times_Y_g, dim3((nmax + 15) / 16, count), dim3(256), lds, s, g);
+  hipLaunchKernelGGL(k_back_transform_g, dim3(cmax, count), dim3(256), 0, s, g);
 }
 void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
                    const double* cvec, const double* pvec, const double* G,

@@ -2,6 +2,8 @@
 // block Arnoldi (general matrix) -- basis growth, full re-orthogonalisation, Rayleigh-Ritz,
 // the convergence analysis that replays the eigengap rule, restarts.  Every O(n) or larger
 // computation is a kernel of eig.hip / eig_general.hip.
+#include <ctime>
+
 #include "handle.h"
 
 // ------------------------------------------------------------------------------
@@ -457,7 +459,10 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
   EigDecision dc;
   int m = 0, passes = 0, cycles = 0;
   EigRequest rq = rq_in;
-  bool fused = getenv("SC_EIG_HOST_CHAIN") == nullptr;
+  // (eig_skip_fused: the lockstep group solve saw this problem latch the fused chain)
+  bool fused = getenv("SC_EIG_HOST_CHAIN") == nullptr && !h->eig_skip_fused;
+  h->eig_skip_fused = false;
+  bool three_pass = false;  // second attempt of the fused chain, see LzChain::three_pass
   // upper-triangle matvec once the matrix no longer fits the caches (below that the full
   // read is served on-die and the second launch costs more than it saves)
   static const int sym_min_n = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N"))
@@ -517,6 +522,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
       const EigWorkspace ws = eig_workspace(h);
       chain = LzChain();
+      chain.three_pass = three_pass;
       // random block + its Gram | CholQR | CholQR again (Gram checked against I) + store
       launch_lz_link(s, ws, &chain, n, 0, 0, 4, -1, vscale, 0, true, seed, false);
       launch_lz_link(s, ws, &chain, n, 0, 4, 3, -1, vscale, 0, false, 0, true);
@@ -565,6 +571,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
         launch_lz_link(s, ws, &chain, n, m, 0, 1, -1, vscale, m - kEigBlock, false, 0, false);
         launch_lz_link(s, ws, &chain, n, m, 1, 2, -1, vscale, m - kEigBlock, false, 0, false);
         launch_lz_link(s, ws, &chain, n, m, 2, 3, -1, vscale, m - kEigBlock, false, 0, false);
+        if (three_pass) launch_lz_link(s, ws, &chain, n, m, 3, 3, -1, vscale, 0, false, 0, false);
         launch_lz_link(s, ws, &chain, n, m, 3, 0, m, vscale, 0, false, 0, false);
         SC_TRY(check_last(h, "block step launch"));
       } else {
@@ -603,9 +610,18 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
         if (h->h_flags[13] != 0) {
           // a dependent column or a hopeless first Cholesky somewhere in the chain: redo the
           // solve with the host-driven chain, which repairs blocks one by one
+          passes = 0;
+          if (!three_pass && h->h_flags[15] == 2000) {
+            // only "Gram far from I after the first pass" (an ill-conditioned block, no
+            // dependent column): once more with the three-pass chain
+            if (getenv("SC_EIG_TRACE"))
+              fprintf(stderr, "[sc] fused chain flagged at m=%d: three-pass chain\n",
+                      h->h_flags[14]);
+            three_pass = true;
+            goto restart_lanczos;
+          }
           if (getenv("SC_EIG_TRACE")) fprintf(stderr, "[sc] fused chain flagged: host chain\n");
           fused = false;
-          passes = 0;
           goto restart_lanczos;
         }
       }
@@ -706,6 +722,191 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
   }
   *out_dc = dc;
   return SC_OK;
+}
+
+// ------------------------------------------------------------------------------
+// lockstep group solve (batch_group.hip)
+// ------------------------------------------------------------------------------
+// The common case of sym_topk -- fused chain, Rayleigh-Ritz on the host, convergence within
+// kHostRR basis vectors, no restart -- for several independent problems at once.  Short
+// utterances leave most of the chip idle and their solve is a chain of ~25 tiny dependent
+// launches and two host synchronisations; here every launch carries one link (or one
+// matvec) of EVERY member and one synchronisation serves all of their checks.  Each member's
+// arithmetic is exactly sym_topk's (same kernels bodies, same arguments, a check after
+// every block from the third on); whatever leaves the common case (a latched chain flag,
+// non-finite input, no convergence by kHostRR vectors, a request for more values than a
+// Krylov basis holds) is handed back with status 1 and goes through sym_topk itself.
+static double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+bool sym_group_eligible(int n, const EigRequest& rq) {
+  static const int sym_min_n = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N"))
+                                                            : 4096;
+  return n > kDenseMax && n < sym_min_n && !wants_full_spectrum(rq) &&
+         getenv("SC_EIG_HOST_CHAIN") == nullptr && getenv("SC_EIG_DEVICE_RR") == nullptr;
+}
+
+int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
+  if (count < 1 || count > kGroupMax) return fail(lead, SC_ERR_INVALID, "group size");
+  hipStream_t s = lead->stream;
+  LzGroupMember lz[kGroupMax];
+  int limit[kGroupMax];
+  for (int z = 0; z < count; ++z) {
+    sc_handle h = mem[z].h;
+    SC_TRY(ensure_eig(h, mem[z].n));
+    SC_HIP(lead, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
+    lz[z].ws = eig_workspace(h);
+    lz[z].chain = LzChain();
+    lz[z].chain.three_pass = true;  // (one more tiny launch per block for the whole group)
+    lz[z].n = mem[z].n;
+    lz[z].vs_scale = h->vs_scale ? h->vs_scale : ptr<double>(h->cvec);
+    lz[z].active = true;
+    const int cap = std::min(kEigBasisCap, ((mem[z].n - kEigBlock) / kEigBlock) * kEigBlock);
+    limit[z] = std::min(cap, kHostRR);
+    mem[z].status = 0;
+    mem[z].passes = 0;
+    mem[z].basis = 0;
+  }
+  const uint64_t seed = 0x5eed5eedull;
+  launch_lz_link_group(s, lz, count, 0, 0, 4, -1, 0, true, seed, false);
+  launch_lz_link_group(s, lz, count, 0, 4, 3, -1, 0, false, 0, true);
+  launch_lz_link_group(s, lz, count, 0, 3, 0, 0, 0, false, 0, false);
+  SC_TRY(check_last(lead, "group start block launch"));
+  const int first_check = 3 * kEigBlock;
+  int m = 0, active = count;
+  const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
+  double us_first_sync = 0.0, us_sync = 0.0, us_host = 0.0;
+  while (active > 0) {
+    MatvecItem mv[kGroupMax];
+    memset(mv, 0, sizeof(mv));
+    for (int z = 0; z < count; ++z) {
+      if (!lz[z].active) continue;
+      sc_handle h = mem[z].h;
+      mv[z].S = mem[z].S;
+      mv[z].ld = mem[z].ld;
+      mv[z].n = mem[z].n;
+      mv[z].cvec = ptr<double>(h->cvec);
+      mv[z].pvec = ptr<double>(h->pvec);
+      mv[z].V = ptr<double>(h->Q) + m;
+      mv[z].ldv = kLdq;
+      mv[z].Vs = ptr<double>(h->Vs);
+      mv[z].W = ptr<double>(h->W);
+      ++mem[z].passes;
+    }
+    launch_block_matvec_group(s, mv, count);
+    m += kEigBlock;
+    launch_lz_link_group(s, lz, count, m, 0, 1, -1, m - kEigBlock, false, 0, false);
+    launch_lz_link_group(s, lz, count, m, 1, 2, -1, m - kEigBlock, false, 0, false);
+    launch_lz_link_group(s, lz, count, m, 2, 3, -1, m - kEigBlock, false, 0, false);
+    launch_lz_link_group(s, lz, count, m, 3, 3, -1, 0, false, 0, false);
+    launch_lz_link_group(s, lz, count, m, 3, 0, m, 0, false, 0, false);
+    SC_TRY(check_last(lead, "group block step launch"));
+    if (m < first_check) continue;
+    // ---- one synchronisation: T, the residual Gram and the flags of every active member
+    for (int z = 0; z < count; ++z) {
+      if (!lz[z].active) continue;
+      sc_handle h = mem[z].h;
+      SC_HIP(lead, hipMemcpy2DAsync(h->h_rr, (size_t)m * sizeof(double), h->T.p,
+                                    (size_t)kLdq * sizeof(double), (size_t)m * sizeof(double),
+                                    m, hipMemcpyDeviceToHost, s));
+      SC_HIP(lead, hipMemcpyAsync(h->h_rr + kHostRR * kHostRR, h->G.p,
+                                  kEigBlock * kEigBlock * sizeof(double), hipMemcpyDeviceToHost,
+                                  s));
+      SC_HIP(lead, hipMemcpyAsync(h->h_flags, h->flags.p, 16 * sizeof(int),
+                                  hipMemcpyDeviceToHost, s));
+    }
+    const double t_sync0 = trace ? now_us() : 0.0;
+    SC_HIP(lead, hipStreamSynchronize(s));
+    const double t_sync1 = trace ? now_us() : 0.0;
+    if (trace) (m == first_check ? us_first_sync : us_sync) += t_sync1 - t_sync0;
+    for (int z = 0; z < count; ++z) {
+      if (!lz[z].active) continue;
+      sc_handle h = mem[z].h;
+      auto hand_back = [&]() {
+        mem[z].status = 1;
+        lz[z].active = false;
+        --active;
+      };
+      // A latched chain (a Krylov block that is linearly dependent at working precision: the
+      // basis spans an invariant subspace, the usual end of a numerically low-rank operator)
+      // cannot go on, but if it latched in THIS block everything the check reads is intact
+      // -- and the Ritz pairs of an invariant subspace are converged.
+      const bool latched = h->h_flags[13] != 0;
+      if (trace && latched)
+        fprintf(stderr, "[sc]   member %d (n %d): chain latched at m=%d (code %d), check at m=%d\n",
+                z, mem[z].n, h->h_flags[14], h->h_flags[15], m);
+      if (h->h_flags[12] != 0 || (latched && h->h_flags[14] != m)) {
+        if (latched) h->eig_skip_fused = true;
+        hand_back();
+        continue;
+      }
+      double* hy = h->h_rr + kHostRR * kHostRR + 64;
+      bool ok = host_rayleigh_ritz(h->h_rr, m, h->h_rr + kHostRR * kHostRR, m, h->h_theta,
+                                   h->h_theta + kLdq, hy, m);
+      for (int i = 0; ok && i < m; ++i) ok = std::isfinite(h->h_theta[i]);
+      if (!ok) {
+        hand_back();
+        continue;
+      }
+      const EigDecision dc = analyze(mem[z].rq, h->h_theta, h->h_theta + kLdq, m, mem[z].n, false);
+      if (dc.unsupported) {
+        hand_back();
+        continue;
+      }
+      if (dc.enough && dc.converged) {
+        SC_HIP(lead, hipMemcpy2DAsync(h->Y.p, (size_t)kLdq * sizeof(double), hy,
+                                      (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
+                                      hipMemcpyHostToDevice, s));
+        SC_HIP(lead, hipMemcpyAsync(h->theta.p, h->h_theta, m * sizeof(double),
+                                    hipMemcpyHostToDevice, s));
+        mem[z].dc = dc;
+        mem[z].basis = m;
+        mem[z].w.resize(dc.kw);
+        for (int i = 0; i < dc.kw; ++i)
+          mem[z].w[i] = mem[z].rq.descend ? h->h_theta[i] : -h->h_theta[i];
+        lz[z].active = false;
+        --active;
+        continue;
+      }
+      if (latched) {
+        if (trace) fprintf(stderr, "[sc]   member %d: latched and not converged\n", z);
+        h->eig_skip_fused = true;
+        hand_back();
+        continue;
+      }
+      if (m + kEigBlock > limit[z]) hand_back();  // restart territory: the single-call path
+    }
+    if (trace) us_host += now_us() - t_sync1;
+  }
+  if (trace)
+    fprintf(stderr, "[sc] group eigen: %d members, blocks %d; wait at first check %.0f us, at "
+            "later checks %.0f us, host Rayleigh-Ritz + analysis %.0f us\n", count,
+            m / kEigBlock, us_first_sync, us_sync, us_host);
+  // ---- Ritz vectors of every solved member: E = normalise(t .* (Q Y))
+  RitzItem rz[kGroupMax];
+  memset(rz, 0, sizeof(rz));
+  for (int z = 0; z < count; ++z) {
+    if (mem[z].status != 0) continue;
+    sc_handle h = mem[z].h;
+    const int cols = std::min(std::max(mem[z].dc.kw, mem[z].dc.kvec), kMaxVectors);
+    rz[z].Q = ptr<double>(h->Q);
+    rz[z].ldq = kLdq;
+    rz[z].m = mem[z].basis;
+    rz[z].Y = ptr<double>(h->Y);
+    rz[z].ldy = kLdq;
+    rz[z].cols = cols;
+    rz[z].E = ptr<double>(h->E);
+    rz[z].lde = round_up(mem[z].n, 16);
+    rz[z].n = mem[z].n;
+    rz[z].tvec = ptr<double>(h->tvec);
+    h->n_vec = cols;
+    h->last_w = mem[z].w;
+  }
+  launch_ritz_vectors_group(s, rz, count);
+  return check_last(lead, "group ritz vector launch");
 }
 
 // ------------------------------------------------------------------------------

@@ -47,6 +47,9 @@ struct sc_handle_s {
   bool affinity_from_embeddings = false;  // symflag[1] then says whether a row was NaN
   int qn = 0;
   int tilemap_nt = 0;     // tile-grid size the resident tilemap was built for
+  DevBuf tilemap_table;   // tile orders of every grid size <= kTilemapTableMax (ensure_tilemap)
+  int tilemap_off[65] = {0};
+  const int2* tilemap_cur = nullptr;  // what ensure_tilemap selected for the current n
   DevBuf blurw;           // device copy of the blur weights
   // eigen workspace
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
@@ -70,6 +73,13 @@ struct sc_handle_s {
   int* h_flags = nullptr;
   double* h_rr = nullptr;     // pinned: T (kHostRR^2) | G (64) | Y (kHostRR^2): host Rayleigh-Ritz
   std::vector<sc_handle_s*> pool;  // extra handles (streams) of sc_predict_batch_streams
+  // grouped batch (batch_group.hip): member arenas (own stream for the stages before the
+  // eigensolver; the lockstep chains run on THIS handle's stream), the RandomState(0) doubles
+  // of every k (k-means++ seeding)
+  std::vector<sc_handle_s*> gslots;
+  hipEvent_t sync_ev = nullptr;    // a member arena: "stages before the eigensolver done"
+  DevBuf gkrnd;
+  bool gkrnd_ready = false;
   hipEvent_t ev[48];
   int nev = 0;
   int profile_level = 1;  // sc_set_profiling: 0 totals only, 1 stages, 2 per-kernel events
@@ -83,6 +93,7 @@ struct sc_handle_s {
   int blurw_radius = -1;
   double blurw_host[2 * SC_MAX_BLUR_RADIUS + 1];
   int krnd_k = -1, krnd_trials = -1;
+  bool eig_skip_fused = false;  // next sym_topk: go straight to the host-driven chain
   int eig_hint_m = 0;
   long long eig_hint_sig = -1;
   int eig_hint_age = 0;
@@ -104,6 +115,7 @@ inline float ev_ms(sc_handle h, int a, int b) {
   return ms;
 }
 
+constexpr int kTilemapTableMax = 64;
 constexpr int kMaxCols = 128;  // eigenvector columns the arena can hold
 // Leading dimension of the n x n matrices.  A row stride that is a multiple of 4 KiB maps
 // the 128 rows of an operand panel onto the same few L2 sets (the GEMM reads one 128-byte
@@ -215,6 +227,40 @@ struct EigDecision {
   int fail_kind = 0;       // 1 consumed value, 2 far-end value, 3 vector, 4 decision (trace)
   int fail_index = -1;
 };
+
+// where eig_ncluster_impl(front_only) left the refined matrix
+struct FrontResult {
+  const double* matrix = nullptr;
+  double* scratch = nullptr;
+  int ld = 0;
+  bool symmetric = false, folded_rownorm = false;
+};
+EigRequest make_eig_request(const sc_config* cfg);
+// `resume`: the stages before the eigensolver already ran (a FrontResult of this handle)
+int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontResult* front_only,
+                      const FrontResult* resume = nullptr);
+// RandomState(0) stream of the k-means seeding: the uniform that picks the first centre, the
+// trial count 2 + int(log k), and the (k - 1) * trials doubles after it (api.hip)
+void kmeans_seed_constants(int k, double* u_first, int* trials, std::vector<double>* rnd);
+KmeansWorkspace kmeans_workspace(sc_handle h);
+
+// One member of a lockstep group solve (eig_driver.hip: sym_topk_group).
+struct GroupEigMember {
+  sc_handle h = nullptr;      // arena of the member (its matrix ready on lead->stream)
+  const double* S = nullptr;  // refined symmetric matrix, scaling vectors resident in h
+  int ld = 0, n = 0;
+  EigRequest rq;
+  // results
+  int status = 0;             // 0 solved; 1 needs the single-call path (rare branch taken)
+  EigDecision dc;
+  std::vector<double> w;      // consumed eigenvalues (reference order)
+  int basis = 0, passes = 0;
+};
+// Block Lanczos of up to kGroupMax members in lockstep: one launch per chain link / matvec
+// for the whole group, one host synchronisation per Rayleigh-Ritz check for the whole group.
+// Leaves Ritz vectors in every solved member's h->E (h->n_vec set).
+int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count);
+bool sym_group_eligible(int n, const EigRequest& rq);
 
 // `scratch`: a free n x ld matrix (the dense full-spectrum path materialises Op there)
 int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq, sc_diag* diag,

@@ -25,6 +25,7 @@
 //                        enqueued four at a time; a `done` word, read with the labels, says
 //                        whether more are needed.
 #include <algorithm>
+#include <cstring>
 #include <mutex>
 
 #include "sc_internal.h"
@@ -95,9 +96,16 @@ __device__ __forceinline__ void km_mean(const KmChain& a, double* mean) {
 }
 
 // mean[j] = (sum over workgroups, in order, of the column sums) / n; one workgroup
-__global__ __launch_bounds__(64) void km_meanreduce(const KmChain a) {
+__device__ __forceinline__ void km_meanreduce_body(const KmChain& a) {
   if ((int)threadIdx.x < a.k)
     a.meang[threadIdx.x] = km_ordered_sum(a.pm + threadIdx.x, 64, a.G) / (double)a.n;
+}
+__global__ __launch_bounds__(64) void km_meanreduce(const KmChain a) { km_meanreduce_body(a); }
+// Grouped forms (batch_group.hip): blockIdx.y picks one of up to kGroupMax independent
+// problems whose argument blocks travel in the kernel arguments; G = 0 marks an idle member.
+__global__ __launch_bounds__(64) void km_meanreduce_g(const GroupOf<KmChain> g) {
+  const KmChain& a = g.s[blockIdx.y];
+  if (a.G > 0) km_meanreduce_body(a);
 }
 
 template <int KC>
@@ -107,7 +115,7 @@ __device__ __forceinline__ void km_load_row(const KmChain& a, int r, double (&v)
 }
 
 template <int KC>
-__global__ __launch_bounds__(kKmT) void km_colsum(const KmChain a) {
+__device__ __forceinline__ void km_colsum_body(const KmChain& a) {
   __shared__ double sm[kKmW][KC];
   const int tid = threadIdx.x, r = blockIdx.x * kKmT + tid;
   double v[KC];
@@ -124,6 +132,16 @@ __global__ __launch_bounds__(kKmT) void km_colsum(const KmChain a) {
     for (int w = 0; w < kKmW; ++w) t += sm[w][tid];
     a.pm[(size_t)blockIdx.x * 64 + tid] = t;
   }
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_colsum(const KmChain a) {
+  km_colsum_body<KC>(a);
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_colsum_g(const GroupOf<KmChain> g) {
+  const KmChain& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.G) return;
+  km_colsum_body<KC>(a);
 }
 
 // squared distance of this thread's (centred) row to a centred candidate row, exactly as
@@ -142,7 +160,7 @@ __device__ __forceinline__ double km_dist(const double (&v)[KC], const double* m
 }
 
 template <int KC>
-__global__ __launch_bounds__(kKmT) void km_first(const KmChain a) {
+__device__ __forceinline__ void km_first_body(const KmChain& a) {
   __shared__ double mean[KC], crow[KC], sm[kKmW];
   __shared__ double csq;
   const int tid = threadIdx.x, r = blockIdx.x * kKmT + tid;
@@ -181,6 +199,16 @@ __global__ __launch_bounds__(kKmT) void km_first(const KmChain a) {
     }
     if (tid < 8) a.cand[1][tid] = a.n - 1;  // np.clip(candidate_ids, None, n - 1)
   }
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_first(const KmChain a) {
+  km_first_body<KC>(a);
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_first_g(const GroupOf<KmChain> g) {
+  const KmChain& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.G) return;
+  km_first_body<KC>(a);
 }
 
 // first index of the minimum of pots[0..trials) (np.argmin)
@@ -221,7 +249,7 @@ __device__ __forceinline__ void km_prefix(const double* src, int stride, int G, 
 // proportional to `closest` (sklearn _kmeans_plusplus: searchsorted(stable_cumsum(closest),
 // rand * pot)).
 template <int KC>
-__global__ __launch_bounds__(kKmT) void km_select(const KmChain a, int c) {
+__device__ __forceinline__ void km_select_body(const KmChain& a, int c) {
   __shared__ double mean[KC], crow[KC], sm[kKmW], pots[8], rvals[8], scan[kKmT];
   __shared__ double part[kKmMaxG + 2];
   __shared__ double csq;
@@ -281,9 +309,19 @@ __global__ __launch_bounds__(kKmT) void km_select(const KmChain a, int c) {
     }
   }
 }
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_select(const KmChain a, int c) {
+  km_select_body<KC>(a, c);
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_select_g(const GroupOf<KmChain> g, int c) {
+  const KmChain& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.G || c >= a.k) return;
+  km_select_body<KC>(a, c);
+}
 
 template <int KC>
-__global__ __launch_bounds__(kKmT) void km_trials(const KmChain a, int c) {
+__device__ __forceinline__ void km_trials_body(const KmChain& a, int c) {
   __shared__ double mean[KC], crow[8][KC], csq[8], sm[kKmW];
   const int tid = threadIdx.x, r = blockIdx.x * kKmT + tid;
   km_mean(a, mean);
@@ -310,6 +348,16 @@ __global__ __launch_bounds__(kKmT) void km_trials(const KmChain a, int c) {
     if (tid == 0) a.pT[(size_t)blockIdx.x * 8 + t] = tot;
   }
   if (blockIdx.x == 0 && tid < 8) a.cand[(c + 1) & 1][tid] = a.n - 1;
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_trials(const KmChain a, int c) {
+  km_trials_body<KC>(a, c);
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_trials_g(const GroupOf<KmChain> g, int c) {
+  const KmChain& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.G || c >= a.k) return;
+  km_trials_body<KC>(a, c);
 }
 
 // Partial sums of one assignment: for every cluster the member count, the count of members
@@ -355,7 +403,7 @@ __device__ __forceinline__ void km_cluster_partials(const KmChain& a, const doub
 }
 
 template <int KC>
-__global__ __launch_bounds__(kKmT) void km_lloyd(const KmChain a) {
+__device__ __forceinline__ void km_lloyd_body(const KmChain& a) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* vals = dyn;                                   // kKmT x KC
   int* labs = reinterpret_cast<int*>(vals + kKmT * KC);  // kKmT
@@ -402,10 +450,20 @@ __global__ __launch_bounds__(kKmT) void km_lloyd(const KmChain a) {
   km_cluster_partials<KC>(a, v, mean, best, r, vals, labs,
                           a.pS[0] + (size_t)blockIdx.x * (k * k + 2 * k));
 }
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_lloyd(const KmChain a) {
+  km_lloyd_body<KC>(a);
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_lloyd_g(const GroupOf<KmChain> g) {
+  const KmChain& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.G) return;
+  km_lloyd_body<KC>(a);
+}
 
 // Cosine iteration `it` of CustomKMeans.predict (:118-141); see the header.
 template <int KC>
-__global__ __launch_bounds__(kKmT) void km_cosine(const KmChain a, int it) {
+__device__ __forceinline__ void km_cosine_body(const KmChain& a, int it) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   double* vals = dyn;
   int* labs = reinterpret_cast<int*>(vals + kKmT * KC);
@@ -500,6 +558,16 @@ __global__ __launch_bounds__(kKmT) void km_cosine(const KmChain a, int it) {
   km_cluster_partials<KC>(a, v, zero, best, r, vals, labs,
                           a.pS[(it + 1) & 1] + (size_t)blockIdx.x * nsum);
 }
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_cosine(const KmChain a, int it) {
+  km_cosine_body<KC>(a, it);
+}
+template <int KC>
+__global__ __launch_bounds__(kKmT) void km_cosine_g(const GroupOf<KmChain> g, int it) {
+  const KmChain& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.G) return;
+  km_cosine_body<KC>(a, it);
+}
 
 // ---------------------------------------------------------------- host side
 size_t kmeans_chain_workspace_doubles(int n) {
@@ -577,6 +645,49 @@ static void km_enqueue(hipStream_t s, const KmChain& a, int it_begin, int it_cou
   }
   for (int it = it_begin; it < it_begin + it_count; ++it)
     hipLaunchKernelGGL(km_cosine<KC>, grid, block, dyn, s, a, it);
+}
+
+template <int KC>
+static void km_enqueue_group(hipStream_t s, const GroupOf<KmChain>& g, int count, int gmax,
+                             int kmax, int it_begin, int it_count) {
+  const dim3 grid(gmax, count), block(kKmT);
+  const size_t dyn = sizeof(double) * kKmT * KC + sizeof(int) * kKmT;
+  SC_OPT_IN_LDS(km_lloyd_g<KC>, 96 * 1024);
+  SC_OPT_IN_LDS(km_cosine_g<KC>, 96 * 1024);
+  if (it_begin == 0) {
+    hipLaunchKernelGGL(km_colsum_g<KC>, grid, block, 0, s, g);
+    hipLaunchKernelGGL(km_meanreduce_g, dim3(1, count), dim3(64), 0, s, g);
+    hipLaunchKernelGGL(km_first_g<KC>, grid, block, 0, s, g);
+    for (int c = 1; c < kmax; ++c) {  // members with k <= c sit the round out
+      hipLaunchKernelGGL(km_select_g<KC>, grid, block, 0, s, g, c);
+      hipLaunchKernelGGL(km_trials_g<KC>, grid, block, 0, s, g, c);
+    }
+    hipLaunchKernelGGL(km_lloyd_g<KC>, grid, block, dyn, s, g);
+  }
+  for (int it = it_begin; it < it_begin + it_count; ++it)
+    hipLaunchKernelGGL(km_cosine_g<KC>, grid, block, dyn, s, g, it);
+}
+
+// The same chain for up to kGroupMax independent problems per launch (items[z].n = 0: idle
+// member).  Every member runs exactly the arithmetic of launch_kmeans_chain: the register
+// tile width KC (taken from the largest k of the group) only sizes arrays, the sums run over
+// j < k in the same order.
+void launch_kmeans_chain_group(hipStream_t s, const KmGroupItem* items, int count, int it_begin,
+                               int it_count) {
+  GroupOf<KmChain> g;
+  memset(&g, 0, sizeof(g));
+  int gmax = 0, kmax = 0;
+  for (int z = 0; z < count; ++z) {
+    const KmGroupItem& it = items[z];
+    if (it.n <= 0) continue;
+    g.s[z] = km_args(it.ET, it.lde, it.n, it.k, it.max_iter, it.first_center, it.trials, it.ws);
+    gmax = std::max(gmax, g.s[z].G);
+    kmax = std::max(kmax, it.k);
+  }
+  if (gmax == 0) return;
+  if (kmax <= 8) km_enqueue_group<8>(s, g, count, gmax, kmax, it_begin, it_count);
+  else if (kmax <= 16) km_enqueue_group<16>(s, g, count, gmax, kmax, it_begin, it_count);
+  else km_enqueue_group<32>(s, g, count, gmax, kmax, it_begin, it_count);
 }
 
 // Enqueue the chain: seeding + Lloyd step (when it_begin == 0) and cosine iterations

@@ -179,11 +179,54 @@ void launch_refill_deficient(hipStream_t s, double* W, int n, const int* flags,
 struct LzChain {
   int parity = 0;   // partial buffer the last link wrote
   int nparts = 0;   // workgroups of the last link
+  // CholQR3 form of a block step: links 0>1, 1>2, 2>3, 3>3, 3>0(store) instead of 0>1, 1>2,
+  // 2>3, 3>0(store).  A Krylov block of condition > ~1e8 (a numerically low-rank operator:
+  // few dominant eigenvalues, the rest 1e-8 below) leaves the first Cholesky pass with an
+  // orthogonality error that two passes do not remove; three do.
+  bool three_pass = false;
 };
 size_t lz_partial_doubles(int n);
 void launch_lz_link(hipStream_t s, const EigWorkspace& ws, LzChain* chain, int n, int m,
                     int pre, int next, int store_col, const double* vs_scale, int col0,
                     bool init_random, uint64_t seed, bool zero_T);
+// ---- grouped launches (batch_group.hip): up to kGroupMax independent problems per launch,
+//      their descriptors passed by value in the kernel arguments (<= 4 KB), blockIdx.y = member
+constexpr int kGroupMax = 16;
+template <typename T>
+struct GroupOf {
+  T s[kGroupMax];
+};
+struct MatvecItem {  // n = 0: idle member
+  const double* S;
+  int ld, n;
+  const double* cvec;
+  const double* pvec;
+  const double* V;
+  int ldv;
+  const double* Vs;
+  double* W;
+};
+struct RitzItem {    // E[:, 0:cols] (column-major, lde) = normalise(t .* (Q[:, 0:m] Y[:, 0:cols]))
+  const double* Q;
+  int ldq, m;
+  const double* Y;
+  int ldy, cols;
+  double* E;
+  int lde, n;
+  const double* tvec;
+};
+struct LzGroupMember {
+  EigWorkspace ws;
+  LzChain chain;
+  int n = 0;
+  const double* vs_scale = nullptr;
+  bool active = false;
+};
+void launch_lz_link_group(hipStream_t s, LzGroupMember* mem, int count, int m, int pre,
+                          int next, int store_col, int col0, bool init_random, uint64_t seed,
+                          bool zero_T);
+void launch_block_matvec_group(hipStream_t s, const MatvecItem* items, int count);
+void launch_ritz_vectors_group(hipStream_t s, const RitzItem* items, int count);
 // Dense symmetric eigensolver (one workgroup, cyclic Jacobi, matrix in LDS).
 // mode 0: A = T (m x m, ldt).  mode 1: A_ij = c_i c_j S_ij + delta_ij p_i.
 void launch_jacobi(hipStream_t s, const double* src, int ldsrc, int m, int mode,
@@ -284,6 +327,13 @@ struct KmeansWorkspace {
 // k-means as a chain of short multi-workgroup kernels (kmeans_chain.hip), cosine metric
 size_t kmeans_chain_workspace_doubles(int n);
 bool kmeans_chain_supported(int n, int k, int trials);
+struct KmGroupItem {  // one member of a grouped chain launch; n = 0: idle
+  const double* ET = nullptr;
+  int lde = 0, n = 0, k = 0, max_iter = 0, first_center = 0, trials = 0;
+  KmeansWorkspace ws;
+};
+void launch_kmeans_chain_group(hipStream_t s, const KmGroupItem* items, int count, int it_begin,
+                               int it_count);
 void launch_kmeans_chain(hipStream_t s, const double* ET, int lde, int n, int k, int max_iter,
                          int first_center, int trials, const KmeansWorkspace& ws, int it_begin,
                          int it_count);

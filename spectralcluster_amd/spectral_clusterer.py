@@ -299,15 +299,18 @@ class SpectralClusterer:
 
   # -------------------------------------------------------------- batch (new)
   def predict_batch(self, utterances: typing.Sequence[np.ndarray],
-                    streams: int = 4) -> typing.List[np.ndarray]:
+                    streams: int = 4, group: int = 0) -> typing.List[np.ndarray]:
     """Independent predict() calls (the reference has no batch API: a batch is a
     Python loop).
 
     Small utterances cannot fill 256 CUs, and their pipeline is a chain of short dependent
-    launches, so the batch is spread (longest-processing-time first) over `streams` HIP
-    streams of this clusterer's device inside ONE library call
-    (`sc_predict_batch_streams`: pooled arenas, one host thread per stream in the C++
-    library; the GIL is released for the whole batch).
+    launches.  Two ways around that, both ONE library call with the GIL released:
+      group > 1   `sc_predict_batch_grouped`: one stream, one host thread, `group` (<= 16)
+                  utterances per launch -- the eigensolver and k-means chains of the group
+                  advance in lockstep;
+      otherwise   `sc_predict_batch_streams`: the batch spread (longest-processing-time
+                  first) over `streams` HIP streams, one host thread and arena per stream.
+    Per-utterance results are those of predict() either way.
     """
     if (self.autotune is not None or self.max_spectral_size is not None or
         self.min_clusters == 1 or self.fallback_options.spectral_min_embeddings > 1 or
@@ -336,8 +339,13 @@ class SpectralClusterer:
     lp = (ctypes.POINTER(ctypes.c_int64) * count)(*[_lib.as_int64_p(l) for l in labels])
     ns = (ctypes.c_int * count)(*[x.shape[0] for x in xs])
     diags = (_lib.ScDiag * count)()
-    handle.check(handle.lib.sc_predict_batch_streams(
-        handle.raw, xp, ns, d, count, self.build_config(), lp, diags,
-        max(1, int(streams))), TypeError)
+    if int(group) > 1:
+      handle.check(handle.lib.sc_predict_batch_grouped(
+          handle.raw, xp, ns, d, count, self.build_config(), lp, diags, int(group)),
+          TypeError)
+    else:
+      handle.check(handle.lib.sc_predict_batch_streams(
+          handle.raw, xp, ns, d, count, self.build_config(), lp, diags,
+          max(1, int(streams))), TypeError)
     self.last_batch_diags = list(diags)
     return labels

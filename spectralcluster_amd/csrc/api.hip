@@ -214,7 +214,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
                     &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
-                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd};
+                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd, &h->gpack, &h->gypack, &h->ginfo, &h->glabels};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);
@@ -222,6 +222,11 @@ extern "C" int sc_destroy(sc_handle h) {
   if (h->h_flags) hipHostFree(h->h_flags);
   if (h->h_rr) hipHostFree(h->h_rr);
   if (h->sync_ev) hipEventDestroy(h->sync_ev);
+  if (h->gcheck_ev) hipEventDestroy(h->gcheck_ev);
+  if (h->h_gpack) hipHostFree(h->h_gpack);
+  if (h->h_gypack) hipHostFree(h->h_gypack);
+  if (h->h_ginfo) hipHostFree(h->h_ginfo);
+  if (h->h_glabels) hipHostFree(h->h_glabels);
   hipStreamDestroy(h->stream);
   delete h;
   return SC_OK;
@@ -756,6 +761,8 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   else
     SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 12, 0, sizeof(int), s));
   launch_check_finite(s, ptr<double>(h->cvec), ptr<double>(h->pvec), n, ptr<int>(h->flags) + 12);
+  if (front_only)  // the lockstep group solve starts from clean chain flags
+    SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
   SC_TRY(check_last(h, "scaling launch"));
   if (getenv("SC_EIG_TRACE") && atoi(getenv("SC_EIG_TRACE")) > 2 && symmetric) {
     std::vector<double> rm(n), rs(n);

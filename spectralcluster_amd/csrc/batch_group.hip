@@ -149,9 +149,26 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
   const double t2 = trace ? now_us() : 0.0;
   // ---- k-means: lockstep over the solved members
   KmGroupItem km[kGroupMax];
-  int kmz[kGroupMax];
-  int info[kGroupMax][16];
+  int kmz[kGroupMax], label_n[kGroupMax];
+  size_t label_off[kGroupMax], label_total = 0;
   int nk = 0;
+  {  // staging for the labels of this group (every member could end up in it)
+    size_t need = 0;
+    for (int z = 0; z < count; ++z) need += (size_t)ns[mb[z].index];
+    SC_TRY(grow(lead, lead->ginfo, (size_t)kGroupMax * 16 * sizeof(int)));
+    SC_TRY(grow(lead, lead->glabels, need * sizeof(int64_t)));
+    if (!lead->h_ginfo)
+      SC_HIP(lead, hipHostMalloc(reinterpret_cast<void**>(&lead->h_ginfo),
+                                 (size_t)kGroupMax * 16 * sizeof(int)));
+    if (lead->h_glabels_count < need) {
+      if (lead->h_glabels) SC_HIP(lead, hipHostFree(lead->h_glabels));
+      lead->h_glabels = nullptr;
+      lead->h_glabels_count = 0;
+      SC_HIP(lead, hipHostMalloc(reinterpret_cast<void**>(&lead->h_glabels),
+                                 need * sizeof(int64_t)));
+      lead->h_glabels_count = need;
+    }
+  }
   for (int e = 0; e < ne; ++e) {
     Member& m = mb[emz[e]];
     if (em[e].status != 0) {
@@ -208,31 +225,39 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
     it.trials = trials;
     it.ws = kmeans_workspace(h);
     it.ws.rnd = ptr<double>(lead->gkrnd) + (size_t)k * kRndStride;
+    // the stop words and the labels of the whole group live side by side: one copy each
+    it.ws.info = ptr<int>(lead->ginfo) + 16 * nk;
+    it.ws.labels64 = ptr<long long>(lead->glabels) + label_total;
+    label_off[nk] = label_total;
+    label_total += (size_t)n;
     kmz[nk++] = emz[e];
   }
   int running = nk;
   for (int it = 0; running > 0; it += 4) {
     launch_kmeans_chain_group(s, km, nk, it, 4);
     SC_TRY(check_last(lead, "group kmeans launch"));
-    for (int q = 0; q < nk; ++q) {
-      if (km[q].n <= 0) continue;
-      Member& m = mb[kmz[q]];
-      SC_HIP(lead, hipMemcpyAsync(labels[m.index], m.h->klab64.p,
-                                  (size_t)km[q].n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-      SC_HIP(lead, hipMemcpyAsync(info[q], m.h->kinfo.p, 9 * sizeof(int),
-                                  hipMemcpyDeviceToHost, s));
-    }
+    SC_HIP(lead, hipMemcpyAsync(lead->h_ginfo, lead->ginfo.p, (size_t)nk * 16 * sizeof(int),
+                                hipMemcpyDeviceToHost, s));
     SC_HIP(lead, hipStreamSynchronize(s));
     for (int q = 0; q < nk; ++q) {
-      if (km[q].n <= 0 || info[q][8] == 0) continue;
+      if (km[q].n <= 0 || lead->h_ginfo[16 * q + 8] == 0) continue;
       Member& m = mb[kmz[q]];
-      if (diags) diags[m.index].kmeans_iterations = info[q][0];
+      if (diags) diags[m.index].kmeans_iterations = lead->h_ginfo[16 * q];
       m.state = 2;
+      label_n[q] = km[q].n;
       km[q].n = 0;  // idle from here on
       --running;
     }
     if (running > 0 && it > cfg->max_iter + 4)
       return fail(lead, SC_ERR_HIP, "k-means chain did not reach its stop rule");
+  }
+  if (nk > 0) {
+    SC_HIP(lead, hipMemcpyAsync(lead->h_glabels, lead->glabels.p, label_total * sizeof(int64_t),
+                                hipMemcpyDeviceToHost, s));
+    SC_HIP(lead, hipStreamSynchronize(s));
+    for (int q = 0; q < nk; ++q)
+      memcpy(labels[mb[kmz[q]].index], lead->h_glabels + label_off[q],
+             (size_t)label_n[q] * sizeof(int64_t));
   }
   if (trace)
     fprintf(stderr, "[sc] group of %d (n %d..%d): eigen %.0f us, k-means %.0f us (%d members)\n",
@@ -280,6 +305,8 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
   }
   if (!grouped.empty()) {
     SC_TRY(ensure_seed_table(h));
+    memset(h->gconv_hist, 0, sizeof(h->gconv_hist));
+    h->gconv_seen = 0;
     // similar sizes together: a group's launches are sized by its largest member
     std::stable_sort(grouped.begin(), grouped.end(), [&](int a, int b) { return ns[a] > ns[b]; });
     const int width = std::min(group, (int)grouped.size());

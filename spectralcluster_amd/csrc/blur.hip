@@ -160,16 +160,16 @@ template <int R>
 __global__ __launch_bounds__(256) void k_gaussian_blur_stream(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ weights, const double* __restrict__ diag,
-    double* __restrict__ rowmax) {
+    double* __restrict__ rowmax, int rows_per_wave) {
   static_assert(R % 4 == 0, "neighbour lanes carry 4 columns each");
   constexpr int S = 2 * R + 1 + kAhead;  // ring slots
   constexpr int NB = R / 4;              // neighbour lanes per side
   constexpr int OW = 256 - 2 * R;        // output columns per strip
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j0 = blockIdx.x * OW;                                // first output column
-  const int r0 = (blockIdx.y * 4 + wv) * kStreamRows;            // first output row
+  const int r0 = (blockIdx.y * 4 + wv) * rows_per_wave;          // first output row
   if (r0 >= n) return;
-  const int rend = min(n, r0 + kStreamRows);
+  const int rend = min(n, r0 + rows_per_wave);
   double w[R + 1];
 #pragma unroll
   for (int j = 0; j <= R; ++j) w[j] = weights[R - j];
@@ -292,13 +292,18 @@ bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, in
                                 double* rowmax_partials) {
   dim3 grid((n + TW - 1) / TW, (n + TH - 1) / TH);
   if ((radius == 4 || radius == 8) && n >= kStreamMinN) {
-    dim3 sgrid(blur_tile_columns(n, radius), (n + 4 * kStreamRows - 1) / (4 * kStreamRows));
+    // A wave walks its rows one after the other (a chain of dependent row loads): 64 rows per
+    // wave amortise the 2 R halo rows at large n; a short utterance has too few column
+    // strips to fill the chip that way, so its waves take fewer rows each (the halo re-reads
+    // are served by L2).  Same arithmetic per output row either way.
+    const int rows = n >= 4096 ? kStreamRows : (n >= 2048 ? kStreamRows / 2 : kStreamRows / 4);
+    dim3 sgrid(blur_tile_columns(n, radius), (n + 4 * rows - 1) / (4 * rows));
     if (radius == 4)
       hipLaunchKernelGGL((k_gaussian_blur_stream<4>), sgrid, dim3(256), 0, s, in, out, n, ld,
-                         weights_dev, diag, rowmax_partials);
+                         weights_dev, diag, rowmax_partials, rows);
     else
       hipLaunchKernelGGL((k_gaussian_blur_stream<8>), sgrid, dim3(256), 0, s, in, out, n, ld,
-                         weights_dev, diag, rowmax_partials);
+                         weights_dev, diag, rowmax_partials, rows);
     return rowmax_partials != nullptr;
   }
   if ((radius == 4 || radius == 8) && n >= 128) {

@@ -1311,6 +1311,29 @@ void launch_lz_link(hipStream_t s, const EigWorkspace& ws, LzChain* chain, int n
   else launch_rows<64>(s, a, nwg);
 }
 
+// What a Rayleigh-Ritz check reads, of every member, compacted into one buffer (one copy to
+// the host for the whole group): T[0:m, 0:m] row-major with pitch m, the 8 x 8 residual Gram,
+// the 16 flag words.  One workgroup per member; T == nullptr: idle.
+__global__ __launch_bounds__(256) void k_group_gather(const GroupOf<GatherItem> g, int m,
+                                                      double* __restrict__ out, int stride) {
+  const GatherItem& a = g.s[blockIdx.x];
+  if (a.T == nullptr) return;
+  double* dst = out + (size_t)blockIdx.x * stride;
+  for (int e = threadIdx.x; e < m * m; e += 256) {
+    const int i = e / m, j = e - i * m;
+    dst[e] = a.T[(size_t)i * kLdq + j];
+  }
+  if (threadIdx.x < B * B) dst[m * m + threadIdx.x] = a.G[threadIdx.x];
+  if (threadIdx.x < 16) reinterpret_cast<int*>(dst + m * m + B * B)[threadIdx.x] = a.flags[threadIdx.x];
+}
+void launch_group_gather(hipStream_t s, const GatherItem* items, int count, int m, double* out,
+                         int stride) {
+  GroupOf<GatherItem> g;
+  memset(&g, 0, sizeof(g));
+  for (int z = 0; z < count; ++z) g.s[z] = items[z];
+  hipLaunchKernelGGL(k_group_gather, dim3(count), dim3(256), 0, s, g, m, out, stride);
+}
+
 // ---- grouped launches: one link / matvec / Ritz-vector product for up to kGroupMax
 //      independent problems that advance in lockstep (same m); idle members carry n = 0
 template <int ROWS>

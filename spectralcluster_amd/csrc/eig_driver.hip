@@ -749,15 +749,32 @@ bool sym_group_eligible(int n, const EigRequest& rq) {
          getenv("SC_EIG_HOST_CHAIN") == nullptr && getenv("SC_EIG_DEVICE_RR") == nullptr;
 }
 
+// pinned host + device staging of the group checks: per member m*m (T) + 64 (G) doubles +
+// 16 flag words going out, kHostRR^2 (Y) doubles coming back
+static int ensure_group_staging(sc_handle lead) {
+  const size_t out_doubles = (size_t)kGroupMax * (kHostRR * kHostRR + 64 + 8);
+  const size_t y_doubles = (size_t)kGroupMax * kHostRR * kHostRR;
+  SC_TRY(grow(lead, lead->gpack, out_doubles * sizeof(double)));
+  SC_TRY(grow(lead, lead->gypack, y_doubles * sizeof(double)));
+  if (!lead->h_gpack) {
+    SC_HIP(lead, hipHostMalloc(reinterpret_cast<void**>(&lead->h_gpack),
+                               out_doubles * sizeof(double)));
+    SC_HIP(lead, hipHostMalloc(reinterpret_cast<void**>(&lead->h_gypack),
+                               y_doubles * sizeof(double)));
+    SC_HIP(lead, hipEventCreateWithFlags(&lead->gcheck_ev, hipEventDisableTiming));
+  }
+  return SC_OK;
+}
+
 int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
   if (count < 1 || count > kGroupMax) return fail(lead, SC_ERR_INVALID, "group size");
   hipStream_t s = lead->stream;
+  SC_TRY(ensure_group_staging(lead));
   LzGroupMember lz[kGroupMax];
   int limit[kGroupMax];
   for (int z = 0; z < count; ++z) {
     sc_handle h = mem[z].h;
-    SC_TRY(ensure_eig(h, mem[z].n));
-    SC_HIP(lead, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
+    SC_TRY(ensure_eig(h, mem[z].n));  // (flags[13..15] were cleared with the member's front)
     lz[z].ws = eig_workspace(h);
     lz[z].chain = LzChain();
     lz[z].chain.three_pass = true;  // (one more tiny launch per block for the whole group)
@@ -776,10 +793,12 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
   launch_lz_link_group(s, lz, count, 0, 3, 0, 0, 0, false, 0, false);
   SC_TRY(check_last(lead, "group start block launch"));
   const int first_check = 3 * kEigBlock;
-  int m = 0, active = count;
+  int active = count;
   const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
   double us_first_sync = 0.0, us_sync = 0.0, us_host = 0.0;
-  while (active > 0) {
+  int steps = 0, wasted = 0;
+  // one block step of every active member: matvec + the five links of the three-pass chain
+  auto block_step = [&](int m_before) -> int {
     MatvecItem mv[kGroupMax];
     memset(mv, 0, sizeof(mv));
     for (int z = 0; z < count; ++z) {
@@ -790,41 +809,72 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
       mv[z].n = mem[z].n;
       mv[z].cvec = ptr<double>(h->cvec);
       mv[z].pvec = ptr<double>(h->pvec);
-      mv[z].V = ptr<double>(h->Q) + m;
+      mv[z].V = ptr<double>(h->Q) + m_before;
       mv[z].ldv = kLdq;
       mv[z].Vs = ptr<double>(h->Vs);
       mv[z].W = ptr<double>(h->W);
       ++mem[z].passes;
     }
     launch_block_matvec_group(s, mv, count);
-    m += kEigBlock;
+    const int m = m_before + kEigBlock;
     launch_lz_link_group(s, lz, count, m, 0, 1, -1, m - kEigBlock, false, 0, false);
     launch_lz_link_group(s, lz, count, m, 1, 2, -1, m - kEigBlock, false, 0, false);
     launch_lz_link_group(s, lz, count, m, 2, 3, -1, m - kEigBlock, false, 0, false);
     launch_lz_link_group(s, lz, count, m, 3, 3, -1, 0, false, 0, false);
     launch_lz_link_group(s, lz, count, m, 3, 0, m, 0, false, 0, false);
-    SC_TRY(check_last(lead, "group block step launch"));
-    if (m < first_check) continue;
-    // ---- one synchronisation: T, the residual Gram and the flags of every active member
+    ++steps;
+    return check_last(lead, "group block step launch");
+  };
+  // T (m x m), the residual Gram and the flags of every active member: one gather kernel, one
+  // copy to the host, an event to wait on
+  const int out_stride = kHostRR * kHostRR + 64 + 8;
+  auto request_check = [&](int m) -> int {
+    GatherItem gi[kGroupMax];
+    memset(gi, 0, sizeof(gi));
     for (int z = 0; z < count; ++z) {
       if (!lz[z].active) continue;
       sc_handle h = mem[z].h;
-      SC_HIP(lead, hipMemcpy2DAsync(h->h_rr, (size_t)m * sizeof(double), h->T.p,
-                                    (size_t)kLdq * sizeof(double), (size_t)m * sizeof(double),
-                                    m, hipMemcpyDeviceToHost, s));
-      SC_HIP(lead, hipMemcpyAsync(h->h_rr + kHostRR * kHostRR, h->G.p,
-                                  kEigBlock * kEigBlock * sizeof(double), hipMemcpyDeviceToHost,
-                                  s));
-      SC_HIP(lead, hipMemcpyAsync(h->h_flags, h->flags.p, 16 * sizeof(int),
-                                  hipMemcpyDeviceToHost, s));
+      gi[z].T = ptr<double>(h->T);
+      gi[z].G = ptr<double>(h->G);
+      gi[z].flags = ptr<int>(h->flags);
     }
+    launch_group_gather(s, gi, count, m, ptr<double>(lead->gpack), out_stride);
+    SC_HIP(lead, hipMemcpyAsync(lead->h_gpack, lead->gpack.p,
+                                (size_t)count * out_stride * sizeof(double),
+                                hipMemcpyDeviceToHost, s));
+    SC_HIP(lead, hipEventRecord(lead->gcheck_ev, s));
+    return SC_OK;
+  };
+  int m = 0;
+  while (m < first_check) {
+    SC_TRY(block_step(m));
+    m += kEigBlock;
+  }
+  SC_TRY(request_check(m));
+  bool any_solved = false;
+  while (active > 0) {
+    // While the host solves the projected problems of this check the device takes every
+    // active member one block further.  For a member that turns out converged (or is handed
+    // back) that block is wasted but harmless: what its results are made of -- Q[:, 0:m],
+    // the Ritz coefficients -- is not touched by it.  Skipped where the batch so far says
+    // that nearly every member is done by this size.
+    const int seen = lead->gconv_seen;
+    int done_by = 0;
+    for (int b = 0; b <= m / kEigBlock && b < 16; ++b) done_by += lead->gconv_hist[b];
+    const bool speculate = seen < 2 * kGroupMax || done_by * 4 < seen * 3;
+    if (speculate) SC_TRY(block_step(m));
     const double t_sync0 = trace ? now_us() : 0.0;
-    SC_HIP(lead, hipStreamSynchronize(s));
+    SC_HIP(lead, hipEventSynchronize(lead->gcheck_ev));
     const double t_sync1 = trace ? now_us() : 0.0;
     if (trace) (m == first_check ? us_first_sync : us_sync) += t_sync1 - t_sync0;
+    const int active_before = active;
     for (int z = 0; z < count; ++z) {
       if (!lz[z].active) continue;
       sc_handle h = mem[z].h;
+      const double* pack = lead->h_gpack + (size_t)z * out_stride;
+      const double* hT = pack;
+      const double* hG = pack + m * m;
+      const int* hflags = reinterpret_cast<const int*>(pack + m * m + 64);
       auto hand_back = [&]() {
         mem[z].status = 1;
         lz[z].active = false;
@@ -834,18 +884,17 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
       // basis spans an invariant subspace, the usual end of a numerically low-rank operator)
       // cannot go on, but if it latched in THIS block everything the check reads is intact
       // -- and the Ritz pairs of an invariant subspace are converged.
-      const bool latched = h->h_flags[13] != 0;
+      const bool latched = hflags[13] != 0;
       if (trace && latched)
         fprintf(stderr, "[sc]   member %d (n %d): chain latched at m=%d (code %d), check at m=%d\n",
-                z, mem[z].n, h->h_flags[14], h->h_flags[15], m);
-      if (h->h_flags[12] != 0 || (latched && h->h_flags[14] != m)) {
+                z, mem[z].n, hflags[14], hflags[15], m);
+      if (hflags[12] != 0 || (latched && hflags[14] != m)) {
         if (latched) h->eig_skip_fused = true;
         hand_back();
         continue;
       }
-      double* hy = h->h_rr + kHostRR * kHostRR + 64;
-      bool ok = host_rayleigh_ritz(h->h_rr, m, h->h_rr + kHostRR * kHostRR, m, h->h_theta,
-                                   h->h_theta + kLdq, hy, m);
+      double* hy = lead->h_gypack + (size_t)z * kHostRR * kHostRR;
+      bool ok = host_rayleigh_ritz(hT, m, hG, m, h->h_theta, h->h_theta + kLdq, hy, m);
       for (int i = 0; ok && i < m; ++i) ok = std::isfinite(h->h_theta[i]);
       if (!ok) {
         hand_back();
@@ -857,18 +906,16 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
         continue;
       }
       if (dc.enough && dc.converged) {
-        SC_HIP(lead, hipMemcpy2DAsync(h->Y.p, (size_t)kLdq * sizeof(double), hy,
-                                      (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
-                                      hipMemcpyHostToDevice, s));
-        SC_HIP(lead, hipMemcpyAsync(h->theta.p, h->h_theta, m * sizeof(double),
-                                    hipMemcpyHostToDevice, s));
         mem[z].dc = dc;
-        mem[z].basis = m;
+        mem[z].basis = m;  // its Ritz coefficients stay in h_gypack[z] until the end
         mem[z].w.resize(dc.kw);
         for (int i = 0; i < dc.kw; ++i)
           mem[z].w[i] = mem[z].rq.descend ? h->h_theta[i] : -h->h_theta[i];
         lz[z].active = false;
         --active;
+        any_solved = true;
+        if (m / kEigBlock < 16) ++lead->gconv_hist[m / kEigBlock];
+        ++lead->gconv_seen;
         continue;
       }
       if (latched) {
@@ -880,14 +927,23 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
       if (m + kEigBlock > limit[z]) hand_back();  // restart territory: the single-call path
     }
     if (trace) us_host += now_us() - t_sync1;
+    if (speculate) wasted += active_before - active;
+    if (active == 0) break;
+    if (!speculate) SC_TRY(block_step(m));
+    m += kEigBlock;
+    SC_TRY(request_check(m));
   }
   if (trace)
-    fprintf(stderr, "[sc] group eigen: %d members, blocks %d; wait at first check %.0f us, at "
-            "later checks %.0f us, host Rayleigh-Ritz + analysis %.0f us\n", count,
-            m / kEigBlock, us_first_sync, us_sync, us_host);
-  // ---- Ritz vectors of every solved member: E = normalise(t .* (Q Y))
+    fprintf(stderr, "[sc] group eigen: %d members, %d block steps (%d member-steps beyond "
+            "convergence); wait at first check %.0f us, at later checks %.0f us, host "
+            "Rayleigh-Ritz + analysis %.0f us\n", count, steps, wasted, us_first_sync, us_sync,
+            us_host);
+  // ---- Ritz vectors of every solved member: E = normalise(t .* (Q Y)), the coefficient
+  //      matrices of all of them in one upload
+  if (!any_solved) return SC_OK;
   RitzItem rz[kGroupMax];
   memset(rz, 0, sizeof(rz));
+  int last = -1;
   for (int z = 0; z < count; ++z) {
     if (mem[z].status != 0) continue;
     sc_handle h = mem[z].h;
@@ -895,8 +951,8 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
     rz[z].Q = ptr<double>(h->Q);
     rz[z].ldq = kLdq;
     rz[z].m = mem[z].basis;
-    rz[z].Y = ptr<double>(h->Y);
-    rz[z].ldy = kLdq;
+    rz[z].Y = ptr<double>(lead->gypack) + (size_t)z * kHostRR * kHostRR;
+    rz[z].ldy = mem[z].basis;
     rz[z].cols = cols;
     rz[z].E = ptr<double>(h->E);
     rz[z].lde = round_up(mem[z].n, 16);
@@ -904,7 +960,11 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
     rz[z].tvec = ptr<double>(h->tvec);
     h->n_vec = cols;
     h->last_w = mem[z].w;
+    last = z;
   }
+  SC_HIP(lead, hipMemcpyAsync(lead->gypack.p, lead->h_gypack,
+                              (size_t)(last + 1) * kHostRR * kHostRR * sizeof(double),
+                              hipMemcpyHostToDevice, s));
   launch_ritz_vectors_group(s, rz, count);
   return check_last(lead, "group ritz vector launch");
 }

@@ -80,6 +80,17 @@ struct sc_handle_s {
   hipEvent_t sync_ev = nullptr;    // a member arena: "stages before the eigensolver done"
   DevBuf gkrnd;
   bool gkrnd_ready = false;
+  // staging of the group's Rayleigh-Ritz checks (device + pinned host twins), the event the
+  // host waits on, the k-means info words and labels of a group in one buffer each
+  DevBuf gpack, gypack, ginfo, glabels;
+  double* h_gpack = nullptr;
+  double* h_gypack = nullptr;
+  int* h_ginfo = nullptr;
+  long long* h_glabels = nullptr;
+  size_t h_glabels_count = 0;
+  hipEvent_t gcheck_ev = nullptr;
+  int gconv_hist[16] = {0};  // members of this batch that converged at basis 8 * index ...
+  int gconv_seen = 0;        // ... of this many: where a speculative block is likely wasted
   hipEvent_t ev[48];
   int nev = 0;
   int profile_level = 1;  // sc_set_profiling: 0 totals only, 1 stages, 2 per-kernel events

@@ -39,21 +39,33 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
 }
 
 // ---- A1: rows of X to unit L2 norm (utils.py:32-33) -------------------------
+// One wave per row (four rows per workgroup, no LDS, no barrier: d is a few hundred).  The sum
+// keeps the order of the 256-thread form it replaces -- accumulator w of lane l adds the
+// elements 64 w + l + 256 i, each accumulator is reduced across the wave, then
+// (s0 + s1) + (s2 + s3) -- so the norms are bit-identical to it.
 __global__ __launch_bounds__(kRowThreads) void k_normalize_rows(
     const double* __restrict__ X, int ldx, int n, int d, double* __restrict__ Xn,
     int* __restrict__ bad_rows) {
-  __shared__ double sm[4];
-  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
   const double* x = X + (size_t)row * ldx;
-  double acc = 0.0;
-  for (int j = threadIdx.x; j < d; j += kRowThreads) acc += x[j] * x[j];
-  const double norm = sqrt(block_sum(acc, sm));
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j0 = 0; j0 < d; j0 += kRowThreads) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int j = j0 + 64 * w + lane;
+      if (j < d) acc[w] += x[j] * x[j];
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) acc[w] = wave_sum(acc[w]);
+  const double norm = sqrt((acc[0] + acc[1]) + (acc[2] + acc[3]));
   // a zero (or non-finite) row turns into NaNs below, like utils.py:33; later max-type
   // kernels would drop them where np.maximum keeps them, so the fact is recorded here
-  if (bad_rows != nullptr && threadIdx.x == 0 && !(norm > 0.0 && isfinite(norm))) *bad_rows = 1;
+  if (bad_rows != nullptr && lane == 0 && !(norm > 0.0 && isfinite(norm))) *bad_rows = 1;
   double* o = Xn + (size_t)row * ldx;
-  for (int j = threadIdx.x; j < ldx; j += kRowThreads)
-    o[j] = j < d ? x[j] / norm : 0.0;
+  for (int j = lane; j < ldx; j += 64) o[j] = j < d ? x[j] / norm : 0.0;
 }
 
 // ---- R1: CropDiagonal (refinement.py:145-151) -------------------------------
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(256) void k_symmetrize(const double* __restrict__ i
 // -------------------------------------------------------------------------------
 void launch_normalize_rows(hipStream_t s, const double* X, int ldx, int n, int d,
                            double* Xn, int* bad_rows) {
-  hipLaunchKernelGGL(k_normalize_rows, dim3(n), dim3(kRowThreads), 0, s, X, ldx, n,
+  hipLaunchKernelGGL(k_normalize_rows, dim3((n + 3) / 4), dim3(kRowThreads), 0, s, X, ldx, n,
                      d, Xn, bad_rows);
 }
 void launch_crop_diagonal(hipStream_t s, const double* in, double* out, int n,

@@ -215,6 +215,13 @@ struct RitzItem {    // E[:, 0:cols] (column-major, lde) = normalise(t .* (Q[:, 
   int lde, n;
   const double* tvec;
 };
+struct GatherItem {  // T == nullptr: idle
+  const double* T;
+  const double* G;
+  const int* flags;
+};
+void launch_group_gather(hipStream_t s, const GatherItem* items, int count, int m, double* out,
+                         int stride);
 struct LzGroupMember {
   EigWorkspace ws;
   LzChain chain;

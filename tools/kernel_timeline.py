@@ -48,5 +48,25 @@ def main(path, skip):
     print("%-60s %8d %12.2f %10.1f" % (k[:60], c, t / 1e3, t / c))
 
 
+def dump(path, frac, ms):
+  """every kernel of a window of `ms` milliseconds starting at `frac` of the trace"""
+  cur = sqlite3.connect(path).cursor()
+  rows = list(cur.execute(
+      "select name, start, end, queue_id, stream_id, grid_x, grid_y, workgroup_x, lds_size "
+      "from kernels order by start"))
+  t0 = rows[0][1] + frac * (rows[-1][2] - rows[0][1])
+  print("# window of %.1f ms at %.0f %% of %s" % (ms, 100 * frac, path))
+  print("%10s %8s %5s %6s %-34s %s" % ("start_us", "dur_us", "queue", "stream", "kernel", "grid"))
+  for name, s, e, q, st, gx, gy, wx, lds in rows:
+    if s < t0 or s > t0 + ms * 1e6:
+      continue
+    k = name.split("(")[0].replace("void ", "").replace("sc::", "")
+    print("%10.1f %8.1f %5d %6d %-34s %dx%d wg%d lds%d" % (
+        (s - t0) / 1e3, (e - s) / 1e3, q, st, k[:34], gx // max(wx, 1), gy, wx, lds))
+
+
 if __name__ == "__main__":
-  main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5)
+  if len(sys.argv) > 3 and sys.argv[2] == "dump":
+    dump(sys.argv[1], float(sys.argv[3]), float(sys.argv[4]) if len(sys.argv) > 4 else 2.0)
+  else:
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5)

@@ -156,12 +156,13 @@ __global__ __launch_bounds__(256) void k_gaussian_blur_r(
 constexpr int kStreamMinN = 512;
 constexpr int kStreamRows = 64;   // output rows per wave
 constexpr int kAhead = 3;         // rows loaded ahead of the vertical stencil
-template <int R>
+template <int R, int ROWS>
 __global__ __launch_bounds__(256) void k_gaussian_blur_stream(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ weights, const double* __restrict__ diag,
-    double* __restrict__ rowmax, int rows_per_wave) {
+    double* __restrict__ rowmax) {
   static_assert(R % 4 == 0, "neighbour lanes carry 4 columns each");
+  constexpr int rows_per_wave = ROWS;
   constexpr int S = 2 * R + 1 + kAhead;  // ring slots
   constexpr int NB = R / 4;              // neighbour lanes per side
   constexpr int OW = 256 - 2 * R;        // output columns per strip
@@ -298,12 +299,19 @@ bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, in
     // are served by L2).  Same arithmetic per output row either way.
     const int rows = n >= 4096 ? kStreamRows : (n >= 2048 ? kStreamRows / 2 : kStreamRows / 4);
     dim3 sgrid(blur_tile_columns(n, radius), (n + 4 * rows - 1) / (4 * rows));
-    if (radius == 4)
-      hipLaunchKernelGGL((k_gaussian_blur_stream<4>), sgrid, dim3(256), 0, s, in, out, n, ld,
-                         weights_dev, diag, rowmax_partials, rows);
-    else
-      hipLaunchKernelGGL((k_gaussian_blur_stream<8>), sgrid, dim3(256), 0, s, in, out, n, ld,
-                         weights_dev, diag, rowmax_partials, rows);
+#define SC_BLUR_STREAM(R_, ROWS_)                                                            \
+  hipLaunchKernelGGL((k_gaussian_blur_stream<R_, ROWS_>), sgrid, dim3(256), 0, s, in, out, n, \
+                     ld, weights_dev, diag, rowmax_partials)
+    if (radius == 4) {
+      if (rows == kStreamRows) SC_BLUR_STREAM(4, kStreamRows);
+      else if (rows == kStreamRows / 2) SC_BLUR_STREAM(4, kStreamRows / 2);
+      else SC_BLUR_STREAM(4, kStreamRows / 4);
+    } else {
+      if (rows == kStreamRows) SC_BLUR_STREAM(8, kStreamRows);
+      else if (rows == kStreamRows / 2) SC_BLUR_STREAM(8, kStreamRows / 2);
+      else SC_BLUR_STREAM(8, kStreamRows / 4);
+    }
+#undef SC_BLUR_STREAM
     return rowmax_partials != nullptr;
   }
   if ((radius == 4 || radius == 8) && n >= 128) {

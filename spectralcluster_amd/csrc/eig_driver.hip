@@ -792,7 +792,11 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
   launch_lz_link_group(s, lz, count, 0, 4, 3, -1, 0, false, 0, true);
   launch_lz_link_group(s, lz, count, 0, 3, 0, 0, 0, false, 0, false);
   SC_TRY(check_last(lead, "group start block launch"));
-  const int first_check = 3 * kEigBlock;
+  // first Rayleigh-Ritz check after three blocks -- after four once the batch so far says that
+  // (almost) nobody is done by three (a check is a host solve per member)
+  int first_check = 3 * kEigBlock;
+  if (lead->gconv_seen >= 2 * kGroupMax && lead->gconv_hist[3] * 20 < lead->gconv_seen)
+    first_check = 4 * kEigBlock;
   int active = count;
   const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
   double us_first_sync = 0.0, us_sync = 0.0, us_host = 0.0;

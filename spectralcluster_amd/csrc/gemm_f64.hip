@@ -755,7 +755,13 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     if (splitk_ws != nullptr) {
       ksplit = g_slots / rem;
       if (const char* e = getenv("SC_GEMM_TAIL_SPLIT")) ksplit = std::max(2, atoi(e));
-      ksplit = std::min(ksplit, std::max(1, ktiles / 8));  // >= 8 k-tiles per chunk
+      static const int min_chunk = getenv("SC_GEMM_SPLIT_MIN_KTILES")
+                                       ? std::max(1, atoi(getenv("SC_GEMM_SPLIT_MIN_KTILES"))) : 8;
+      ksplit = std::min(ksplit, std::max(1, ktiles / min_chunk));  // >= 8 k-tiles per chunk
+      // a short product that does not fill the chip anyway (an utterance of a few thousand
+      // rows against d = 256 features): the K loop of a whole tile is a third of the tile's
+      // epilogue, splitting it only adds the partial stores and two more launches
+      if (K <= 512 && full == 0) ksplit = 1;
     }
     if (ksplit < 2) {  // no workspace, or not worth splitting: whole tiles only
       full = tiles;

@@ -312,12 +312,15 @@ def first_strict_minimum(ratios: np.ndarray) -> int:
 # --------------------------------------------------------------------------------
 def predict_batch_distributed(comm: Comm, clusterer,
                               utterances: typing.Sequence[np.ndarray],
-                              streams: int = 4) -> typing.List[np.ndarray]:
+                              streams: typing.Optional[int] = None,
+                              group: typing.Optional[int] = None) -> typing.List[np.ndarray]:
   """BASELINE config 5: utterances partitioned over the ranks (LPT), each rank runs its
-  share as a multi-stream batch on its own GPU, labels all-gathered."""
+  share as one batch on its own GPU (grouped by default, `streams` for the multi-stream
+  form: see SpectralClusterer.predict_batch), labels all-gathered."""
   return predict_batch_sharded(
       comm, None, utterances,
-      predict_many_fn=lambda share: clusterer.predict_batch(share, streams=streams))
+      predict_many_fn=lambda share: clusterer.predict_batch(share, streams=streams,
+                                                            group=group))
 
 
 def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,

@@ -299,19 +299,26 @@ class SpectralClusterer:
 
   # -------------------------------------------------------------- batch (new)
   def predict_batch(self, utterances: typing.Sequence[np.ndarray],
-                    streams: int = 4, group: int = 0) -> typing.List[np.ndarray]:
+                    streams: typing.Optional[int] = None,
+                    group: typing.Optional[int] = None) -> typing.List[np.ndarray]:
     """Independent predict() calls (the reference has no batch API: a batch is a
     Python loop).
 
     Small utterances cannot fill 256 CUs, and their pipeline is a chain of short dependent
     launches.  Two ways around that, both ONE library call with the GIL released:
-      group > 1   `sc_predict_batch_grouped`: one stream, one host thread, `group` (<= 16)
-                  utterances per launch -- the eigensolver and k-means chains of the group
-                  advance in lockstep;
-      otherwise   `sc_predict_batch_streams`: the batch spread (longest-processing-time
-                  first) over `streams` HIP streams, one host thread and arena per stream.
+      group       `sc_predict_batch_grouped` (the default, group=16): one host thread,
+                  `group` (<= 16) utterances per launch -- the eigensolver and k-means
+                  chains of a group advance in lockstep on one stream while the GEMMs and
+                  refinement passes of the next group run on the members' streams;
+      streams     `sc_predict_batch_streams` (when `streams` is given and `group` is not):
+                  the batch spread (longest-processing-time first) over `streams` HIP
+                  streams, one host thread and arena per stream; streams=1 is a plain loop.
     Per-utterance results are those of predict() either way.
     """
+    if group is None:
+      group = 16 if streams is None else 0
+    if streams is None:
+      streams = 1
     if (self.autotune is not None or self.max_spectral_size is not None or
         self.min_clusters == 1 or self.fallback_options.spectral_min_embeddings > 1 or
         self.affinity_function is not utils.compute_affinity_matrix or

@@ -374,6 +374,42 @@ def test_predict_batch_falls_back_to_predict_for_custom_functions(monkeypatch):
     c.predict_batch(utts)
 
 
+def test_predict_batch_mode_selection(monkeypatch):
+  """predict_batch(utts) is the grouped batch (16 utterances per launch); `streams` alone
+  selects the multi-stream form; an explicit `group` wins."""
+  calls = []
+
+  class FakeLib:
+    def sc_clear_constraint(self, raw):
+      return 0
+
+    def sc_predict_batch_grouped(self, raw, xp, ns, d, count, cfg, lp, diags, group):
+      calls.append(("grouped", group, count))
+      return 0
+
+    def sc_predict_batch_streams(self, raw, xp, ns, d, count, cfg, lp, diags, streams):
+      calls.append(("streams", streams, count))
+      return 0
+
+  class FakeHandle:
+    lib, raw = FakeLib(), None
+
+    def check(self, rc, *a):
+      assert rc == 0
+
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=4)
+  monkeypatch.setattr(c, "_handle", lambda: FakeHandle())
+  monkeypatch.setattr(c, "build_config", lambda: None)
+  utts = [np.ones((5, 3)), np.ones((7, 3)), np.ones((4, 3))]
+  c.predict_batch(utts)
+  c.predict_batch(utts, streams=4)
+  c.predict_batch(utts, streams=1)
+  c.predict_batch(utts, group=8)
+  c.predict_batch(utts, streams=2, group=3)
+  assert calls == [("grouped", 16, 3), ("streams", 4, 3), ("streams", 1, 3), ("grouped", 8, 3),
+                   ("grouped", 3, 3)]
+
+
 def test_comm_header_and_id_file(monkeypatch, tmp_path):
   """Rendezvous plumbing of RcclComm.from_env that needs no GPU: the id file name is
   unique per launch (MASTER_PORT + parent pid) and can be overridden."""

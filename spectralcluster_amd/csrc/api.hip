@@ -222,6 +222,10 @@ extern "C" int sc_destroy(sc_handle h) {
   if (h->h_flags) hipHostFree(h->h_flags);
   if (h->h_rr) hipHostFree(h->h_rr);
   if (h->sync_ev) hipEventDestroy(h->sync_ev);
+  for (int b = 0; b < 2; ++b) {
+    if (h->gbank_ev[b]) hipEventDestroy(h->gbank_ev[b]);
+    if (h->gbank_stream[b]) hipStreamDestroy(h->gbank_stream[b]);
+  }
   if (h->gcheck_ev) hipEventDestroy(h->gcheck_ev);
   if (h->h_gpack) hipHostFree(h->h_gpack);
   if (h->h_gypack) hipHostFree(h->h_gypack);
@@ -449,7 +453,7 @@ int validate_config(sc_handle h, const sc_config* cfg) {
 }
 
 // device copy of the blur weights; the upload is skipped while they do not change
-static int upload_blur_weights(sc_handle h, const sc_config* cfg) {
+int upload_blur_weights(sc_handle h, const sc_config* cfg) {
   const int count = 2 * cfg->blur_radius + 1;
   if (h->blurw_radius == cfg->blur_radius &&
       memcmp(h->blurw_host, cfg->blur_weights, count * sizeof(double)) == 0)

@@ -15,6 +15,8 @@
 //           launch carries one link of every member (blockIdx.y = member, descriptors in the
 //           kernel arguments), one synchronisation per Rayleigh-Ritz check for all of them,
 //   k-means ONE lockstep chain for the group (kmeans_chain.hip: launch_kmeans_chain_group).
+// (When the refinement sequence is the ICASSP2018 one, the front itself is grouped launches
+// too -- enqueue_front_grouped: both GEMMs take the tiles of all members in one launch.)
 // Each member runs the same kernel bodies with the same arguments as a single call; members
 // that leave the common path (rare branches of the eigensolver, k > 32, a non-symmetric
 // refinement, n <= 128 or n >= 4096) go through the single-call path, so results are those of
@@ -125,13 +127,138 @@ int enqueue_front(sc_handle lead, const double* const* xs, const int* ns, int d,
   return SC_OK;
 }
 
+// The ICASSP2018 sequence (CropDiagonal, GaussianBlur, RowWiseThreshold, Symmetrize, Diffuse,
+// RowWiseNormalize with the fusions eig_ncluster_impl applies to it: crop value out of the
+// affinity epilogue, blur with the diagonal override and per-strip row maxima, threshold +
+// symmetrise in one pass, row statistics out of the Diffuse epilogue, RowWiseNormalize folded
+// into the scaling vectors) is what the grouped front covers; anything else takes the
+// member-by-member front above.
+bool grouped_front_covers(const sc_config* cfg) {
+  static const int seq[6] = {SC_OP_CROP_DIAGONAL, SC_OP_GAUSSIAN_BLUR, SC_OP_ROW_WISE_THRESHOLD,
+                             SC_OP_SYMMETRIZE, SC_OP_DIFFUSE, SC_OP_ROW_WISE_NORMALIZE};
+  if (cfg->n_ops != 6 || getenv("SC_GROUP_FRONT_BY_MEMBER")) return false;
+  for (int i = 0; i < 6; ++i)
+    if (cfg->ops[i] != seq[i]) return false;
+  return (cfg->blur_radius == 4 || cfg->blur_radius == 8) &&
+         cfg->threshold_type == SC_THRESHOLD_ROW_MAX && !cfg->preserve_diagonal;
+}
+
+// Stages before the eigensolver of one group as GROUPED launches on the bank's stream: the
+// two GEMMs take the tiles of all members in one launch each (one utterance's 36..300 tiles
+// cannot fill the chip, those of 16 can), the passes between them one launch each with
+// blockIdx.y / z = member.  Same kernel bodies and arguments per member as
+// sc_compute_affinity + eig_ncluster_impl; the GEMMs compute every tile whole (a single call
+// splits the tiles of a short utterance over K: the sums differ in the last bits).
+int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns, int d,
+                          const sc_config* cfg, sc_diag* diags, const int* idx, int count,
+                          int slot0, Member* mb, int bank) {
+  hipStream_t s = lead->gbank_stream[bank];
+  FrontItem fi[kGroupMax];
+  GemmGroupItem aff[kGroupMax], dif[kGroupMax];
+  memset(fi, 0, sizeof(fi));
+  for (int z = 0; z < count; ++z) {
+    Member& m = mb[z];
+    m = Member();
+    m.index = idx[z];
+    SC_TRY(group_slot(lead, slot0 + z, &m.h));
+    sc_handle h = m.h;
+    h->err.clear();
+    const int n = ns[m.index];
+    if (!xs[m.index] || n <= 0 || d <= 0) return fail(lead, SC_ERR_INVALID, "embeddings must be (n, d)");
+    int rc = ensure_matrices(h, n, d);
+    if (rc == SC_OK) rc = ensure_eig(h, n);
+    if (rc == SC_OK) rc = ensure_tilemap(h, n);
+    if (rc == SC_OK) rc = grow(h, h->symflag, 16);
+    if (rc != SC_OK) {
+      lead->err = h->err;
+      return rc;
+    }
+    h->n = n;
+    h->d = d;
+    h->ldn = matrix_ld(n);
+    h->ldx = round_up(d, 16);
+    h->n_vec = 0;
+    h->nev = 0;
+    h->have_x = h->have_affinity = h->have_cropval = true;
+    h->affinity_symmetric = h->affinity_from_embeddings = true;
+    h->constraint_applied = false;
+    if (diags) memset(diags + m.index, 0, sizeof(sc_diag));
+    SC_HIP(lead, hipMemcpy2DAsync(h->X.p, (size_t)h->ldx * sizeof(double), xs[m.index],
+                                  (size_t)d * sizeof(double), (size_t)d * sizeof(double), n,
+                                  hipMemcpyHostToDevice, s));
+    FrontItem& f = fi[z];
+    f.X = ptr<double>(h->X);
+    f.Xn = ptr<double>(h->Xn);
+    f.ldx = h->ldx;
+    f.n = n;
+    f.d = d;
+    f.ldn = h->ldn;
+    f.A0 = ptr<double>(h->A0);
+    f.B1 = ptr<double>(h->B1);
+    f.B2 = ptr<double>(h->B2);
+    f.cropval = ptr<double>(h->cropval);
+    f.rmpart = ptr<double>(h->rmpart);
+    f.blur_cols = blur_tile_columns(n, cfg->blur_radius);
+    f.cut = ptr<double>(h->cut);
+    f.rowmax = ptr<double>(h->rowmax);
+    f.rowsum = ptr<double>(h->rowsum);
+    f.cvec = ptr<double>(h->cvec);
+    f.pvec = ptr<double>(h->pvec);
+    f.tvec = ptr<double>(h->tvec);
+    f.symflag = ptr<int>(h->symflag);
+    f.flags = ptr<int>(h->flags);
+    const int nt = gemm_tile_dim(n);
+    aff[z] = GemmGroupItem();
+    aff[z].A = f.Xn;
+    aff[z].lda = h->ldx;
+    aff[z].C = f.A0;
+    aff[z].ldc = h->ldn;
+    aff[z].n = n;
+    aff[z].K = d;
+    aff[z].tilemap = h->tilemap_cur;
+    aff[z].partial_max = ptr<double>(h->statp);
+    aff[z].rowmax = ptr<double>(h->cropval);
+    dif[z] = GemmGroupItem();
+    dif[z].A = f.B2;
+    dif[z].lda = h->ldn;
+    dif[z].C = f.B1;
+    dif[z].ldc = h->ldn;
+    dif[z].n = n;
+    dif[z].K = n;
+    dif[z].tilemap = h->tilemap_cur;
+    dif[z].partial_max = ptr<double>(h->statp);
+    dif[z].partial_sum = ptr<double>(h->statp) + (size_t)n * nt;
+    dif[z].rowmax = ptr<double>(h->rowmax);
+    dif[z].rowsum = ptr<double>(h->rowsum);
+    m.front.matrix = f.B1;
+    m.front.scratch = f.B2;
+    m.front.ld = h->ldn;
+    m.front.symmetric = true;
+    m.front.folded_rownorm = true;
+  }
+  launch_front_begin_group(s, fi, count);
+  launch_gemm_nt_group(s, aff, count, kEpiAffinity, 2);
+  launch_gaussian_blur_group(s, fi, count, cfg->blur_radius, ptr<double>(lead->blurw));
+  launch_threshold_symmetrize_group(s, fi, count, cfg->p_percentile, cfg->soft_multiplier,
+                                    cfg->binarize, cfg->symmetrize_type, cfg->preserve_diagonal);
+  launch_gemm_nt_group(s, dif, count, kEpiNone, 1);
+  launch_scaling_vectors_group(s, fi, count, cfg->laplacian_type, 1);
+  SC_TRY(check_last(lead, "grouped front launch"));
+  SC_HIP(lead, hipEventRecord(lead->gbank_ev[bank], s));
+  return SC_OK;
+}
+
 // Eigensolver and k-means of a group whose stages before are enqueued (enqueue_front), in
 // lockstep on the owner's stream; then the members that left the common path.
 int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* const* labels,
-                 sc_diag* diags, Member* mb, int count, const EigRequest& rq) {
+                 sc_diag* diags, Member* mb, int count, const EigRequest& rq, int front_bank) {
   hipStream_t s = lead->stream;
   const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
-  for (int z = 0; z < count; ++z) SC_HIP(lead, hipStreamWaitEvent(s, mb[z].h->sync_ev, 0));
+  if (front_bank >= 0) {
+    SC_HIP(lead, hipStreamWaitEvent(s, lead->gbank_ev[front_bank], 0));
+  } else {
+    for (int z = 0; z < count; ++z) SC_HIP(lead, hipStreamWaitEvent(s, mb[z].h->sync_ev, 0));
+  }
   const double t1 = trace ? now_us() : 0.0;
   // ---- eigen: lockstep over the symmetric members
   GroupEigMember em[kGroupMax];
@@ -323,18 +450,41 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
       hz->have_constraint = false;
     }
     Member mbs[2][kGroupMax];
+    int front_bank[2] = {-1, -1};
     auto group_count = [&](int g) {
       return (int)std::min<size_t>(width, grouped.size() - (size_t)g * width);
     };
     const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
-    SC_TRY(enqueue_front(h, xs, ns, d, cfg, diags, grouped.data(), group_count(0), 0, mbs[0]));
+    const bool covers = grouped_front_covers(cfg);
+    if (covers) {
+      for (int b = 0; b < 2; ++b)
+        if (!h->gbank_stream[b]) {
+          SC_HIP(h, hipStreamCreateWithFlags(&h->gbank_stream[b], hipStreamNonBlocking));
+          SC_HIP(h, hipEventCreateWithFlags(&h->gbank_ev[b], hipEventDisableTiming));
+        }
+      SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
+      SC_TRY(upload_blur_weights(h, cfg));
+      SC_HIP(h, hipStreamSynchronize(h->stream));  // the bank streams read them
+    }
+    auto front = [&](int g) -> int {
+      const int b = g & 1, cnt = group_count(g);
+      const int* idx = grouped.data() + (size_t)g * width;
+      // (the streaming blur of the grouped front needs every member at n >= 512; the sizes
+      //  are sorted, the last member of the group is its smallest)
+      if (covers && blur_group_supported(ns[idx[cnt - 1]], cfg->blur_radius)) {
+        front_bank[b] = b;
+        return enqueue_front_grouped(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b], b);
+      }
+      front_bank[b] = -1;
+      return enqueue_front(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b]);
+    };
+    SC_TRY(front(0));
     for (int g = 0; g < ngroups; ++g) {
       const double t0 = trace ? now_us() : 0.0;
-      if (g + 1 < ngroups)
-        SC_TRY(enqueue_front(h, xs, ns, d, cfg, diags, grouped.data() + (size_t)(g + 1) * width,
-                             group_count(g + 1), ((g + 1) & 1) * width, mbs[(g + 1) & 1]));
+      if (g + 1 < ngroups) SC_TRY(front(g + 1));
       if (trace) fprintf(stderr, "[sc] next group's front enqueued in %.0f us\n", now_us() - t0);
-      SC_TRY(finish_group(h, ns, cfg, labels, diags, mbs[g & 1], group_count(g), rq));
+      SC_TRY(finish_group(h, ns, cfg, labels, diags, mbs[g & 1], group_count(g), rq,
+                          front_bank[g & 1]));
     }
   }
   for (int i : single)

@@ -8,6 +8,9 @@
 // scipy's float64 intermediate array), the axis-1 pass writes the output tile.
 // HBM traffic: 1 read (+ halo re-reads served by L2) + 1 write of n^2.
 // Compiled with -ffp-contract=off so mul/add round separately like the C code.
+#include <algorithm>
+#include <cstring>
+
 #include "sc_internal.h"
 
 namespace sc {
@@ -157,18 +160,18 @@ constexpr int kStreamMinN = 512;
 constexpr int kStreamRows = 64;   // output rows per wave
 constexpr int kAhead = 3;         // rows loaded ahead of the vertical stencil
 template <int R, int ROWS>
-__global__ __launch_bounds__(256) void k_gaussian_blur_stream(
+__device__ __forceinline__ void gaussian_blur_stream_body(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ weights, const double* __restrict__ diag,
-    double* __restrict__ rowmax) {
+    double* __restrict__ rowmax, const int bx, const int by, const int ncols) {
   static_assert(R % 4 == 0, "neighbour lanes carry 4 columns each");
   constexpr int rows_per_wave = ROWS;
   constexpr int S = 2 * R + 1 + kAhead;  // ring slots
   constexpr int NB = R / 4;              // neighbour lanes per side
   constexpr int OW = 256 - 2 * R;        // output columns per strip
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j0 = blockIdx.x * OW;                                // first output column
-  const int r0 = (blockIdx.y * 4 + wv) * rows_per_wave;          // first output row
+  const int j0 = bx * OW;                                // first output column
+  const int r0 = (by * 4 + wv) * rows_per_wave;          // first output row
   if (r0 >= n) return;
   const int rend = min(n, r0 + rows_per_wave);
   double w[R + 1];
@@ -262,10 +265,28 @@ __global__ __launch_bounds__(256) void k_gaussian_blur_stream(
       if (rowmax != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-        if (lane == 0) rowmax[(size_t)gi * gridDim.x + blockIdx.x] = m;
+        if (lane == 0) rowmax[(size_t)gi * ncols + bx] = m;
       }
     }
   }
+}
+template <int R, int ROWS>
+__global__ __launch_bounds__(256) void k_gaussian_blur_stream(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    const double* __restrict__ weights, const double* __restrict__ diag,
+    double* __restrict__ rowmax) {
+  gaussian_blur_stream_body<R, ROWS>(in, out, n, ld, weights, diag, rowmax, blockIdx.x, blockIdx.y,
+                                     gridDim.x);
+}
+// grouped form (batch_group.hip): blockIdx.z = member of a batch group; A0 -> B1 with the
+// CropDiagonal value applied on load, per-strip row maxima into rmpart
+template <int R, int ROWS>
+__global__ __launch_bounds__(256) void k_gaussian_blur_stream_g(const GroupOf<FrontItem> g,
+                                                                const double* __restrict__ weights) {
+  const FrontItem& a = g.s[blockIdx.z];
+  if ((int)blockIdx.x >= a.blur_cols || (int)blockIdx.y * 4 * ROWS >= a.n) return;
+  gaussian_blur_stream_body<R, ROWS>(a.A0, a.B1, a.n, a.ldn, weights, a.cropval, a.rmpart,
+                                     blockIdx.x, blockIdx.y, a.blur_cols);
 }
 
 __global__ void k_copy_matrix(const double* __restrict__ in,
@@ -335,6 +356,38 @@ bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, in
   hipLaunchKernelGGL(k_gaussian_blur, grid, dim3(256), lds, s, in, out, n, ld, radius,
                      weights_dev);
   return false;
+}
+
+// The streaming blur of every member of a batch group (all n >= kStreamMinN) in one launch.
+bool blur_group_supported(int n_min, int radius) {
+  return (radius == 4 || radius == 8) && n_min >= kStreamMinN;
+}
+void launch_gaussian_blur_group(hipStream_t s, const FrontItem* items, int count, int radius,
+                                const double* weights_dev) {
+  GroupOf<FrontItem> g;
+  memset(&g, 0, sizeof(g));
+  int nmax = 0, cmax = 0;
+  for (int z = 0; z < count; ++z) {
+    g.s[z] = items[z];
+    nmax = std::max(nmax, items[z].n);
+    cmax = std::max(cmax, items[z].n > 0 ? items[z].blur_cols : 0);
+  }
+  if (nmax == 0) return;
+  // rows per wave from the largest member (the members of a group are of similar size)
+  const int rows = nmax >= 4096 ? kStreamRows : (nmax >= 2048 ? kStreamRows / 2 : kStreamRows / 4);
+  dim3 grid(cmax, (nmax + 4 * rows - 1) / (4 * rows), count);
+#define SC_BLUR_STREAM_G(R_, ROWS_)                                                        \
+  hipLaunchKernelGGL((k_gaussian_blur_stream_g<R_, ROWS_>), grid, dim3(256), 0, s, g, weights_dev)
+  if (radius == 4) {
+    if (rows == kStreamRows) SC_BLUR_STREAM_G(4, kStreamRows);
+    else if (rows == kStreamRows / 2) SC_BLUR_STREAM_G(4, kStreamRows / 2);
+    else SC_BLUR_STREAM_G(4, kStreamRows / 4);
+  } else {
+    if (rows == kStreamRows) SC_BLUR_STREAM_G(8, kStreamRows);
+    else if (rows == kStreamRows / 2) SC_BLUR_STREAM_G(8, kStreamRows / 2);
+    else SC_BLUR_STREAM_G(8, kStreamRows / 4);
+  }
+#undef SC_BLUR_STREAM_G
 }
 
 }  // namespace sc

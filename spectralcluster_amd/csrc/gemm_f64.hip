@@ -23,6 +23,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <cstring>
+
 #include "sc_internal.h"
 
 namespace sc {
@@ -189,8 +191,27 @@ __global__ void k_gemm_stats_reduce(const double* __restrict__ pmax,
 // workgroups after full_tiles write raw accumulators to `partial` (fragment order), to be
 // summed by k_gemm_reduce.  Being last in dispatch order they fill the slots that free up
 // while the last whole tiles drain, so the chip does not idle on a ragged tail.
-template <int EPI, bool SYM>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A,
+// Grouped form (GROUPED, k_gemm_nt_g): one launch computes the products A_z A_z^T of up to
+// kGroupMax independent symmetric problems (the members of a batch group, batch_group.hip).
+// Workgroup b takes whole tile b - first[z] of the member z whose run [first[z], first[z+1])
+// holds b: a short utterance's 36..300 tiles cannot fill the chip (and pay a split over K with
+// partial stores and a reduce for trying), the tiles of 16 of them can.  Everything after the
+// lookup is the single-problem tile body with the member's operands.
+struct GemmMember {
+  const double* A;
+  double* C;
+  double* pmax;
+  double* psum;
+  const int2* tilemap;
+  int lda, ldc, n, K, nt;
+};
+struct GemmGroup {
+  GemmMember m[kGroupMax];
+  int first[kGroupMax + 1];
+};
+
+template <int EPI, bool SYM, bool GROUPED>
+__device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
                                                  int lda,
                                                  const double* __restrict__ B,
                                                  int ldb, double* __restrict__ C,
@@ -203,7 +224,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  int xcd_chunk, GemmStats stats,
                                                  int* __restrict__ ksync,
                                                  int* __restrict__ queue, int edge_prio,
-                                                 int nunits, int persist) {
+                                                 int nunits, int persist,
+                                                 const GemmGroup* __restrict__ grp) {
   // one 64 KB block: As[2] | Bs[2] in the K loop, reduction scratch + the transposed
   // staging of the mirror tile in the epilogue
   __shared__ __attribute__((aligned(16))) double smem[2 * BM * BK + 2 * BN * BK];
@@ -239,6 +261,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   // SC_GEMM_CLOCK_DUMP: both gaps coincided at every generation boundary, ~4 % of the launch
   // with the MFMA pipe idle).  Which workgroup computes which item does not change any result.
   int item_blk = (int)blockIdx.x;
+  if constexpr (GROUPED) {
+    int z = 0;
+    while (item_blk >= grp->first[z + 1]) ++z;  // (uniform: scalar loads from the kernel arguments)
+    const GemmMember& g = grp->m[z];
+    item_blk -= grp->first[z];
+    A = B = g.A;
+    lda = ldb = g.lda;
+    C = g.C;
+    ldc = g.ldc;
+    M = N = g.n;
+    K = g.K;
+    ntiles_m = ntiles_n = g.nt;
+    tilemap = g.tilemap;
+    stats.pmax = g.pmax;
+    stats.psum = g.psum;
+  }
   if (queue != nullptr) {
     int* s_item = reinterpret_cast<int*>(smem);  // (one LDS object per kernel: no second array)
     if (threadIdx.x == 0) {
@@ -608,6 +646,57 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
   }  // item loop
 }
 
+template <int EPI, bool SYM>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A,
+                                                 int lda,
+                                                 const double* __restrict__ B,
+                                                 int ldb, double* __restrict__ C,
+                                                 int ldc, int M, int N, int K,
+                                                 int ntiles_m, int ntiles_n,
+                                                 int full_tiles, int ksplit_tail,
+                                                 double* __restrict__ partial,
+                                                 double* __restrict__ probe_out,
+                                                 const int2* __restrict__ tilemap,
+                                                 int xcd_chunk, GemmStats stats,
+                                                 int* __restrict__ ksync,
+                                                 int* __restrict__ queue, int edge_prio,
+                                                 int nunits, int persist) {
+  gemm_nt_body<EPI, SYM, false>(A, lda, B, ldb, C, ldc, M, N, K, ntiles_m, ntiles_n, full_tiles,
+                                ksplit_tail, partial, probe_out, tilemap, xcd_chunk, stats, ksync,
+                                queue, edge_prio, nunits, persist, nullptr);
+}
+// every workgroup: one whole tile of one member (no queue, no split, no probe)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_g(const GemmGroup grp, int stats_mode,
+                                                     int edge_prio) {
+  GemmStats stats{nullptr, nullptr, stats_mode, nullptr};
+  gemm_nt_body<EPI, true, true>(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0, 0x7fffffff, 1,
+                                nullptr, nullptr, nullptr, 0, stats, nullptr, nullptr, edge_prio,
+                                0, 0, &grp);
+}
+
+// rowmax / rowsum of every member from its per-tile partials (k_gemm_stats_reduce, grouped)
+struct StatsReduceItem {
+  const double* pmax;
+  const double* psum;
+  double* rowmax;
+  double* rowsum;
+  int n, nt;
+};
+__global__ void k_gemm_stats_reduce_g(const GroupOf<StatsReduceItem> g, int mode) {
+  const StatsReduceItem& a = g.s[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  double mx = -INFINITY, sm = 0.0;
+  for (int t = 0; t < a.nt; ++t) {
+    mx = fmax(mx, a.pmax[(size_t)i * a.nt + t]);
+    if (mode == 1) sm += a.psum[(size_t)i * a.nt + t];
+  }
+  if (mode == 2) mx = fmax(mx, 0.0);  // CropDiagonal: the zero-filled diagonal takes part
+  a.rowmax[i] = mx;
+  if (mode == 1) a.rowsum[i] = sm;
+}
+
 // Sums the ksplit partial tiles of k_gemm_nt (fixed order: deterministic), applies
 // the epilogue and stores the tile (+ mirror).  Same fragment -> (row, col) map.
 template <int EPI, bool SYM>
@@ -894,6 +983,41 @@ void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
     else SC_GEMM_CASE(kEpiNone, false);
   }
 #undef SC_GEMM_CASE
+}
+
+// C_z = A_z A_z^T (+ the affinity epilogue) of every member in ONE launch, row statistics from
+// the tile epilogues (`stats_mode` 1: row max and sum, 2: CropDiagonal's value) reduced by one
+// more grouped launch.  items[z].n = 0: idle member.
+void launch_gemm_nt_group(hipStream_t s, const GemmGroupItem* items, int count, int epilogue,
+                          int stats_mode) {
+  GemmGroup grp;
+  memset(&grp, 0, sizeof(grp));
+  GroupOf<StatsReduceItem> red;
+  memset(&red, 0, sizeof(red));
+  int total = 0, nmax = 0;
+  for (int z = 0; z < kGroupMax; ++z) {
+    grp.first[z] = total;
+    if (z >= count || items[z].n <= 0) continue;
+    const GemmGroupItem& it = items[z];
+    const int nt = (it.n + BM - 1) / BM;
+    grp.m[z] = GemmMember{it.A, it.C, it.partial_max, it.partial_sum, it.tilemap,
+                          it.lda, it.ldc, it.n, it.K, nt};
+    red.s[z] = StatsReduceItem{it.partial_max, it.partial_sum, it.rowmax, it.rowsum, it.n, nt};
+    total += nt * (nt + 1) / 2;
+    nmax = std::max(nmax, it.n);
+  }
+  grp.first[kGroupMax] = total;
+  if (total == 0) return;
+  static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 3;
+  if (epilogue == kEpiAffinity)
+    hipLaunchKernelGGL((k_gemm_nt_g<kEpiAffinity>), dim3(total), dim3(256), 0, s, grp, stats_mode,
+                       edge_prio);
+  else
+    hipLaunchKernelGGL((k_gemm_nt_g<kEpiNone>), dim3(total), dim3(256), 0, s, grp, stats_mode,
+                       edge_prio);
+  if (stats_mode != 0)
+    hipLaunchKernelGGL(k_gemm_stats_reduce_g, dim3((nmax + 255) / 256, count), dim3(256), 0, s,
+                       red, stats_mode);
 }
 
 }  // namespace sc

@@ -89,6 +89,10 @@ struct sc_handle_s {
   long long* h_glabels = nullptr;
   size_t h_glabels_count = 0;
   hipEvent_t gcheck_ev = nullptr;
+  // grouped front: the stages before the eigensolver of a whole group as grouped launches on
+  // the stream of the group's bank, handed to this handle's stream through the bank's event
+  hipStream_t gbank_stream[2] = {nullptr, nullptr};
+  hipEvent_t gbank_ev[2] = {nullptr, nullptr};
   int gconv_hist[16] = {0};  // members of this batch that converged at basis 8 * index ...
   int gconv_seen = 0;        // ... of this many: where a speculative block is likely wasted
   hipEvent_t ev[48];
@@ -247,6 +251,7 @@ struct FrontResult {
   bool symmetric = false, folded_rownorm = false;
 };
 EigRequest make_eig_request(const sc_config* cfg);
+int upload_blur_weights(sc_handle h, const sc_config* cfg);  // into h->blurw, on h->stream
 // `resume`: the stages before the eigensolver already ran (a FrontResult of this handle)
 int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontResult* front_only,
                       const FrontResult* resume = nullptr);

@@ -6,6 +6,9 @@
 //
 // Compiled with -ffp-contract=off: the elementwise arithmetic keeps the
 // reference's operation order and rounding (no fused multiply-add).
+#include <algorithm>
+#include <cstring>
+
 #include "sc_internal.h"
 
 namespace sc {
@@ -43,7 +46,7 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
 // keeps the order of the 256-thread form it replaces -- accumulator w of lane l adds the
 // elements 64 w + l + 256 i, each accumulator is reduced across the wave, then
 // (s0 + s1) + (s2 + s3) -- so the norms are bit-identical to it.
-__global__ __launch_bounds__(kRowThreads) void k_normalize_rows(
+__device__ __forceinline__ void normalize_rows_body(
     const double* __restrict__ X, int ldx, int n, int d, double* __restrict__ Xn,
     int* __restrict__ bad_rows) {
   const int lane = threadIdx.x & 63;
@@ -66,6 +69,26 @@ __global__ __launch_bounds__(kRowThreads) void k_normalize_rows(
   if (bad_rows != nullptr && lane == 0 && !(norm > 0.0 && isfinite(norm))) *bad_rows = 1;
   double* o = Xn + (size_t)row * ldx;
   for (int j = lane; j < ldx; j += 64) o[j] = j < d ? x[j] / norm : 0.0;
+}
+__global__ __launch_bounds__(kRowThreads) void k_normalize_rows(
+    const double* __restrict__ X, int ldx, int n, int d, double* __restrict__ Xn,
+    int* __restrict__ bad_rows) {
+  normalize_rows_body(X, ldx, n, d, Xn, bad_rows);
+}
+// ---- grouped forms of the row kernels (batch_group.hip): blockIdx.y = member of a batch
+//      group, argument blocks by value in the kernel arguments, n = 0 = idle member
+__global__ __launch_bounds__(kRowThreads) void k_normalize_rows_g(const GroupOf<FrontItem> g) {
+  const FrontItem& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x * 4 >= a.n) return;
+  normalize_rows_body(a.X, a.ldx, a.n, a.d, a.Xn, a.symflag + 1);
+}
+// the words the stages of a member latch into: symflag[1] (a zero / non-finite embedding
+// row), flags[12] (non-finite scaling vectors), flags[13..15] (the Lanczos chain's latch)
+__global__ void k_front_words_init_g(const GroupOf<FrontItem> g) {
+  const FrontItem& a = g.s[blockIdx.x];
+  if (a.n <= 0) return;
+  if (threadIdx.x == 0) a.symflag[1] = 0;
+  if (threadIdx.x >= 12 && threadIdx.x < 16) a.flags[threadIdx.x] = 0;
 }
 
 // ---- R1: CropDiagonal (refinement.py:145-151) -------------------------------
@@ -108,9 +131,9 @@ __global__ __launch_bounds__(kRowThreads) void k_crop_value(
 
 // cut[i] = (max over the per-tile partial row maxima) * p   (refinement.py:188-191)
 // one wave per row: lanes stride the row's partials (coalesced), wave max
-__global__ __launch_bounds__(256) void k_cut_from_partials(const double* __restrict__ partials,
-                                                           int n, int ntiles, double p,
-                                                           double* __restrict__ cut) {
+__device__ __forceinline__ void cut_from_partials_body(const double* __restrict__ partials,
+                                                       int n, int ntiles, double p,
+                                                       double* __restrict__ cut) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= n) return;
@@ -118,6 +141,17 @@ __global__ __launch_bounds__(256) void k_cut_from_partials(const double* __restr
   for (int t = lane; t < ntiles; t += 64) m = fmax(m, partials[(size_t)i * ntiles + t]);
   m = wave_max(m);
   if (lane == 0) cut[i] = m * p;
+}
+__global__ __launch_bounds__(256) void k_cut_from_partials(const double* __restrict__ partials,
+                                                           int n, int ntiles, double p,
+                                                           double* __restrict__ cut) {
+  cut_from_partials_body(partials, n, ntiles, p, cut);
+}
+__global__ __launch_bounds__(256) void k_cut_from_partials_g(const GroupOf<FrontItem> g,
+                                                             double p) {
+  const FrontItem& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x * 4 >= a.n) return;
+  cut_from_partials_body(a.rmpart, a.n, a.blur_cols, p, a.cut);
 }
 __global__ __launch_bounds__(kRowThreads) void k_cut_from_rows(
     const double* __restrict__ in, int n, int ld, double p, double* __restrict__ cut,
@@ -259,7 +293,7 @@ __global__ __launch_bounds__(kRowThreads) void k_row_threshold_cut(
 // handles tiles (I, J) and (J, I), I <= J: both are read once, the symmetric result is
 // computed once and written to both places (the mirror through LDS, so both stores are
 // coalesced): 1 read + 1 write of n^2 for the two ops together.
-__global__ __launch_bounds__(256) void k_threshold_symmetrize(
+__device__ __forceinline__ void threshold_symmetrize_body(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles,
     int preserve_diag) {
@@ -311,6 +345,21 @@ __global__ __launch_bounds__(256) void k_threshold_symmetrize(
       }
     }
   }
+}
+__global__ __launch_bounds__(256) void k_threshold_symmetrize(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles,
+    int preserve_diag) {
+  threshold_symmetrize_body(in, out, n, ld, cut, mult, binarize, symtype, ntiles, preserve_diag);
+}
+__global__ __launch_bounds__(256) void k_threshold_symmetrize_g(const GroupOf<FrontItem> g,
+                                                                double mult, int binarize,
+                                                                int symtype, int preserve_diag) {
+  const FrontItem& a = g.s[blockIdx.y];
+  const int t = (a.n + 31) / 32;
+  if ((int)blockIdx.x >= t * (t + 1) / 2) return;
+  threshold_symmetrize_body(a.B1, a.B2, a.n, a.ldn, a.cut, mult, binarize, symtype, t,
+                            preserve_diag);
 }
 
 // ---- R3: RowWiseThreshold, RowMax (refinement.py:182-210) --------------------
@@ -406,10 +455,12 @@ __global__ __launch_bounds__(kRowThreads) void k_row_stats(
 //   GraphCut      : h = 1/(sqrt(deg)+eps)     c = h sqrt(a), p = -h^2 deg, t = sqrt(a)
 // with deg = a * rowsum(S) (laplacian.py:41 on W).  Eigenvector of the
 // reference matrix = normalise(t .* u) for an eigenvector u of Op.
-__global__ void k_scaling_vectors(const double* __restrict__ rowmax,
-                                  const double* __restrict__ rowsum, int n,
-                                  int lap, int rownorm, double* __restrict__ c,
-                                  double* __restrict__ p, double* __restrict__ t) {
+__device__ __forceinline__ void scaling_vectors_body(const double* __restrict__ rowmax,
+                                                     const double* __restrict__ rowsum, int n,
+                                                     int lap, int rownorm,
+                                                     double* __restrict__ c,
+                                                     double* __restrict__ p,
+                                                     double* __restrict__ t) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double eps = 1e-10;  // laplacian.py:6
@@ -432,6 +483,22 @@ __global__ void k_scaling_vectors(const double* __restrict__ rowmax,
   c[i] = cv;
   p[i] = pv;
   t[i] = tv;
+}
+__global__ void k_scaling_vectors(const double* __restrict__ rowmax,
+                                  const double* __restrict__ rowsum, int n,
+                                  int lap, int rownorm, double* __restrict__ c,
+                                  double* __restrict__ p, double* __restrict__ t) {
+  scaling_vectors_body(rowmax, rowsum, n, lap, rownorm, c, p, t);
+}
+// scaling vectors + the finite-ness word of every member (flags[12] = a NaN embedding row or
+// a non-finite scaling entry: what the single-call path gets from its copy + k_check_finite)
+__global__ void k_scaling_vectors_g(const GroupOf<FrontItem> g, int lap, int rownorm) {
+  const FrontItem& a = g.s[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  scaling_vectors_body(a.rowmax, a.rowsum, a.n, lap, rownorm, a.cvec, a.pvec, a.tvec);
+  if (!isfinite(a.cvec[i]) || !isfinite(a.pvec[i]) || (i == 0 && a.symflag[1] != 0))
+    a.flags[12] = 1;
 }
 
 // flag = 1 if any entry of a or b is NaN / inf (np.linalg.eig raises on such input)
@@ -578,6 +645,43 @@ void launch_scaling_vectors(hipStream_t s, const double* rowmax,
                             int row_normalized, double* c, double* p, double* t) {
   hipLaunchKernelGGL(k_scaling_vectors, dim3((n + 255) / 256), dim3(256), 0, s,
                      rowmax, rowsum, n, laplacian_type, row_normalized, c, p, t);
+}
+// ---- grouped launches of the stages between the two GEMMs of a batch group
+static GroupOf<FrontItem> front_pack(const FrontItem* items, int count, int* nmax) {
+  GroupOf<FrontItem> g;
+  memset(&g, 0, sizeof(g));
+  *nmax = 0;
+  for (int z = 0; z < count; ++z) {
+    g.s[z] = items[z];
+    *nmax = std::max(*nmax, items[z].n);
+  }
+  return g;
+}
+void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count) {
+  int nmax;
+  const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_front_words_init_g, dim3(count), dim3(64), 0, s, g);
+  hipLaunchKernelGGL(k_normalize_rows_g, dim3((nmax + 3) / 4, count), dim3(kRowThreads), 0, s, g);
+}
+void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,
+                                       double p, double mult, int binarize, int symtype,
+                                       int preserve_diag) {
+  int nmax;
+  const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_cut_from_partials_g, dim3((nmax + 3) / 4, count), dim3(256), 0, s, g, p);
+  const int t = (nmax + 31) / 32;
+  hipLaunchKernelGGL(k_threshold_symmetrize_g, dim3(t * (t + 1) / 2, count), dim3(256), 0, s, g,
+                     mult, binarize, symtype, preserve_diag);
+}
+void launch_scaling_vectors_group(hipStream_t s, const FrontItem* items, int count,
+                                  int laplacian_type, int row_normalized) {
+  int nmax;
+  const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_scaling_vectors_g, dim3((nmax + 255) / 256, count), dim3(256), 0, s, g,
+                     laplacian_type, row_normalized);
 }
 void launch_check_finite(hipStream_t s, const double* a, const double* b, int n, int* flag) {
   hipLaunchKernelGGL(k_check_finite, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, flag);

@@ -64,6 +64,22 @@ void launch_gemm_nt(hipStream_t s, const double* A, int lda, const double* B,
                     int epilogue, bool symmetric, double* splitk_ws,
                     const int2* tilemap, const GemmRowStats* rs = nullptr,
                     const double* addend = nullptr);
+// One member of a grouped symmetric product C = A A^T (launch_gemm_nt_group); n = 0: idle.
+// partial_max / partial_sum: n x gemm_tile_dim(n) doubles each (sum only for stats mode 1).
+struct GemmGroupItem {
+  const double* A = nullptr;
+  int lda = 0;
+  double* C = nullptr;
+  int ldc = 0;
+  int n = 0, K = 0;
+  const int2* tilemap = nullptr;
+  double* partial_max = nullptr;
+  double* partial_sum = nullptr;
+  double* rowmax = nullptr;
+  double* rowsum = nullptr;
+};
+void launch_gemm_nt_group(hipStream_t s, const GemmGroupItem* items, int count, int epilogue,
+                          int stats_mode);
 // patch-ordered (ti, tj) list of the upper triangle, for `tilemap` (symmetric launches)
 void gemm_build_sym_tilemap(int nt, std::vector<int2>* out);
 int gemm_tile_dim(int n);
@@ -215,6 +231,36 @@ struct RitzItem {    // E[:, 0:cols] (column-major, lde) = normalise(t .* (Q[:, 
   int lde, n;
   const double* tvec;
 };
+// One member of a batch group in the stages before its eigensolver (ICASSP2018 refinement
+// sequence with the fused kernels): where its arena keeps what.  n = 0: idle.
+struct FrontItem {
+  const double* X;   // (n, d) embeddings, row pitch ldx
+  double* Xn;        // unit rows
+  int ldx, n, d, ldn;
+  double* A0;        // affinity
+  double* B1;        // blurred, later the Diffuse result
+  double* B2;        // thresholded + symmetrised
+  const double* cropval;
+  double* rmpart;    // per-strip row maxima of the blur
+  int blur_cols;     // strips per row (blur_tile_columns)
+  double* cut;
+  const double* rowmax;
+  const double* rowsum;
+  double* cvec;
+  double* pvec;
+  double* tvec;
+  int* symflag;
+  int* flags;
+};
+void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count);
+bool blur_group_supported(int n_min, int radius);
+void launch_gaussian_blur_group(hipStream_t s, const FrontItem* items, int count, int radius,
+                                const double* weights_dev);
+void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,
+                                       double p, double mult, int binarize, int symtype,
+                                       int preserve_diag);
+void launch_scaling_vectors_group(hipStream_t s, const FrontItem* items, int count,
+                                  int laplacian_type, int row_normalized);
 struct GatherItem {  // T == nullptr: idle
   const double* T;
   const double* G;

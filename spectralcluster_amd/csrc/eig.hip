@@ -1349,12 +1349,14 @@ void launch_lz_link_group(hipStream_t s, LzGroupMember* mem, int count, int m, i
                           bool zero_T) {
   GroupOf<LzStep> g;
   memset(&g, 0, sizeof(g));
-  const int rows = lz_rows_for(m);
+  static const int rows_cap = getenv("SC_GROUP_LZ_ROWS") ? atoi(getenv("SC_GROUP_LZ_ROWS")) : 256;
+  const int rows = std::min(lz_rows_for(m), rows_cap);
   int nwg = 0;
   for (int z = 0; z < count; ++z) {
     if (!mem[z].active) continue;  // n stays 0: every workgroup of the member returns
     g.s[z] = lz_make_step(mem[z].ws, &mem[z].chain, mem[z].n, m, pre, next, store_col,
                           mem[z].vs_scale, col0, init_random, seed, zero_T);
+    mem[z].chain.nparts = (mem[z].n + rows - 1) / rows;  // (rows may be capped here)
     nwg = std::max(nwg, mem[z].chain.nparts);
   }
   if (nwg == 0) return;

@@ -865,7 +865,8 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
     const int seen = lead->gconv_seen;
     int done_by = 0;
     for (int b = 0; b <= m / kEigBlock && b < 16; ++b) done_by += lead->gconv_hist[b];
-    const bool speculate = seen < 2 * kGroupMax || done_by * 4 < seen * 3;
+    static const bool never = getenv("SC_GROUP_NO_SPECULATE") != nullptr;
+    const bool speculate = !never && (seen < 2 * kGroupMax || done_by * 4 < seen * 3);
     if (speculate) SC_TRY(block_step(m));
     const double t_sync0 = trace ? now_us() : 0.0;
     SC_HIP(lead, hipEventSynchronize(lead->gcheck_ev));

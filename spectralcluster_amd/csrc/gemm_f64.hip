@@ -244,7 +244,12 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   // tiles are taken by whoever finishes first.
   for (int iter = 0;; ++iter) {
   if (iter > 0) {
-    if (!persist || queue == nullptr) break;
+    if constexpr (GROUPED) {
+      // grouped form, optional: a workgroup walks the tile list with the grid as its stride
+      if ((int)blockIdx.x + iter * (int)gridDim.x >= grp->first[kGroupMax]) break;
+    } else {
+      if (!persist || queue == nullptr) break;
+    }
     __syncthreads();  // the previous item's epilogue is done with the LDS
   }
   if (edge_prio & 1) __builtin_amdgcn_s_setprio(3);
@@ -262,6 +267,7 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   // with the MFMA pipe idle).  Which workgroup computes which item does not change any result.
   int item_blk = (int)blockIdx.x;
   if constexpr (GROUPED) {
+    item_blk += iter * (int)gridDim.x;
     int z = 0;
     while (item_blk >= grp->first[z + 1]) ++z;  // (uniform: scalar loads from the kernel arguments)
     const GemmMember& g = grp->m[z];
@@ -1009,11 +1015,16 @@ void launch_gemm_nt_group(hipStream_t s, const GemmGroupItem* items, int count, 
   grp.first[kGroupMax] = total;
   if (total == 0) return;
   static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 3;
+  // (SC_GEMM_GROUP_PERSIST=1: one workgroup per resident slot walking the tile list with the
+  //  grid as its stride -- measured 2 % slower on config 5 than one workgroup per tile: no
+  //  balancing between slots, and the loop-carried state costs a few spilled registers)
+  static const int persist = getenv("SC_GEMM_GROUP_PERSIST") ? atoi(getenv("SC_GEMM_GROUP_PERSIST")) : 0;
+  const int grid = persist ? std::min(total, gemm_resident_slots()) : total;
   if (epilogue == kEpiAffinity)
-    hipLaunchKernelGGL((k_gemm_nt_g<kEpiAffinity>), dim3(total), dim3(256), 0, s, grp, stats_mode,
+    hipLaunchKernelGGL((k_gemm_nt_g<kEpiAffinity>), dim3(grid), dim3(256), 0, s, grp, stats_mode,
                        edge_prio);
   else
-    hipLaunchKernelGGL((k_gemm_nt_g<kEpiNone>), dim3(total), dim3(256), 0, s, grp, stats_mode,
+    hipLaunchKernelGGL((k_gemm_nt_g<kEpiNone>), dim3(grid), dim3(256), 0, s, grp, stats_mode,
                        edge_prio);
   if (stats_mode != 0)
     hipLaunchKernelGGL(k_gemm_stats_reduce_g, dim3((nmax + 255) / 256, count), dim3(256), 0, s,

@@ -46,6 +46,50 @@ def test_grouped_labels_equal_single_calls(group, lap):
     np.testing.assert_allclose(w[idx], w1[idx], rtol=2e-6)
 
 
+@pytest.mark.parametrize("lap", [sca.LaplacianType.Unnormalized, sca.LaplacianType.RandomWalk])
+def test_grouped_front_with_the_other_laplacians(lap):
+  """the grouped scaling-vector launch carries the Laplacian type"""
+  utts = mixed_utterances(18, seed=61, lo=520, hi=1500)
+  c = icassp(laplacian_type=lap, max_clusters=10)
+  got = c.predict_batch(utts, group=16)
+  for u, lab in zip(utts, got):
+    assert np.array_equal(lab, c.predict(u))
+
+
+def test_other_refinement_sequences_take_the_member_front():
+  """The grouped front covers the ICASSP2018 sequence with its fusions; any other sequence
+  (here: percentile threshold without blur, and the full sequence with a diagonal-preserving
+  threshold) runs the single-call stages member by member, then the lockstep chains."""
+  utts = mixed_utterances(14, seed=71, lo=520, hi=1400, d=32)
+  seqs = [
+      sca.RefinementOptions(
+          p_percentile=0.9, thresholding_soft_multiplier=0.01,
+          thresholding_type=sca.ThresholdType.Percentile,
+          refinement_sequence=[sca.RefinementName.RowWiseThreshold, sca.RefinementName.Symmetrize,
+                               sca.RefinementName.Diffuse, sca.RefinementName.RowWiseNormalize]),
+      sca.RefinementOptions(
+          gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
+          thresholding_preserve_diagonal=True,
+          refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE),
+  ]
+  for opts in seqs:
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=opts)
+    got = c.predict_batch(utts, group=8)
+    for u, lab in zip(utts, got):
+      assert np.array_equal(lab, c.predict(u))
+
+
+def test_blur_radius_eight_in_the_grouped_front():
+  opts = sca.RefinementOptions(gaussian_blur_sigma=2, p_percentile=0.95,
+                               thresholding_soft_multiplier=0.01,
+                               refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=opts)
+  utts = mixed_utterances(10, seed=81, lo=600, hi=2300, d=32)
+  got = c.predict_batch(utts, group=16)
+  for u, lab in zip(utts, got):
+    assert np.array_equal(lab, c.predict(u))
+
+
 def test_grouped_batch_vs_oracle():
   utts = mixed_utterances(12, seed=11, lo=140, hi=900, d=24)
   c = icassp()

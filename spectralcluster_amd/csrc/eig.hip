@@ -158,7 +158,7 @@ constexpr int kSymPitch = 34;  // doubles per row of a wave's 32 x 32 LDS patch
 __device__ __forceinline__ int sym_item_id(int I, int J, int nt) {
   return I * nt - I * (I - 1) / 2 + (J - I);
 }
-__global__ __launch_bounds__(256) void k_block_matvec_sym(
+__device__ __forceinline__ void block_matvec_sym_body(
     const double* __restrict__ S, int ld, int n, const double* __restrict__ Vs,
     double* __restrict__ pdirect, double* __restrict__ pmirror, int nt) {
   __shared__ __attribute__((aligned(16))) double smem[4 * 32 * kSymPitch];
@@ -285,9 +285,20 @@ __global__ __launch_bounds__(256) void k_block_matvec_sym(
     pmirror[item * (kSymTile * B) + e] =
         ((red[e] + red[kSymTile * B + e]) + red[2 * kSymTile * B + e]) + red[3 * kSymTile * B + e];
 }
+__global__ __launch_bounds__(256) void k_block_matvec_sym(
+    const double* __restrict__ S, int ld, int n, const double* __restrict__ Vs,
+    double* __restrict__ pdirect, double* __restrict__ pmirror, int nt) {
+  block_matvec_sym_body(S, ld, n, Vs, pdirect, pmirror, nt);
+}
+__global__ __launch_bounds__(256) void k_block_matvec_sym_g(const GroupOf<MatvecItem> g) {
+  const MatvecItem& a = g.s[blockIdx.y];
+  const int nt = (a.n + kSymTile - 1) / kSymTile;
+  if ((int)blockIdx.x >= nt * (nt + 1) / 2) return;  // (n = 0: idle member)
+  block_matvec_sym_body(a.S, a.ld, a.n, a.Vs, a.slabs, a.slabs + (size_t)(nt * (nt + 1) / 2) * kSymTile * B, nt);
+}
 
 // W[r, :] = p[r] V[r, :] + c[r] * (sum of the slabs of block row R = r / 128, fixed order)
-__global__ __launch_bounds__(256) void k_matvec_sym_reduce(
+__device__ __forceinline__ void matvec_sym_reduce_body(
     const double* __restrict__ pdirect, const double* __restrict__ pmirror, int nt, int n,
     const double* __restrict__ cvec, const double* __restrict__ pvec,
     const double* __restrict__ V, int ldv, double* __restrict__ W) {
@@ -316,6 +327,19 @@ __global__ __launch_bounds__(256) void k_matvec_sym_reduce(
   }
   if (row < n) W[(size_t)row * B + v] =
       __builtin_fma(cvec[row], acc, pvec[row] * V[(size_t)row * ldv + v]);
+}
+__global__ __launch_bounds__(256) void k_matvec_sym_reduce(
+    const double* __restrict__ pdirect, const double* __restrict__ pmirror, int nt, int n,
+    const double* __restrict__ cvec, const double* __restrict__ pvec,
+    const double* __restrict__ V, int ldv, double* __restrict__ W) {
+  matvec_sym_reduce_body(pdirect, pmirror, nt, n, cvec, pvec, V, ldv, W);
+}
+__global__ __launch_bounds__(256) void k_matvec_sym_reduce_g(const GroupOf<MatvecItem> g) {
+  const MatvecItem& a = g.s[blockIdx.y];
+  const int nt = (a.n + kSymTile - 1) / kSymTile;
+  if ((int)blockIdx.x >= nt * 4) return;
+  matvec_sym_reduce_body(a.slabs, a.slabs + (size_t)(nt * (nt + 1) / 2) * kSymTile * B, nt, a.n,
+                         a.cvec, a.pvec, a.V, a.ldv, a.W);
 }
 
 // ---------------------------------------------------------------- projections
@@ -1364,7 +1388,11 @@ void launch_lz_link_group(hipStream_t s, LzGroupMember* mem, int count, int m, i
   else if (rows == 128) launch_rows_group<128>(s, g, m, nwg, count);
   else launch_rows_group<64>(s, g, m, nwg, count);
 }
-void launch_block_matvec_group(hipStream_t s, const MatvecItem* items, int count) {
+// `symmetric`: from the upper triangles only (k_block_matvec_sym + its reduce; every member
+// needs its slab workspace, MatvecItem::slabs).  The matrices of a group rarely fit the
+// caches together, so the halved traffic pays from much smaller n than for a single call.
+void launch_block_matvec_group(hipStream_t s, const MatvecItem* items, int count,
+                               bool symmetric) {
   GroupOf<MatvecItem> g;
   memset(&g, 0, sizeof(g));
   int nmax = 0;
@@ -1373,6 +1401,12 @@ void launch_block_matvec_group(hipStream_t s, const MatvecItem* items, int count
     nmax = std::max(nmax, items[z].n);
   }
   if (nmax == 0) return;
+  if (symmetric) {
+    const int nt = (nmax + kSymTile - 1) / kSymTile;
+    hipLaunchKernelGGL(k_block_matvec_sym_g, dim3(nt * (nt + 1) / 2, count), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(k_matvec_sym_reduce_g, dim3(nt * 4, count), dim3(256), 0, s, g);
+    return;
+  }
   hipLaunchKernelGGL(k_block_matvec_g, dim3((nmax + 15) / 16, count), dim3(64 * kMvWaves), 0,
                      s, g);
 }

@@ -787,6 +787,13 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
     mem[z].passes = 0;
     mem[z].basis = 0;
   }
+  // upper-triangle matvec once the group's matrices no longer fit the caches together
+  size_t matrix_bytes = 0;
+  for (int z = 0; z < count; ++z) matrix_bytes += (size_t)mem[z].n * mem[z].ld * sizeof(double);
+  static const size_t sym_min_bytes = getenv("SC_GROUP_MATVEC_SYM_MIN_MB")
+                                          ? (size_t)atol(getenv("SC_GROUP_MATVEC_SYM_MIN_MB")) << 20
+                                          : (size_t)128 << 20;
+  const bool sym_matvec = matrix_bytes >= sym_min_bytes;
   const uint64_t seed = 0x5eed5eedull;
   launch_lz_link_group(s, lz, count, 0, 0, 4, -1, 0, true, seed, false);
   launch_lz_link_group(s, lz, count, 0, 4, 3, -1, 0, false, 0, true);
@@ -817,9 +824,10 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
       mv[z].ldv = kLdq;
       mv[z].Vs = ptr<double>(h->Vs);
       mv[z].W = ptr<double>(h->W);
+      mv[z].slabs = ptr<double>(h->mvsym);
       ++mem[z].passes;
     }
-    launch_block_matvec_group(s, mv, count);
+    launch_block_matvec_group(s, mv, count, sym_matvec);
     const int m = m_before + kEigBlock;
     launch_lz_link_group(s, lz, count, m, 0, 1, -1, m - kEigBlock, false, 0, false);
     launch_lz_link_group(s, lz, count, m, 1, 2, -1, m - kEigBlock, false, 0, false);

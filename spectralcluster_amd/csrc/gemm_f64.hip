@@ -246,7 +246,7 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   if (iter > 0) {
     if constexpr (GROUPED) {
       // grouped form, optional: a workgroup walks the tile list with the grid as its stride
-      if ((int)blockIdx.x + iter * (int)gridDim.x >= grp->first[kGroupMax]) break;
+      if (!persist || (int)blockIdx.x + iter * (int)gridDim.x >= 8 * xcd_chunk) break;
     } else {
       if (!persist || queue == nullptr) break;
     }
@@ -267,7 +267,13 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   // with the MFMA pipe idle).  Which workgroup computes which item does not change any result.
   int item_blk = (int)blockIdx.x;
   if constexpr (GROUPED) {
+    // XCD-aware order (workgroup ids go round-robin over the 8 XCDs, each with its own L2):
+    // XCD x walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the concatenated,
+    // patch-ordered tile lists, so the ~64 tiles it has in flight come from one 8 x 8 patch of
+    // one member and share 8 + 8 operand panels (by block index they would share 1 + 8)
     item_blk += iter * (int)gridDim.x;
+    item_blk = (item_blk & 7) * xcd_chunk + (item_blk >> 3);
+    if (item_blk >= grp->first[kGroupMax]) continue;  // (the runs' ragged end)
     int z = 0;
     while (item_blk >= grp->first[z + 1]) ++z;  // (uniform: scalar loads from the kernel arguments)
     const GemmMember& g = grp->m[z];
@@ -346,7 +352,7 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
     sync_size = min(64, xcd_chunk - (grp << 6));
     sync_cnt = ksync + ((size_t)(tile & 7) * ngrp + grp) * kSyncWindows;
   }
-  if (whole && xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
+  if (!GROUPED && whole && xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
   if (!whole) stats.mode = 0;  // k_gemm_tail_stats covers the split tiles
   if (tilemap != nullptr) {
     const int2 t = tilemap[tile];
@@ -674,11 +680,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
 // every workgroup: one whole tile of one member (no queue, no split, no probe)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_g(const GemmGroup grp, int stats_mode,
-                                                     int edge_prio) {
+                                                     int edge_prio, int xcd_chunk, int persist) {
   GemmStats stats{nullptr, nullptr, stats_mode, nullptr};
   gemm_nt_body<EPI, true, true>(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0, 0x7fffffff, 1,
-                                nullptr, nullptr, nullptr, 0, stats, nullptr, nullptr, edge_prio,
-                                0, 0, &grp);
+                                nullptr, nullptr, nullptr, xcd_chunk, stats, nullptr, nullptr,
+                                edge_prio, 0, persist, &grp);
 }
 
 // rowmax / rowsum of every member from its per-tile partials (k_gemm_stats_reduce, grouped)
@@ -1019,13 +1025,14 @@ void launch_gemm_nt_group(hipStream_t s, const GemmGroupItem* items, int count, 
   //  grid as its stride -- measured 2 % slower on config 5 than one workgroup per tile: no
   //  balancing between slots, and the loop-carried state costs a few spilled registers)
   static const int persist = getenv("SC_GEMM_GROUP_PERSIST") ? atoi(getenv("SC_GEMM_GROUP_PERSIST")) : 0;
-  const int grid = persist ? std::min(total, gemm_resident_slots()) : total;
+  const int xcd_chunk = (total + 7) / 8;
+  const int grid = persist ? std::min(8 * xcd_chunk, gemm_resident_slots()) : 8 * xcd_chunk;
   if (epilogue == kEpiAffinity)
     hipLaunchKernelGGL((k_gemm_nt_g<kEpiAffinity>), dim3(grid), dim3(256), 0, s, grp, stats_mode,
-                       edge_prio);
+                       edge_prio, xcd_chunk, persist);
   else
     hipLaunchKernelGGL((k_gemm_nt_g<kEpiNone>), dim3(grid), dim3(256), 0, s, grp, stats_mode,
-                       edge_prio);
+                       edge_prio, xcd_chunk, persist);
   if (stats_mode != 0)
     hipLaunchKernelGGL(k_gemm_stats_reduce_g, dim3((nmax + 255) / 256, count), dim3(256), 0, s,
                        red, stats_mode);

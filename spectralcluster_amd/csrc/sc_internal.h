@@ -221,6 +221,7 @@ struct MatvecItem {  // n = 0: idle member
   int ldv;
   const double* Vs;
   double* W;
+  double* slabs;  // matvec_sym_workspace_doubles(n) doubles (symmetric form only)
 };
 struct RitzItem {    // E[:, 0:cols] (column-major, lde) = normalise(t .* (Q[:, 0:m] Y[:, 0:cols]))
   const double* Q;
@@ -278,7 +279,8 @@ struct LzGroupMember {
 void launch_lz_link_group(hipStream_t s, LzGroupMember* mem, int count, int m, int pre,
                           int next, int store_col, int col0, bool init_random, uint64_t seed,
                           bool zero_T);
-void launch_block_matvec_group(hipStream_t s, const MatvecItem* items, int count);
+void launch_block_matvec_group(hipStream_t s, const MatvecItem* items, int count,
+                               bool symmetric);
 void launch_ritz_vectors_group(hipStream_t s, const RitzItem* items, int count);
 // Dense symmetric eigensolver (one workgroup, cyclic Jacobi, matrix in LDS).
 // mode 0: A = T (m x m, ldt).  mode 1: A_ij = c_i c_j S_ij + delta_ij p_i.

@@ -65,8 +65,23 @@ def dump(path, frac, ms):
         (s - t0) / 1e3, (e - s) / 1e3, q, st, k[:34], gx // max(wx, 1), gy, wx, lds))
 
 
+def listing(path, needle):
+  """every launch whose kernel name contains `needle`: start, duration, grid"""
+  cur = sqlite3.connect(path).cursor()
+  rows = list(cur.execute(
+      "select name, start, end, grid_x, grid_y, grid_z, workgroup_x from kernels order by start"))
+  t0 = rows[0][1]
+  for name, s, e, gx, gy, gz, wx in rows:
+    if needle in name:
+      k = name.split("(")[0].replace("void ", "").replace("sc::", "")
+      print("%10.2f ms %9.1f us  %-30s %dx%dx%d" % ((s - t0) / 1e6, (e - s) / 1e3, k[:30],
+                                                   gx // max(wx, 1), gy, gz))
+
+
 if __name__ == "__main__":
-  if len(sys.argv) > 3 and sys.argv[2] == "dump":
+  if len(sys.argv) > 3 and sys.argv[2] == "list":
+    listing(sys.argv[1], sys.argv[3])
+  elif len(sys.argv) > 3 and sys.argv[2] == "dump":
     dump(sys.argv[1], float(sys.argv[3]), float(sys.argv[4]) if len(sys.argv) > 4 else 2.0)
   else:
     main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5)

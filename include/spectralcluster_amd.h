@@ -264,6 +264,12 @@ int sc_apply_constraint(sc_handle h, const sc_config* cfg);
 /* affinity + eig_ncluster + cluster on the resident embeddings (no H2D of X) */
 int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* labels,
                     sc_diag* diag);
+/* one AutoTune search level (autotune.py:98-111): sc_eig_ncluster for `count` values of
+ * p_percentile on the resident affinity; diags[i] reports what sc_eig_ncluster would for
+ * p_values[i].  The values of a level differ only in the row threshold: the stages after it
+ * run as grouped launches, the eigensolvers in lockstep.  Leaves no eigenvectors resident. */
+int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const double* p_values, int count,
+                          sc_diag* diags);
 /* a Python `for` over predict() in the reference: count
  * independent utterances, xs[i] is (ns[i], d); labels[i] has ns[i] slots. */
 int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,

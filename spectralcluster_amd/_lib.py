@@ -179,6 +179,8 @@ PROTOTYPES = {
                                                 ctypes.POINTER(ScConfig),
                                                 ctypes.POINTER(_c_int64_p),
                                                 ctypes.POINTER(ScDiag), ctypes.c_int]),
+    "sc_eig_ncluster_sweep": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), _c_double_p,
+                                             ctypes.c_int, ctypes.POINTER(ScDiag)]),
     "sc_predict_batch_grouped": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),
                                                 _c_int_p, ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ScConfig),

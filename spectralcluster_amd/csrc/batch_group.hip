@@ -236,7 +236,7 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
     m.front.symmetric = true;
     m.front.folded_rownorm = true;
   }
-  launch_front_begin_group(s, fi, count);
+  launch_front_begin_group(s, fi, count, true);
   launch_gemm_nt_group(s, aff, count, kEpiAffinity, 2);
   launch_gaussian_blur_group(s, fi, count, cfg->blur_radius, ptr<double>(lead->blurw));
   launch_threshold_symmetrize_group(s, fi, count, cfg->p_percentile, cfg->soft_multiplier,
@@ -499,3 +499,144 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     SC_TRY(sc_predict(h, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr));
   return SC_OK;
 }
+
+// ------------------------------------------------------------------------------
+// AutoTune: one search level as a group (reference autotune.py:98-111)
+// ------------------------------------------------------------------------------
+// sc_eig_ncluster for `count` values of p_percentile on the resident affinity.  The values of
+// a level differ in nothing but the row threshold: CropDiagonal + GaussianBlur run once, then
+// the members (one per value, up to kGroupMax per round) go through threshold + symmetrise,
+// the Diffuse GEMM (all members' tiles in one launch) and the scaling vectors as grouped
+// launches and through ONE lockstep block Lanczos (sym_topk_group, eigenvalues + eigengap
+// decision only).  diags[i] is what sc_eig_ncluster would report for p_values[i]; no
+// eigenvectors are left resident (evaluate the winner with sc_eig_ncluster).  Configurations
+// the grouped stages do not cover are evaluated one by one.
+extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const double* p_values,
+                                     int count, sc_diag* diags) {
+  if (!h) return SC_ERR_INVALID;
+  if (!p_values || !diags || count < 0) return fail(h, SC_ERR_INVALID, "NULL argument");
+  SC_TRY(validate_config(h, cfg));
+  if (!h->have_affinity) return fail(h, SC_ERR_INVALID, "no affinity resident");
+  SC_HIP(h, hipSetDevice(h->device));
+  const int n = h->n, ld = h->ldn;
+  const EigRequest rq = make_eig_request(cfg);
+  auto one_by_one = [&](int i) -> int {
+    sc_config c = *cfg;
+    c.p_percentile = p_values[i];
+    return sc_eig_ncluster(h, &c, diags + i);
+  };
+  const bool grouped = count > 1 && grouped_front_covers(cfg) && h->affinity_symmetric &&
+                       !constraint_active(h, cfg, false) &&
+                       blur_group_supported(n, cfg->blur_radius) &&
+                       sym_group_eligible(n, rq, true) && !getenv("SC_SWEEP_ONE_BY_ONE");
+  if (!grouped) {
+    for (int i = 0; i < count; ++i) SC_TRY(one_by_one(i));
+    return SC_OK;
+  }
+  hipStream_t s = h->stream;
+  // ---- shared by every value: CropDiagonal's value and the blurred matrix (+ row maxima)
+  const double* crop = ptr<double>(h->cropval);
+  if (!h->have_cropval) {
+    launch_crop_value(s, ptr<double>(h->A0), n, ld, ptr<double>(h->dvec));
+    crop = ptr<double>(h->dvec);
+  }
+  SC_TRY(upload_blur_weights(h, cfg));
+  if (!launch_gaussian_blur_fused(s, ptr<double>(h->A0), ptr<double>(h->B1), n, ld,
+                                  cfg->blur_radius, ptr<double>(h->blurw), crop,
+                                  ptr<double>(h->rmpart)))
+    return fail(h, SC_ERR_HIP, "fused blur not taken");
+  SC_TRY(check_last(h, "sweep blur launch"));
+  memset(h->gconv_hist, 0, sizeof(h->gconv_hist));
+  h->gconv_seen = 0;
+  std::vector<int> later;  // values whose solve left the common path
+  for (int base = 0; base < count; base += kGroupMax) {
+    const int cnt = std::min(kGroupMax, count - base);
+    FrontItem fi[kGroupMax];
+    GemmGroupItem dif[kGroupMax];
+    GroupEigMember em[kGroupMax];
+    memset(fi, 0, sizeof(fi));
+    const int nt = gemm_tile_dim(n);
+    for (int z = 0; z < cnt; ++z) {
+      sc_handle hz = nullptr;
+      SC_TRY(group_slot(h, z, &hz));
+      int rc = sc_reserve(hz, n, 0);
+      if (rc == SC_OK) rc = ensure_tilemap(hz, n);
+      if (rc != SC_OK) return fail(h, rc, hz->err);
+      hz->n = n;
+      hz->ldn = ld;
+      hz->n_vec = 0;
+      FrontItem& f = fi[z];
+      f.n = n;
+      f.ldn = ld;
+      f.B1 = ptr<double>(h->B1);  // the shared blurred matrix: read only
+      f.B2 = ptr<double>(hz->B2);
+      f.rmpart = ptr<double>(h->rmpart);
+      f.blur_cols = blur_tile_columns(n, cfg->blur_radius);
+      f.cut = ptr<double>(hz->cut);
+      f.rowmax = ptr<double>(hz->rowmax);
+      f.rowsum = ptr<double>(hz->rowsum);
+      f.cvec = ptr<double>(hz->cvec);
+      f.pvec = ptr<double>(hz->pvec);
+      f.tvec = ptr<double>(hz->tvec);
+      f.symflag = h->affinity_from_embeddings ? ptr<int>(h->symflag) : nullptr;
+      f.flags = ptr<int>(hz->flags);
+      f.p_own = p_values[base + z];
+      dif[z] = GemmGroupItem();
+      dif[z].A = f.B2;
+      dif[z].lda = ld;
+      dif[z].C = ptr<double>(hz->B1);
+      dif[z].ldc = ld;
+      dif[z].n = n;
+      dif[z].K = n;
+      dif[z].tilemap = hz->tilemap_cur;
+      dif[z].partial_max = ptr<double>(hz->statp);
+      dif[z].partial_sum = ptr<double>(hz->statp) + (size_t)n * nt;
+      dif[z].rowmax = ptr<double>(hz->rowmax);
+      dif[z].rowsum = ptr<double>(hz->rowsum);
+      em[z] = GroupEigMember();
+      em[z].h = hz;
+      em[z].S = ptr<double>(hz->B1);
+      em[z].ld = ld;
+      em[z].n = n;
+      em[z].rq = rq;
+    }
+    {  // (the init kernel must not clear the shared symflag word)
+      FrontItem init[kGroupMax];
+      memcpy(init, fi, sizeof(init));
+      for (int z = 0; z < cnt; ++z) init[z].symflag = nullptr;
+      launch_front_begin_group(s, init, cnt, false);
+    }
+    launch_threshold_symmetrize_group(s, fi, cnt, cfg->p_percentile, cfg->soft_multiplier,
+                                      cfg->binarize, cfg->symmetrize_type,
+                                      cfg->preserve_diagonal);
+    launch_gemm_nt_group(s, dif, cnt, kEpiNone, 1);
+    launch_scaling_vectors_group(s, fi, cnt, cfg->laplacian_type, 1);
+    SC_TRY(check_last(h, "sweep launch"));
+    SC_TRY(sym_topk_group(h, em, cnt, false));
+    for (int z = 0; z < cnt; ++z) {
+      sc_diag* dg = diags + base + z;
+      if (em[z].status != 0) {
+        later.push_back(base + z);  // (after the rounds: it overwrites the shared blur)
+        continue;
+      }
+      memset(dg, 0, sizeof(*dg));
+      dg->n = n;
+      dg->n_clusters_raw = em[z].dc.n_clusters_raw;
+      dg->max_delta = em[z].dc.max_delta;
+      dg->eig_descending = rq.descend;
+      dg->n_eigenvalues = std::min((int)em[z].w.size(), SC_MAX_EIG);
+      for (int i = 0; i < dg->n_eigenvalues; ++i) dg->eigenvalues[i] = em[z].w[i];
+      dg->symmetry_state = 2;
+      dg->eig_path = SC_EIG_PATH_BLOCK_LANCZOS;
+      dg->eig_matvec_passes = em[z].passes;
+      dg->eig_block = kEigBlock;
+      dg->eig_basis = em[z].basis;
+      dg->eig_max_residual = em[z].dc.max_resid;
+    }
+  }
+  SC_HIP(h, hipStreamSynchronize(s));
+  for (int i : later) SC_TRY(one_by_one(i));  // the single-call solver
+  h->n_vec = 0;  // nothing of any member is resident in this handle
+  return SC_OK;
+}
+

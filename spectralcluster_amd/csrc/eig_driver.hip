@@ -742,10 +742,10 @@ static double now_us() {
   return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 
-bool sym_group_eligible(int n, const EigRequest& rq) {
+bool sym_group_eligible(int n, const EigRequest& rq, bool any_size) {
   static const int sym_min_n = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N"))
                                                             : 4096;
-  return n > kDenseMax && n < sym_min_n && !wants_full_spectrum(rq) &&
+  return n > kDenseMax && (any_size || n < sym_min_n) && !wants_full_spectrum(rq) &&
          getenv("SC_EIG_HOST_CHAIN") == nullptr && getenv("SC_EIG_DEVICE_RR") == nullptr;
 }
 
@@ -766,7 +766,7 @@ static int ensure_group_staging(sc_handle lead) {
   return SC_OK;
 }
 
-int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
+int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vectors) {
   if (count < 1 || count > kGroupMax) return fail(lead, SC_ERR_INVALID, "group size");
   hipStream_t s = lead->stream;
   SC_TRY(ensure_group_staging(lead));
@@ -953,7 +953,7 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count) {
             us_host);
   // ---- Ritz vectors of every solved member: E = normalise(t .* (Q Y)), the coefficient
   //      matrices of all of them in one upload
-  if (!any_solved) return SC_OK;
+  if (!any_solved || !want_vectors) return SC_OK;
   RitzItem rz[kGroupMax];
   memset(rz, 0, sizeof(rz));
   int last = -1;

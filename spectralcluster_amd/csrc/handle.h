@@ -275,8 +275,10 @@ struct GroupEigMember {
 // Block Lanczos of up to kGroupMax members in lockstep: one launch per chain link / matvec
 // for the whole group, one host synchronisation per Rayleigh-Ritz check for the whole group.
 // Leaves Ritz vectors in every solved member's h->E (h->n_vec set).
-int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count);
-bool sym_group_eligible(int n, const EigRequest& rq);
+// `want_vectors` false: eigenvalues and the eigengap decision only (AutoTune sweep).
+int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vectors = true);
+// `any_size`: also n >= 4096 (the group takes the upper-triangle matvec there)
+bool sym_group_eligible(int n, const EigRequest& rq, bool any_size = false);
 
 // `scratch`: a free n x ld matrix (the dense full-spectrum path materialises Op there)
 int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq, sc_diag* diag,

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kRowThreads) void k_normalize_rows_g(const GroupOf<
 __global__ void k_front_words_init_g(const GroupOf<FrontItem> g) {
   const FrontItem& a = g.s[blockIdx.x];
   if (a.n <= 0) return;
-  if (threadIdx.x == 0) a.symflag[1] = 0;
+  if (threadIdx.x == 0 && a.symflag != nullptr) a.symflag[1] = 0;
   if (threadIdx.x >= 12 && threadIdx.x < 16) a.flags[threadIdx.x] = 0;
 }
 
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void k_cut_from_partials_g(const GroupOf<Front
                                                              double p) {
   const FrontItem& a = g.s[blockIdx.y];
   if ((int)blockIdx.x * 4 >= a.n) return;
-  cut_from_partials_body(a.rmpart, a.n, a.blur_cols, p, a.cut);
+  // (p_own: the members of an AutoTune sweep differ in nothing but their p_percentile)
+  cut_from_partials_body(a.rmpart, a.n, a.blur_cols, a.p_own > 0.0 ? a.p_own : p, a.cut);
 }
 __global__ __launch_bounds__(kRowThreads) void k_cut_from_rows(
     const double* __restrict__ in, int n, int ld, double p, double* __restrict__ cut,
@@ -497,7 +498,8 @@ __global__ void k_scaling_vectors_g(const GroupOf<FrontItem> g, int lap, int row
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   scaling_vectors_body(a.rowmax, a.rowsum, a.n, lap, rownorm, a.cvec, a.pvec, a.tvec);
-  if (!isfinite(a.cvec[i]) || !isfinite(a.pvec[i]) || (i == 0 && a.symflag[1] != 0))
+  if (!isfinite(a.cvec[i]) || !isfinite(a.pvec[i]) ||
+      (i == 0 && a.symflag != nullptr && a.symflag[1] != 0))
     a.flags[12] = 1;
 }
 
@@ -657,12 +659,15 @@ static GroupOf<FrontItem> front_pack(const FrontItem* items, int count, int* nma
   }
   return g;
 }
-void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count) {
+void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count,
+                              bool normalize_rows) {
   int nmax;
   const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
   if (nmax == 0) return;
   hipLaunchKernelGGL(k_front_words_init_g, dim3(count), dim3(64), 0, s, g);
-  hipLaunchKernelGGL(k_normalize_rows_g, dim3((nmax + 3) / 4, count), dim3(kRowThreads), 0, s, g);
+  if (normalize_rows)
+    hipLaunchKernelGGL(k_normalize_rows_g, dim3((nmax + 3) / 4, count), dim3(kRowThreads), 0, s,
+                       g);
 }
 void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,
                                        double p, double mult, int binarize, int symtype,

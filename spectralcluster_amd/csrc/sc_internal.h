@@ -250,10 +250,12 @@ struct FrontItem {
   double* cvec;
   double* pvec;
   double* tvec;
-  int* symflag;
+  int* symflag;      // [1]: a zero / non-finite embedding row was seen (may be null)
   int* flags;
+  double p_own;      // > 0: this member's own p_percentile (AutoTune sweep)
 };
-void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count);
+void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count,
+                              bool normalize_rows);
 bool blur_group_supported(int n_min, int radius);
 void launch_gaussian_blur_group(hipStream_t s, const FrontItem* items, int count, int radius,
                                 const double* weights_dev);

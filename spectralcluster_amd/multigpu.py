@@ -274,16 +274,23 @@ def predict_batch_sharded(
 
 def autotune_sharded(
     comm: Comm,
-    evaluate_fn: typing.Callable[[float], typing.Tuple[float, int]],
-    grid: typing.Sequence[float]) -> typing.Tuple[np.ndarray, np.ndarray]:
+    evaluate_fn: typing.Optional[typing.Callable[[float], typing.Tuple[float, int]]],
+    grid: typing.Sequence[float],
+    evaluate_share_fn: typing.Optional[typing.Callable] = None
+) -> typing.Tuple[np.ndarray, np.ndarray]:
   """One AutoTune search level (reference autotune.py:98-111): rank r evaluates
-  grid[r::world]; `evaluate_fn(p) -> (ratio, n_clusters)`.  Returns the full
+  grid[r::world]; `evaluate_fn(p) -> (ratio, n_clusters)`, or `evaluate_share_fn(list of p)
+  -> list of (ratio, n_clusters)` for the rank's whole share at once.  Returns the full
   (ratios, n_clusters) arrays on every rank (all-gather of 2 doubles per p)."""
   world, rank = comm.size, comm.rank
   per = (len(grid) + world - 1) // world
   mine = np.full((per, 2), np.nan)
-  for s, i in enumerate(range(rank, len(grid), world)):
-    ratio, k = evaluate_fn(float(grid[i]))
+  share = [float(grid[i]) for i in range(rank, len(grid), world)]
+  if evaluate_share_fn is not None:
+    results = evaluate_share_fn(share) if share else []
+  else:
+    results = [evaluate_fn(p) for p in share]
+  for s, (ratio, k) in enumerate(results):
     mine[s, 0] = float(ratio)
     mine[s, 1] = float(k)
   blocks = comm.allgather_bytes(mine.tobytes())
@@ -342,20 +349,20 @@ def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
   if constrained and clusterer.constraint_options.apply_before_refinement:
     handle.check(handle.lib.sc_apply_constraint(handle.raw, clusterer.build_config()))
 
-  def evaluate(p):
-    # a rank that fails mid-sweep must still reach the all-gather, or the others hang:
-    # report NaN and raise after the level
+  def evaluate(ps):
+    # this rank's share of a level as one grouped sweep.  A rank that fails mid-sweep must
+    # still reach the all-gather, or the others hang: report NaN and raise after the level
     try:
-      diag = clusterer._eig_resident(handle, p)
-      return tuner.ratio(p, diag.max_delta), int(diag.n_clusters_raw)
+      diags = clusterer._eig_sweep(handle, ps)
+      return [(tuner.ratio(p, d.max_delta), int(d.n_clusters_raw)) for p, d in zip(ps, diags)]
     except Exception as exc:  # pylint: disable=broad-except
       evaluate.error = exc
-      return float("nan"), 0
+      return [(float("nan"), 0)] * len(ps)
 
   evaluate.error = None
 
   def evaluate_many(ps):
-    ratios, ks = autotune_sharded(comm, evaluate, ps)
+    ratios, ks = autotune_sharded(comm, None, ps, evaluate_share_fn=evaluate)
     if evaluate.error is not None:
       raise evaluate.error
     if np.isnan(ratios).any():

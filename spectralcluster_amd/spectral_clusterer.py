@@ -144,6 +144,16 @@ class SpectralClusterer:
     self.last_diag = diag
     return diag
 
+  def _eig_sweep(self, handle: _lib.Handle,
+                 p_values: typing.Sequence[float]) -> typing.List[_lib.ScDiag]:
+    """`_eig_resident` for every p of one AutoTune level (no eigenvectors left resident)."""
+    count = len(p_values)
+    diags = (_lib.ScDiag * count)()
+    ps = (ctypes.c_double * count)(*[float(p) for p in p_values])
+    handle.check(handle.lib.sc_eig_ncluster_sweep(handle.raw, self.build_config(), ps, count,
+                                                  diags), TypeError)
+    return list(diags)
+
   def consumed_eigenvalues(self) -> np.ndarray:
     """Every eigenvalue the last eigen call consumed, in the reference's order
     (`compute_sorted_eigenvectors`, utils.py:62-70): max_clusters + 1 of them, or all n
@@ -265,18 +275,19 @@ class SpectralClusterer:
             "contains RowWiseThreshold")
       evaluated = []
 
-      def p_percentile_to_ratio(p):
-        diag = self._eig_resident(handle, p)
-        evaluated.append(p)
-        return (self.autotune.ratio(p, diag.max_delta), p, int(diag.n_clusters_raw))
+      def evaluate_level(ps):
+        # one search level = one library call: the values of a level differ only in the row
+        # threshold, the device evaluates them as a group (sc_eig_ncluster_sweep)
+        diags = self._eig_sweep(handle, ps)
+        evaluated.extend(ps)
+        return [(self.autotune.ratio(p, d.max_delta), p, int(d.n_clusters_raw))
+                for p, d in zip(ps, diags)]
 
-      _, n_clusters, best_p = self.autotune.tune(p_percentile_to_ratio)
+      _, n_clusters, best_p = self.autotune.tune(None, evaluate_many=evaluate_level)
       # reference closure leaves refinement_options.p_percentile at the LAST
       # evaluated value (spectral_clusterer.py:277); keep that observable state
       self.refinement_options.p_percentile = evaluated[-1]
-      if evaluated[-1] != best_p:
-        self._eig_resident(handle, best_p)  # bring the winner's vectors back
-      diag = self.last_diag
+      diag = self._eig_resident(handle, best_p)  # the winner's vectors, resident
     else:
       diag = self._eig_resident(handle)
       n_clusters = int(diag.n_clusters_raw)

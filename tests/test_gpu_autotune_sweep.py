@@ -1,0 +1,69 @@
+"""One AutoTune search level as a group (sc_eig_ncluster_sweep): every p_percentile of the level
+gets what its own sc_eig_ncluster call reports -- eigengap decision, proxy input, consumed
+eigenvalues -- and predict() with AutoTune picks the same p and labels as before."""
+import numpy as np
+import pytest
+
+import spectralcluster_amd as sca
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def clusterer(lap, max_clusters, **kw):
+  return sca.SpectralClusterer(
+      min_clusters=2, max_clusters=max_clusters, laplacian_type=lap,
+      refinement_options=sca.RefinementOptions(
+          gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
+          refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE), **kw)
+
+
+@pytest.mark.parametrize("n,lap,count", [(700, None, 9), (1500, sca.LaplacianType.GraphCut, 20),
+                                         (4100, sca.LaplacianType.GraphCut, 5)])
+def test_sweep_reports_what_single_evaluations_report(n, lap, count):
+  x = so.blobs(n, 64, 5, seed=n)
+  c = clusterer(lap, 7 if lap is None else 12)
+  handle = c._handle()
+  c._upload(handle, x)
+  ps = [float(p) for p in np.linspace(0.55, 0.95, count)]
+  diags = c._eig_sweep(handle, ps)
+  for p, d in zip(ps, diags):
+    one = c._eig_resident(handle, p)
+    assert d.n_clusters_raw == one.n_clusters_raw, p
+    assert abs(d.max_delta - one.max_delta) <= 1e-6 * abs(one.max_delta), p
+    w, w1 = d.eigenvalue_array(), one.eigenvalue_array()
+    idx = so.consumed_eigen_indices(n, c.max_clusters, lap is None, w1, 1e-2)
+    np.testing.assert_allclose(w[idx], w1[idx], rtol=2e-6)
+    assert d.eig_path == 2 and d.n == n
+
+
+def test_sweep_falls_back_for_sequences_it_does_not_cover():
+  x = so.blobs(600, 32, 3, seed=6)
+  opts = sca.RefinementOptions(
+      p_percentile=0.9, thresholding_soft_multiplier=0.01,
+      refinement_sequence=[sca.RefinementName.RowWiseThreshold, sca.RefinementName.Symmetrize,
+                           sca.RefinementName.Diffuse, sca.RefinementName.RowWiseNormalize])
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=opts)
+  handle = c._handle()
+  c._upload(handle, x)
+  ps = [0.6, 0.8, 0.95]
+  for p, d in zip(ps, c._eig_sweep(handle, ps)):
+    one = c._eig_resident(handle, p)
+    assert d.n_clusters_raw == one.n_clusters_raw and d.max_delta == one.max_delta
+
+
+@pytest.mark.parametrize("lap", [None, sca.LaplacianType.GraphCut])
+def test_autotune_predict_vs_oracle(lap):
+  """two search levels through the grouped sweep: same winner and labels as the oracle's
+  one-by-one search (reference autotune.py:76-132)"""
+  x = so.blobs(900, 48, 4, seed=17)
+  c = clusterer(lap, 8, autotune=sca.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95,
+                                              init_search_step=0.05, search_level=2))
+  got = c.predict(x)
+  cfg = so.icassp2018_config(laplacian_type=0 if lap is None else 4, max_clusters=8)
+  vecs, k, best_p, seen = so.autotune_search(so.affinity(x), cfg, 0.55, 0.95, 0.05,
+                                             search_level=2)
+  k = max(k, 2)
+  want = so.run_kmeans(vecs[:, :k], k, 300)
+  assert so.adjusted_rand_index(got, want) == 1.0
+  assert c.last_diag.n_clusters == k

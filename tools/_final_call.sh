@@ -9,8 +9,8 @@ timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pyt
 tail -3 $O/pytest.log
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 cut -c1-600 $O/bench.json
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o run -- python bench.py --no-extras > $O/bench_under_rocprof.json 2> $O/rocprof.err
-DB=$(ls $O/prof/*/*.db | head -1)
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o run -- python bench.py --no-extras --no-concurrent --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
+DB=$(ls $O/prof/*/*.db $O/prof/*.db 2>/dev/null | head -1)
 python tools/rocprof_summary.py $DB > $O/kernel_stats.txt
 head -12 $O/kernel_stats.txt
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2> $O/pmc_fetch.err

@@ -180,8 +180,13 @@ extern "C" int sc_create(int device, sc_handle* out) {
     delete h;
     return SC_ERR_HIP;
   }
+  // stage timers only (never used to synchronise, never to make memory visible): without the
+  // system-scope fence a recorded event would otherwise carry -- a cache write-back and
+  // invalidate between the stages it separates
+  static const unsigned ev_flags = getenv("SC_EVENT_SYSTEM_FENCE") ? hipEventDefault
+                                                                   : hipEventDisableSystemFence;
   for (int i = 0; i < 48; ++i) {
-    if (hipEventCreate(&h->ev[i]) != hipSuccess) {
+    if (hipEventCreateWithFlags(&h->ev[i], ev_flags) != hipSuccess) {
       delete h;
       return SC_ERR_HIP;
     }
@@ -598,8 +603,31 @@ EigRequest make_eig_request(const sc_config* cfg) {
 // `front_only`: stop after the refinement and the scaling vectors (everything before the
 // eigensolver, no host synchronisation) and say where the refined matrix is -- the grouped
 // batch (batch_group.hip) solves several such problems in lockstep from there.
+// stage timers of a call whose events were still in flight when eig_ncluster_impl returned
+static void resolve_stage_times(sc_handle h, sc_diag* diag) {
+  StageEvents& t = h->stage_events;
+  if (!t.pending) return;
+  t.pending = false;
+  if (!diag) return;
+  float dms = 0.f;
+  for (int i = 0; i < t.n_diffuse; ++i) dms += ev_ms(h, t.diffuse[i][0], t.diffuse[i][1]);
+  diag->stage_ms[SC_STAGE_DIFFUSE] = dms;
+  diag->stage_ms[SC_STAGE_REFINE] = ev_ms(h, t.begin, t.after_refine) - dms;
+  diag->stage_ms[SC_STAGE_SCALING] = ev_ms(h, t.after_refine, t.after_scaling);
+  diag->stage_ms[SC_STAGE_EIG] = ev_ms(h, t.after_scaling, t.after_eig);
+  if (t.fine) {
+    diag->stage_ms[SC_STAGE_BLUR] = ev_ms(h, t.blur[0], t.blur[1]);
+    diag->stage_ms[SC_STAGE_THRESHOLD_SYM] = ev_ms(h, t.thr[0], t.thr[1]);
+    float mv = 0.f;
+    for (int i = 0; i < h->n_mv_ev; ++i) mv += ev_ms(h, h->mv_ev[i][0], h->mv_ev[i][1]);
+    diag->stage_ms[SC_STAGE_MATVEC] = mv;
+  }
+}
+
+// `defer_timing`: return without waiting for the stream (the caller enqueues k-means right
+// behind the Ritz vectors and resolves the stage timers after its own synchronisation)
 int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontResult* front_only,
-                      const FrontResult* resume) {
+                      const FrontResult* resume, bool defer_timing) {
   const int n = h->n, ld = h->ldn;
   hipStream_t s = h->stream;
   const double* cur = ptr<double>(h->A0);
@@ -804,7 +832,6 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   }
   int e_after_eig;
   ev_rec(h, &e_after_eig);
-  SC_HIP(h, hipStreamSynchronize(s));
   h->last_w = w;
   if (diag) {
     diag->n = n;
@@ -814,21 +841,26 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
     diag->n_eigenvalues = std::min((int)w.size(), SC_MAX_EIG);
     for (int i = 0; i < diag->n_eigenvalues; ++i) diag->eigenvalues[i] = w[i];
     diag->symmetry_state = !symmetric ? 3 : (folded_rownorm ? 2 : 1);
-    float dms = 0.f;
-    for (int i = 0; i < n_diffuse; ++i)
-      dms += ev_ms(h, (int)diffuse_ms_events[i][0], (int)diffuse_ms_events[i][1]);
-    diag->stage_ms[SC_STAGE_DIFFUSE] = dms;
-    diag->stage_ms[SC_STAGE_REFINE] = ev_ms(h, e_begin, e_after_refine) - dms;
-    diag->stage_ms[SC_STAGE_SCALING] = ev_ms(h, e_after_refine, e_after_scaling);
-    diag->stage_ms[SC_STAGE_EIG] = ev_ms(h, e_after_scaling, e_after_eig);
-    if (fine) {
-      diag->stage_ms[SC_STAGE_BLUR] = ev_ms(h, eb0, eb1);
-      diag->stage_ms[SC_STAGE_THRESHOLD_SYM] = ev_ms(h, et0, et1);
-      float mv = 0.f;
-      for (int i = 0; i < h->n_mv_ev; ++i) mv += ev_ms(h, h->mv_ev[i][0], h->mv_ev[i][1]);
-      diag->stage_ms[SC_STAGE_MATVEC] = mv;
-    }
   }
+  StageEvents& t = h->stage_events;
+  t.pending = true;
+  t.begin = e_begin;
+  t.after_refine = e_after_refine;
+  t.after_scaling = e_after_scaling;
+  t.after_eig = e_after_eig;
+  t.n_diffuse = n_diffuse;
+  for (int i = 0; i < n_diffuse; ++i) {
+    t.diffuse[i][0] = (int)diffuse_ms_events[i][0];
+    t.diffuse[i][1] = (int)diffuse_ms_events[i][1];
+  }
+  t.fine = fine;
+  t.blur[0] = eb0;
+  t.blur[1] = eb1;
+  t.thr[0] = et0;
+  t.thr[1] = et1;
+  if (defer_timing) return SC_OK;
+  SC_HIP(h, hipStreamSynchronize(s));
+  resolve_stage_times(h, diag);
   return SC_OK;
 }
 
@@ -909,7 +941,11 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   // RandomState(0): first centre via choice(n, p=uniform) = cdf.searchsorted(u, 'right')
   Mt19937 rng(0);
   const double u = rng.next_double();
-  const int first = sc_uniform_choice(n, u);
+  if (h->kfirst_n != n) {  // (two passes of n dependent adds: ~20 us at n = 8192)
+    h->kfirst = sc_uniform_choice(n, u);
+    h->kfirst_n = n;
+  }
+  const int first = h->kfirst;
   const int trials = 2 + (int)std::log((double)k);
   const size_t nrnd = (size_t)std::max(1, (k - 1) * trials);
   if (nrnd > 1024) return fail(h, SC_ERR_UNSUPPORTED, "too many k-means++ trials");
@@ -1019,12 +1055,18 @@ extern "C" int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* label
   SC_TRY(sc_compute_affinity(h));
   if (constraint_active(h, cfg, true)) SC_TRY(sc_apply_constraint(h, cfg));  // :259-264
   ev_rec(h, &e1);
-  SC_TRY(eig_ncluster_impl(h, cfg, dg, nullptr));
+  // (no wait between the eigensolver and k-means: its launches queue behind the Ritz vectors)
+  SC_TRY(eig_ncluster_impl(h, cfg, dg, nullptr, nullptr, true));
   int k = dg->n_clusters_raw;
   if (cfg->min_clusters > 0 && k < cfg->min_clusters) k = cfg->min_clusters;  // :295-296
-  SC_TRY(sc_cluster(h, cfg, k, labels, dg));
+  const int rc_cluster = sc_cluster(h, cfg, k, labels, dg);
+  if (rc_cluster != SC_OK) {
+    h->stage_events.pending = false;
+    return rc_cluster;
+  }
   ev_rec(h, &e2);
   SC_HIP(h, hipStreamSynchronize(h->stream));
+  resolve_stage_times(h, dg);
   dg->stage_ms[SC_STAGE_AFFINITY] = ev_ms(h, e0, e1);
   dg->stage_ms[SC_STAGE_TOTAL] = ev_ms(h, e0, e2);
   if (h->profile_level >= 2)

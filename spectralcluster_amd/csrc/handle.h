@@ -26,6 +26,15 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// event slots of the stage timers of the current call (resolved once the stream has drained)
+struct StageEvents {
+  bool pending = false, fine = false;
+  int begin = -1, after_refine = -1, after_scaling = -1, after_eig = -1;
+  int diffuse[SC_MAX_OPS][2];
+  int n_diffuse = 0;
+  int blur[2] = {-1, -1}, thr[2] = {-1, -1};
+};
+
 struct sc_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -97,6 +106,7 @@ struct sc_handle_s {
   int gconv_seen = 0;        // ... of this many: where a speculative block is likely wasted
   hipEvent_t ev[48];
   int nev = 0;
+  StageEvents stage_events;
   int profile_level = 1;  // sc_set_profiling: 0 totals only, 1 stages, 2 per-kernel events
   int mv_ev[16][2];       // event pairs around the block matvec launches (level 2)
   int n_mv_ev = 0;
@@ -108,6 +118,7 @@ struct sc_handle_s {
   int blurw_radius = -1;
   double blurw_host[2 * SC_MAX_BLUR_RADIUS + 1];
   int krnd_k = -1, krnd_trials = -1;
+  int kfirst_n = -1, kfirst = 0;  // first k-means++ centre of the last n (RandomState(0) draw)
   bool eig_skip_fused = false;  // next sym_topk: go straight to the host-driven chain
   int eig_hint_m = 0;
   long long eig_hint_sig = -1;
@@ -254,7 +265,7 @@ EigRequest make_eig_request(const sc_config* cfg);
 int upload_blur_weights(sc_handle h, const sc_config* cfg);  // into h->blurw, on h->stream
 // `resume`: the stages before the eigensolver already ran (a FrontResult of this handle)
 int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontResult* front_only,
-                      const FrontResult* resume = nullptr);
+                      const FrontResult* resume = nullptr, bool defer_timing = false);
 // RandomState(0) stream of the k-means seeding: the uniform that picks the first centre, the
 // trial count 2 + int(log k), and the (k - 1) * trials doubles after it (api.hip)
 void kmeans_seed_constants(int k, double* u_first, int* trials, std::vector<double>* rnd);

@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-O=gpurun_out/final
-mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o run -- python bench.py --no-extras --no-concurrent --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
-DB=$(ls $O/prof/*/*.db $O/prof/*.db 2>/dev/null | head -1)
-python tools/rocprof_summary.py $DB > $O/kernel_stats.txt
-head -14 $O/kernel_stats.txt
-rm -rf $O/prof
+show() { python -c "
+import json,sys
+j=json.loads(sys.stdin.read())
+print(round(j['value'],2), round(j['ms_per_step'],4), {k: round(v,4) for k,v in j['stage_ms'].items() if v}, [round(k['us'],1) for k in j['roofline']['kernels']])"; }
+for i in 1 2; do
+echo nofence; timeout 600 python bench.py --no-extras --no-concurrent --no-cpu-baseline | show
+echo fence; SC_EVENT_SYSTEM_FENCE=1 timeout 600 python bench.py --no-extras --no-concurrent --no-cpu-baseline | show
+done
+timeout 300 python tools/single_sizes.py 500 1650 3000

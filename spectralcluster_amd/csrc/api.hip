@@ -227,7 +227,7 @@ extern "C" int sc_destroy(sc_handle h) {
   if (h->h_flags) hipHostFree(h->h_flags);
   if (h->h_rr) hipHostFree(h->h_rr);
   if (h->sync_ev) hipEventDestroy(h->sync_ev);
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < kGroupBanks; ++b) {
     if (h->gbank_ev[b]) hipEventDestroy(h->gbank_ev[b]);
     if (h->gbank_stream[b]) hipStreamDestroy(h->gbank_stream[b]);
   }

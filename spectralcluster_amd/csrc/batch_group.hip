@@ -438,10 +438,15 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     std::stable_sort(grouped.begin(), grouped.end(), [&](int a, int b) { return ns[a] > ns[b]; });
     const int width = std::min(group, (int)grouped.size());
     const int ngroups = ((int)grouped.size() + width - 1) / width;
-    // Two banks of member arenas: while the eigensolver and k-means chains of group g run
-    // (short launches, host synchronisations, Rayleigh-Ritz on the host), the GEMMs and
-    // refinement passes of group g + 1 keep the chip busy on the other bank's streams.
-    const int nslots = std::min(2 * width, (int)grouped.size());
+    // Banks of member arenas: while the eigensolver and k-means chains of group g run (short
+    // launches, host synchronisations, Rayleigh-Ritz on the host), the GEMMs and refinement
+    // passes of group g + 1 keep the chip busy on the other bank's stream.  (Two banks; a
+    // third one, SC_GROUP_BANKS=3, puts two more GEMMs next to the chains and costs 9 % on
+    // config 5: the chains' short kernels wait longer for a free CU.)
+    static const int banks = getenv("SC_GROUP_BANKS")
+                                 ? std::max(2, std::min(kGroupBanks, atoi(getenv("SC_GROUP_BANKS"))))
+                                 : 2;
+    const int nslots = std::min(banks * width, (int)grouped.size());
     for (int z = 0; z < nslots; ++z) {  // arenas once, for the largest member each will see
       sc_handle hz = nullptr;
       SC_TRY(group_slot(h, z, &hz));
@@ -449,15 +454,15 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
       if (rc != SC_OK) return fail(h, rc, hz->err);
       hz->have_constraint = false;
     }
-    Member mbs[2][kGroupMax];
-    int front_bank[2] = {-1, -1};
+    Member mbs[kGroupBanks][kGroupMax];
+    int front_bank[kGroupBanks];
     auto group_count = [&](int g) {
       return (int)std::min<size_t>(width, grouped.size() - (size_t)g * width);
     };
     const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
     const bool covers = grouped_front_covers(cfg);
     if (covers) {
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < banks; ++b)
         if (!h->gbank_stream[b]) {
           // (same priority as the chains' stream: a lower one for the banks, so that the short
           //  kernels of the other group's chains go first, cost 8 % -- the GEMMs are the
@@ -475,7 +480,7 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
       SC_HIP(h, hipStreamSynchronize(h->stream));  // the bank streams read them
     }
     auto front = [&](int g) -> int {
-      const int b = g & 1, cnt = group_count(g);
+      const int b = g % banks, cnt = group_count(g);
       const int* idx = grouped.data() + (size_t)g * width;
       // (the streaming blur of the grouped front needs every member at n >= 512; the sizes
       //  are sorted, the last member of the group is its smallest)
@@ -486,13 +491,13 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
       front_bank[b] = -1;
       return enqueue_front(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b]);
     };
-    SC_TRY(front(0));
+    for (int g = 0; g < std::min(banks - 1, ngroups); ++g) SC_TRY(front(g));
     for (int g = 0; g < ngroups; ++g) {
       const double t0 = trace ? now_us() : 0.0;
-      if (g + 1 < ngroups) SC_TRY(front(g + 1));
-      if (trace) fprintf(stderr, "[sc] next group's front enqueued in %.0f us\n", now_us() - t0);
-      SC_TRY(finish_group(h, ns, cfg, labels, diags, mbs[g & 1], group_count(g), rq,
-                          front_bank[g & 1]));
+      if (g + banks - 1 < ngroups) SC_TRY(front(g + banks - 1));
+      if (trace) fprintf(stderr, "[sc] next front enqueued in %.0f us\n", now_us() - t0);
+      SC_TRY(finish_group(h, ns, cfg, labels, diags, mbs[g % banks], group_count(g), rq,
+                          front_bank[g % banks]));
     }
   }
   for (int i : single)

@@ -26,6 +26,8 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+constexpr int kGroupBanks = 3;  // banks of member arenas of the grouped batch (groups in flight)
+
 // event slots of the stage timers of the current call (resolved once the stream has drained)
 struct StageEvents {
   bool pending = false, fine = false;
@@ -100,8 +102,8 @@ struct sc_handle_s {
   hipEvent_t gcheck_ev = nullptr;
   // grouped front: the stages before the eigensolver of a whole group as grouped launches on
   // the stream of the group's bank, handed to this handle's stream through the bank's event
-  hipStream_t gbank_stream[2] = {nullptr, nullptr};
-  hipEvent_t gbank_ev[2] = {nullptr, nullptr};
+  hipStream_t gbank_stream[kGroupBanks] = {nullptr};
+  hipEvent_t gbank_ev[kGroupBanks] = {nullptr};
   int gconv_hist[16] = {0};  // members of this batch that converged at basis 8 * index ...
   int gconv_seen = 0;        // ... of this many: where a speculative block is likely wasted
   hipEvent_t ev[48];

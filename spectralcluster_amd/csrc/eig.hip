@@ -1261,6 +1261,12 @@ void launch_apply_rinv(hipStream_t s, double* W, int n, const double* Rinv,
 // rows per workgroup of k_lz_rows: as many as the basis rows leave room for in LDS (fewer,
 // fatter workgroups = fewer partials for the next link to add)
 static int lz_rows_for(int m) {
+  // (128-row workgroups by default: twice the workgroups of the 256-row form, half the LDS
+  //  fill and half the serial length of the epilogue sums per link -- eigen stage 0.536 ->
+  //  0.492 ms at n = 8192; 64 rows: 0.499)
+  static const int cap = getenv("SC_LZ_ROWS_CAP") ? atoi(getenv("SC_LZ_ROWS_CAP")) : 128;
+  if (cap <= 64) return 64;
+  if (cap <= 128 && (size_t)128 * (m + 1) * sizeof(double) <= 112 * 1024) return 128;
   if ((size_t)256 * (m + 1) * sizeof(double) <= 96 * 1024) return 256;
   if ((size_t)128 * (m + 1) * sizeof(double) <= 112 * 1024) return 128;
   return 64;

@@ -32,7 +32,10 @@
 
 namespace sc {
 
-constexpr int kKmT = 256;  // threads per workgroup = rows per workgroup
+// threads per workgroup = rows per workgroup (128: every link's serial part -- the per-cluster
+// sums over the workgroup's rows, the scan -- is half as long as with 256; k-means stage at
+// n = 1650: 0.126 -> 0.107 ms, n = 8192: unchanged)
+constexpr int kKmT = 128;
 constexpr int kKmW = kKmT / 64;
 constexpr int kKmMaxG = 1024;  // workgroups (n <= 262144) the chain is used for
 

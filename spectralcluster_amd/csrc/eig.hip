@@ -1150,12 +1150,15 @@ __global__ void k_copy_block(const double* __restrict__ src, int ldsrc,
 
 // Column-major eigenvectors: ET[j * ld + r].  One workgroup per column:
 // v = t .* u, then v / ||v||_2  (LAPACK dgeev returns unit 2-norm columns).
+// (blockDim.x = 256 or 1024 threads per column: a column of n = 8192 is two latency-bound
+//  passes, 19 us with 256 threads)
 __device__ __forceinline__ void back_transform_body(double* __restrict__ ET, int ld, int n,
                                                     const double* __restrict__ tvec) {
-  __shared__ double sm[4];
+  __shared__ double sm[16];
   double* col = ET + (size_t)blockIdx.x * ld;
+  const int nthr = blockDim.x;
   double acc = 0.0;
-  for (int r = threadIdx.x; r < n; r += 256) {
+  for (int r = threadIdx.x; r < n; r += nthr) {
     const double v = tvec[r] * col[r];
     col[r] = v;
     acc = __builtin_fma(v, v, acc);
@@ -1164,12 +1167,14 @@ __device__ __forceinline__ void back_transform_body(double* __restrict__ ET, int
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  const double inv = 1.0 / sqrt((sm[0] + sm[1]) + (sm[2] + sm[3]));
-  for (int r = threadIdx.x; r < n; r += 256) col[r] *= inv;
+  double tot = 0.0;
+  for (int w = 0; w < nthr / 64; w += 4) tot += (sm[w] + sm[w + 1]) + (sm[w + 2] + sm[w + 3]);
+  const double inv = 1.0 / sqrt(tot);
+  for (int r = threadIdx.x; r < n; r += nthr) col[r] *= inv;
 }
-__global__ __launch_bounds__(256) void k_back_transform(double* __restrict__ ET, int ld,
-                                                        int n,
-                                                        const double* __restrict__ tvec) {
+__global__ __launch_bounds__(1024) void k_back_transform(double* __restrict__ ET, int ld,
+                                                         int n,
+                                                         const double* __restrict__ tvec) {
   back_transform_body(ET, ld, n, tvec);
 }
 __global__ __launch_bounds__(256) void k_back_transform_g(const GroupOf<RitzItem> g) {
@@ -1475,7 +1480,8 @@ void launch_copy_block(hipStream_t s, const double* src, int ldsrc, double* dst,
 }
 void launch_back_transform(hipStream_t s, double* ET, int ld, int n, int cols,
                            const double* tvec) {
-  hipLaunchKernelGGL(k_back_transform, dim3(cols), dim3(256), 0, s, ET, ld, n, tvec);
+  hipLaunchKernelGGL(k_back_transform, dim3(cols), dim3(n >= 4096 ? 1024 : 256), 0, s, ET, ld, n,
+                     tvec);
 }
 void launch_rowmajor_to_colmajor(hipStream_t s, const double* src, int lds, int n, int cols,
                                  double* dst, int ldd) {

@@ -5,7 +5,7 @@
 // Why a chain: the single-workgroup kernel streams the (n, k) embedding ~35 times through
 // one CU (one pass per k-means++ trial pair, per assignment, per update) and is bound by that
 // CU's L2 bandwidth (0.57-0.71 ms at n = 8192, k = 8).  Every phase here is one launch of
-// n / 256 workgroups, one row per thread, that re-reads its 256 rows (2 KB per column, L2) and
+// n / 128 workgroups, one row per thread, that re-reads its 128 rows (1 KB per column, L2) and
 // leaves a handful of per-workgroup partial sums; the NEXT launch's prologue adds the partials
 // of all workgroups in workgroup order (the launch-boundary reduce: a dependent kernel
 // boundary costs ~1.5 us, cheaper than any in-kernel cross-workgroup hand-off).  All sums

@@ -410,6 +410,61 @@ def test_predict_batch_mode_selection(monkeypatch):
                    ("grouped", 3, 3)]
 
 
+def test_autotune_hands_whole_levels_to_the_sweep(monkeypatch):
+  """predict() with AutoTune: every search level is ONE _eig_sweep call with the level's new
+  p values (reference autotune.py:98-111 evaluates them one by one), the winner is evaluated
+  once more for its eigenvectors, and refinement_options.p_percentile is left at the LAST
+  evaluated value like the reference's closure does (spectral_clusterer.py:277)."""
+  levels, singles = [], []
+
+  class Diag:
+    def __init__(self, p):
+      self.max_delta = 1.0 + 10.0 * (1.0 - abs(p - 0.7))  # proxy minimal at p = 0.7
+      self.n_clusters_raw = 3
+      self.n_clusters = 3
+
+  c = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=5,
+      refinement_options=sca.RefinementOptions(
+          p_percentile=0.95, refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE),
+      autotune=sca.AutoTune(p_percentile_min=0.5, p_percentile_max=0.9, init_search_step=0.1,
+                            search_level=2, proxy=sca.AutoTuneProxy.PercentileOverNME))
+
+  class FakeLib:
+    def sc_cluster(self, raw, cfg, k, labels, diag):
+      return 0
+
+  class FakeHandle:
+    lib, raw = FakeLib(), None
+
+    def check(self, rc, *a):
+      assert rc == 0
+
+  def fake_sweep(handle, ps):
+    levels.append(list(ps))
+    return [Diag(p) for p in ps]
+
+  def fake_single(handle, p=None):
+    singles.append(p)
+    c.last_diag = Diag(p)
+    return c.last_diag
+
+  monkeypatch.setattr(c, "_handle", lambda: FakeHandle())
+  monkeypatch.setattr(c, "_set_constraint", lambda *a, **k: False)
+  monkeypatch.setattr(c, "_upload", lambda *a, **k: None)
+  monkeypatch.setattr(c, "_eig_sweep", fake_sweep)
+  monkeypatch.setattr(c, "_eig_resident", fake_single)
+  c.predict(np.ones((12, 3)))
+  assert len(levels) == 2 and len(levels[0]) == 4
+  assert not set(levels[0]) & set(levels[1])  # a level only evaluates what is new
+  assert len(singles) == 1
+  # (the reference restarts its running minimum at every level, autotune.py:99: the winner is
+  #  the best of the LAST level's new values)
+  best = min(levels[1], key=lambda p: (1 - p) / Diag(p).max_delta)
+  assert singles[0] == best
+  assert c.refinement_options.p_percentile == levels[1][-1]
+
+
 def test_comm_header_and_id_file(monkeypatch, tmp_path):
   """Rendezvous plumbing of RcclComm.from_env that needs no GPU: the id file name is
   unique per launch (MASTER_PORT + parent pid) and can be overridden."""

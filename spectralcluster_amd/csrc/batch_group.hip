@@ -390,6 +390,10 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
     fprintf(stderr, "[sc] group of %d (n %d..%d): eigen %.0f us, k-means %.0f us (%d members)\n",
             count, ns[mb[count - 1].index], ns[mb[0].index], t2 - t1, now_us() - t2, nk);
   // ---- members that left the common path: the single-call pipeline on their own arena
+  bool any_back = false;
+  for (int z = 0; z < count; ++z) any_back = any_back || mb[z].state == 1;
+  // (their speculative block steps may still be running on this stream)
+  if (any_back) SC_HIP(lead, hipStreamSynchronize(s));
   for (int z = 0; z < count; ++z) {
     Member& m = mb[z];
     if (m.state != 1) continue;

@@ -626,6 +626,7 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       sc_diag* dg = diags + base + z;
       if (em[z].status != 0) {
         later.push_back(base + z);  // (after the rounds: it overwrites the shared blur)
+        em[z].h->eig_skip_fused = false;  // (a hint for a re-solve on that arena: none follows)
         continue;
       }
       memset(dg, 0, sizeof(*dg));

@@ -409,7 +409,11 @@ def main():
                    "n_samples": N_SAMPLES, "n_features": N_FEATURES,
                    "speakers": N_SPEAKERS, "parallelism": "replicas x%d" % world,
                    "step": "sc_run_resident: embeddings resident in HBM, labels D2H inside",
-                   "collectives": "RCCL via the C ABI (sc_comm_*)" if world > 1 else "none"},
+                   "collectives": ("none" if world == 1 else
+                                   "RCCL via the C ABI (sc_comm_*)"
+                                   if isinstance(comm, multigpu.RcclComm) else
+                                   "TCP fallback (RCCL did not come up: %s)"
+                                   % getattr(comm, "note", ""))},
         "predict_incl_h2d": {
             "value": world * k / elapsed_h2d, "unit": "calls/s",
             "ms_per_step": 1e3 * elapsed_h2d / k,

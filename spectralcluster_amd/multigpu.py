@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import socket
 import struct
 import time
 import typing
@@ -97,6 +98,115 @@ def _id_file() -> str:
   return os.path.join(os.environ.get("TMPDIR", "/tmp"), "sc_comm_%s.id" % tag)
 
 
+class SocketComm(Comm):
+  """The same byte collectives over TCP on one node, rank 0 as the hub: the fallback of
+  `RcclComm.from_env` when RCCL cannot be brought up, and the channel the ranks agree on
+  that through.  The replicas of this package exchange a few hundred bytes per job (timing
+  reductions, labels of a sharded batch, AutoTune scalars): nothing here is on a data path."""
+
+  def __init__(self, rank: int, size: int, conns, server=None):
+    self.rank, self.size = int(rank), int(size)
+    self._conns = conns    # rank 0: {rank: socket} of the others; else: {0: socket}
+    self._server = server
+    self.note = ""
+
+  @staticmethod
+  def _send(sock, blob: bytes) -> None:
+    sock.sendall(struct.pack("<Q", len(blob)) + blob)
+
+  @staticmethod
+  def _recv(sock) -> bytes:
+    def exactly(k):
+      parts = []
+      while k:
+        chunk = sock.recv(min(k, 1 << 20))
+        if not chunk:
+          raise ConnectionError("peer closed the connection")
+        parts.append(chunk)
+        k -= len(chunk)
+      return b"".join(parts)
+    (count,) = struct.unpack("<Q", exactly(8))
+    return exactly(count)
+
+  @classmethod
+  def from_env(cls, rank: int, size: int, timeout_s: float = 120.0) -> "SocketComm":
+    """Rank 0 listens on an ephemeral port of MASTER_ADDR (127.0.0.1 by default) and publishes
+    the port through the launch's id file; the others connect and say who they are."""
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if rank == 0:
+      server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+      server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+      server.bind((addr, 0))
+      server.listen(size)
+      server.settimeout(timeout_s)
+      port = server.getsockname()[1]
+      RcclComm.exchange_id(0, lambda: struct.pack("<I", port) + bytes(124), timeout_s)
+      conns = {}
+      while len(conns) < size - 1:
+        peer, _ = server.accept()
+        peer.settimeout(timeout_s)
+        peer.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        (who,) = struct.unpack("<I", cls._recv(peer))
+        conns[who] = peer
+      try:
+        os.unlink(_id_file())
+      except OSError:
+        pass
+      return cls(rank, size, conns, server)
+    blob = RcclComm.exchange_id(rank, lambda: b"", timeout_s)
+    (port,) = struct.unpack("<I", blob[:4])
+    deadline = time.monotonic() + timeout_s
+    while True:
+      try:
+        sock = socket.create_connection((addr, port), timeout=timeout_s)
+        break
+      except OSError:
+        if time.monotonic() > deadline:
+          raise
+        time.sleep(0.05)
+    sock.settimeout(timeout_s)
+    sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+    cls._send(sock, struct.pack("<I", rank))
+    return cls(rank, size, {0: sock})
+
+  def _exchange(self, blob: bytes) -> typing.List[bytes]:
+    """Every rank contributes a blob (any length); every rank gets all of them, rank order."""
+    if self.rank == 0:
+      blobs = [bytes(blob)] + [self._recv(self._conns[r]) for r in range(1, self.size)]
+      packed = b"".join(struct.pack("<Q", len(b)) + b for b in blobs)
+      for r in range(1, self.size):
+        self._send(self._conns[r], packed)
+      return blobs
+    self._send(self._conns[0], bytes(blob))
+    packed = self._recv(self._conns[0])
+    out, pos = [], 0
+    for _ in range(self.size):
+      (count,) = struct.unpack_from("<Q", packed, pos)
+      out.append(packed[pos + 8:pos + 8 + count])
+      pos += 8 + count
+    return out
+
+  def broadcast_bytes(self, data, nbytes, root=0):
+    return self._exchange(bytes(data) if self.rank == root else b"")[root]
+
+  def allgather_bytes(self, data):
+    return self._exchange(bytes(data))
+
+  def allreduce_max(self, value):
+    return max(struct.unpack("<d", b)[0] for b in self._exchange(struct.pack("<d", float(value))))
+
+  def close(self):
+    for sock in self._conns.values():
+      try:
+        sock.close()
+      except OSError:
+        pass
+    self._conns = {}
+    if self._server is not None:
+      self._server.close()
+      self._server = None
+
+
 class RcclComm(Comm):
   """RCCL communicator behind the C ABI (`sc_comm_*`), one rank per GPU."""
 
@@ -157,15 +267,32 @@ class RcclComm(Comm):
     rank = int(os.environ.get("RANK", "0"))
     if size == 1:
       return LocalComm()
-    uid = cls.exchange_id(rank, cls.new_unique_id, timeout_s)
-    comm = cls(handle, rank, size, uid)
-    comm.barrier()  # everyone has read the id
+    # The ranks first meet over TCP (always possible on one node), hand the RCCL unique id
+    # over that way and then agree on whether RCCL came up on EVERY rank; if not, the TCP
+    # communicator itself carries the job's few hundred bytes (`comm.note` says why).
+    sock = SocketComm.from_env(rank, size, timeout_s)
+    head, why = b"\0" + bytes(128), ""
     if rank == 0:
       try:
-        os.unlink(_id_file())
-      except OSError:
-        pass
-    return comm
+        head = b"\1" + cls.new_unique_id()
+      except Exception as exc:  # pylint: disable=broad-except
+        why = "rank 0: %s" % exc
+    head = sock.broadcast_bytes(head, 129)
+    comm = None
+    if head[:1] == b"\1":
+      try:
+        comm = cls(handle, rank, size, head[1:])
+      except Exception as exc:  # pylint: disable=broad-except
+        why = "rank %d: %s" % (rank, exc)
+    reports = sock.allgather_bytes((b"\1" if comm is not None else b"\0") + why.encode()[:200])
+    if all(r[:1] == b"\1" for r in reports):
+      comm.barrier()
+      sock.close()
+      return comm
+    if comm is not None:
+      comm.close()
+    sock.note = "; ".join(r[1:].decode(errors="replace") for r in reports if r[1:])
+    return sock
 
   def _check(self, rc, what):
     if rc != 0:

@@ -147,3 +147,46 @@ def test_unique_id_rendezvous_between_processes(tmp_path):
       multigpu.RcclComm.exchange_id(1, lambda: b"", timeout_s=0.2)
   finally:
     del os.environ["SC_COMM_ID_FILE"]
+
+
+def _fallback_worker(rank, world, path, out):
+  sys.path.insert(0, ROOT)
+  os.environ.update({"SC_COMM_ID_FILE": path, "WORLD_SIZE": str(world), "RANK": str(rank),
+                     "MASTER_ADDR": "127.0.0.1"})
+  import numpy as np
+  from spectralcluster_amd import multigpu
+  # no device handle here: RCCL cannot come up on any rank, every rank must notice and agree
+  comm = multigpu.RcclComm.from_env(None, timeout_s=60.0)
+  assert isinstance(comm, multigpu.SocketComm) and comm.size == world and comm.note
+  got = comm.allgather_bytes(bytes([rank]) * 3)
+  assert got == [bytes([r]) * 3 for r in range(world)]
+  assert comm.broadcast_bytes(b"hello" if rank == 1 else None, 5, root=1) == b"hello"
+  assert comm.allreduce_max(float(rank)) == float(world - 1)
+  comm.barrier()
+  # the sharded batch driver on top of it: labels of every utterance on every rank
+  utts = [np.full((5 + i, 2), float(i)) for i in range(7)]
+  labels = multigpu.predict_batch_sharded(
+      comm, lambda u: np.full(u.shape[0], int(u[0, 0]), dtype=np.int64), utts)
+  assert [int(l[0]) for l in labels] == list(range(7))
+  assert [l.shape[0] for l in labels] == [5 + i for i in range(7)]
+  ratios, ks = multigpu.autotune_sharded(comm, lambda p: (1.0 - p, 3), [0.5, 0.6, 0.7, 0.8])
+  assert np.allclose(ratios, [0.5, 0.4, 0.3, 0.2]) and list(ks) == [3, 3, 3, 3]
+  comm.close()
+  with open("%s.%d" % (out, rank), "w") as f:
+    f.write("ok")
+
+
+def test_tcp_fallback_when_rccl_cannot_come_up(tmp_path):
+  """RcclComm.from_env on a launch where RCCL fails on every rank: the ranks meet over TCP,
+  agree that RCCL is out, and the same communicator carries the collectives of the sharded
+  drivers (three processes, no GPU)."""
+  import multiprocessing as mp
+  ctx = mp.get_context("spawn")
+  path, out = str(tmp_path / "id"), str(tmp_path / "done")
+  procs = [ctx.Process(target=_fallback_worker, args=(r, 3, path, out)) for r in (2, 1, 0)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(120)
+    assert p.exitcode == 0
+  assert all(os.path.exists("%s.%d" % (out, r)) for r in range(3))

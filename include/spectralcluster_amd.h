@@ -96,7 +96,11 @@ enum {
   /* symmetric, n > 128, every eigenvalue consumed (max_clusters=None with a Laplacian,
    * or the ascending NormalizedDiff gap's np.max): Householder tridiagonalisation +
    * Sturm bisection for the values, block Lanczos for the few vectors k-means takes */
-  SC_EIG_PATH_DENSE_TRIDIAG = 5
+  SC_EIG_PATH_DENSE_TRIDIAG = 5,
+  /* block Lanczos gave up (sc_diag.eig_fallback says why): values as above and the vectors by
+   * inverse iteration on the tridiagonal form + the Householder back-transform.  Always
+   * returns, like np.linalg.eig (utils.py:59) */
+  SC_EIG_PATH_DENSE_FULL = 6
 };
 
 /* Stage slots of sc_diag.stage_ms */
@@ -174,7 +178,9 @@ typedef struct sc_diag {
   int32_t symmetry_state;        /* 1 SYM, 2 DIAG*SYM (after RowWiseNormalize), 3 GENERAL */
   int32_t eig_host_chain;        /* 1: the fused Lanczos chain met a rank-deficient block and
                                     the host-driven repair chain redid the solve */
-  int32_t reserved0;
+  int32_t eig_fallback;          /* 0, or why block Lanczos handed over to the dense path:
+                                    1 restart budget spent, 2 projected eigenproblem failed,
+                                    3 no full-rank Krylov block, 4 forced (SC_EIG_FORCE_DENSE) */
   float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */
 } sc_diag;
 
@@ -365,6 +371,14 @@ int sc_uniform_choice(int n, double u);
  * the columns of `vectors` (Householder tridiagonalisation + implicit QL).  Host-only;
  * exported so it can be pinned without a GPU. */
 int sc_host_symmetric_eig(const double* a, int m, double* values, double* vectors);
+/* Eigenvectors of the symmetric tridiagonal matrix (d[0..n), e[0..n-1)) for the k given
+ * eigenvalues `lam` by inverse iteration (LAPACK dstein's method): vectors is (n, k)
+ * row-major, column q belongs to lam[q], unit 2-norm.  The host step of the dense landing
+ * pad (SC_EIG_PATH_DENSE_FULL) that takes over whenever block Lanczos gives up, so that
+ * predict() returns wherever np.linalg.eig (utils.py:59) does.  Host-only; exported so it
+ * can be pinned without a GPU. */
+int sc_host_tridiag_eigvectors(const double* d, const double* e, int n, const double* lam,
+                               int k, double* vectors);
 /* utils.compute_number_of_clusters (utils.py:74-130) -- host scalar loop */
 int sc_eigengap(const double* eigenvalues, int count, int max_clusters,
                 double stop_eigenvalue, int eigengap_type, int descend,

@@ -3,7 +3,7 @@
 Run in the build container only (needs /root/reference, which does not exist
 on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general | --size-reduction | --fallback | --autotune4096 | --batch512 | --dense]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general | --size-reduction | --fallback | --autotune4096 | --autotune4096-ttd | --batch512 | --dense | --hard]
 
 `--autotune4096` and `--batch512` pin BASELINE.json configs 4 and 5 at their
 full sizes (about 6 and 20 minutes of CPU).
@@ -420,6 +420,50 @@ def autotune4096_golden():
        labels=labels.astype(np.int8), ref_seconds=np.float64(secs))
 
 
+def ttd_options(p=0.95):
+  """configs.py:53-59 (a fresh object: the preset singleton is mutated by AutoTune)."""
+  return ref_refinement.RefinementOptions(
+      p_percentile=p, thresholding_soft_multiplier=0.01,
+      thresholding_type=ref_refinement.ThresholdType.Percentile,
+      thresholding_with_binarization=True, thresholding_preserve_diagonal=True,
+      symmetrize_type=ref_refinement.SymmetrizeType.Average,
+      refinement_sequence=ref_configs.TURNTODIARIZE_REFINEMENT_SEQUENCE)
+
+
+def autotune4096_ttd_golden():
+  """11b. BASELINE config 4, secondary variant: the same 16-value AutoTune
+  at n=4096 under the Turn-to-Diarize refinement (Percentile + binarise + preserve-diag +
+  Average, configs.py:49-59), GraphCut, max_clusters=20, row_wise_renorm like the preset
+  (configs.py:76-85); no constraint matrix."""
+  n, d, k, seed, max_clusters = 4096, 256, 8, 4096, 20
+  x = so.blobs(n, d, k, seed)
+  tuner = ref_autotune.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95,
+                                init_search_step=0.025, search_level=1)
+  grid = np.array(tuner.get_percentile_range())
+  assert len(grid) == 16
+  clusterer = ref_sc.SpectralClusterer(
+      min_clusters=2, max_clusters=max_clusters, refinement_options=ttd_options(),
+      autotune=tuner, laplacian_type=LAP[4], row_wise_renorm=True)
+  idx = so.consumed_eigen_indices(n, max_clusters, False)
+  t0 = time.perf_counter()
+  with _Spy() as spy:
+    labels = clusterer.predict(x)
+  secs = time.perf_counter() - t0
+  sweep = spy.calls[:16]
+  assert len(spy.calls) == 16
+  ratios = np.array([np.sqrt(1 - p) / c["delta"] for p, c in zip(grid, sweep)])
+  print("ratios", ratios, "argmin", int(np.argmin(ratios)), flush=True)
+  save("autotune_ttd_n4096.npz",
+       params=np.array([n, d, k, seed, 4, max_clusters]), grid=grid,
+       ratios=ratios, n_clusters=np.array([c["k"] for c in sweep]),
+       max_delta=np.array([c["delta"] for c in sweep]),
+       consumed_index=idx,
+       consumed_eigenvalues=np.stack([np.real(c["w"])[idx] for c in sweep]),
+       final_p=np.float64(clusterer.refinement_options.p_percentile),
+       best_p=np.float64(grid[int(np.argmin(ratios))]),
+       labels=labels.astype(np.int8), ref_seconds=np.float64(secs))
+
+
 def batch512_inputs():
   """BASELINE config 5: sizes / cluster counts of the batch."""
   rng = np.random.default_rng(512)
@@ -484,9 +528,48 @@ def dense_goldens():
          ref_seconds=np.float64(secs))
 
 
+HARD_CASES = [(kind, n, lap) for kind in so.HARD_KINDS for n in (1000, 2048, 4096)
+              for lap in (0, 4)]
+
+
+def hard_goldens(only_n=None, only_kinds=None):
+  """14. Unfriendly spectra: unstructured / overlapping / many-cluster /
+  unbalanced / interleaved inputs at n in {1000, 2048, 4096}, laplacian None (max 7) and
+  GraphCut (max 20), ICASSP2018 refinement, d=256.  The reference's eigensolver
+  (np.linalg.eig, utils.py:59) always returns; so must the device path."""
+  for kind, n, lap in HARD_CASES:
+    if (only_n and n not in only_n) or (only_kinds and kind not in only_kinds):
+      continue
+    maxc = 7 if lap == 0 else 20
+    seed = 7000 + n
+    x = so.hard_inputs(kind, n, 256, seed)
+    clusterer = ref_sc.SpectralClusterer(
+        min_clusters=2, max_clusters=maxc, refinement_options=icassp_options(),
+        laplacian_type=LAP[lap])
+    t0 = time.perf_counter()
+    with _Spy() as spy:
+      labels = clusterer.predict(x)
+    secs = time.perf_counter() - t0
+    c = spy.calls[-1]
+    w = np.real(c["w"])
+    idx = so.consumed_eigen_indices(n, maxc, lap == 0, w, 1e-2)
+    save("hard_%s_n%d_lap%d.npz" % (kind, n, lap),
+         params=np.array([n, 256, seed, lap, maxc]), kind=np.array(kind),
+         consumed_index=idx, consumed_eigenvalues=w[idx], head_eigenvalues=w[:maxc + 4],
+         n_clusters_raw=np.int64(c["k"]), max_delta=np.float64(c["delta"]),
+         labels=labels.astype(np.int8), ref_seconds=np.float64(secs))
+    print("  %s n=%d lap=%d: k=%d delta=%.6g head=%s  %.1f s" % (
+        kind, n, lap, c["k"], c["delta"], np.array2string(w[:6], precision=5), secs),
+          flush=True)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
+  if "--hard" in sys.argv:  # only section 14 (optionally: --hard kind [kind ...])
+    kinds = [a for a in sys.argv[sys.argv.index("--hard") + 1:] if a in so.HARD_KINDS]
+    hard_goldens(only_kinds=kinds or None)
+    return
   if "--constraints" in sys.argv:  # only section 7
     constraint_goldens()
     return
@@ -504,6 +587,9 @@ def main():
     return
   if "--autotune4096" in sys.argv:  # only section 11
     autotune4096_golden()
+    return
+  if "--autotune4096-ttd" in sys.argv:  # only section 11b
+    autotune4096_ttd_golden()
     return
   if "--batch512" in sys.argv:  # only section 12
     batch512_golden()

@@ -99,7 +99,7 @@ class ScDiag(ctypes.Structure):
       ("kmeans_iterations", ctypes.c_int32),
       ("symmetry_state", ctypes.c_int32),
       ("eig_host_chain", ctypes.c_int32),
-      ("reserved0", ctypes.c_int32),
+      ("eig_fallback", ctypes.c_int32),
       ("stage_ms", ctypes.c_float * SC_MAX_STAGES),
   ]
 
@@ -204,6 +204,8 @@ PROTOTYPES = {
     "sc_uniform_choice": (ctypes.c_int, [ctypes.c_int, ctypes.c_double]),
     "sc_host_symmetric_eig": (ctypes.c_int, [_c_double_p, ctypes.c_int, _c_double_p,
                                              _c_double_p]),
+    "sc_host_tridiag_eigvectors": (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_int,
+                                                  _c_double_p, ctypes.c_int, _c_double_p]),
     "sc_eigengap": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                    _c_int_p, _c_double_p]),

@@ -19,10 +19,10 @@
 // ------------------------------------------------------------------------------
 // device arena
 // ------------------------------------------------------------------------------
-int ensure_matrices(sc_handle h, int n, int d) {
+int ensure_matrices(sc_handle h, int n, int d, bool affinity_copy) {
   const size_t ldn = matrix_ld(n);
   const size_t nn = (size_t)n * ldn * sizeof(double);
-  SC_TRY(grow(h, h->A0, nn));
+  if (affinity_copy) SC_TRY(grow(h, h->A0, nn));
   SC_TRY(grow(h, h->B1, nn));
   SC_TRY(grow(h, h->B2, nn));
   if (d > 0) {
@@ -217,7 +217,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
-                    &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->mvsym,
+                    &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->td_tau, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
                     &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd, &h->gpack, &h->gypack, &h->ginfo, &h->glabels};
   for (DevBuf* b : bufs)
@@ -1242,8 +1242,10 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
     SC_TRY(grow(h, h->td_e, (size_t)n * sizeof(double)));
     SC_TRY(grow(h, h->td_theta, (size_t)n * sizeof(double)));
     SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 16) * sizeof(double)));
+    SC_TRY(grow(h, h->td_tau, (size_t)n * sizeof(double)));
     launch_tridiagonalize(h->stream, ptr<double>(h->B1), ld, n, ptr<double>(h->td_d),
-                          ptr<double>(h->td_e), ptr<double>(h->td_work));
+                          ptr<double>(h->td_e), ptr<double>(h->td_tau),
+                          ptr<double>(h->td_work));
     launch_tridiagonal_eigenvalues(h->stream, ptr<double>(h->td_d), ptr<double>(h->td_e), n,
                                    ptr<double>(h->td_theta), ptr<double>(h->td_work));
     SC_TRY(check_last(h, "dense eigenvalue launch"));

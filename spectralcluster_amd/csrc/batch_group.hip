@@ -558,8 +558,33 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
   memset(h->gconv_hist, 0, sizeof(h->gconv_hist));
   h->gconv_seen = 0;
   std::vector<int> later;  // values whose solve left the common path
-  for (int base = 0; base < count; base += kGroupMax) {
-    const int cnt = std::min(kGroupMax, count - base);
+  // A member arena of a sweep holds the thresholded matrix (B2), its Diffuse product (B1),
+  // the n-vectors and the eigensolver workspace -- no affinity copy, no k-means workspace.
+  // The group is as wide as free memory allows (16 members of n = 16384 are 69 GB); whatever
+  // does not fit is evaluated one value at a time on this handle, like before the grouping.
+  const size_t member_bytes = 2 * (size_t)n * ld * sizeof(double) + (size_t)n * 8192;
+  int width = 0;
+  {
+    size_t free_b = 0, total_b = 0;
+    SC_HIP(h, hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (size_t)(0.85 * (double)free_b);
+    for (; width < std::min(kGroupMax, count); ++width) {
+      const bool ready = width < (int)h->gslots.size() &&
+                         h->gslots[width]->B1.bytes >= (size_t)n * ld * sizeof(double) &&
+                         h->gslots[width]->B2.bytes >= (size_t)n * ld * sizeof(double) &&
+                         h->gslots[width]->Q.bytes > 0;
+      if (ready) continue;
+      if (budget < member_bytes) break;
+      budget -= member_bytes;
+    }
+  }
+  if (width < 2) {
+    for (int i = 0; i < count; ++i) SC_TRY(one_by_one(i));
+    return SC_OK;
+  }
+  bool out_of_memory = false;
+  for (int base = 0; base < count && !out_of_memory; base += width) {
+    const int cnt = std::min(width, count - base);
     FrontItem fi[kGroupMax];
     GemmGroupItem dif[kGroupMax];
     GroupEigMember em[kGroupMax];
@@ -568,8 +593,13 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
     for (int z = 0; z < cnt; ++z) {
       sc_handle hz = nullptr;
       SC_TRY(group_slot(h, z, &hz));
-      int rc = sc_reserve(hz, n, 0);
+      int rc = ensure_matrices(hz, n, 0, false);
+      if (rc == SC_OK) rc = ensure_eig(hz, n);
       if (rc == SC_OK) rc = ensure_tilemap(hz, n);
+      if (rc == SC_ERR_OOM) {  // the estimate above was optimistic: the rest one by one
+        out_of_memory = true;
+        break;
+      }
       if (rc != SC_OK) return fail(h, rc, hz->err);
       hz->n = n;
       hz->ldn = ld;
@@ -609,6 +639,11 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       em[z].n = n;
       em[z].rq = rq;
     }
+    if (out_of_memory) {
+      (void)hipGetLastError();
+      for (int i = base; i < count; ++i) later.push_back(i);
+      break;
+    }
     {  // (the init kernel must not clear the shared symflag word)
       FrontItem init[kGroupMax];
       memcpy(init, fi, sizeof(init));
@@ -645,6 +680,15 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
     }
   }
   SC_HIP(h, hipStreamSynchronize(s));
+  {  // member arenas that hold a large share of the device do not outlive the sweep
+    size_t free_b = 0, total_b = 0, held = 0;
+    SC_HIP(h, hipMemGetInfo(&free_b, &total_b));
+    for (sc_handle sub : h->gslots) held += sub->A0.bytes + sub->B1.bytes + sub->B2.bytes;
+    if (out_of_memory || held > total_b / 4) {
+      for (sc_handle sub : h->gslots) sc_destroy(sub);
+      h->gslots.clear();
+    }
+  }
   for (int i : later) SC_TRY(one_by_one(i));  // the single-call solver
   h->n_vec = 0;  // nothing of any member is resident in this handle
   return SC_OK;

@@ -9,8 +9,14 @@
 // Why bisection and not implicit QL on the tridiagonal: QL is one serial chain of ~3 n^2
 // rotations; the Sturm count is independent per eigenvalue, so n threads each run ~60
 // counts of n steps -- the same eigenvalues to ulp * ||T||, in parallel.
-// Eigenvectors are NOT accumulated here: only the few columns k-means takes are needed and
-// the block Lanczos solver (eig.hip) delivers exactly those from the untouched S.
+// Eigenvectors: the few columns k-means takes normally come from the block Lanczos solver
+// (eig.hip) on the untouched S.  When that solver cannot deliver them (clustered spectra:
+// no convergence within its restart budget) they come from HERE, like LAPACK dstein +
+// dormtr: inverse iteration on the tridiagonal form (host, O(n) per vector and iteration:
+// host_tridiag_eigvectors in eig_driver.hip) and the back-transform Q z on the device
+// (k_td_backtransform).  For that the reflectors are kept: v_j (v_j[j+1] = 1) in ROW j of
+// the destroyed matrix, columns j+1 .. n-1 -- row j is dead once column j is eliminated and a
+// row is contiguous, so the back-transform streams whole rows -- and tau_j in taus[j].
 //
 // Tridiagonalisation, per column j (two launches; all O(n^2) traffic is in the second):
 //   k_td_column : finishes w of the previous reflector (needs v^T y), applies the pending
@@ -56,9 +62,10 @@ __device__ __forceinline__ double td_block_sum(double v, double* sm) {
 
 // scal[0] = tau of the previous reflector (read), tau of the new one (written)
 __global__ __launch_bounds__(1024) void k_td_column(
-    const double* __restrict__ A, int ld, int n, int j, const double* __restrict__ vprev,
+    double* __restrict__ A, int ld, int n, int j, const double* __restrict__ vprev,
     double* __restrict__ vnew, double* __restrict__ w, const double* __restrict__ y,
-    double* __restrict__ d, double* __restrict__ e, double* __restrict__ scal) {
+    double* __restrict__ d, double* __restrict__ e, double* __restrict__ scal,
+    double* __restrict__ taus) {
   __shared__ double sm[16];
   __shared__ double s_wj;
   const int tid = threadIdx.x;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_td_column(
   // ---- row j with the pending update; d_j; x = row[j+1 ..]
   const double wj = has_prev ? s_wj : 0.0;
   const double vj = has_prev ? vprev[j] : 0.0;
-  const double* row = A + (size_t)j * ld;
+  double* row = A + (size_t)j * ld;
   double norm2 = 0.0;
   for (int k = j + tid; k < n; k += 1024) {
     double a = row[k];
@@ -93,7 +100,10 @@ __global__ __launch_bounds__(1024) void k_td_column(
     }
   }
   const int m = n - j - 1;
-  if (m <= 0) return;
+  if (m <= 0) {
+    if (tid == 0) taus[j] = 0.0;
+    return;
+  }
   const double xnorm2 = td_block_sum(norm2, sm);  // (barriers also publish vnew[j + 1])
   const double alpha = vnew[j + 1];
   double tau = 0.0, scale = 0.0, beta = alpha;
@@ -103,10 +113,15 @@ __global__ __launch_bounds__(1024) void k_td_column(
     scale = 1.0 / (alpha - beta);
   }
   __syncthreads();  // everyone has read alpha before it is overwritten
-  for (int k = j + 1 + tid; k < n; k += 1024) vnew[k] = k == j + 1 ? 1.0 : vnew[k] * scale;
+  for (int k = j + 1 + tid; k < n; k += 1024) {
+    const double vk = k == j + 1 ? 1.0 : vnew[k] * scale;
+    vnew[k] = vk;
+    row[k] = vk;  // kept for the back-transform (row j is dead from here on)
+  }
   if (tid == 0) {
     e[j] = beta;
     scal[0] = tau;
+    taus[j] = tau;
   }
 }
 
@@ -253,6 +268,45 @@ __global__ __launch_bounds__(64) void k_td_bisect(const double* __restrict__ d,
   if (k < n) theta_desc[n - 1 - k] = 0.5 * (lo + hi);
 }
 
+// ---------------------------------------------------------------- back-transform
+// Z[:, q] <- Q Z[:, q],  Q = H_0 H_1 ... H_{n-2},  H_j = I - tau_j v_j v_j^T (LAPACK dormtr,
+// unblocked): one workgroup per column, the column in LDS (n <= kTdLdsRows) or in place in
+// global memory, reflectors applied last to first; each is one contiguous row of A.  The
+// workgroups of all columns walk the rows in step, so a row is fetched from HBM once.
+constexpr int kTdLdsRows = 16384;
+
+template <bool LDS>
+__global__ __launch_bounds__(1024) void k_td_backtransform(
+    const double* __restrict__ A, int ld, int n, const double* __restrict__ taus,
+    double* __restrict__ Z, int ldz) {
+  extern __shared__ double td_x[];
+  __shared__ double sm[16];
+  const int tid = threadIdx.x;
+  double* zg = Z + (size_t)blockIdx.x * ldz;
+  double* x = LDS ? td_x : zg;
+  if (LDS) {
+    for (int i = tid; i < n; i += 1024) x[i] = zg[i];
+  }
+  __syncthreads();
+  // thread t owns x[t], x[t + 1024], ... for every reflector: no barrier is needed for x
+  // itself, only the two inside the block sum
+  for (int j = n - 2; j >= 0; --j) {
+    const double tau = taus[j];
+    if (tau == 0.0) continue;  // (uniform)
+    const double* v = A + (size_t)j * ld;
+    int i0 = tid;
+    if (i0 < j + 1) i0 += ((j + 1 - i0 + 1023) >> 10) << 10;
+    double part = 0.0;
+    for (int i = i0; i < n; i += 1024) part = __builtin_fma(v[i], x[i], part);
+    const double s = tau * td_block_sum(part, sm);
+    for (int i = i0; i < n; i += 1024) x[i] = __builtin_fma(-s, v[i], x[i]);
+  }
+  __syncthreads();
+  if (LDS) {
+    for (int i = tid; i < n; i += 1024) zg[i] = x[i];
+  }
+}
+
 // ---------------------------------------------------------------- launchers
 void launch_td_materialize(hipStream_t s, const double* S, int ld, int n, const double* c,
                            const double* p, double* M) {
@@ -260,9 +314,10 @@ void launch_td_materialize(hipStream_t s, const double* S, int ld, int n, const 
                      s, S, ld, n, c, p, M);
 }
 
-// A (n x n, ld; destroyed) -> d[0..n), e[0..n-1).  work: 4 n + 8 doubles.
+// A (n x n, ld; destroyed) -> d[0..n), e[0..n-1), taus[0..n); reflector j is left in
+// A[j, j+1 .. n-1].  work: 4 n + 8 doubles.
 void launch_tridiagonalize(hipStream_t s, double* A, int ld, int n, double* d, double* e,
-                           double* work) {
+                           double* taus, double* work) {
   double* v[2] = {work, work + n};
   double* w = work + 2 * (size_t)n;
   double* y = work + 3 * (size_t)n;
@@ -271,7 +326,7 @@ void launch_tridiagonalize(hipStream_t s, double* A, int ld, int n, double* d, d
     double* vnew = v[j & 1];
     const double* vprev = v[(j & 1) ^ 1];
     hipLaunchKernelGGL(k_td_column, dim3(1), dim3(1024), 0, s, A, ld, n, j, vprev, vnew, w, y,
-                       d, e, scal);
+                       d, e, scal, taus);
     const int m = n - j - 1;
     if (m > 0)
       hipLaunchKernelGGL(k_td_update, dim3((m + 15) / 16), dim3(256), 0, s, A, ld, n, j,
@@ -288,6 +343,28 @@ void launch_tridiagonal_eigenvalues(hipStream_t s, const double* d, const double
   hipLaunchKernelGGL(k_td_bounds, dim3(1), dim3(1024), 0, s, d, e, n, e2, bounds);
   hipLaunchKernelGGL(k_td_bisect, dim3((n + 63) / 64), dim3(64), 0, s, d, e2, n, bounds,
                      theta_desc);
+}
+
+// Z (column-major, `cols` columns of n, ldz) <- Q Z with the reflectors launch_tridiagonalize
+// left in A / taus.
+void launch_td_backtransform(hipStream_t s, const double* A, int ld, int n, const double* taus,
+                             double* Z, int ldz, int cols) {
+  if (cols <= 0) return;
+  if (n <= kTdLdsRows) {
+    const size_t lds = (size_t)n * sizeof(double);
+    static bool raised = false;
+    if (!raised) {  // above the 64 KB default of dynamic LDS
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_td_backtransform<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                          kTdLdsRows * (int)sizeof(double));
+      raised = true;
+    }
+    hipLaunchKernelGGL(k_td_backtransform<true>, dim3(cols), dim3(1024), lds, s, A, ld, n, taus,
+                       Z, ldz);
+  } else {
+    hipLaunchKernelGGL(k_td_backtransform<false>, dim3(cols), dim3(1024), 0, s, A, ld, n, taus,
+                       Z, ldz);
+  }
 }
 
 }  // namespace sc

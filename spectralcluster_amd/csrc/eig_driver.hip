@@ -270,6 +270,147 @@ extern "C" int sc_host_symmetric_eig(const double* a, int m, double* values, dou
   return host_symmetric_eig(vectors, m, m, values, e.data()) ? SC_OK : SC_ERR_NOT_CONVERGED;
 }
 
+// ------------------------------------------------------------------------------
+// eigenvectors of a symmetric tridiagonal matrix by inverse iteration (host)
+// ------------------------------------------------------------------------------
+// LAPACK dstein's method for a handful of eigenvalues `lam` (any order; neighbours in the
+// list closer than 1e-3 ||T|| are treated as a cluster and kept orthogonal by modified
+// Gram-Schmidt, exact duplicates are separated by 10 ulp like dstein's `pertol`): LU of
+// T - lam I with partial pivoting (dlagtf's elimination), a random start, solves until
+// the iterate has grown past dstein's threshold plus two more.  O(n) per vector and
+// iteration -- a serial recurrence, which is why it runs here and not on the device; the
+// O(n^2) back-transform is k_td_backtransform.  Z: column-major, column q at Z + q * ldz,
+// unit 2-norm, largest component positive.  Returns false if a vector failed to grow.
+static bool host_tridiag_eigvectors(const double* d, const double* e, int n, const double* lam,
+                                    int k, double* Z, size_t ldz) {
+  if (n == 1) {
+    for (int q = 0; q < k; ++q) Z[q * ldz] = 1.0;
+    return true;
+  }
+  const double eps = 2.220446049250313e-16;
+  double onenrm = std::fabs(d[0]) + std::fabs(e[0]);
+  onenrm = std::max(onenrm, std::fabs(d[n - 1]) + std::fabs(e[n - 2]));
+  for (int i = 1; i < n - 1; ++i)
+    onenrm = std::max(onenrm, std::fabs(d[i]) + std::fabs(e[i - 1]) + std::fabs(e[i]));
+  if (!(onenrm > 0.0)) onenrm = 1.0;
+  const double ortol = 1e-3 * onenrm;
+  const double pivtol = eps * onenrm;
+  const double grow = std::sqrt(0.1 / n);  // dstein's dtpcrt
+  std::vector<double> u0(n), u1(n), u2(n), l(n), x(n);
+  std::vector<char> piv(n);
+  std::vector<double> used(k);
+  uint64_t rng = 0x9e3779b97f4a7c15ull;
+  bool all_ok = true;
+  int cluster_begin = 0;
+  for (int q = 0; q < k; ++q) {
+    double xj = lam[q];
+    if (q > 0 && std::fabs(lam[q] - lam[q - 1]) >= ortol) cluster_begin = q;
+    // separate (numerically) repeated shifts inside a cluster, keeping the list's direction
+    for (int r = cluster_begin; r < q; ++r) {
+      const double pert = 10.0 * eps * std::max(std::fabs(xj), onenrm * 1e-3);
+      if (std::fabs(xj - used[r]) < pert) xj = used[r] + (lam[q] <= lam[cluster_begin] ? -pert : pert);
+    }
+    used[q] = xj;
+    // ---- P L U = T - xj I  (row i of U: u0 diagonal, u1, u2 superdiagonals)
+    double a = d[0] - xj;       // current diagonal entry of the row being eliminated with
+    double b = n > 1 ? e[0] : 0.0;  // its first superdiagonal
+    for (int i = 0; i < n - 1; ++i) {
+      const double c = e[i];                      // subdiagonal entry (i + 1, i)
+      const double an = d[i + 1] - xj;            // row i + 1: (c, an, bn)
+      const double bn = i + 2 < n ? e[i + 1] : 0.0;
+      if (std::fabs(a) >= std::fabs(c)) {         // no interchange
+        double pv = a;
+        if (std::fabs(pv) < pivtol) pv = pv < 0.0 ? -pivtol : pivtol;
+        const double m = c / pv;
+        piv[i] = 0; l[i] = m;
+        u0[i] = pv; u1[i] = b; u2[i] = 0.0;
+        a = an - m * b;
+        b = bn;
+      } else {                                    // rows i and i + 1 swapped
+        const double m = a / c;
+        piv[i] = 1; l[i] = m;
+        u0[i] = c; u1[i] = an; u2[i] = bn;
+        a = b - m * an;
+        b = -m * bn;
+      }
+    }
+    if (std::fabs(a) < pivtol) a = a < 0.0 ? -pivtol : pivtol;
+    u0[n - 1] = a; u1[n - 1] = 0.0; u2[n - 1] = 0.0;
+    // ---- inverse iteration
+    for (int i = 0; i < n; ++i) {
+      rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+      x[i] = (double)(int64_t)(rng >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+    }
+    double* z = Z + (size_t)q * ldz;
+    int extra = 0;
+    bool ok = false;
+    for (int it = 0; it < 12; ++it) {
+      // scale the right-hand side to norm ~ n * onenrm * eps-ish (dstein) so that the solve
+      // of a nearly singular system cannot overflow
+      double amax = 0.0;
+      for (int i = 0; i < n; ++i) amax = std::max(amax, std::fabs(x[i]));
+      if (!(amax > 0.0)) { x[0] = 1.0; amax = 1.0; }
+      const double scl = n * onenrm * std::max(eps, std::fabs(u0[n - 1])) / amax;
+      for (int i = 0; i < n; ++i) x[i] *= scl;
+      // L^-1 P
+      for (int i = 0; i < n - 1; ++i) {
+        if (piv[i]) {
+          const double t = x[i];
+          x[i] = x[i + 1];
+          x[i + 1] = t - l[i] * x[i];
+        } else {
+          x[i + 1] -= l[i] * x[i];
+        }
+      }
+      // U^-1
+      x[n - 1] /= u0[n - 1];
+      if (n > 1) x[n - 2] = (x[n - 2] - u1[n - 2] * x[n - 1]) / u0[n - 2];
+      for (int i = n - 3; i >= 0; --i)
+        x[i] = (x[i] - u1[i] * x[i + 1] - u2[i] * x[i + 2]) / u0[i];
+      // keep the cluster orthogonal
+      for (int r = cluster_begin; r < q; ++r) {
+        const double* zr = Z + (size_t)r * ldz;
+        double dot = 0.0;
+        for (int i = 0; i < n; ++i) dot += x[i] * zr[i];
+        for (int i = 0; i < n; ++i) x[i] -= dot * zr[i];
+      }
+      double nrm = 0.0;
+      for (int i = 0; i < n; ++i) nrm = std::max(nrm, std::fabs(x[i]));
+      if (!std::isfinite(nrm)) break;
+      if (nrm >= grow) {
+        if (++extra > 2) { ok = true; break; }
+      }
+    }
+    double s2 = 0.0;
+    int imax = 0;
+    for (int i = 0; i < n; ++i) {
+      s2 += x[i] * x[i];
+      if (std::fabs(x[i]) > std::fabs(x[imax])) imax = i;
+    }
+    if (!(s2 > 0.0) || !std::isfinite(s2)) {
+      ok = false;
+      for (int i = 0; i < n; ++i) z[i] = 0.0;
+    } else {
+      const double inv = (x[imax] < 0.0 ? -1.0 : 1.0) / std::sqrt(s2);
+      for (int i = 0; i < n; ++i) z[i] = x[i] * inv;
+    }
+    all_ok = all_ok && ok;
+  }
+  return all_ok;
+}
+
+// host-only export: lets the CPU tests pin the routine without a GPU.  vectors: (n, k)
+// row-major (column q = eigenvector of lam[q]).
+extern "C" int sc_host_tridiag_eigvectors(const double* d, const double* e, int n,
+                                          const double* lam, int k, double* vectors) {
+  if (!d || (!e && n > 1) || !lam || !vectors || n < 1 || k < 1) return SC_ERR_INVALID;
+  std::vector<double> z((size_t)n * k);
+  const bool ok = host_tridiag_eigvectors(d, e, n, lam, k, z.data(), (size_t)n);
+  for (int q = 0; q < k; ++q)
+    for (int i = 0; i < n; ++i) vectors[(size_t)i * k + q] = z[(size_t)q * n + i];
+  return ok ? SC_OK : SC_ERR_NOT_CONVERGED;
+}
+
 // T (m x m, from the device, row-major ld) and the residual block's Gram G (B x B) ->
 // theta descending, resid estimates sqrt(y_last^T G y_last), Y (m x m, row-major ldy,
 // column `rank` = Ritz vector of theta[rank]).  Same outputs as k_jacobi.
@@ -398,9 +539,10 @@ static int dense_spectrum(sc_handle h, const double* S, int ld, int n, double* s
   SC_TRY(grow(h, h->td_e, (size_t)n * sizeof(double)));
   SC_TRY(grow(h, h->td_theta, (size_t)n * sizeof(double)));
   SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 16) * sizeof(double)));
+  SC_TRY(grow(h, h->td_tau, (size_t)n * sizeof(double)));
   launch_td_materialize(s, S, ld, n, ptr<double>(h->cvec), ptr<double>(h->pvec), scratch);
   launch_tridiagonalize(s, scratch, ld, n, ptr<double>(h->td_d), ptr<double>(h->td_e),
-                        ptr<double>(h->td_work));
+                        ptr<double>(h->td_tau), ptr<double>(h->td_work));
   launch_tridiagonal_eigenvalues(s, ptr<double>(h->td_d), ptr<double>(h->td_e), n,
                                  ptr<double>(h->td_theta), ptr<double>(h->td_work));
   SC_TRY(check_last(h, "dense eigenvalue launch"));
@@ -413,6 +555,37 @@ static int dense_spectrum(sc_handle h, const double* S, int ld, int n, double* s
   if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
   for (int i = 0; i < n; ++i)
     if (!std::isfinite(h->spectrum[i])) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+  return SC_OK;
+}
+
+// The leading `cols` eigenvectors of Op (largest eigenvalues first) from the tridiagonal form
+// dense_spectrum left behind (reflectors in `scratch`, taus, d, e; h->spectrum): inverse
+// iteration on T (host), Q z on the device, then the usual t .* u / ||.|| back-transform.
+// The landing pad of every spectrum block Lanczos gives up on: like np.linalg.eig
+// (utils.py:59) it always returns.
+static int dense_vectors(sc_handle h, const double* scratch, int ld, int n, int cols) {
+  hipStream_t s = h->stream;
+  if (cols < 1 || cols > kMaxCols || cols > n)
+    return fail(h, SC_ERR_UNSUPPORTED, "dense eigenvector request out of range");
+  std::vector<double> de(2 * (size_t)n);
+  SC_HIP(h, hipMemcpyAsync(de.data(), h->td_d.p, (size_t)n * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipMemcpyAsync(de.data() + n, h->td_e.p, (size_t)n * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipStreamSynchronize(s));
+  const int lde = round_up(n, 16);
+  std::vector<double> z((size_t)lde * cols, 0.0);
+  if (!host_tridiag_eigvectors(de.data(), de.data() + n, n, h->spectrum.data(), cols, z.data(),
+                               (size_t)lde))
+    return fail(h, SC_ERR_NOT_CONVERGED, "inverse iteration on the tridiagonal form failed");
+  SC_HIP(h, hipMemcpyAsync(h->E.p, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice,
+                           s));
+  launch_td_backtransform(s, scratch, ld, n, ptr<double>(h->td_tau), ptr<double>(h->E), lde,
+                          cols);
+  back_transform_cols(h, n, cols);
+  SC_TRY(check_last(h, "dense eigenvector launch"));
+  SC_HIP(h, hipStreamSynchronize(s));  // z is a local
+  h->n_vec = cols;
   return SC_OK;
 }
 
@@ -487,6 +660,27 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     return SC_OK;
   };
   if (n > kDenseMax && wants_full_spectrum(rq_in)) SC_TRY(run_dense());
+  // Block Lanczos gave up (`reason`: 1 restart budget, 2 projected problem, 3 no full-rank
+  // block): eigenvalues AND eigenvectors from the tridiagonal form.  np.linalg.eig
+  // (utils.py:59) always returns, so must this.
+  bool vectors_from_dense = false;
+  int fallback_reason = 0;
+  auto dense_fallback = [&](int reason) -> int {
+    if (scratch == nullptr || scratch == S)
+      return fail(h, SC_ERR_NOT_CONVERGED,
+                  "block Lanczos did not converge and no scratch matrix is free for the dense path");
+    if (getenv("SC_EIG_TRACE"))
+      fprintf(stderr, "[sc] block Lanczos gave up (reason %d, %d passes): dense path\n", reason,
+              passes);
+    if (!dense) SC_TRY(run_dense());
+    int cols = dense_dc.kvec;
+    if (rq_in.fixed_count > 0 || rq_in.max_clusters > 0) cols = std::max(dense_dc.kw, cols);
+    cols = std::max(1, std::min(cols, kMaxVectors));
+    SC_TRY(dense_vectors(h, scratch, ld, n, cols));
+    vectors_from_dense = true;
+    fallback_reason = reason;
+    return SC_OK;
+  };
 
   if (n <= kDenseMax) {
     // ---- direct dense path: every eigenpair, one Jacobi launch
@@ -513,6 +707,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
   restart_lanczos:
     m = 0;
     cycles = 0;
+    bool done = false;
     uint64_t seed = 0x5eed5eedull;
     const double* vscale = h->vs_scale ? h->vs_scale : cvec;
     LzChain chain;
@@ -531,8 +726,19 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     } else {
       launch_random_block(s, ptr<double>(h->W), n, seed);
       SC_TRY(orthonormalize(h, n, 0, false, 0, 0, false));
-      SC_TRY(finish_block(h, n, 0, 0, &seed));
+      const int rc0 = finish_block(h, n, 0, 0, &seed);
+      if (rc0 == SC_ERR_NOT_CONVERGED) {
+        SC_TRY(dense_fallback(3));
+        done = true;
+      } else {
+        SC_TRY(rc0);
+      }
       SC_HIP(h, hipMemsetAsync(h->T.p, 0, (size_t)kLdq * kLdq * sizeof(double), s));
+    }
+    // test switch: take the landing pad straight away (tests/test_gpu_alternate_paths.py)
+    if (!done && getenv("SC_EIG_FORCE_DENSE")) {
+      SC_TRY(dense_fallback(4));
+      done = true;
     }
     // basis cap: LDS Jacobi limit, and basis + next block must fit in R^n
     const int cap = std::min(kEigBasisCap, ((n - kEigBlock) / kEigBlock) * kEigBlock);
@@ -551,7 +757,6 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     } else {
       h->eig_hint_age = 0;
     }
-    bool done = false;
     while (!done) {
       // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
       const bool time_mv = h->profile_level >= 2 && h->n_mv_ev < 16;
@@ -603,7 +808,12 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
                                  hipMemcpyDeviceToHost, s));
       }
       if (!fused) {
-        SC_TRY(finish_block(h, n, m, m, &seed));  // syncs the stream
+        const int rcb = finish_block(h, n, m, m, &seed);  // syncs the stream
+        if (rcb == SC_ERR_NOT_CONVERGED) {
+          SC_TRY(dense_fallback(3));
+          break;
+        }
+        SC_TRY(rcb);
       } else if (check) {
         int mask = 0;
         SC_TRY(read_flags(h, &mask));  // the one synchronisation of the fused chain
@@ -628,8 +838,10 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       if (host_rr) {
         double* hy = h->h_rr + kHostRR * kHostRR + 64;
         if (!host_rayleigh_ritz(h->h_rr, m, h->h_rr + kHostRR * kHostRR, m, h->h_theta,
-                                h->h_theta + kLdq, hy, m))
-          return fail(h, SC_ERR_NOT_CONVERGED, "Rayleigh-Ritz (QL) did not converge");
+                                h->h_theta + kLdq, hy, m)) {
+          SC_TRY(dense_fallback(2));
+          break;
+        }
         for (int i = 0; i < m; ++i)
           if (!std::isfinite(h->h_theta[i])) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
         // the Ritz vectors (and values, for a restart) go back to where k_jacobi leaves them
@@ -674,8 +886,10 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       }
       if (m + kEigBlock > cap) {
         // ---- thick restart: keep the leading Ritz vectors + the new block
-        if (++cycles > rq.max_cycles)
-          return fail(h, SC_ERR_NOT_CONVERGED, "block Lanczos did not converge");
+        if (++cycles > rq.max_cycles) {
+          SC_TRY(dense_fallback(1));
+          break;
+        }
         int want = dc.enough ? std::max(dc.kw, dc.kvec) : cap / 4;
         int keep = round_up(want + kEigBlock, kEigBlock);
         keep = std::max(kEigBlock, std::min(keep, cap - 2 * kEigBlock));
@@ -689,13 +903,18 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
         m = keep;
       }
     }
-    const int cols = std::min(std::max(dc.kw, dc.kvec), kMaxVectors);
-    launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, cols,
-                         ptr<double>(h->E), round_up(n, 16), n, 1);
-    back_transform_cols(h, n, cols);
-    SC_TRY(check_last(h, "ritz vector launch"));
-    h->n_vec = cols;
-    if (diag) diag->eig_path = dense ? SC_EIG_PATH_DENSE_TRIDIAG : SC_EIG_PATH_BLOCK_LANCZOS;
+    if (vectors_from_dense) {
+      dc.max_resid = 0.0;
+      if (diag) diag->eig_path = SC_EIG_PATH_DENSE_FULL;
+    } else {
+      const int cols = std::min(std::max(dc.kw, dc.kvec), kMaxVectors);
+      launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, cols,
+                           ptr<double>(h->E), round_up(n, 16), n, 1);
+      back_transform_cols(h, n, cols);
+      SC_TRY(check_last(h, "ritz vector launch"));
+      h->n_vec = cols;
+      if (diag) diag->eig_path = dense ? SC_EIG_PATH_DENSE_TRIDIAG : SC_EIG_PATH_BLOCK_LANCZOS;
+    }
   }
   if (dense) {
     // values and the eigengap decision come from the full spectrum; the Lanczos pass above
@@ -719,6 +938,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     diag->eig_cycles = cycles;
     diag->eig_max_residual = dc.max_resid;
     diag->eig_host_chain = (n > kDenseMax && !fused) ? 1 : 0;
+    diag->eig_fallback = fallback_reason;
   }
   *out_dc = dc;
   return SC_OK;

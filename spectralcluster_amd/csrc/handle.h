@@ -68,7 +68,7 @@ struct sc_handle_s {
   DevBuf E, Ek, Eio;      // eigenvectors (col-major), renormed copy, row-major I/O staging
   DevBuf mvsym;           // slabs of the symmetric block matvec
   // dense full-spectrum path (eig_dense.hip): d, e, all eigenvalues, reflector work vectors
-  DevBuf td_d, td_e, td_theta, td_work;
+  DevBuf td_d, td_e, td_theta, td_work, td_tau;
   std::vector<double> spectrum;  // host copy: every eigenvalue of Op, descending
   std::vector<double> last_w;    // eigenvalues the last eig call consumed (reference order)
   // general (non-symmetric) eigen path: right scaling, Im(theta), complex Ritz vectors
@@ -193,7 +193,8 @@ inline T* ptr(const DevBuf& b) {
   return reinterpret_cast<T*>(b.p);
 }
 
-int ensure_matrices(sc_handle h, int n, int d);
+// `affinity_copy` false: no A0 (a member arena of an AutoTune sweep only holds B1 / B2)
+int ensure_matrices(sc_handle h, int n, int d, bool affinity_copy = true);
 
 // (ti, tj) order of the symmetric GEMM tiles for problems of n rows (cached per handle)
 int ensure_tilemap(sc_handle h, int n);

@@ -311,10 +311,13 @@ void launch_colmajor_to_rowmajor(hipStream_t s, const double* src, int lds, int 
 // M = diag(p) + diag(c) S diag(c), exactly symmetric
 void launch_td_materialize(hipStream_t s, const double* S, int ld, int n, const double* c,
                            const double* p, double* M);
-// Householder tridiagonalisation of A (n x n, ld; destroyed): d[0..n), e[0..n-1).
-// work: 4 n + 8 doubles.  2 n launches.
+// Householder tridiagonalisation of A (n x n, ld; destroyed): d[0..n), e[0..n-1), taus[0..n);
+// reflector j (v[j+1] = 1) is left in A[j, j+1 .. n-1].  work: 4 n + 8 doubles.  2 n launches.
 void launch_tridiagonalize(hipStream_t s, double* A, int ld, int n, double* d, double* e,
-                           double* work);
+                           double* taus, double* work);
+// Z (column-major: column q at Z + q * ldz) <- Q Z, Q = H_0 ... H_{n-2} from the above
+void launch_td_backtransform(hipStream_t s, const double* A, int ld, int n, const double* taus,
+                             double* Z, int ldz, int cols);
 // all eigenvalues of the tridiagonal (d, e) by Sturm bisection, DESCENDING; work: n + 4
 void launch_tridiagonal_eigenvalues(hipStream_t s, const double* d, const double* e, int n,
                                     double* theta_desc, double* work);

@@ -87,15 +87,40 @@ class LocalComm(Comm):
     return float(value)
 
 
+_ID_MAGIC = b"SCCOMM1\0"
+
+
 def _id_file() -> str:
-  """Where rank 0 leaves the RCCL unique id for the other ranks of this launch.  All
-  ranks of one `torch.distributed.run` / mpirun launch share a parent process and a
-  MASTER_PORT, which makes the name unique per launch on the node."""
+  """Where rank 0 leaves the rendezvous blob for the other ranks of this launch.  All ranks of
+  one `torch.distributed.run` launch share TORCHELASTIC_RUN_ID (when exported), a MASTER_PORT
+  and a parent process, which makes the name unique per launch on the node; it lives in a
+  per-user 0700 directory.  Launchers whose ranks have no common parent (some srun set-ups)
+  must export SC_COMM_ID_FILE."""
   explicit = os.environ.get("SC_COMM_ID_FILE")
   if explicit:
     return explicit
-  tag = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
-  return os.path.join(os.environ.get("TMPDIR", "/tmp"), "sc_comm_%s.id" % tag)
+  base = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sc_comm_%d" % os.getuid())
+  try:
+    os.mkdir(base, 0o700)
+  except FileExistsError:
+    pass
+  st = os.lstat(base)
+  import stat as _stat
+  if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+    raise PermissionError("%s is not a private directory of this user" % base)
+  run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+  run_id = "".join(ch for ch in run_id if ch.isalnum())[:32]
+  tag = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), run_id or "x", os.getppid())
+  return os.path.join(base, "%s.id" % tag)
+
+
+def _collective_timeout() -> typing.Optional[float]:
+  """Timeout of an established TCP collective.  None (the default) blocks: one rank may
+  compute minutes longer than another between two collectives (an unbalanced batch share, a
+  large-n AutoTune level), and a dead peer is noticed through its closed socket anyway.
+  SC_COMM_TIMEOUT_S overrides."""
+  v = os.environ.get("SC_COMM_TIMEOUT_S")
+  return float(v) if v else None
 
 
 class SocketComm(Comm):
@@ -144,9 +169,10 @@ class SocketComm(Comm):
       conns = {}
       while len(conns) < size - 1:
         peer, _ = server.accept()
-        peer.settimeout(timeout_s)
+        peer.settimeout(timeout_s)  # the handshake only ...
         peer.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
         (who,) = struct.unpack("<I", cls._recv(peer))
+        peer.settimeout(_collective_timeout())  # ... collectives wait for the slowest rank
         conns[who] = peer
       try:
         os.unlink(_id_file())
@@ -167,6 +193,7 @@ class SocketComm(Comm):
     sock.settimeout(timeout_s)
     sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
     cls._send(sock, struct.pack("<I", rank))
+    sock.settimeout(_collective_timeout())
     return cls(rank, size, {0: sock})
 
   def _exchange(self, blob: bytes) -> typing.List[bytes]:
@@ -241,19 +268,31 @@ class RcclComm(Comm):
     path = _id_file()
     if rank == 0:
       uid = make_id()
+      # magic | creation time | payload, written under a private temporary name (O_EXCL and
+      # O_NOFOLLOW: nothing pre-planted is followed or reused) and renamed into place
+      blob = _ID_MAGIC + struct.pack("<d", time.time()) + uid
       tmp = "%s.%d.tmp" % (path, os.getpid())
-      with open(tmp, "wb") as f:
-        f.write(uid)
+      try:
+        os.unlink(tmp)
+      except OSError:
+        pass
+      fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+      with os.fdopen(fd, "wb") as f:
+        f.write(blob)
       os.replace(tmp, path)
       return uid
     deadline = time.monotonic() + timeout_s
     while True:
       try:
-        with open(path, "rb") as f:
-          uid = f.read()
-        if len(uid) == 128:
-          return uid
-      except FileNotFoundError:
+        fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+        with os.fdopen(fd, "rb") as f:
+          owner = os.fstat(f.fileno()).st_uid
+          blob = f.read()
+        if (owner == os.getuid() and len(blob) == 144 and blob[:8] == _ID_MAGIC and
+            # a file a crashed earlier launch left behind is not this launch's
+            time.time() - struct.unpack("<d", blob[8:16])[0] < timeout_s + 60.0):
+          return blob[16:]
+      except OSError:  # not there yet (or a symlink: O_NOFOLLOW refuses it)
         pass
       if time.monotonic() > deadline:
         raise TimeoutError("rank %d: no RCCL unique id at %s" % (rank, path))
@@ -278,12 +317,26 @@ class RcclComm(Comm):
       except Exception as exc:  # pylint: disable=broad-except
         why = "rank 0: %s" % exc
     head = sock.broadcast_bytes(head, 129)
+    # ncclCommInitRank blocks until EVERY rank has entered it: a rank whose local preflight
+    # fails (device not settable, librccl not loadable) must say so BEFORE anyone enters
+    pre = ""
+    try:
+      from spectralcluster_amd import _lib
+      if not handle.lib.sc_comm_available():
+        pre = "rank %d: librccl cannot be loaded" % rank
+      elif handle.lib.sc_synchronize(handle.raw) != _lib.SC_OK:
+        pre = "rank %d: device not usable: %s" % (rank, handle.last_error())
+    except Exception as exc:  # pylint: disable=broad-except
+      pre = "rank %d: %s" % (rank, exc)
+    ready = sock.allgather_bytes((b"\0" if pre else b"\1") + pre.encode()[:200])
     comm = None
-    if head[:1] == b"\1":
+    if head[:1] == b"\1" and all(r[:1] == b"\1" for r in ready):
       try:
         comm = cls(handle, rank, size, head[1:])
       except Exception as exc:  # pylint: disable=broad-except
         why = "rank %d: %s" % (rank, exc)
+    elif pre:
+      why = pre
     reports = sock.allgather_bytes((b"\1" if comm is not None else b"\0") + why.encode()[:200])
     if all(r[:1] == b"\1" for r in reports):
       comm.barrier()

@@ -78,6 +78,9 @@ class SpectralClusterer:
     self.post_eigen_cluster_function = post_eigen_cluster_function
     self.device = device
     self.last_diag: typing.Optional[_lib.ScDiag] = None
+    # not in the reference: restart cycles block Lanczos may spend before the dense
+    # eigensolver takes over (0 = the library default, 40); predict() returns either way
+    self.eig_max_cycles = 0
 
   # ----------------------------------------------------------------- plumbing
   def _handle(self) -> _lib.Handle:
@@ -104,6 +107,7 @@ class SpectralClusterer:
     cfg.stop_eigenvalue = float(self.stop_eigenvalue)
     cfg.row_wise_renorm = int(bool(self.row_wise_renorm))
     cfg.max_iter = int(self.max_iter)
+    cfg.eig_max_cycles = int(getattr(self, "eig_max_cycles", 0) or 0)
     if self.post_eigen_cluster_function is custom_distance_kmeans.run_kmeans:
       cfg.kmeans_metric = _lib.kmeans_metric_code(self.custom_dist)
     if self.constraint_options is not None:
@@ -287,6 +291,7 @@ class SpectralClusterer:
       # reference closure leaves refinement_options.p_percentile at the LAST
       # evaluated value (spectral_clusterer.py:277); keep that observable state
       self.refinement_options.p_percentile = evaluated[-1]
+      self.last_best_p = best_p  # (not in the reference: the value the labels come from)
       diag = self._eig_resident(handle, best_p)  # the winner's vectors, resident
     else:
       diag = self._eig_resident(handle)

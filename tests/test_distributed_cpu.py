@@ -190,3 +190,41 @@ def test_tcp_fallback_when_rccl_cannot_come_up(tmp_path):
     p.join(120)
     assert p.exitcode == 0
   assert all(os.path.exists("%s.%d" % (out, r)) for r in range(3))
+
+
+def test_rendezvous_file_rejects_stale_and_planted_files(tmp_path, monkeypatch):
+  """the id file of a crashed earlier launch (old timestamp), a truncated blob and
+  a pre-planted symlink must not be taken for this launch's rendezvous blob."""
+  import struct
+  import threading
+  import time
+  from spectralcluster_amd import multigpu
+  path = tmp_path / "launch.id"
+  monkeypatch.setenv("SC_COMM_ID_FILE", str(path))
+  uid = bytes(range(128))
+  # stale: right format, written "an hour ago"
+  path.write_bytes(multigpu._ID_MAGIC + struct.pack("<d", time.time() - 3600.0) + bytes(128))
+  with pytest.raises(TimeoutError):
+    multigpu.RcclComm.exchange_id(1, lambda: b"", timeout_s=0.3)
+  # old 128-byte format / truncated
+  path.write_bytes(bytes(128))
+  with pytest.raises(TimeoutError):
+    multigpu.RcclComm.exchange_id(1, lambda: b"", timeout_s=0.2)
+  # a symlink somebody planted at the path: never followed by the reader ...
+  target = tmp_path / "elsewhere"
+  target.write_bytes(multigpu._ID_MAGIC + struct.pack("<d", time.time()) + bytes(128))
+  path.unlink()
+  path.symlink_to(target)
+  with pytest.raises(TimeoutError):
+    multigpu.RcclComm.exchange_id(1, lambda: b"", timeout_s=0.2)
+  # ... and replaced (not written through) by rank 0; a polling reader then gets the id
+  got = {}
+  t = threading.Thread(target=lambda: got.setdefault(
+      "uid", multigpu.RcclComm.exchange_id(1, lambda: b"", timeout_s=5.0)))
+  t.start()
+  time.sleep(0.1)
+  assert multigpu.RcclComm.exchange_id(0, lambda: uid) == uid
+  t.join()
+  assert got["uid"] == uid
+  assert not path.is_symlink() and target.read_bytes()[16:] == bytes(128)
+  assert (path.stat().st_mode & 0o777) == 0o600

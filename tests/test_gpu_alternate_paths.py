@@ -10,6 +10,10 @@ they are the repair / large-problem routes of the default ones:
   SC_MATVEC_SYM_MIN_N=129  upper-triangle block matvec on every Krylov solve, not only for
                         n >= 4096 (edge tiles, restarts, the repair chain all go through it)
 
+  SC_EIG_FORCE_DENSE=1  the landing pad of spectra block Lanczos gives up on: eigenvalues by
+                        tridiagonalisation + bisection, eigenvectors by inverse iteration +
+                        Householder back-transform (sc_diag.eig_path == 6)
+
 Each runs in a fresh interpreter (the switches are read once per process) over reference
 goldens of both Laplacian branches."""
 
@@ -52,6 +56,8 @@ for name in ("e2e_n1000_lap0_max7", "e2e_n1000_lap4_max20", "e2e_n1000_lap3_max2
     assert so.adjusted_rand_index(labels, g["labels"]) == 1.0, name
   if os.environ.get("SC_EIG_HOST_CHAIN"):
     assert dg.eig_host_chain == 1
+  if os.environ.get("SC_EIG_FORCE_DENSE"):
+    assert dg.eig_path == 6 and dg.eig_fallback == 4
 km = np.load(os.path.join(ROOT, "tests", "golden", "kmeans.npz"))
 for tag, k in (("a", 4), ("b", 8), ("c", 2), ("d", 20)):
   got = sca.custom_distance_kmeans.run_kmeans(km["e_" + tag], k, "cosine", 300)
@@ -77,7 +83,8 @@ print("ALTERNATE_PATH_OK")
 
 
 @pytest.mark.parametrize("switch", ["SC_EIG_HOST_CHAIN", "SC_EIG_DEVICE_RR", "SC_KMEANS_SINGLE",
-                                    "SC_EIG_NO_HINT", "SC_MATVEC_SYM_MIN_N"])
+                                    "SC_EIG_NO_HINT", "SC_MATVEC_SYM_MIN_N",
+                                    "SC_EIG_FORCE_DENSE"])
 def test_alternate_path(tmp_path, switch):
   script = tmp_path / "alt.py"
   script.write_text(_SCRIPT)

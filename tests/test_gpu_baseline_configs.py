@@ -51,8 +51,9 @@ def test_config4_autotune_n4096_vs_reference():
   labels = clusterer.predict(x)
   # the closure leaves p_percentile at the last evaluated value (spectral_clusterer.py:277);
   # the winner is what the labels come from
-  best = grid[int(np.argmin(g["ratios"]))]
-  assert best == float(g["best_p"]) or True  # (golden stores the reference's own final p)
+  # (the golden's `best_p` is that final state of the reference)
+  assert clusterer.refinement_options.p_percentile == float(g["best_p"]) == grid[-1]
+  assert clusterer.last_best_p == grid[int(np.argmin(g["ratios"]))]
   assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
   # the sharded form of the same sweep (what bench.py --gpus N runs), world of one
   from spectralcluster_amd import multigpu

@@ -1,0 +1,112 @@
+"""GPU: predict() on inputs whose refined affinity has an UNFRIENDLY spectrum.
+
+The reference's eigensolver is np.linalg.eig (utils.py:59): it always returns, whatever the
+spectrum looks like.  Block Lanczos does not: on unstructured embeddings the 21 eigenvalues
+the GraphCut eigengap reads sit 1e-4 .. 1e-3 apart on the edge of a dense bulk.  The device
+path must still return -- from the dense landing pad (tridiagonalisation + bisection +
+inverse iteration + back-transform, sc_diag.eig_path == 6) when the Krylov solver gives up
+-- with the reference's n_clusters, its consumed eigenvalues at 1e-5 and its labels.
+
+Goldens: tests/golden/hard_*.npz, made by `oracle/make_golden.py --hard` from the REAL
+reference (inputs: spectral_oracle.hard_inputs).  Bars: BASELINE.json north_star.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+import spectral_oracle as so
+from conftest import GOLDEN, golden
+
+import spectralcluster_amd as sca
+
+pytestmark = pytest.mark.gpu
+
+LAP = {0: None, 4: sca.LaplacianType.GraphCut}
+EIG_RTOL = 1e-5  # north_star
+CASES = [(kind, n, lap) for kind in so.HARD_KINDS for n in (1000, 2048, 4096)
+         for lap in (0, 4)]
+
+
+def _clusterer(lap, maxc):
+  return sca.SpectralClusterer(
+      min_clusters=2, max_clusters=maxc, laplacian_type=LAP[lap],
+      refinement_options=sca.RefinementOptions(
+          gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
+          thresholding_type=sca.ThresholdType.RowMax,
+          refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE))
+
+
+def _check(g, labels, n_clusters_raw, max_delta, w, name):
+  idx, ref = g["consumed_index"], g["consumed_eigenvalues"]
+  scale = np.abs(g["head_eigenvalues"]).max()
+  # relative to the value, with an absolute floor for the Laplacian's exact zero
+  err = np.abs(w[idx] - ref) / np.maximum(np.abs(ref), 1e-9 * scale)
+  assert err.max() < EIG_RTOL, (name, err.max(), int(np.argmax(err)))
+  assert n_clusters_raw == int(g["n_clusters_raw"]), name
+  np.testing.assert_allclose(max_delta, float(g["max_delta"]), rtol=1e-5, err_msg=name)
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0, name
+
+
+@pytest.mark.parametrize("kind,n,lap", CASES)
+def test_hard_input_vs_reference(kind, n, lap):
+  name = "hard_%s_n%d_lap%d" % (kind, n, lap)
+  g = golden(name + ".npz")
+  nn, d, seed, lap_g, maxc = (int(v) for v in g["params"])
+  assert (nn, lap_g) == (n, lap)
+  x = so.hard_inputs(kind, n, d, seed)
+  c = _clusterer(lap, maxc)
+  labels = c.predict(x)  # must not raise
+  dg = c.last_diag
+  _check(g, labels, dg.n_clusters_raw, dg.max_delta, dg.eigenvalue_array(), name)
+  if dg.eig_fallback:
+    assert dg.eig_path == 6  # SC_EIG_PATH_DENSE_FULL
+
+
+@pytest.mark.parametrize("n,lap", [(1000, 0), (1000, 4), (2048, 0), (2048, 4)])
+def test_hard_inputs_through_the_grouped_batch(n, lap):
+  """The same inputs as one predict_batch(group=16): members the lockstep solver cannot
+  finish are handed back to the single-call solver, which lands on the dense path."""
+  gs = [golden("hard_%s_n%d_lap%d.npz" % (kind, n, lap)) for kind in so.HARD_KINDS]
+  xs = [so.hard_inputs(kind, n, int(g["params"][1]), int(g["params"][2]))
+        for kind, g in zip(so.HARD_KINDS, gs)]
+  # friendly neighbours in the same group
+  xs += [so.blobs(n - 100, 256, 4, seed=n + 1), so.blobs(n + 100, 256, 3, seed=n + 2)]
+  c = _clusterer(lap, int(gs[0]["params"][4]))
+  out = c.predict_batch(xs, group=16)
+  assert len(out) == len(xs)
+  for kind, g, labels in zip(so.HARD_KINDS, gs, out):
+    assert so.adjusted_rand_index(labels, g["labels"]) == 1.0, (kind, n, lap)
+  single = [c.predict(x) for x in xs[-2:]]
+  for a, b in zip(out[-2:], single):
+    assert so.adjusted_rand_index(a, b) == 1.0
+
+
+def test_golden_files_present():
+  for kind, n, lap in CASES:
+    assert os.path.exists(os.path.join(GOLDEN, "hard_%s_n%d_lap%d.npz" % (kind, n, lap)))
+
+
+@pytest.mark.parametrize("n,lap,maxc", [(1500, 4, 20), (1500, 0, 7), (3000, 4, 20)])
+def test_restart_budget_exhausted_lands_on_dense_path(n, lap, maxc):
+  """eig_max_cycles = 1 on an unstructured input: block Lanczos runs out of budget at once;
+  the result must still be the oracle's."""
+  x = so.hard_inputs("iid", n, 64, seed=n)
+  cfg = so.icassp2018_config(laplacian_type=lap, max_clusters=maxc)
+  dump = {}
+  want = so.predict(x, cfg, dump)
+  c = _clusterer(lap, maxc)
+  c.eig_max_cycles = 1
+  got = c.predict(x)
+  dg = c.last_diag
+  ref = np.real(dump["eigenvalues"])
+  idx = so.consumed_eigen_indices(n, maxc, lap == 0, ref, 1e-2)
+  w = dg.eigenvalue_array()
+  err = np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-9 * np.abs(ref).max())
+  assert err.max() < EIG_RTOL
+  if lap == 4:  # 21 bulk-edge values at a 1e-6 residual: never within one restart cycle
+    assert dg.eig_path == 6 and dg.eig_fallback == 1  # SC_EIG_PATH_DENSE_FULL, budget spent
+  assert max(dg.n_clusters_raw, 2) == dump["n_clusters"]
+  np.testing.assert_allclose(dg.max_delta, dump["max_delta"], rtol=1e-5)
+  assert so.adjusted_rand_index(got, want) == 1.0

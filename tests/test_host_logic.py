@@ -501,6 +501,41 @@ def test_host_rayleigh_ritz_solver_vs_numpy():
     assert np.abs(v.T @ v - np.eye(m)).max() < 1e-13 * m
 
 
+def test_host_tridiag_eigvectors_vs_scipy():
+  """The host step of the dense landing pad (inverse iteration on the tridiagonal form,
+  LAPACK dstein's method) against scipy's eigh_tridiagonal, including clustered spectra."""
+  from scipy.linalg import eigh_tridiagonal
+  lib = _lib.load()
+  rng = np.random.default_rng(5)
+  cases = []
+  for n in (2, 3, 50, 1000, 3001):
+    cases.append((rng.standard_normal(n), rng.standard_normal(n - 1), min(n, 20)))
+  cases.append((np.abs(np.arange(1001) - 500.0), np.ones(1000), 20))      # Wilkinson pairs
+  cases.append((np.ones(500), np.full(499, 1e-9), 20))                    # one tight cluster
+  cases.append((np.r_[np.ones(10), np.zeros(90)], np.zeros(99), 20))      # exact repeats
+  cases.append((np.full(2048, 2.0), np.full(2047, -1.0), 64))             # 1-D Laplacian edge
+  for d, e, k in cases:
+    n = d.size
+    d = np.ascontiguousarray(d)
+    e = np.ascontiguousarray(e)
+    w = eigh_tridiagonal(d, e, eigvals_only=True)
+    lam = np.ascontiguousarray(w[::-1][:k])  # the driver asks for the largest ones first
+    out = np.empty((n, k))
+    assert lib.sc_host_tridiag_eigvectors(_lib.as_double_p(d), _lib.as_double_p(e), n,
+                                          _lib.as_double_p(lam), k, _lib.as_double_p(out)) == 0
+    tv = d[:, None] * out
+    tv[:-1] += e[:, None] * out[1:]
+    tv[1:] += e[:, None] * out[:-1]
+    scale = max(1.0, np.abs(d).max() + 2 * np.abs(e).max())
+    assert np.abs(tv - out * lam).max() < 1e-12 * scale
+    assert np.abs(out.T @ out - np.eye(k)).max() < 1e-12
+  one = np.empty((1, 1))
+  assert lib.sc_host_tridiag_eigvectors(_lib.as_double_p(np.array([3.0])),
+                                        _lib.as_double_p(np.zeros(1)), 1,
+                                        _lib.as_double_p(np.array([3.0])), 1,
+                                        _lib.as_double_p(one)) == 0 and one[0, 0] == 1.0
+
+
 def test_use_device_scope_is_thread_local_and_nested():
   assert getattr(_lib._scope, "device", None) is None
   with _lib.use_device(3):

@@ -92,7 +92,7 @@ def test_toy_stage_dump(lap):
   for i, st in enumerate(dump["stages"]):
     assert np.array_equal(st, g["stage%d" % i])
   assert np.array_equal(dump["eigenvalues"], g["eigenvalues"])
-  assert dump["n_clusters"] == max(int(g["n_clusters_raw"]), 0) or True
+  assert dump["n_clusters"] == int(g["n_clusters_raw"])  # (min_clusters is None here)
   assert np.array_equal(labels, g["labels"])
   assert np.array_equal(so.ordered_labels(labels), [0, 0, 1, 1, 0, 1])
 
@@ -323,3 +323,21 @@ def test_algorithm_matched_cpu_path_vs_reference_golden(name):
   rel = np.abs(w[idx] - ref) / np.maximum(np.abs(ref), 1e-12)
   assert rel.max() < 1e-8, rel.max()
   assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+
+
+@pytest.mark.parametrize("kind", so.HARD_KINDS)
+@pytest.mark.parametrize("lap", [0, 4])
+def test_hard_inputs_n1000(kind, lap):
+  """Unfriendly spectra (oracle/make_golden.py --hard): the restatement must reproduce the
+  real reference there too -- consumed eigenvalues, cluster count, labels."""
+  g = golden("hard_%s_n1000_lap%d.npz" % (kind, lap))
+  n, d, seed, lap_g, maxc = (int(v) for v in g["params"])
+  x = so.hard_inputs(kind, n, d, seed)
+  cfg = so.icassp2018_config(laplacian_type=lap, max_clusters=maxc)
+  dump = {}
+  labels = so.predict(x, cfg, dump)
+  w = np.real(dump["eigenvalues"])
+  assert np.array_equal(w[g["consumed_index"]], g["consumed_eigenvalues"])
+  assert dump["max_delta"] == float(g["max_delta"])
+  assert dump["n_clusters"] == max(int(g["n_clusters_raw"]), 2)
+  assert np.array_equal(labels, g["labels"])

@@ -9,11 +9,10 @@ rank 0.
 
 Headline workload (BASELINE.json configs[2], the one `metric` is quoted on): n=8192 d=256
 synthetic Gaussian blobs (8 speakers), ICASSP2018 refinement, GraphCut Laplacian,
-eigengap k in [2, 20], cosine k-means.  One "step" = one pass of the whole device
-pipeline over one utterance whose embeddings are already resident in HBM
-(`sc_run_resident`; the label D2H, n*8 bytes, is inside the step).  The same K steps
-are then repeated through `sc_predict` -- the call `predict()` makes, including the
-16.8 MB pageable-memory H2D of X -- and reported as `predict_incl_h2d`.
+eigengap k in [2, 20], cosine k-means.  One "step" = one `sc_predict` -- the call
+`SpectralClusterer.predict()` makes: H2D of X (16.8 MB from a pageable numpy buffer), the
+whole device pipeline, D2H of the labels.  The same K steps through `sc_run_resident`
+(embeddings already in HBM: the same pipeline without the H2D) are reported as `resident`.
 Multi-GPU = independent replicas (every rank runs the same per-GPU work, no data-path
 collective, weak scaling).
 
@@ -22,7 +21,12 @@ Extra keys (not the headline): `batch512` = BASELINE config 5 (512 utterances, n
 16 utterances per launch -- labels all-gathered; the multi-stream form and the plain loop are
 timed beside it) in utterances/s, and `autotune16` = config 4 (16-value p_percentile sweep at
 n=4096, grid round-robin over the ranks) in ms per sweep -- the quantities the 8-GPU
-target is stated on.  `--workload batch512|autotune16` makes one of them the `value`.
+target is stated on; both carry their own `roofline` (algorithmic flops + HBM bytes -> floor)
+and, on one GPU, `projected`: every rank's share of a world of 2 / 4 / 8 timed on its own on
+this GPU (what N GPUs would give, fixed per-rank costs included).  `hard8192` = the headline
+configuration on UNSTRUCTURED N(0, I) embeddings (clustered spectrum: which eigen path
+finished, passes, restart cycles).  `autotune16_ttd` = config 4's Turn-to-Diarize variant.
+`--workload batch512|autotune16` makes one of them the `value`.
 """
 
 import argparse
@@ -41,6 +45,7 @@ N_SAMPLES, N_FEATURES, N_SPEAKERS, SEED = 8192, 256, 8, 0
 MAX_CLUSTERS = 20
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak
 PEAK_HBM_TBS = 8.0            # MI355X HBM3E (MI355X_MICROARCH.md)
+ACHIEVABLE_HBM_TBS = 6.3      # what a streaming copy reaches (MI355X_MICROARCH.md: 6.29 measured)
 GEMM_TILE = 128               # gemm_f64.hip block tile
 
 
@@ -115,14 +120,23 @@ def cpu_baseline_legs(gpu_clusterer):
   port_s, port_reps, port_labels = timed(lambda: so.predict(x, cfg), 20.0, 3)
   am_s, am_reps, (am_labels, _) = timed(lambda: so.predict_algorithm_matched(x, cfg),
                                         10.0, 5)
-  gpu_clusterer.predict(x)
+  # the GPU sat idle for ~30 s of CPU legs: the first call meets idle clocks.  Report that
+  # latency on its own, then warm the device (>= 50 ms of work) before timing the sample.
   t0 = time.perf_counter()
-  for _ in range(5):
+  gpu_clusterer.predict(x)
+  first_after_idle_s = time.perf_counter() - t0
+  t0 = time.perf_counter()
+  while time.perf_counter() - t0 < 0.25:
+    gpu_clusterer.predict(x)
+  reps = 50
+  t0 = time.perf_counter()
+  for _ in range(reps):
     glab = gpu_clusterer.predict(x)
-  gpu_s = (time.perf_counter() - t0) / 5
+  gpu_s = (time.perf_counter() - t0) / reps
   scale = (N_SAMPLES / n_s) ** 3
   common = {"unit": "calls/s", "cores": threads, "cpu_model": model, "nproc": nproc,
-            "gpu_same_sample_calls_per_s": 1.0 / gpu_s}
+            "gpu_same_sample_calls_per_s": 1.0 / gpu_s,
+            "gpu_first_call_after_idle_ms": 1e3 * first_after_idle_s}
   port = dict(common, value=1.0 / port_s, kind="port",
               sample=("oracle/spectral_oracle.predict (np.linalg.eig) on n=%d d=%d k=%d blobs, "
                       "same config; %d reps; n=8192 extrapolates by (8192/2048)^3"
@@ -180,19 +194,48 @@ def batch512_sizes():
   return rng.integers(300, 3001, 512), rng.integers(2, 8, 512)
 
 
-def batch512_leg(sca, multigpu, comm, fence, group=16, streams=8):
+def tri_tiles(n):
+  nt = (n + GEMM_TILE - 1) // GEMM_TILE
+  return nt * (nt + 1) // 2
+
+
+def icassp_work(n, d, passes):
+  """Algorithmic work of one ICASSP2018 predict() (fused lower bound):
+  the two symmetric products on upper-triangle tiles; A1 write, Crop+Blur R/W,
+  Threshold+Symmetrize R/W, Diffuse R/W (normalise + Laplacian folded) = 7 n^2 passes, plus
+  one per executed block matvec."""
+  flops = tri_tiles(n) * 2.0 * GEMM_TILE * GEMM_TILE * (n + d)
+  hbm = (7.0 + passes) * n * n * 8.0 + n * d * 8.0
+  return flops, hbm
+
+
+def workload_roofline(flops, hbm_bytes, seconds):
+  """A whole workload against its floor: MFMA time of its flops + HBM time of its
+  algorithmic bytes (the stages are data-dependent, so the two add)."""
+  floor = flops / (PEAK_F64_MFMA_TFLOPS * 1e12) + hbm_bytes / (ACHIEVABLE_HBM_TBS * 1e12)
+  return {"flops": flops, "hbm_bytes": hbm_bytes, "floor_ms": 1e3 * floor,
+          "measured_ms": 1e3 * seconds, "achieved_tflops": flops / seconds / 1e12,
+          "frac": floor / seconds,
+          "floor_terms": "flops / %.1f TF/s (fp64 MFMA peak) + bytes / %.1f TB/s (achievable "
+                         "HBM streaming rate; %.1f peak)"
+                         % (PEAK_F64_MFMA_TFLOPS, ACHIEVABLE_HBM_TBS, PEAK_HBM_TBS)}
+
+
+def batch512_leg(sca, multigpu, comm, fence, group=16, streams=8, project=True):
   """Config 5: the 512 utterances are LPT-partitioned over the ranks by size alone, so each
-  rank only synthesises its own share; per rank ONE grouped batch (one host thread, `group`
-  utterances per launch); labels all-gathered.  The multi-stream form (one host thread and
-  arena per stream) is timed beside it."""
+  rank only synthesises its own share and uploads it itself; per rank ONE grouped batch (one
+  host thread, `group` utterances per launch); labels all-gathered.  The multi-stream form
+  (one host thread and arena per stream) is timed beside it."""
   ns, ks = batch512_sizes()
   sizes = [int(n) for n in ns]
   owned = multigpu.lpt_assignment(sizes, comm.size)[comm.rank]
-  mine = {i: blobs(sizes[i], N_FEATURES, int(ks[i]), seed=i)[0] for i in owned}
+  everything = comm.size == 1 and project
+  have = range(512) if everything else owned
+  mine = {i: blobs(sizes[i], N_FEATURES, int(ks[i]), seed=i)[0] for i in have}
   clusterer = sca.configs.icassp2018_clusterer
 
   def timed(**how):
-    clusterer.predict_batch([mine[i] for i in owned[:32]], **how)  # arenas
+    clusterer.predict_batch([mine[i] for i in owned], **how)  # the WHOLE share: warm arenas
     fence()
     t0 = time.perf_counter()
     labels = multigpu.predict_batch_sharded(
@@ -204,13 +247,23 @@ def batch512_leg(sca, multigpu, comm, fence, group=16, streams=8):
   _, t_streams = timed(streams=streams)
   _, t_loop = timed(streams=1)
   labels, elapsed = timed(group=group)
+  diags = clusterer.last_batch_diags
+  passes = {i: int(dg.eig_matvec_passes) for i, dg in zip(owned, diags)}
   out = {"value": 512 / elapsed, "unit": "utterances/s", "seconds": elapsed,
          "mode": "grouped: one host thread per GPU, %d utterances per launch" % group,
          "utterances": 512, "n_gpus": comm.size,
-         "scaling": "strong", "partition": "LPT on n^3 + 64 n^2",
+         "scaling": "strong", "partition": "LPT on multigpu.cost_model",
          "multi_stream": {"value": 512 / t_streams, "streams_per_gpu": streams,
                           "host_threads_per_gpu": streams},
          "plain_loop": {"value": 512 / t_loop}}
+  if comm.size == 1:
+    flops = hbm = 0.0
+    for i in owned:
+      f, b = icassp_work(sizes[i], N_FEATURES, passes[i])
+      flops += f
+      hbm += b
+    out["roofline"] = workload_roofline(flops, hbm, elapsed)
+    out["roofline"]["matvec_passes_mean"] = float(np.mean(list(passes.values())))
   gpath = os.path.join(ROOT, "tests", "golden", "batch512.npz")
   if comm.rank == 0 and os.path.exists(gpath):
     g = np.load(gpath)
@@ -219,20 +272,66 @@ def batch512_leg(sca, multigpu, comm, fence, group=16, streams=8):
       ok += ari(labels[i], ref[pos:pos + n]) == 1.0
       pos += n
     out["ari1_vs_reference_labels"] = int(ok)
+  if everything:
+    out["projected"] = project_shares(
+        lambda world: multigpu.lpt_assignment(sizes, world),
+        lambda share: clusterer.predict_batch([mine[i] for i in share], group=group),
+        elapsed, fence,
+        "each rank's LPT share of the 512 utterances as its own predict_batch(group=%d) on "
+        "this one GPU: arenas warm (a long-lived server process), pageable H2D of the share "
+        "and the group pipeline's fill/drain inside; the all-gather of < 1 MB of labels is "
+        "not" % group)
   return out
 
 
-def autotune16_leg(sca, multigpu, comm, fence):
+def project_shares(partition, run_share, t_whole, fence, note):
+  """What a world of 2 / 4 / 8 GPUs would give, measured on ONE: every rank's share runs on
+  its own here (they are independent), so the job takes max over ranks of the share times.
+  `sum_share_s` > `t_whole` is the fixed per-rank cost that strong scaling does not divide."""
+  rows = {}
+  for world in (2, 4, 8):
+    secs = []
+    for share in partition(world):
+      if not share:
+        secs.append(0.0)
+        continue
+      fence()
+      t0 = time.perf_counter()
+      run_share(share)
+      fence()
+      secs.append(time.perf_counter() - t0)
+    rows[str(world)] = {"max_share_s": max(secs), "sum_share_s": sum(secs),
+                        "imbalance": max(secs) / (sum(secs) / world),
+                        "speedup": t_whole / max(secs)}
+  rows["one_gpu_s"] = t_whole
+  rows["method"] = note
+  return rows
+
+
+def autotune16_leg(sca, multigpu, comm, fence, variant="icassp", project=True):
   """Config 4: one AutoTune level of 16 p_percentile values at n=4096, the grid
-  round-robin over the ranks, (ratio, n_clusters) all-gathered per level."""
-  x, _ = blobs(4096, N_FEATURES, N_SPEAKERS, 4096)
+  round-robin over the ranks, (ratio, n_clusters) all-gathered per level.  `variant`
+  "ttd": the Turn-to-Diarize refinement (Percentile threshold + binarisation + preserved
+  diagonal + Average symmetrisation, reference configs.py:49-59) under the same sweep."""
+  n = 4096
+  x, _ = blobs(n, N_FEATURES, N_SPEAKERS, 4096)
 
   def make():
+    if variant == "ttd":
+      opts = sca.RefinementOptions(
+          p_percentile=0.95, thresholding_soft_multiplier=0.01,
+          thresholding_type=sca.ThresholdType.Percentile,
+          thresholding_with_binarization=True, thresholding_preserve_diagonal=True,
+          symmetrize_type=sca.SymmetrizeType.Average,
+          refinement_sequence=[sca.RefinementName.RowWiseThreshold,
+                               sca.RefinementName.Symmetrize])
+    else:
+      opts = sca.RefinementOptions(
+          gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
+          refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
     return sca.SpectralClusterer(
         min_clusters=2, max_clusters=MAX_CLUSTERS, laplacian_type=sca.LaplacianType.GraphCut,
-        refinement_options=sca.RefinementOptions(
-            gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
-            refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE),
+        refinement_options=opts, row_wise_renorm=variant == "ttd",
         autotune=sca.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95,
                               init_search_step=0.025, search_level=1))
 
@@ -245,16 +344,95 @@ def autotune16_leg(sca, multigpu, comm, fence):
     labels = multigpu.predict_autotune_distributed(comm, c, x)
   fence()
   elapsed = comm.allreduce_max(time.perf_counter() - t0) / reps
-  out = {"value": 1e3 * elapsed, "unit": "ms/sweep", "p_values": 16, "n_samples": 4096,
-         "n_gpus": comm.size, "scaling": "strong",
-         "best_p": float(c.refinement_options.p_percentile)}
-  gpath = os.path.join(ROOT, "tests", "golden", "autotune_n4096.npz")
+  out = {"value": 1e3 * elapsed, "unit": "ms/sweep", "p_values": 16, "n_samples": n,
+         "n_gpus": comm.size, "scaling": "strong", "refinement": variant,
+         "final_p": float(c.refinement_options.p_percentile),
+         "best_p": float(c.last_best_p)}
+  sweep = getattr(c, "last_sweep_diags", None)
+  if comm.size == 1 and sweep:
+    # one sweep: affinity (1 product, 1 n^2 write), [Crop+Blur once: 2 n^2], then per value
+    # threshold+symmetrise (2 n^2) [+ Diffuse: 1 product, 2 n^2] + its matvec passes, and the
+    # winner once more (eigenvectors) + k-means
+    mat = n * n * 8.0
+    prod = tri_tiles(n) * 2.0 * GEMM_TILE * GEMM_TILE
+    per_value_passes = [int(d.eig_matvec_passes) for d in sweep]
+    diffuse = variant != "ttd"
+    evals = len(sweep) + 1
+    flops = prod * N_FEATURES + (evals * prod * n if diffuse else 0.0)
+    hbm = (mat + n * N_FEATURES * 8.0 + (2 * mat if diffuse else 0.0) +
+           evals * (2 * mat + (2 * mat if diffuse else 0.0)) +
+           (sum(per_value_passes) + float(np.mean(per_value_passes))) * mat)
+    out["roofline"] = workload_roofline(flops, hbm, elapsed)
+    out["roofline"]["matvec_passes_per_value"] = per_value_passes
+    out["eig_paths"] = [int(d.eig_path) for d in sweep]
+  gname = "autotune_ttd_n4096.npz" if variant == "ttd" else "autotune_n4096.npz"
+  gpath = os.path.join(ROOT, "tests", "golden", gname)
   if os.path.exists(gpath):
     g = np.load(gpath)
-    out["best_p_reference"] = float(g["best_p"])
+    out["final_p_reference"] = float(g["final_p"] if "final_p" in g else g["best_p"])
+    out["best_p_reference"] = float(g["grid"][int(np.argmin(g["ratios"]))])
     out["ari_vs_reference_labels"] = ari(labels, g["labels"])
     out["reference_seconds_8vcpu"] = float(g["ref_seconds"])
+  if comm.size == 1 and project:
+    grid = list(make().autotune.get_percentile_range())
+    c2 = make()
+    handle = c2._handle()
+    c2._upload(handle, x)
+
+    def run_share(ps):
+      # what one rank does per sweep: upload + affinity, its values as one grouped sweep,
+      # then (every rank) the winner's eigenvectors + k-means
+      c2._upload(handle, x)
+      c2._eig_sweep(handle, ps)
+      dg = c2._eig_resident(handle, out["best_p"])
+      lab = np.empty(n, dtype=np.int64)
+      from spectralcluster_amd import _lib
+      handle.check(handle.lib.sc_cluster(handle.raw, c2.build_config(out["best_p"]),
+                                         max(int(dg.n_clusters_raw), 2), _lib.as_int64_p(lab),
+                                         dg))
+
+    run_share(grid)
+    fence()
+    t0 = time.perf_counter()
+    run_share(grid)
+    fence()
+    whole = time.perf_counter() - t0
+    out["projected"] = project_shares(
+        lambda world: [grid[r::world] for r in range(world)], run_share, whole, fence,
+        "each rank's round-robin share of the 16 values (upload + affinity + Crop/Blur are "
+        "per rank, the winner's eigenvectors + k-means too) on this one GPU; the all-gather "
+        "of 16 x 2 doubles is not")
   return out
+
+
+def hard8192_leg(sca, _lib):
+  """The headline configuration on UNSTRUCTURED embeddings (N(0, I), n=8192, d=256): the 21
+  eigenvalues the GraphCut eigengap reads sit on the edge of a dense bulk.  predict() must
+  return (np.linalg.eig always does); the record says what that costs and which path did it."""
+  rng = np.random.default_rng(8192)
+  x = np.ascontiguousarray(rng.standard_normal((N_SAMPLES, N_FEATURES)))
+  c = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=MAX_CLUSTERS,
+      refinement_options=sca.configs.icassp2018_refinement_options,
+      laplacian_type=sca.LaplacianType.GraphCut)
+  c.predict(x)
+  reps = 2
+  t0 = time.perf_counter()
+  for _ in range(reps):
+    labels = c.predict(x)
+  ms = 1e3 * (time.perf_counter() - t0) / reps
+  dg = c.last_diag
+  names = {1: "dense Jacobi", 2: "block Lanczos", 5: "dense values + Lanczos vectors",
+           6: "dense landing pad (tridiagonalisation + bisection + inverse iteration)"}
+  return {"input": "N(0, I) embeddings, n=%d d=%d, default_rng(8192)" % (N_SAMPLES, N_FEATURES),
+          "ms_per_call": ms, "unit": "ms/call", "eig_path": int(dg.eig_path),
+          "eig_path_name": names.get(int(dg.eig_path), "?"),
+          "eig_fallback_reason": int(dg.eig_fallback),
+          "matvec_passes": int(dg.eig_matvec_passes), "restart_cycles": int(dg.eig_cycles),
+          "basis": int(dg.eig_basis), "n_clusters_raw": int(dg.n_clusters_raw),
+          "n_clusters": int(dg.n_clusters), "labels_used": int(np.unique(labels).size),
+          "eig_ms": float(dg.stage_times_ms().get("eig", 0.0)),
+          "leading_eigenvalues": [float(v) for v in dg.eigenvalue_array()[:6]]}
 
 
 def kernel_roofline(stage_ms, passes):
@@ -290,7 +468,17 @@ def kernel_roofline(stage_ms, passes):
   hbm("k_threshold_symmetrize (RowWiseThreshold+Symmetrize)", "threshold_sym", 2 * mat,
       "1 read + 1 write of n^2")
   hbm("block matvec of the eigen stage", "matvec", passes * mat,
-      "%g passes x n^2 * 8 B" % passes)
+      "%g passes x n^2 * 8 B (SURVEY 8d's algorithmic figure)" % passes)
+  if rows and rows[-1]["kernel"].startswith("block matvec"):
+    # what the kernel actually moves: it reads the upper-triangle tiles only (n >= 4096) and
+    # writes + re-reads two 128 x 8 slabs per tile
+    moved = passes * tri_tiles(n) * (GEMM_TILE * GEMM_TILE * 8.0 + 2 * 2 * GEMM_TILE * 8 * 8.0)
+    r = rows[-1]
+    r["bytes_moved"] = moved
+    r["moved_tbs"] = moved / (r["us"] * 1e-6) / 1e12
+    r["moved_frac_of_peak"] = r["moved_tbs"] / PEAK_HBM_TBS
+    r["bytes_moved_source"] = ("analytic: upper-triangle tiles + per-tile slabs; rocprofv3 "
+                               "FETCH_SIZE x2 of the same kernel: profiles/r03_*_pmc*")
   return rows
 
 
@@ -353,7 +541,7 @@ def main():
     return comm.allreduce_max(time.perf_counter() - t0)
 
   for _ in range(args.warmup):
-    step()
+    step_h2d()
   names = _lib.STAGE_NAMES
   stage_sum = np.zeros(len(names))
   passes = [0]
@@ -363,18 +551,19 @@ def main():
     passes[0] += diag.eig_matvec_passes
 
   k = args.steps
-  elapsed = timed(step, k, collect)
+  elapsed = timed(step_h2d, k, collect)  # THE timed region: K predict() calls
   stage_ms = {name: float(stage_sum[i] / k) for i, name in enumerate(names)}
   passes_per_call = passes[0] / k
   eig_info = {"matvec_passes_per_call": passes_per_call, "block": int(diag.eig_block),
               "basis": int(diag.eig_basis), "cycles": int(diag.eig_cycles),
               "path": int(diag.eig_path)}
-  resident_labels = labels.copy()
+  predict_labels = labels.copy()
   n_clusters = int(diag.n_clusters)
   eigenvalues = diag.eigenvalue_array()
 
-  step_h2d()
-  elapsed_h2d = timed(step_h2d, k)
+  step()
+  elapsed_resident = timed(step, k)
+  resident_labels = labels.copy()
 
   # per-kernel timers (a few extra steps with event pairs around the hot kernels)
   handle.check(lib.sc_set_profiling(handle.raw, 2))
@@ -392,6 +581,11 @@ def main():
       extras["batch512"] = batch512_leg(sca, multigpu, comm, fence)
     if not args.no_extras or args.workload == "autotune16":
       extras["autotune16"] = autotune16_leg(sca, multigpu, comm, fence)
+    if not args.no_extras:
+      extras["autotune16_ttd"] = autotune16_leg(sca, multigpu, comm, fence, variant="ttd",
+                                                project=False)
+      if world == 1:
+        extras["hard8192"] = hard8192_leg(sca, _lib)
 
   if rank == 0:
     nt = (N_SAMPLES + GEMM_TILE - 1) // GEMM_TILE
@@ -408,17 +602,18 @@ def main():
         "config": {"workload": "icassp2018_graphcut_n8192_d256_k8_max20",
                    "n_samples": N_SAMPLES, "n_features": N_FEATURES,
                    "speakers": N_SPEAKERS, "parallelism": "replicas x%d" % world,
-                   "step": "sc_run_resident: embeddings resident in HBM, labels D2H inside",
+                   "step": "sc_predict = SpectralClusterer.predict(): H2D of X (16.8 MB, "
+                           "pageable numpy buffer), the device pipeline, D2H of the labels",
                    "collectives": ("none" if world == 1 else
                                    "RCCL via the C ABI (sc_comm_*)"
                                    if isinstance(comm, multigpu.RcclComm) else
                                    "TCP fallback (RCCL did not come up: %s)"
                                    % getattr(comm, "note", ""))},
-        "predict_incl_h2d": {
-            "value": world * k / elapsed_h2d, "unit": "calls/s",
-            "ms_per_step": 1e3 * elapsed_h2d / k,
-            "step": "sc_predict: H2D of X (16.8 MB, pageable numpy buffer, "
-                    "hipMemcpy2DAsync + sync) + the resident pipeline"},
+        "resident": {
+            "value": world * k / elapsed_resident, "unit": "calls/s",
+            "ms_per_step": 1e3 * elapsed_resident / k,
+            "step": "sc_run_resident: the same pipeline with the embeddings already in HBM "
+                    "(no H2D of X; labels D2H inside)"},
         "roofline": {"bound": "mfma", "kernel": "k_gemm_nt<EpiNone,SYM> (Diffuse)",
                      "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS,
@@ -429,8 +624,9 @@ def main():
                      if kk in ("affinity", "refine", "diffuse", "scaling", "eig", "kmeans",
                                "total")},
         "eig": eig_info,
-        "parity": {"n_clusters": n_clusters, "ari_vs_truth": ari(resident_labels, truth),
-                   "labels_equal_with_h2d_path": bool(np.array_equal(resident_labels, labels))},
+        "parity": {"n_clusters": n_clusters, "ari_vs_truth": ari(predict_labels, truth),
+                   "labels_equal_with_resident_path": bool(np.array_equal(resident_labels,
+                                                                         predict_labels))},
     }
     gpath = os.path.join(ROOT, "tests", "golden", "e2e_n8192_lap4_max20.npz")
     if os.path.exists(gpath):
@@ -438,7 +634,7 @@ def main():
       w = eigenvalues[g["consumed_index"]]
       rel = np.abs(w - g["consumed_eigenvalues"]) / np.maximum(
           np.abs(g["consumed_eigenvalues"]), 1e-12)
-      out["parity"]["ari_vs_reference_labels"] = ari(resident_labels, g["labels"])
+      out["parity"]["ari_vs_reference_labels"] = ari(predict_labels, g["labels"])
       out["parity"]["max_rel_err_consumed_eigenvalues"] = float(np.max(rel))
       # the bulk values (~0.99999) pass 1e-5 for any Ritz value in range: the meaningful
       # figure is the error on the informative (non-bulk) eigenvalues
@@ -451,6 +647,13 @@ def main():
       t = json.load(open(tpath))
       out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
       out["roofline"]["traffic_source"] = t["source"]
+      # stamped with the kernel source it was measured on: stale once gemm_f64.hip changes
+      import hashlib
+      src = os.path.join(ROOT, "spectralcluster_amd", "csrc", "gemm_f64.hip")
+      now = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+      out["roofline"]["traffic_measured_on"] = {
+          "commit": t.get("commit"), "gemm_f64_sha16": t.get("gemm_f64_sha16"),
+          "kernel_source_unchanged_since": t.get("gemm_f64_sha16") == now}
     out.update(extras)
     if args.workload != "predict8192":
       leg = extras[args.workload]

@@ -149,7 +149,8 @@ typedef struct sc_config {
   double eig_value_tol;          /* residual bound / |eigenvalue| on consumed values (1e-6) */
   double eig_vector_tol;         /* residual tol, relative to ||M||, on the
                                     eigenvectors handed to k-means (1e-10) */
-  int32_t eig_max_cycles;        /* restart cycles before NOT_CONVERGED (40) */
+  int32_t eig_max_cycles;        /* restart cycles block Lanczos may spend before the dense
+                                    eigensolver takes over (0: default 40; < 0: none) */
   /* ConstraintOptions (constraint.py:26-48); used only while a constraint matrix
    * is resident (sc_set_constraint), like constraint_matrix=None in the reference */
   int32_t constraint_name;       /* SC_CONSTRAINT_* */

@@ -196,7 +196,7 @@ extern "C" int sc_create(int device, sc_handle* out) {
       hipHostMalloc(reinterpret_cast<void**>(&h->h_flags), 16 * sizeof(int)) !=
           hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&h->h_rr),
-                    (2 * kHostRR * kHostRR + 64) * sizeof(double)) != hipSuccess) {
+                    (2 * kHostRRSingle * kHostRRSingle + 64) * sizeof(double)) != hipSuccess) {
     delete h;
     return SC_ERR_HIP;
   }
@@ -590,7 +590,7 @@ EigRequest make_eig_request(const sc_config* cfg) {
   rq.use_stop = rq.descend;  // spectral_clusterer.py:163-167: not passed when ascending
   rq.value_tol = cfg->eig_value_tol > 0 ? cfg->eig_value_tol : 1e-6;
   rq.vector_tol = cfg->eig_vector_tol > 0 ? cfg->eig_vector_tol : 1e-10;
-  rq.max_cycles = cfg->eig_max_cycles > 0 ? cfg->eig_max_cycles : 40;
+  rq.max_cycles = cfg->eig_max_cycles > 0 ? cfg->eig_max_cycles : (cfg->eig_max_cycles < 0 ? 0 : 40);
   rq.fixed_count = 0;
   {  // p_percentile and the Laplacian shape the spectrum: part of the hint's signature
     long long pbits;

@@ -416,11 +416,14 @@ extern "C" int sc_host_tridiag_eigvectors(const double* d, const double* e, int 
 // column `rank` = Ritz vector of theta[rank]).  Same outputs as k_jacobi.
 static bool host_rayleigh_ritz(const double* T, int ld, const double* G, int m, double* theta,
                                double* resid, double* Y, int ldy) {
-  std::vector<double> a((size_t)m * m), d(m), e(m);
+  // (an odd row stride: tql2 walks columns, and a stride of 64 or 128 doubles maps a whole
+  //  column onto a handful of cache sets)
+  const int lda = m | 1;
+  std::vector<double> a((size_t)m * lda), d(m), e(m);
   for (int i = 0; i < m; ++i)
     for (int j = 0; j < m; ++j)  // the mirrored upper triangle is what the chain wrote
-      a[(size_t)i * m + j] = i <= j ? T[(size_t)i * ld + j] : T[(size_t)j * ld + i];
-  if (!host_symmetric_eig(a.data(), m, m, d.data(), e.data())) return false;
+      a[(size_t)i * lda + j] = i <= j ? T[(size_t)i * ld + j] : T[(size_t)j * ld + i];
+  if (!host_symmetric_eig(a.data(), lda, m, d.data(), e.data())) return false;
   std::vector<int> order(m);
   for (int i = 0; i < m; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d[x] > d[y]; });
@@ -431,11 +434,11 @@ static bool host_rayleigh_ritz(const double* T, int ld, const double* G, int m, 
     for (int p = 0; p < kEigBlock; ++p) {
       double t = 0.0;
       for (int q = 0; q < kEigBlock; ++q)
-        t += G[p * kEigBlock + q] * a[(size_t)(m - kEigBlock + q) * m + c];
-      r2 += a[(size_t)(m - kEigBlock + p) * m + c] * t;
+        t += G[p * kEigBlock + q] * a[(size_t)(m - kEigBlock + q) * lda + c];
+      r2 += a[(size_t)(m - kEigBlock + p) * lda + c] * t;
     }
     resid[rank] = std::sqrt(std::max(r2, 0.0));
-    for (int r = 0; r < m; ++r) Y[(size_t)r * ldy + rank] = a[(size_t)r * m + c];
+    for (int r = 0; r < m; ++r) Y[(size_t)r * ldy + rank] = a[(size_t)r * lda + c];
   }
   return true;
 }
@@ -788,13 +791,13 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
                                                                m % (2 * kEigBlock) == 0 ||
                                                                m + kEigBlock > cap))
                                      : (m + kEigBlock > cap);
-      const bool host_rr = check && m <= kHostRR && !getenv("SC_EIG_DEVICE_RR");
+      const bool host_rr = check && m <= kHostRRSingle && !getenv("SC_EIG_DEVICE_RR");
       if (host_rr) {
         // small projected problem: T and G come back with the flags; solved on the host
         SC_HIP(h, hipMemcpy2DAsync(h->h_rr, (size_t)m * sizeof(double), h->T.p,
                                    (size_t)kLdq * sizeof(double), (size_t)m * sizeof(double), m,
                                    hipMemcpyDeviceToHost, s));
-        SC_HIP(h, hipMemcpyAsync(h->h_rr + kHostRR * kHostRR, h->G.p,
+        SC_HIP(h, hipMemcpyAsync(h->h_rr + kHostRRSingle * kHostRRSingle, h->G.p,
                                  kEigBlock * kEigBlock * sizeof(double), hipMemcpyDeviceToHost,
                                  s));
       } else if (check) {
@@ -836,8 +839,8 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
         }
       }
       if (host_rr) {
-        double* hy = h->h_rr + kHostRR * kHostRR + 64;
-        if (!host_rayleigh_ritz(h->h_rr, m, h->h_rr + kHostRR * kHostRR, m, h->h_theta,
+        double* hy = h->h_rr + kHostRRSingle * kHostRRSingle + 64;
+        if (!host_rayleigh_ritz(h->h_rr, m, h->h_rr + kHostRRSingle * kHostRRSingle, m, h->h_theta,
                                 h->h_theta + kLdq, hy, m)) {
           SC_TRY(dense_fallback(2));
           break;

@@ -18,8 +18,13 @@ constexpr int kEigBlock = 8;         // Lanczos block width (half an MFMA tile c
 constexpr int kEigBasisCap = 128;    // Rayleigh-Ritz size limit (LDS Jacobi)
 constexpr int kLdq = kEigBasisCap + kEigBlock;  // row stride of the Krylov basis
 constexpr int kDenseMax = 128;       // n <= this: direct dense Jacobi
-constexpr int kHostRR = 64;          // Rayleigh-Ritz problems up to this order are solved on
-                                     // the host (O(m^3) scalars, like the eigengap loop)
+constexpr int kHostRR = 64;          // lockstep group solve: Rayleigh-Ritz problems up to this
+                                     // order are solved on the host (O(m^3) scalars, like the
+                                     // eigengap loop); larger ones leave the group
+constexpr int kHostRRSingle = kEigBasisCap;  // single-call solve: every check on the host (the
+                                     // one-workgroup Jacobi takes 1.7 / 2.7 / 4.7 / 6.4 ms at
+                                     // m = 80 / 96 / 112 / 128; tred2 + tql2 on a host core a
+                                     // fraction of that) -- clustered spectra reach these sizes
 constexpr int kGenMax = 64;          // general eigen path: dense limit and Arnoldi basis cap
 constexpr int kMaxVectors = 64;      // eigenvector columns kept resident
 constexpr int kProjBlocks = 128;     // partial-sum blocks for tall-skinny products

@@ -29,9 +29,18 @@ import numpy as np
 
 
 def cost_model(n: int) -> float:
-  """Relative cost of one predict(): the n^3 Diffuse GEMM dominates, the O(n^2)
-  row ops / eigen passes matter for small n."""
-  return float(n) ** 3 + 64.0 * float(n) ** 2
+  """Cost of one utterance of n samples inside a grouped batch (predict_batch(group=16), the
+  execution the partition schedules), in microseconds on one MI355X.  Calibrated on measured
+  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r03b_cost_fit.txt: 109 us
+  at n=650 ... 757 us at n=3000; non-negative least squares on the relative error, 2 %):
+  a fixed per-utterance share of the group's launch chains, the O(n^2) passes, the O(n^3)
+  Diffuse product.  Below n=512 the stages before the eigensolver run member by member
+  (143-156 us measured, flat).  Round 2's n^3 + 64 n^2 put a factor 900 between n=300 and
+  n=3000 where the measured factor is 5."""
+  n = float(n)
+  if n < 512.0:
+    return 150.0
+  return 89.4 + 3.26e-5 * n * n + 1.45e-8 * n * n * n
 
 
 def lpt_assignment(sizes: typing.Sequence[int], world: int) -> typing.List[typing.List[int]]:
@@ -540,8 +549,10 @@ def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
       return [(float("nan"), 0)] * len(ps)
 
   evaluate.error = None
+  evaluate.last_p = clusterer.refinement_options.p_percentile
 
   def evaluate_many(ps):
+    evaluate.last_p = ps[-1]
     ratios, ks = autotune_sharded(comm, None, ps, evaluate_share_fn=evaluate)
     if evaluate.error is not None:
       raise evaluate.error
@@ -550,6 +561,10 @@ def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
     return [(float(r), p, int(k)) for r, p, k in zip(ratios, ps, ks)]
 
   _, n_clusters, best_p = tuner.tune(None, evaluate_many=evaluate_many)
+  clusterer.last_best_p = best_p
+  # the reference's closure leaves p_percentile at the LAST evaluated value
+  # (spectral_clusterer.py:277); keep that observable state, like predict()
+  clusterer.refinement_options.p_percentile = evaluate.last_p
   diag = clusterer._eig_resident(handle, best_p)
   if clusterer.min_clusters is not None:
     n_clusters = max(n_clusters, clusterer.min_clusters)

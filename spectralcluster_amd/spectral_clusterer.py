@@ -156,7 +156,8 @@ class SpectralClusterer:
     ps = (ctypes.c_double * count)(*[float(p) for p in p_values])
     handle.check(handle.lib.sc_eig_ncluster_sweep(handle.raw, self.build_config(), ps, count,
                                                   diags), TypeError)
-    return list(diags)
+    self.last_sweep_diags = list(diags)
+    return self.last_sweep_diags
 
   def consumed_eigenvalues(self) -> np.ndarray:
     """Every eigenvalue the last eigen call consumed, in the reference's order

@@ -467,12 +467,22 @@ def test_autotune_hands_whole_levels_to_the_sweep(monkeypatch):
 
 def test_comm_header_and_id_file(monkeypatch, tmp_path):
   """Rendezvous plumbing of RcclComm.from_env that needs no GPU: the id file name is
-  unique per launch (MASTER_PORT + parent pid) and can be overridden."""
+  unique per launch (MASTER_PORT + torchrun's run id + parent pid), lives in a private
+  per-user directory, and can be overridden."""
   monkeypatch.delenv("SC_COMM_ID_FILE", raising=False)
+  monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
   monkeypatch.setenv("MASTER_PORT", "29517")
   monkeypatch.setenv("TMPDIR", str(tmp_path))
   path = multigpu._id_file()
-  assert path == os.path.join(str(tmp_path), "sc_comm_29517_%d.id" % os.getppid())
+  base = os.path.join(str(tmp_path), "sc_comm_%d" % os.getuid())
+  assert path == os.path.join(base, "29517_x_%d.id" % os.getppid())
+  assert (os.stat(base).st_mode & 0o777) == 0o700
+  monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run/../42")
+  assert multigpu._id_file() == os.path.join(base, "29517_run42_%d.id" % os.getppid())
+  os.chmod(base, 0o755)  # a directory others could write into is refused
+  with pytest.raises(PermissionError):
+    multigpu._id_file()
+  os.chmod(base, 0o700)
   monkeypatch.setenv("SC_COMM_ID_FILE", str(tmp_path / "x.id"))
   assert multigpu._id_file() == str(tmp_path / "x.id")
   assert _lib.load().sc_comm_rank(None) == -1 and _lib.load().sc_comm_size(None) == 0
@@ -482,7 +492,7 @@ def test_host_rayleigh_ritz_solver_vs_numpy():
   """The host routine behind the small Rayleigh-Ritz problems (tred2 / tql2)."""
   lib = _lib.load()
   rng = np.random.default_rng(0)
-  for m in (1, 2, 3, 8, 24, 32, 48, 64):
+  for m in (1, 2, 3, 8, 24, 32, 48, 64, 96, 128):
     a = rng.standard_normal((m, m))
     a = 0.5 * (a + a.T)
     if m == 24:  # the shape of a projected Laplacian: a few informative values + a tight bulk
@@ -546,3 +556,40 @@ def test_use_device_scope_is_thread_local_and_nested():
       assert _lib._scope.device == 1
     assert _lib._scope.device == 3
   assert _lib._scope.device is None
+
+
+def test_integration_md_stub_mirrors_and_config_flattening():
+  """INTEGRATION.md section 2 (the reference-side ctypes binding) without a GPU: its code
+  blocks execute against the built library up to handle creation, its struct mirrors have
+  the sizes the library reports, and its `_to_config` flattens a clusterer like
+  SpectralClusterer.build_config does.  (The GPU twin runs predict() through it:
+  tests/test_gpu_integration_stub.py.)"""
+  import re
+  import ctypes
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  text = open(os.path.join(root, "INTEGRATION.md")).read()
+  section = text[text.index("## 2."):text.index("## 3.")]
+  blocks = re.findall(r"```python\n(.*?)```", section, flags=re.S)
+  assert len(blocks) == 2
+  so_path = os.path.join(root, "spectralcluster_amd", "csrc", "libspectralcluster_amd.so")
+  code = "\n".join(blocks).replace('ctypes.CDLL("libspectralcluster_amd.so")',
+                                   "ctypes.CDLL(%r)" % so_path)
+  create = "assert _lib.sc_create(0, ctypes.byref(_handle)) == 0"
+  assert create in code
+  ns = {}
+  exec(compile(code.replace(create, "pass"), "INTEGRATION.md#2", "exec"), ns)  # pylint: disable=exec-used
+  assert ctypes.sizeof(ns["_ScConfig"]) == ctypes.sizeof(_lib.ScConfig)
+  assert ctypes.sizeof(ns["_ScDiag"]) == ctypes.sizeof(_lib.ScDiag)
+  import spectralcluster_amd as sca
+  for c in (sca.SpectralClusterer(min_clusters=2, max_clusters=7,
+                                  refinement_options=sca.configs.icassp2018_refinement_options,
+                                  laplacian_type=sca.LaplacianType.GraphCut),
+            sca.configs.turntodiarize_clusterer):
+    got, want = ns["_to_config"](c), c.build_config()
+    for field, _ in ns["_ScConfig"]._fields_:
+      if field in ("reserved", "integration_type"):  # (unused by ConstraintPropagation)
+        continue
+      a, b = getattr(got, field), getattr(want, field)
+      if hasattr(a, "__len__"):
+        a, b = list(a), list(b)
+      assert a == b, field

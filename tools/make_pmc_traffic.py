@@ -7,8 +7,13 @@ x 1024, averaged over the dispatches of k_gemm_nt<0, true> (+ its split-K reduce
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_dispatch(d, counter):
@@ -38,4 +43,11 @@ print(json.dumps({
               "(+ split-K reduce): FETCH_SIZE %.4g KiB x 2 (gfx950 16 B/lane correction) + WRITE_SIZE "
               "%.4g KiB" % (label, fetch[main][1], f, w),
     "algorithmic_bytes_per_launch": 2 * n * n * 8,
+    # what it was measured on (bench.py compares the hash with the current source)
+    "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
+                             capture_output=True, text=True).stdout.strip() or None,
+    "gemm_f64_sha16": hashlib.sha256(open(os.path.join(
+        ROOT, "spectralcluster_amd", "csrc", "gemm_f64.hip"), "rb").read()).hexdigest()[:16],
+    "per_kernel_bytes": {k: int(fetch[k][0] * 2048 + (write[k][0] if k in write else 0.0) * 1024)
+                         for k in sorted(fetch)},
 }, indent=1))

@@ -200,11 +200,12 @@ def tri_tiles(n):
 
 
 def icassp_work(n, d, passes):
-  """Algorithmic work of one ICASSP2018 predict() (fused lower bound):
-  the two symmetric products on upper-triangle tiles; A1 write, Crop+Blur R/W,
-  Threshold+Symmetrize R/W, Diffuse R/W (normalise + Laplacian folded) = 7 n^2 passes, plus
-  one per executed block matvec."""
-  flops = tri_tiles(n) * 2.0 * GEMM_TILE * GEMM_TILE * (n + d)
+  """Algorithmic work of one ICASSP2018 predict() (fused lower bound): the
+  two products with their symmetry exploited, n^2 (n + d) flops (no tile rounding: padding a
+  300-row utterance to 384 is the implementation's cost, not the problem's); A1 write,
+  Crop+Blur R/W, Threshold+Symmetrize R/W, Diffuse R/W (normalise + Laplacian folded) = 7
+  n^2 passes, plus one per executed block matvec."""
+  flops = float(n) * n * (n + d)
   hbm = (7.0 + passes) * n * n * 8.0 + n * d * 8.0
   return flops, hbm
 
@@ -351,17 +352,16 @@ def autotune16_leg(sca, multigpu, comm, fence, variant="icassp", project=True):
   sweep = getattr(c, "last_sweep_diags", None)
   if comm.size == 1 and sweep:
     # one sweep: affinity (1 product, 1 n^2 write), [Crop+Blur once: 2 n^2], then per value
-    # threshold+symmetrise (2 n^2) [+ Diffuse: 1 product, 2 n^2] + its matvec passes, and the
-    # winner once more (eigenvectors) + k-means
+    # threshold+symmetrise (2 n^2) [+ Diffuse: 1 product, 2 n^2] + its matvec passes; the
+    # winner's eigenvectors are adopted from the sweep; k-means is O(n k)
     mat = n * n * 8.0
-    prod = tri_tiles(n) * 2.0 * GEMM_TILE * GEMM_TILE
+    prod = float(n) * n  # flops per unit of K of a symmetric product (n^2 K)
     per_value_passes = [int(d.eig_matvec_passes) for d in sweep]
     diffuse = variant != "ttd"
-    evals = len(sweep) + 1
+    evals = len(sweep)
     flops = prod * N_FEATURES + (evals * prod * n if diffuse else 0.0)
     hbm = (mat + n * N_FEATURES * 8.0 + (2 * mat if diffuse else 0.0) +
-           evals * (2 * mat + (2 * mat if diffuse else 0.0)) +
-           (sum(per_value_passes) + float(np.mean(per_value_passes))) * mat)
+           evals * (2 * mat + (2 * mat if diffuse else 0.0)) + sum(per_value_passes) * mat)
     out["roofline"] = workload_roofline(flops, hbm, elapsed)
     out["roofline"]["matvec_passes_per_value"] = per_value_passes
     out["eig_paths"] = [int(d.eig_path) for d in sweep]
@@ -379,17 +379,30 @@ def autotune16_leg(sca, multigpu, comm, fence, variant="icassp", project=True):
     handle = c2._handle()
     c2._upload(handle, x)
 
-    def run_share(ps):
-      # what one rank does per sweep: upload + affinity, its values as one grouped sweep,
-      # then (every rank) the winner's eigenvectors + k-means
+    from spectralcluster_amd import _lib
+    parts = {}
+
+    def run_share(ps, timed_parts=False):
+      # what one rank does per sweep: upload + affinity, its values as one grouped sweep
+      # (Crop + Blur once per rank inside), and -- on the rank that evaluated the winner only
+      # -- adopting its eigenvectors + k-means (the labels are then broadcast: n int32)
+      def lap(name, t0):
+        if timed_parts:
+          fence()
+          parts[name] = parts.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+      t = time.perf_counter()
       c2._upload(handle, x)
+      t = lap("upload_affinity_s", t)
       c2._eig_sweep(handle, ps)
-      dg = c2._eig_resident(handle, out["best_p"])
-      lab = np.empty(n, dtype=np.int64)
-      from spectralcluster_amd import _lib
-      handle.check(handle.lib.sc_cluster(handle.raw, c2.build_config(out["best_p"]),
-                                         max(int(dg.n_clusters_raw), 2), _lib.as_int64_p(lab),
-                                         dg))
+      t = lap("sweep_s", t)
+      if out["best_p"] in [float(p) for p in ps]:
+        dg = c2._adopt_or_evaluate(handle, out["best_p"])
+        lab = np.empty(n, dtype=np.int64)
+        handle.check(handle.lib.sc_cluster(handle.raw, c2.build_config(out["best_p"]),
+                                           max(int(dg.n_clusters_raw), 2), _lib.as_int64_p(lab),
+                                           dg))
+        lap("winner_kmeans_s", t)
 
     run_share(grid)
     fence()
@@ -400,8 +413,13 @@ def autotune16_leg(sca, multigpu, comm, fence, variant="icassp", project=True):
     out["projected"] = project_shares(
         lambda world: [grid[r::world] for r in range(world)], run_share, whole, fence,
         "each rank's round-robin share of the 16 values (upload + affinity + Crop/Blur are "
-        "per rank, the winner's eigenvectors + k-means too) on this one GPU; the all-gather "
-        "of 16 x 2 doubles is not")
+        "per rank; the winner's eigenvectors are adopted and clustered on the rank that "
+        "evaluated it) on this one GPU; the all-gather of 16 x 2 doubles and the broadcast of "
+        "n int32 labels are not")
+    # where a rank's time goes at world = 8 (2 values per rank), summed over the 8 shares
+    for share in [grid[r::8] for r in range(8)]:
+      run_share(share, timed_parts=True)
+    out["projected"]["world8_parts_sum_s"] = dict(parts)
   return out
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3
+#define SC_ABI_VERSION 4
 #define SC_MAX_OPS 16
 #define SC_MAX_BLUR_RADIUS 32
 #define SC_MAX_EIG 128 /* max eigenvalues reported in sc_diag */
@@ -274,9 +274,17 @@ int sc_run_resident(sc_handle h, const sc_config* cfg, int64_t* labels,
 /* one AutoTune search level (autotune.py:98-111): sc_eig_ncluster for `count` values of
  * p_percentile on the resident affinity; diags[i] reports what sc_eig_ncluster would for
  * p_values[i].  The values of a level differ only in the row threshold: the stages after it
- * run as grouped launches, the eigensolvers in lockstep.  Leaves no eigenvectors resident. */
+ * run as grouped launches, the eigensolvers in lockstep.  Leaves no eigenvectors resident
+ * in the handle itself (sc_sweep_adopt fetches a value's). */
 int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const double* p_values, int count,
                           sc_diag* diags);
+/* The eigenvectors of value `index` of the last sweep become the resident ones -- what
+ * sc_eig_ncluster with p_values[index] would leave, without evaluating the winner a second
+ * time (the reference's search keeps the winner's eigenvectors, spectral_clusterer.py:
+ * 274-292).  cfg: the sweep's configuration with p_percentile = p_values[index] (checked).
+ * SC_ERR_UNSUPPORTED when that value's solve left the grouped path or the configuration is
+ * not the sweep's (then call sc_eig_ncluster).  Follow with sc_cluster. */
+int sc_sweep_adopt(sc_handle h, const sc_config* cfg, int index, sc_diag* diag);
 /* a Python `for` over predict() in the reference: count
  * independent utterances, xs[i] is (ns[i], d); labels[i] has ns[i] slots. */
 int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,
@@ -291,8 +299,10 @@ int sc_predict_batch_streams(sc_handle h, const double* const* xs, const int* ns
 /* the same on ONE stream with ONE host thread, `group` (<= 16) utterances per launch: the
  * stages before the eigensolver are enqueued member after member, the block Lanczos chain
  * and the k-means chain of the members advance in lockstep (one launch per step and one
- * host synchronisation per check for the whole group).  Per-utterance results are those of
- * sc_predict; utterances outside the grouped path's range (n <= 128, n >= 4096, a
+ * host synchronisation per check for the whole group).  Per-utterance results agree with
+ * sc_predict to the solver's tolerance (whole-K tile sums where a short single call splits
+ * K; the group's check schedule), not bit for bit; the same batch always gives the same
+ * results.  Utterances outside the grouped path's range (n <= 128, n >= 4096, a
  * full-spectrum request, non-cosine k-means, constraints) take the single-call path. */
 int sc_predict_batch_grouped(sc_handle h, const double* const* xs, const int* ns, int d,
                              int count, const sc_config* cfg, int64_t* const* labels,
@@ -372,6 +382,12 @@ int sc_uniform_choice(int n, double u);
  * the columns of `vectors` (Householder tridiagonalisation + implicit QL).  Host-only;
  * exported so it can be pinned without a GPU. */
 int sc_host_symmetric_eig(const double* a, int m, double* values, double* vectors);
+/* The Rayleigh-Ritz solve of larger bases (64 < m <= 128): ALL eigenvalues of the symmetric
+ * m x m matrix `a` (row-major; upper triangle read), descending, and the eigenvectors of the
+ * leading `need` of them ((m, need) row-major): Householder tridiagonalisation with kept
+ * reflectors + QL for the values + inverse iteration + back-transform.  Host-only. */
+int sc_host_symmetric_eig_partial(const double* a, int m, int need, double* values,
+                                  double* vectors);
 /* Eigenvectors of the symmetric tridiagonal matrix (d[0..n), e[0..n-1)) for the k given
  * eigenvalues `lam` by inverse iteration (LAPACK dstein's method): vectors is (n, k)
  * row-major, column q belongs to lam[q], unit 2-norm.  The host step of the dense landing

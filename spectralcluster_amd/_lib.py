@@ -45,7 +45,7 @@ class EigenSolverNotConverged(RuntimeError):
   """The block-Lanczos eigensolver did not reach its tolerance."""
 
 
-SC_ABI_VERSION = 3
+SC_ABI_VERSION = 4
 
 
 class ScConfig(ctypes.Structure):
@@ -181,6 +181,8 @@ PROTOTYPES = {
                                                 ctypes.POINTER(ScDiag), ctypes.c_int]),
     "sc_eig_ncluster_sweep": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), _c_double_p,
                                              ctypes.c_int, ctypes.POINTER(ScDiag)]),
+    "sc_sweep_adopt": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), ctypes.c_int,
+                                      ctypes.POINTER(ScDiag)]),
     "sc_predict_batch_grouped": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),
                                                 _c_int_p, ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ScConfig),
@@ -204,6 +206,8 @@ PROTOTYPES = {
     "sc_uniform_choice": (ctypes.c_int, [ctypes.c_int, ctypes.c_double]),
     "sc_host_symmetric_eig": (ctypes.c_int, [_c_double_p, ctypes.c_int, _c_double_p,
                                              _c_double_p]),
+    "sc_host_symmetric_eig_partial": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int,
+                                                     _c_double_p, _c_double_p]),
     "sc_host_tridiag_eigvectors": (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_int,
                                                   _c_double_p, ctypes.c_int, _c_double_p]),
     "sc_eigengap": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int,

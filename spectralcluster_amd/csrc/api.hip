@@ -524,6 +524,7 @@ extern "C" int sc_set_embeddings(sc_handle h, const double* x, int n, int d) {
   h->ldx = round_up(d, 16);
   h->have_affinity = h->have_cropval = false;
   h->n_vec = 0;
+  h->sweep_slot.clear();  // (eigenvectors of a sweep on the previous affinity)
   SC_TRY(h2d_matrix(h, x, n, d, ptr<double>(h->X), h->ldx));
   SC_HIP(h, hipStreamSynchronize(h->stream));  // caller may reuse x immediately
   h->have_x = true;
@@ -554,6 +555,7 @@ extern "C" int sc_compute_affinity(sc_handle h) {
   h->affinity_symmetric = true;
   h->constraint_applied = false;
   h->n_vec = 0;
+  h->sweep_slot.clear();
   return SC_OK;
 }
 
@@ -566,6 +568,7 @@ extern "C" int sc_set_affinity(sc_handle h, const double* a, int n) {
   h->ldn = matrix_ld(n);
   h->have_x = false;
   h->n_vec = 0;
+  h->sweep_slot.clear();
   SC_TRY(h2d_matrix(h, a, n, n, ptr<double>(h->A0), h->ldn));
   SC_TRY(device_is_symmetric(h, ptr<double>(h->A0), n, h->ldn, &h->affinity_symmetric));
   h->have_affinity = true;
@@ -592,11 +595,6 @@ EigRequest make_eig_request(const sc_config* cfg) {
   rq.vector_tol = cfg->eig_vector_tol > 0 ? cfg->eig_vector_tol : 1e-10;
   rq.max_cycles = cfg->eig_max_cycles > 0 ? cfg->eig_max_cycles : (cfg->eig_max_cycles < 0 ? 0 : 40);
   rq.fixed_count = 0;
-  {  // p_percentile and the Laplacian shape the spectrum: part of the hint's signature
-    long long pbits;
-    memcpy(&pbits, &cfg->p_percentile, sizeof(pbits));
-    rq.hint_key = pbits ^ ((long long)cfg->laplacian_type << 3) ^ ((long long)cfg->n_ops << 7);
-  }
   return rq;
 }
 

@@ -19,8 +19,9 @@
 // too -- enqueue_front_grouped: both GEMMs take the tiles of all members in one launch.)
 // Each member runs the same kernel bodies with the same arguments as a single call; members
 // that leave the common path (rare branches of the eigensolver, k > 32, a non-symmetric
-// refinement, n <= 128 or n >= 4096) go through the single-call path, so results are those of
-// sc_predict for every utterance.
+// refinement, n <= 128 or n >= 4096) go through the single-call path.  Results agree with
+// sc_predict to the solver's tolerance (the grouped GEMMs sum whole K tiles, the group sets
+// the check schedule), and a batch call is a deterministic function of its input.
 #include <ctime>
 
 #include "handle.h"
@@ -558,6 +559,10 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
   memset(h->gconv_hist, 0, sizeof(h->gconv_hist));
   h->gconv_seen = 0;
   std::vector<int> later;  // values whose solve left the common path
+  h->sweep_slot.assign(count, -1);  // which member arena holds value i's eigenvectors
+  h->sweep_n = n;
+  h->sweep_p.assign(p_values, p_values + count);
+  h->sweep_cfg = *cfg;
   // A member arena of a sweep holds the thresholded matrix (B2), its Diffuse product (B1),
   // the n-vectors and the eigensolver workspace -- no affinity copy, no k-means workspace.
   // The group is as wide as free memory allows (16 members of n = 16384 are 69 GB); whatever
@@ -656,9 +661,14 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
     launch_gemm_nt_group(s, dif, cnt, kEpiNone, 1);
     launch_scaling_vectors_group(s, fi, cnt, cfg->laplacian_type, 1);
     SC_TRY(check_last(h, "sweep launch"));
-    SC_TRY(sym_topk_group(h, em, cnt, false));
+    // (with the Ritz vectors: the level's winner is then adopted, not evaluated again --
+    //  one upload and one launch for the whole group against a Diffuse + a solve)
+    SC_TRY(sym_topk_group(h, em, cnt, true));
+    for (int& slot : h->sweep_slot)
+      if (slot >= 0 && slot < cnt) slot = -1;  // an earlier round's member: arena reused
     for (int z = 0; z < cnt; ++z) {
       sc_diag* dg = diags + base + z;
+      if (em[z].status == 0) h->sweep_slot[base + z] = z;
       if (em[z].status != 0) {
         later.push_back(base + z);  // (after the rounds: it overwrites the shared blur)
         em[z].h->eig_skip_fused = false;  // (a hint for a re-solve on that arena: none follows)
@@ -687,10 +697,45 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
     if (out_of_memory || held > total_b / 4) {
       for (sc_handle sub : h->gslots) sc_destroy(sub);
       h->gslots.clear();
+      h->sweep_slot.assign(count, -1);
     }
   }
   for (int i : later) SC_TRY(one_by_one(i));  // the single-call solver
   h->n_vec = 0;  // nothing of any member is resident in this handle
+  h->sweep_diags.assign(diags, diags + count);
+  return SC_OK;
+}
+
+// The eigenvectors of value `index` of the last sc_eig_ncluster_sweep become the handle's
+// resident eigenvectors (what sc_eig_ncluster with that p_percentile would leave): a copy
+// of n x cols doubles out of the member arena instead of a second refinement + Diffuse +
+// eigen solve for the AutoTune winner (reference spectral_clusterer.py:274-292 keeps the
+// winner's eigenvectors from the search).  `cfg`: the sweep's configuration with p_percentile =
+// that value (checked).  SC_ERR_UNSUPPORTED when that value's solve left the grouped path, its
+// arena has been reused or the configuration differs: evaluate it with sc_eig_ncluster then.
+extern "C" int sc_sweep_adopt(sc_handle h, const sc_config* cfg, int index, sc_diag* diag) {
+  if (!h || !cfg) return SC_ERR_INVALID;
+  {  // the same configuration as the sweep's, at that value's p_percentile
+    sc_config want = h->sweep_cfg;
+    if (index >= 0 && index < (int)h->sweep_p.size()) want.p_percentile = h->sweep_p[index];
+    if (h->sweep_slot.empty() || memcmp(&want, cfg, sizeof(sc_config)) != 0)
+      return fail(h, SC_ERR_UNSUPPORTED, "the last sweep was not run with this configuration");
+  }
+  if (index < 0 || index >= (int)h->sweep_slot.size() || h->sweep_slot[index] < 0 ||
+      h->sweep_slot[index] >= (int)h->gslots.size() || h->sweep_n != h->n ||
+      index >= (int)h->sweep_diags.size())
+    return fail(h, SC_ERR_UNSUPPORTED, "no eigenvectors of that sweep value are resident");
+  SC_HIP(h, hipSetDevice(h->device));
+  sc_handle hz = h->gslots[h->sweep_slot[index]];
+  const int n = h->n, cols = hz->n_vec;
+  if (cols < 1 || hz->n != n)
+    return fail(h, SC_ERR_UNSUPPORTED, "no eigenvectors of that sweep value are resident");
+  SC_TRY(ensure_eig(h, n));
+  SC_HIP(h, hipMemcpyAsync(h->E.p, hz->E.p, (size_t)round_up(n, 16) * cols * sizeof(double),
+                           hipMemcpyDeviceToDevice, h->stream));
+  h->n_vec = cols;
+  h->last_w = hz->last_w;
+  if (diag) *diag = h->sweep_diags[index];
   return SC_OK;
 }
 

@@ -156,16 +156,24 @@ __global__ __launch_bounds__(256) void k_gaussian_blur_r(
 // (2R/4 shuffles of 4 doubles per 4 outputs, against 2R per output in the tile kernel above);
 // stores are 32 contiguous bytes per lane.  Read amplification: (64 + 2R)/64 vertically,
 // 256/(256 - 2R) horizontally.  Same summation order as scipy in both passes.
+//
+// Rows per wave are chosen per launch so that the grid fills the chip in WHOLE rounds: the
+// kernel keeps 165 (R = 4) / 252 (R = 8) VGPRs, i.e. 3 / 2 workgroups per CU = 768 / 512
+// resident workgroups.  The fixed 64 rows of round 2 made 1088 workgroups at n = 8192 -- a
+// full round and a 42 % one behind it, each wave a dependent chain of row loads (318 us,
+// 0.42 of the HBM peak, VALUBusy 29 %) -- and 272 at n = 4096, a third of the slots.  Same
+// arithmetic per output row whatever the split.
 constexpr int kStreamMinN = 512;
-constexpr int kStreamRows = 64;   // output rows per wave
+constexpr int kStreamRowsMin = 16;   // fewer rows per wave: the 2 R halo rows dominate
+constexpr int kStreamRowsMax = 128;
 constexpr int kAhead = 3;         // rows loaded ahead of the vertical stencil
-template <int R, int ROWS>
+template <int R>
 __device__ __forceinline__ void gaussian_blur_stream_body(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ weights, const double* __restrict__ diag,
-    double* __restrict__ rowmax, const int bx, const int by, const int ncols) {
+    double* __restrict__ rowmax, const int bx, const int by, const int ncols,
+    const int rows_per_wave) {
   static_assert(R % 4 == 0, "neighbour lanes carry 4 columns each");
-  constexpr int rows_per_wave = ROWS;
   constexpr int S = 2 * R + 1 + kAhead;  // ring slots
   constexpr int NB = R / 4;              // neighbour lanes per side
   constexpr int OW = 256 - 2 * R;        // output columns per strip
@@ -270,23 +278,35 @@ __device__ __forceinline__ void gaussian_blur_stream_body(
     }
   }
 }
-template <int R, int ROWS>
+template <int R>
 __global__ __launch_bounds__(256) void k_gaussian_blur_stream(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ weights, const double* __restrict__ diag,
-    double* __restrict__ rowmax) {
-  gaussian_blur_stream_body<R, ROWS>(in, out, n, ld, weights, diag, rowmax, blockIdx.x, blockIdx.y,
-                                     gridDim.x);
+    double* __restrict__ rowmax, int rows) {
+  gaussian_blur_stream_body<R>(in, out, n, ld, weights, diag, rowmax, blockIdx.x, blockIdx.y,
+                               gridDim.x, rows);
 }
 // grouped form (batch_group.hip): blockIdx.z = member of a batch group; A0 -> B1 with the
 // CropDiagonal value applied on load, per-strip row maxima into rmpart
-template <int R, int ROWS>
+template <int R>
 __global__ __launch_bounds__(256) void k_gaussian_blur_stream_g(const GroupOf<FrontItem> g,
-                                                                const double* __restrict__ weights) {
+                                                                const double* __restrict__ weights,
+                                                                int rows) {
   const FrontItem& a = g.s[blockIdx.z];
-  if ((int)blockIdx.x >= a.blur_cols || (int)blockIdx.y * 4 * ROWS >= a.n) return;
-  gaussian_blur_stream_body<R, ROWS>(a.A0, a.B1, a.n, a.ldn, weights, a.cropval, a.rmpart,
-                                     blockIdx.x, blockIdx.y, a.blur_cols);
+  if ((int)blockIdx.x >= a.blur_cols || (int)blockIdx.y * 4 * rows >= a.n) return;
+  gaussian_blur_stream_body<R>(a.A0, a.B1, a.n, a.ldn, weights, a.cropval, a.rmpart,
+                               blockIdx.x, blockIdx.y, a.blur_cols, rows);
+}
+
+// Rows per wave for `wave_rows_total` = sum over the launch's matrices of strips * n (one
+// wave-row = one output row of one 256-column strip): the smallest number of whole rounds
+// of resident workgroups whose share per wave stays within [kStreamRowsMin, kStreamRowsMax].
+static int stream_rows_per_wave(long long wave_rows_total, int radius) {
+  const long long slots = 256LL * (radius == 4 ? 3 : 2) * 4;  // resident waves on the chip
+  for (int rounds = 1;; ++rounds) {
+    const long long rows = (wave_rows_total + slots * rounds - 1) / (slots * rounds);
+    if (rows <= kStreamRowsMax) return (int)std::max<long long>(rows, kStreamRowsMin);
+  }
 }
 
 __global__ void k_copy_matrix(const double* __restrict__ in,
@@ -314,25 +334,25 @@ bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, in
                                 double* rowmax_partials) {
   dim3 grid((n + TW - 1) / TW, (n + TH - 1) / TH);
   if ((radius == 4 || radius == 8) && n >= kStreamMinN) {
-    // A wave walks its rows one after the other (a chain of dependent row loads): 64 rows per
-    // wave amortise the 2 R halo rows at large n; a short utterance has too few column
-    // strips to fill the chip that way, so its waves take fewer rows each (the halo re-reads
-    // are served by L2).  Same arithmetic per output row either way.
-    const int rows = n >= 4096 ? kStreamRows : (n >= 2048 ? kStreamRows / 2 : kStreamRows / 4);
-    dim3 sgrid(blur_tile_columns(n, radius), (n + 4 * rows - 1) / (4 * rows));
-#define SC_BLUR_STREAM(R_, ROWS_)                                                            \
-  hipLaunchKernelGGL((k_gaussian_blur_stream<R_, ROWS_>), sgrid, dim3(256), 0, s, in, out, n, \
-                     ld, weights_dev, diag, rowmax_partials)
-    if (radius == 4) {
-      if (rows == kStreamRows) SC_BLUR_STREAM(4, kStreamRows);
-      else if (rows == kStreamRows / 2) SC_BLUR_STREAM(4, kStreamRows / 2);
-      else SC_BLUR_STREAM(4, kStreamRows / 4);
-    } else {
-      if (rows == kStreamRows) SC_BLUR_STREAM(8, kStreamRows);
-      else if (rows == kStreamRows / 2) SC_BLUR_STREAM(8, kStreamRows / 2);
-      else SC_BLUR_STREAM(8, kStreamRows / 4);
+    // A wave walks its rows one after the other (a chain of dependent row loads); the rows
+    // per wave make the grid a whole number of rounds of resident workgroups (above)
+    const int strips = blur_tile_columns(n, radius);
+    int rows = stream_rows_per_wave((long long)strips * n, radius);
+    // (the grid is strips x ceil(n / (4 rows)) workgroups: the rounding of the second factor
+    //  must not push it past the round)
+    const int per_round = 256 * (radius == 4 ? 3 : 2);
+    while (rows < kStreamRowsMax) {
+      const long long wgs = (long long)strips * ((n + 4 * rows - 1) / (4 * rows));
+      if (wgs <= per_round || wgs % per_round == 0 || wgs % per_round > per_round * 3 / 4) break;
+      ++rows;
     }
-#undef SC_BLUR_STREAM
+    dim3 sgrid(strips, (n + 4 * rows - 1) / (4 * rows));
+    if (radius == 4)
+      hipLaunchKernelGGL((k_gaussian_blur_stream<4>), sgrid, dim3(256), 0, s, in, out, n, ld,
+                         weights_dev, diag, rowmax_partials, rows);
+    else
+      hipLaunchKernelGGL((k_gaussian_blur_stream<8>), sgrid, dim3(256), 0, s, in, out, n, ld,
+                         weights_dev, diag, rowmax_partials, rows);
     return rowmax_partials != nullptr;
   }
   if ((radius == 4 || radius == 8) && n >= 128) {
@@ -373,21 +393,18 @@ void launch_gaussian_blur_group(hipStream_t s, const FrontItem* items, int count
     cmax = std::max(cmax, items[z].n > 0 ? items[z].blur_cols : 0);
   }
   if (nmax == 0) return;
-  // rows per wave from the largest member (the members of a group are of similar size)
-  const int rows = nmax >= 4096 ? kStreamRows : (nmax >= 2048 ? kStreamRows / 2 : kStreamRows / 4);
+  // rows per wave from the work of the whole group (whole rounds of resident workgroups)
+  long long total = 0;
+  for (int z = 0; z < count; ++z)
+    if (items[z].n > 0) total += (long long)items[z].blur_cols * items[z].n;
+  const int rows = stream_rows_per_wave(total, radius);
   dim3 grid(cmax, (nmax + 4 * rows - 1) / (4 * rows), count);
-#define SC_BLUR_STREAM_G(R_, ROWS_)                                                        \
-  hipLaunchKernelGGL((k_gaussian_blur_stream_g<R_, ROWS_>), grid, dim3(256), 0, s, g, weights_dev)
-  if (radius == 4) {
-    if (rows == kStreamRows) SC_BLUR_STREAM_G(4, kStreamRows);
-    else if (rows == kStreamRows / 2) SC_BLUR_STREAM_G(4, kStreamRows / 2);
-    else SC_BLUR_STREAM_G(4, kStreamRows / 4);
-  } else {
-    if (rows == kStreamRows) SC_BLUR_STREAM_G(8, kStreamRows);
-    else if (rows == kStreamRows / 2) SC_BLUR_STREAM_G(8, kStreamRows / 2);
-    else SC_BLUR_STREAM_G(8, kStreamRows / 4);
-  }
-#undef SC_BLUR_STREAM_G
+  if (radius == 4)
+    hipLaunchKernelGGL((k_gaussian_blur_stream_g<4>), grid, dim3(256), 0, s, g, weights_dev,
+                       rows);
+  else
+    hipLaunchKernelGGL((k_gaussian_blur_stream_g<8>), grid, dim3(256), 0, s, g, weights_dev,
+                       rows);
 }
 
 }  // namespace sc

@@ -135,6 +135,7 @@ extern "C" int sc_apply_constraint(sc_handle h, const sc_config* cfg) {
   SC_TRY(validate_config(h, cfg));
   if (!h->have_affinity) return fail(h, SC_ERR_INVALID, "no affinity resident");
   if (!h->have_constraint) return fail(h, SC_ERR_INVALID, "no constraint matrix resident");
+  h->sweep_slot.clear();  // (a sweep on the unadjusted affinity)
   if (cfg->constraint_name == SC_CONSTRAINT_NONE)
     return fail(h, SC_ERR_INVALID, "no constraint operation configured");
   if (h->qn != h->n)

@@ -5,6 +5,7 @@
 #include <ctime>
 
 #include "handle.h"
+#include "host_eig.h"
 
 // ------------------------------------------------------------------------------
 // symmetric top-k eigensolver driver
@@ -147,270 +148,6 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
   return dc;
 }
 
-// ------------------------------------------------------------------------------
-// Rayleigh-Ritz on the host for small projected problems (m <= kHostRR)
-// ------------------------------------------------------------------------------
-// The projected matrix T = Q^T Op Q of the first checks is 24 x 24 .. 48 x 48: 4.6-18 KB that
-// come back with the flags the host reads anyway.  A one-workgroup Jacobi takes 170-330 us
-// for it on the device (a chain of ~160 barrier-separated rounds); Householder
-// tridiagonalisation + implicit QL (the textbook tred2 / tql2 recurrences) on one host core
-// takes ~20-60 us.  Larger bases (after restarts) stay on the device (k_jacobi).
-//
-// a: m x m symmetric (row-major, lda), overwritten with the eigenvectors (columns);
-// d: eigenvalues ascending.  Returns false if QL did not converge (30 iterations).
-static bool host_symmetric_eig(double* a, int lda, int m, double* d, double* e) {
-  auto A = [&](int i, int j) -> double& { return a[(size_t)i * lda + j]; };
-  // ---- tred2: Householder reduction to tridiagonal form, accumulating the transformation
-  for (int i = m - 1; i >= 1; --i) {
-    const int l = i - 1;
-    double h = 0.0, scale = 0.0;
-    if (l > 0) {
-      for (int k = 0; k <= l; ++k) scale += std::fabs(A(i, k));
-      if (scale == 0.0) {
-        e[i] = A(i, l);
-      } else {
-        for (int k = 0; k <= l; ++k) {
-          A(i, k) /= scale;
-          h += A(i, k) * A(i, k);
-        }
-        double f = A(i, l);
-        double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
-        e[i] = scale * g;
-        h -= f * g;
-        A(i, l) = f - g;
-        f = 0.0;
-        for (int j = 0; j <= l; ++j) {
-          A(j, i) = A(i, j) / h;
-          g = 0.0;
-          for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
-          for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
-          e[j] = g / h;
-          f += e[j] * A(i, j);
-        }
-        const double hh = f / (h + h);
-        for (int j = 0; j <= l; ++j) {
-          f = A(i, j);
-          e[j] = g = e[j] - hh * f;
-          for (int k = 0; k <= j; ++k) A(j, k) -= (f * e[k] + g * A(i, k));
-        }
-      }
-    } else {
-      e[i] = A(i, l);
-    }
-    d[i] = h;
-  }
-  d[0] = 0.0;
-  e[0] = 0.0;
-  for (int i = 0; i < m; ++i) {
-    const int l = i - 1;
-    if (d[i] != 0.0) {
-      for (int j = 0; j <= l; ++j) {
-        double g = 0.0;
-        for (int k = 0; k <= l; ++k) g += A(i, k) * A(k, j);
-        for (int k = 0; k <= l; ++k) A(k, j) -= g * A(k, i);
-      }
-    }
-    d[i] = A(i, i);
-    A(i, i) = 1.0;
-    for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
-  }
-  // ---- tql2: implicit QL with eigenvector accumulation
-  for (int i = 1; i < m; ++i) e[i - 1] = e[i];
-  e[m - 1] = 0.0;
-  for (int l = 0; l < m; ++l) {
-    int iter = 0, mm;
-    do {
-      for (mm = l; mm < m - 1; ++mm) {
-        const double dd = std::fabs(d[mm]) + std::fabs(d[mm + 1]);
-        if (std::fabs(e[mm]) <= 2.220446049250313e-16 * dd) break;
-      }
-      if (mm != l) {
-        if (iter++ == 60) return false;
-        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-        double r = std::hypot(g, 1.0);
-        g = d[mm] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
-        double s = 1.0, c = 1.0, p = 0.0;
-        int i;
-        for (i = mm - 1; i >= l; --i) {
-          double f = s * e[i];
-          const double b = c * e[i];
-          e[i + 1] = r = std::hypot(f, g);
-          if (r == 0.0) {
-            d[i + 1] -= p;
-            e[mm] = 0.0;
-            break;
-          }
-          s = f / r;
-          c = g / r;
-          g = d[i + 1] - p;
-          r = (d[i] - g) * s + 2.0 * c * b;
-          d[i + 1] = g + (p = s * r);
-          g = c * r - b;
-          for (int k = 0; k < m; ++k) {
-            f = A(k, i + 1);
-            A(k, i + 1) = s * A(k, i) + c * f;
-            A(k, i) = c * A(k, i) - s * f;
-          }
-        }
-        if (r == 0.0 && i >= l) continue;
-        d[l] -= p;
-        e[l] = g;
-        e[mm] = 0.0;
-      }
-    } while (mm != l);
-  }
-  return true;
-}
-
-// host-only export: lets the CPU tests pin the routine without a GPU
-extern "C" int sc_host_symmetric_eig(const double* a, int m, double* values, double* vectors) {
-  if (!a || !values || !vectors || m < 1) return SC_ERR_INVALID;
-  std::vector<double> e(m);
-  for (size_t i = 0; i < (size_t)m * m; ++i) vectors[i] = a[i];
-  return host_symmetric_eig(vectors, m, m, values, e.data()) ? SC_OK : SC_ERR_NOT_CONVERGED;
-}
-
-// ------------------------------------------------------------------------------
-// eigenvectors of a symmetric tridiagonal matrix by inverse iteration (host)
-// ------------------------------------------------------------------------------
-// LAPACK dstein's method for a handful of eigenvalues `lam` (any order; neighbours in the
-// list closer than 1e-3 ||T|| are treated as a cluster and kept orthogonal by modified
-// Gram-Schmidt, exact duplicates are separated by 10 ulp like dstein's `pertol`): LU of
-// T - lam I with partial pivoting (dlagtf's elimination), a random start, solves until
-// the iterate has grown past dstein's threshold plus two more.  O(n) per vector and
-// iteration -- a serial recurrence, which is why it runs here and not on the device; the
-// O(n^2) back-transform is k_td_backtransform.  Z: column-major, column q at Z + q * ldz,
-// unit 2-norm, largest component positive.  Returns false if a vector failed to grow.
-static bool host_tridiag_eigvectors(const double* d, const double* e, int n, const double* lam,
-                                    int k, double* Z, size_t ldz) {
-  if (n == 1) {
-    for (int q = 0; q < k; ++q) Z[q * ldz] = 1.0;
-    return true;
-  }
-  const double eps = 2.220446049250313e-16;
-  double onenrm = std::fabs(d[0]) + std::fabs(e[0]);
-  onenrm = std::max(onenrm, std::fabs(d[n - 1]) + std::fabs(e[n - 2]));
-  for (int i = 1; i < n - 1; ++i)
-    onenrm = std::max(onenrm, std::fabs(d[i]) + std::fabs(e[i - 1]) + std::fabs(e[i]));
-  if (!(onenrm > 0.0)) onenrm = 1.0;
-  const double ortol = 1e-3 * onenrm;
-  const double pivtol = eps * onenrm;
-  const double grow = std::sqrt(0.1 / n);  // dstein's dtpcrt
-  std::vector<double> u0(n), u1(n), u2(n), l(n), x(n);
-  std::vector<char> piv(n);
-  std::vector<double> used(k);
-  uint64_t rng = 0x9e3779b97f4a7c15ull;
-  bool all_ok = true;
-  int cluster_begin = 0;
-  for (int q = 0; q < k; ++q) {
-    double xj = lam[q];
-    if (q > 0 && std::fabs(lam[q] - lam[q - 1]) >= ortol) cluster_begin = q;
-    // separate (numerically) repeated shifts inside a cluster, keeping the list's direction
-    for (int r = cluster_begin; r < q; ++r) {
-      const double pert = 10.0 * eps * std::max(std::fabs(xj), onenrm * 1e-3);
-      if (std::fabs(xj - used[r]) < pert) xj = used[r] + (lam[q] <= lam[cluster_begin] ? -pert : pert);
-    }
-    used[q] = xj;
-    // ---- P L U = T - xj I  (row i of U: u0 diagonal, u1, u2 superdiagonals)
-    double a = d[0] - xj;       // current diagonal entry of the row being eliminated with
-    double b = n > 1 ? e[0] : 0.0;  // its first superdiagonal
-    for (int i = 0; i < n - 1; ++i) {
-      const double c = e[i];                      // subdiagonal entry (i + 1, i)
-      const double an = d[i + 1] - xj;            // row i + 1: (c, an, bn)
-      const double bn = i + 2 < n ? e[i + 1] : 0.0;
-      if (std::fabs(a) >= std::fabs(c)) {         // no interchange
-        double pv = a;
-        if (std::fabs(pv) < pivtol) pv = pv < 0.0 ? -pivtol : pivtol;
-        const double m = c / pv;
-        piv[i] = 0; l[i] = m;
-        u0[i] = pv; u1[i] = b; u2[i] = 0.0;
-        a = an - m * b;
-        b = bn;
-      } else {                                    // rows i and i + 1 swapped
-        const double m = a / c;
-        piv[i] = 1; l[i] = m;
-        u0[i] = c; u1[i] = an; u2[i] = bn;
-        a = b - m * an;
-        b = -m * bn;
-      }
-    }
-    if (std::fabs(a) < pivtol) a = a < 0.0 ? -pivtol : pivtol;
-    u0[n - 1] = a; u1[n - 1] = 0.0; u2[n - 1] = 0.0;
-    // ---- inverse iteration
-    for (int i = 0; i < n; ++i) {
-      rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-      x[i] = (double)(int64_t)(rng >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
-    }
-    double* z = Z + (size_t)q * ldz;
-    int extra = 0;
-    bool ok = false;
-    for (int it = 0; it < 12; ++it) {
-      // scale the right-hand side to norm ~ n * onenrm * eps-ish (dstein) so that the solve
-      // of a nearly singular system cannot overflow
-      double amax = 0.0;
-      for (int i = 0; i < n; ++i) amax = std::max(amax, std::fabs(x[i]));
-      if (!(amax > 0.0)) { x[0] = 1.0; amax = 1.0; }
-      const double scl = n * onenrm * std::max(eps, std::fabs(u0[n - 1])) / amax;
-      for (int i = 0; i < n; ++i) x[i] *= scl;
-      // L^-1 P
-      for (int i = 0; i < n - 1; ++i) {
-        if (piv[i]) {
-          const double t = x[i];
-          x[i] = x[i + 1];
-          x[i + 1] = t - l[i] * x[i];
-        } else {
-          x[i + 1] -= l[i] * x[i];
-        }
-      }
-      // U^-1
-      x[n - 1] /= u0[n - 1];
-      if (n > 1) x[n - 2] = (x[n - 2] - u1[n - 2] * x[n - 1]) / u0[n - 2];
-      for (int i = n - 3; i >= 0; --i)
-        x[i] = (x[i] - u1[i] * x[i + 1] - u2[i] * x[i + 2]) / u0[i];
-      // keep the cluster orthogonal
-      for (int r = cluster_begin; r < q; ++r) {
-        const double* zr = Z + (size_t)r * ldz;
-        double dot = 0.0;
-        for (int i = 0; i < n; ++i) dot += x[i] * zr[i];
-        for (int i = 0; i < n; ++i) x[i] -= dot * zr[i];
-      }
-      double nrm = 0.0;
-      for (int i = 0; i < n; ++i) nrm = std::max(nrm, std::fabs(x[i]));
-      if (!std::isfinite(nrm)) break;
-      if (nrm >= grow) {
-        if (++extra > 2) { ok = true; break; }
-      }
-    }
-    double s2 = 0.0;
-    int imax = 0;
-    for (int i = 0; i < n; ++i) {
-      s2 += x[i] * x[i];
-      if (std::fabs(x[i]) > std::fabs(x[imax])) imax = i;
-    }
-    if (!(s2 > 0.0) || !std::isfinite(s2)) {
-      ok = false;
-      for (int i = 0; i < n; ++i) z[i] = 0.0;
-    } else {
-      const double inv = (x[imax] < 0.0 ? -1.0 : 1.0) / std::sqrt(s2);
-      for (int i = 0; i < n; ++i) z[i] = x[i] * inv;
-    }
-    all_ok = all_ok && ok;
-  }
-  return all_ok;
-}
-
-// host-only export: lets the CPU tests pin the routine without a GPU.  vectors: (n, k)
-// row-major (column q = eigenvector of lam[q]).
-extern "C" int sc_host_tridiag_eigvectors(const double* d, const double* e, int n,
-                                          const double* lam, int k, double* vectors) {
-  if (!d || (!e && n > 1) || !lam || !vectors || n < 1 || k < 1) return SC_ERR_INVALID;
-  std::vector<double> z((size_t)n * k);
-  const bool ok = host_tridiag_eigvectors(d, e, n, lam, k, z.data(), (size_t)n);
-  for (int q = 0; q < k; ++q)
-    for (int i = 0; i < n; ++i) vectors[(size_t)i * k + q] = z[(size_t)q * n + i];
-  return ok ? SC_OK : SC_ERR_NOT_CONVERGED;
-}
-
 // T (m x m, from the device, row-major ld) and the residual block's Gram G (B x B) ->
 // theta descending, resid estimates sqrt(y_last^T G y_last), Y (m x m, row-major ldy,
 // column `rank` = Ritz vector of theta[rank]).  Same outputs as k_jacobi.
@@ -439,6 +176,39 @@ static bool host_rayleigh_ritz(const double* T, int ld, const double* G, int m, 
     }
     resid[rank] = std::sqrt(std::max(r2, 0.0));
     for (int r = 0; r < m; ++r) Y[(size_t)r * ldy + rank] = a[(size_t)r * lda + c];
+  }
+  return true;
+}
+
+// The same for a basis of more than kHostRR vectors (clustered spectra, restarts): every Ritz
+// value, but only the leading Ritz VECTORS -- those the analysis reads residuals of and a
+// thick restart keeps (host_eig.cpp: 4/3 m^3 + O(need m^2) instead of ~9 m^3).  `count_fn`
+// maps the Ritz values to the number of leading pairs the caller will look at.  Columns
+// >= need of Y are zero, their residual estimates infinite.
+template <typename CountFn>
+static bool host_rayleigh_ritz_leading(const double* T, int ld, const double* G, int m,
+                                       double* theta, double* resid, double* Y, int ldy,
+                                       CountFn count_fn) {
+  HostTridiag tw;
+  if (!host_partial_values(T, ld, m, &tw)) return false;
+  for (int i = 0; i < m; ++i) theta[i] = tw.theta[i];
+  const int need = std::max(1, std::min(m, count_fn(theta)));
+  for (int r = 0; r < m; ++r)
+    for (int c = 0; c < m; ++c) Y[(size_t)r * ldy + c] = 0.0;
+  if (!host_partial_vectors(tw, need, Y, ldy)) return false;
+  for (int rank = 0; rank < m; ++rank) {
+    if (rank >= need) {
+      resid[rank] = __builtin_huge_val();
+      continue;
+    }
+    double r2 = 0.0;
+    for (int p = 0; p < kEigBlock; ++p) {
+      double t = 0.0;
+      for (int q = 0; q < kEigBlock; ++q)
+        t += G[p * kEigBlock + q] * Y[(size_t)(m - kEigBlock + q) * ldy + rank];
+      r2 += Y[(size_t)(m - kEigBlock + p) * ldy + rank] * t;
+    }
+    resid[rank] = std::sqrt(std::max(r2, 0.0));
   }
   return true;
 }
@@ -745,21 +515,11 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     }
     // basis cap: LDS Jacobi limit, and basis + next block must fit in R^n
     const int cap = std::min(kEigBasisCap, ((n - kEigBlock) / kEigBlock) * kEigBlock);
-    // first Rayleigh-Ritz check after 3 blocks -- or where the previous solve of the same
-    // kind converged (re-probed from 3 blocks every 16th call, so the hint can also shrink)
-    const long long sig = ((long long)rq.descend << 40) ^ ((long long)rq.max_clusters << 20) ^
-                          ((long long)rq.fixed_count << 8) ^ rq.eigengap_type ^
-                          ((long long)(n > 4096) << 50) ^ rq.hint_key;
-    int first_check = std::min(3 * kEigBlock, cap);
-    if (h->eig_hint_sig == sig && h->eig_hint_m > first_check && h->eig_hint_age < 16 &&
-        !getenv("SC_EIG_NO_HINT")) {
-      // (one block at most: a later check costs a pass per block if this problem would have
-      //  converged earlier -- an AutoTune sweep changes the spectrum from call to call)
-      first_check = std::min(std::min(h->eig_hint_m, 4 * kEigBlock), cap);
-      ++h->eig_hint_age;
-    } else {
-      h->eig_hint_age = 0;
-    }
+    // first Rayleigh-Ritz check after 3 blocks.  (Round 2 moved it to where the previous
+    // solve on this handle had converged; that made the basis size at exit -- hence results
+    // at the tolerance level -- depend on the call history.  A solve is now a function of
+    // its input alone: tests/test_gpu_predict.py::test_results_do_not_depend_on_call_history.)
+    const int first_check = std::min(3 * kEigBlock, cap);
     while (!done) {
       // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
       const bool time_mv = h->profile_level >= 2 && h->n_mv_ev < 16;
@@ -840,8 +600,22 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       }
       if (host_rr) {
         double* hy = h->h_rr + kHostRRSingle * kHostRRSingle + 64;
-        if (!host_rayleigh_ritz(h->h_rr, m, h->h_rr + kHostRRSingle * kHostRRSingle, m, h->h_theta,
-                                h->h_theta + kLdq, hy, m)) {
+        const double* hG = h->h_rr + kHostRRSingle * kHostRRSingle;
+        bool rr_ok;
+        if (m <= kHostRR) {
+          rr_ok = host_rayleigh_ritz(h->h_rr, m, hG, m, h->h_theta, h->h_theta + kLdq, hy, m);
+        } else {
+          // the pairs the analysis reads and a thick restart keeps (its `keep` below), + a block
+          auto leading = [&](const double* theta) {
+            std::vector<double> zero(m, 0.0);
+            const EigDecision d0 = analyze(rq, theta, zero.data(), m, n, false);
+            const int want = d0.enough ? std::max(d0.kw, d0.kvec) : cap / 4;
+            return round_up(want + kEigBlock, kEigBlock) + kEigBlock;
+          };
+          rr_ok = host_rayleigh_ritz_leading(h->h_rr, m, hG, m, h->h_theta, h->h_theta + kLdq,
+                                             hy, m, leading);
+        }
+        if (!rr_ok) {
           SC_TRY(dense_fallback(2));
           break;
         }
@@ -879,10 +653,6 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
           goto restart_lanczos;
         }
         if (dc.enough && dc.converged) {
-          if (cycles == 0) {
-            h->eig_hint_sig = sig;
-            h->eig_hint_m = m;
-          }
           done = true;
           break;
         }

@@ -88,6 +88,13 @@ struct sc_handle_s {
   // eigensolver; the lockstep chains run on THIS handle's stream), the RandomState(0) doubles
   // of every k (k-means++ seeding)
   std::vector<sc_handle_s*> gslots;
+  // last sc_eig_ncluster_sweep: member arena that holds value i's eigenvectors (-1: none),
+  // what it reported, and the problem size it ran on (sc_sweep_adopt)
+  std::vector<int> sweep_slot;
+  std::vector<sc_diag> sweep_diags;
+  std::vector<double> sweep_p;
+  sc_config sweep_cfg;
+  int sweep_n = 0;
   hipEvent_t sync_ev = nullptr;    // a member arena: "stages before the eigensolver done"
   DevBuf gkrnd;
   bool gkrnd_ready = false;
@@ -113,18 +120,12 @@ struct sc_handle_s {
   int mv_ev[16][2];       // event pairs around the block matvec launches (level 2)
   int n_mv_ev = 0;
   int aff_ev[2] = {-1, -1};  // around the affinity GEMM launch (level 2)
-  // Rayleigh-Ritz scheduling hint: basis size at which the previous solve with the same
-  // request signature converged (a check costs a ~0.2 ms Jacobi + a host sync; consecutive
-  // calls of one workload converge at the same size)
   // what the small per-call uploads last carried (skipped when unchanged)
   int blurw_radius = -1;
   double blurw_host[2 * SC_MAX_BLUR_RADIUS + 1];
   int krnd_k = -1, krnd_trials = -1;
   int kfirst_n = -1, kfirst = 0;  // first k-means++ centre of the last n (RandomState(0) draw)
   bool eig_skip_fused = false;  // next sym_topk: go straight to the host-driven chain
-  int eig_hint_m = 0;
-  long long eig_hint_sig = -1;
-  int eig_hint_age = 0;
 };
 
 // hipEvent slots of the current call (reset by the entry points); -1 when exhausted
@@ -241,7 +242,6 @@ struct EigRequest {
   // the others must be accurate enough that, with their residual intervals, no other gap
   // can reach the maximum and no comparison with stop_eigenvalue can flip.
   int decision_aware = 0;
-  long long hint_key = 0;  // distinguishes workloads for the Rayleigh-Ritz scheduling hint
 };
 
 struct EigDecision {

@@ -1,0 +1,437 @@
+// Host-side dense kernels of the eigen drivers: see host_eig.h.  Textbook algorithms
+// (EISPACK tred2 / tql2 / tql1, LAPACK dsytd2 / dstein), none of them from the reference,
+// which calls numpy.linalg.eig (utils.py:59).
+#include "host_eig.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/spectralcluster_amd.h"
+
+// ------------------------------------------------------------------------------
+// Rayleigh-Ritz on the host for small projected problems (m <= kHostRR)
+// ------------------------------------------------------------------------------
+// The projected matrix T = Q^T Op Q of the first checks is 24 x 24 .. 48 x 48: 4.6-18 KB that
+// come back with the flags the host reads anyway.  A one-workgroup Jacobi takes 170-330 us
+// for it on the device (a chain of ~160 barrier-separated rounds); Householder
+// tridiagonalisation + implicit QL (the textbook tred2 / tql2 recurrences) on one host core
+// takes ~20-60 us.  Larger bases (after restarts) stay on the device (k_jacobi).
+//
+// a: m x m symmetric (row-major, lda), overwritten with the eigenvectors (columns);
+// d: eigenvalues ascending.  Returns false if QL did not converge (30 iterations).
+bool host_symmetric_eig(double* a, int lda, int m, double* d, double* e) {
+  auto A = [&](int i, int j) -> double& { return a[(size_t)i * lda + j]; };
+  // ---- tred2: Householder reduction to tridiagonal form, accumulating the transformation
+  for (int i = m - 1; i >= 1; --i) {
+    const int l = i - 1;
+    double h = 0.0, scale = 0.0;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale += std::fabs(A(i, k));
+      if (scale == 0.0) {
+        e[i] = A(i, l);
+      } else {
+        for (int k = 0; k <= l; ++k) {
+          A(i, k) /= scale;
+          h += A(i, k) * A(i, k);
+        }
+        double f = A(i, l);
+        double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+        e[i] = scale * g;
+        h -= f * g;
+        A(i, l) = f - g;
+        f = 0.0;
+        for (int j = 0; j <= l; ++j) {
+          A(j, i) = A(i, j) / h;
+          g = 0.0;
+          for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
+          for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
+          e[j] = g / h;
+          f += e[j] * A(i, j);
+        }
+        const double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) {
+          f = A(i, j);
+          e[j] = g = e[j] - hh * f;
+          for (int k = 0; k <= j; ++k) A(j, k) -= (f * e[k] + g * A(i, k));
+        }
+      }
+    } else {
+      e[i] = A(i, l);
+    }
+    d[i] = h;
+  }
+  d[0] = 0.0;
+  e[0] = 0.0;
+  for (int i = 0; i < m; ++i) {
+    const int l = i - 1;
+    if (d[i] != 0.0) {
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= l; ++k) g += A(i, k) * A(k, j);
+        for (int k = 0; k <= l; ++k) A(k, j) -= g * A(k, i);
+      }
+    }
+    d[i] = A(i, i);
+    A(i, i) = 1.0;
+    for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
+  }
+  // ---- tql2: implicit QL with eigenvector accumulation
+  for (int i = 1; i < m; ++i) e[i - 1] = e[i];
+  e[m - 1] = 0.0;
+  for (int l = 0; l < m; ++l) {
+    int iter = 0, mm;
+    do {
+      for (mm = l; mm < m - 1; ++mm) {
+        const double dd = std::fabs(d[mm]) + std::fabs(d[mm + 1]);
+        if (std::fabs(e[mm]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (mm != l) {
+        if (iter++ == 60) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[mm] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = mm - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          e[i + 1] = r = std::hypot(f, g);
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[mm] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          d[i + 1] = g + (p = s * r);
+          g = c * r - b;
+          for (int k = 0; k < m; ++k) {
+            f = A(k, i + 1);
+            A(k, i + 1) = s * A(k, i) + c * f;
+            A(k, i) = c * A(k, i) - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[mm] = 0.0;
+      }
+    } while (mm != l);
+  }
+  return true;
+}
+
+// host-only export: lets the CPU tests pin the routine without a GPU
+extern "C" int sc_host_symmetric_eig(const double* a, int m, double* values, double* vectors) {
+  if (!a || !values || !vectors || m < 1) return SC_ERR_INVALID;
+  std::vector<double> e(m);
+  for (size_t i = 0; i < (size_t)m * m; ++i) vectors[i] = a[i];
+  return host_symmetric_eig(vectors, m, m, values, e.data()) ? SC_OK : SC_ERR_NOT_CONVERGED;
+}
+
+// ------------------------------------------------------------------------------
+// eigenvectors of a symmetric tridiagonal matrix by inverse iteration (host)
+// ------------------------------------------------------------------------------
+// LAPACK dstein's method for a handful of eigenvalues `lam` (any order; neighbours in the
+// list closer than 1e-3 ||T|| are treated as a cluster and kept orthogonal by modified
+// Gram-Schmidt, exact duplicates are separated by 10 ulp like dstein's `pertol`): LU of
+// T - lam I with partial pivoting (dlagtf's elimination), a random start, solves until
+// the iterate has grown past dstein's threshold plus two more.  O(n) per vector and
+// iteration -- a serial recurrence, which is why it runs here and not on the device; the
+// O(n^2) back-transform is k_td_backtransform.  Z: column-major, column q at Z + q * ldz,
+// unit 2-norm, largest component positive.  Returns false if a vector failed to grow.
+bool host_tridiag_eigvectors(const double* d, const double* e, int n, const double* lam,
+                                    int k, double* Z, size_t ldz) {
+  if (n == 1) {
+    for (int q = 0; q < k; ++q) Z[q * ldz] = 1.0;
+    return true;
+  }
+  const double eps = 2.220446049250313e-16;
+  double onenrm = std::fabs(d[0]) + std::fabs(e[0]);
+  onenrm = std::max(onenrm, std::fabs(d[n - 1]) + std::fabs(e[n - 2]));
+  for (int i = 1; i < n - 1; ++i)
+    onenrm = std::max(onenrm, std::fabs(d[i]) + std::fabs(e[i - 1]) + std::fabs(e[i]));
+  if (!(onenrm > 0.0)) onenrm = 1.0;
+  const double ortol = 1e-3 * onenrm;
+  const double pivtol = eps * onenrm;
+  const double grow = std::sqrt(0.1 / n);  // dstein's dtpcrt
+  std::vector<double> u0(n), u1(n), u2(n), l(n), x(n);
+  std::vector<char> piv(n);
+  std::vector<double> used(k);
+  uint64_t rng = 0x9e3779b97f4a7c15ull;
+  bool all_ok = true;
+  int cluster_begin = 0;
+  for (int q = 0; q < k; ++q) {
+    double xj = lam[q];
+    if (q > 0 && std::fabs(lam[q] - lam[q - 1]) >= ortol) cluster_begin = q;
+    // separate (numerically) repeated shifts inside a cluster, keeping the list's direction
+    for (int r = cluster_begin; r < q; ++r) {
+      const double pert = 10.0 * eps * std::max(std::fabs(xj), onenrm * 1e-3);
+      if (std::fabs(xj - used[r]) < pert) xj = used[r] + (lam[q] <= lam[cluster_begin] ? -pert : pert);
+    }
+    used[q] = xj;
+    // ---- P L U = T - xj I  (row i of U: u0 diagonal, u1, u2 superdiagonals)
+    double a = d[0] - xj;       // current diagonal entry of the row being eliminated with
+    double b = n > 1 ? e[0] : 0.0;  // its first superdiagonal
+    for (int i = 0; i < n - 1; ++i) {
+      const double c = e[i];                      // subdiagonal entry (i + 1, i)
+      const double an = d[i + 1] - xj;            // row i + 1: (c, an, bn)
+      const double bn = i + 2 < n ? e[i + 1] : 0.0;
+      if (std::fabs(a) >= std::fabs(c)) {         // no interchange
+        double pv = a;
+        if (std::fabs(pv) < pivtol) pv = pv < 0.0 ? -pivtol : pivtol;
+        const double m = c / pv;
+        piv[i] = 0; l[i] = m;
+        u0[i] = pv; u1[i] = b; u2[i] = 0.0;
+        a = an - m * b;
+        b = bn;
+      } else {                                    // rows i and i + 1 swapped
+        const double m = a / c;
+        piv[i] = 1; l[i] = m;
+        u0[i] = c; u1[i] = an; u2[i] = bn;
+        a = b - m * an;
+        b = -m * bn;
+      }
+    }
+    if (std::fabs(a) < pivtol) a = a < 0.0 ? -pivtol : pivtol;
+    u0[n - 1] = a; u1[n - 1] = 0.0; u2[n - 1] = 0.0;
+    // ---- inverse iteration
+    for (int i = 0; i < n; ++i) {
+      rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+      x[i] = (double)(int64_t)(rng >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+    }
+    double* z = Z + (size_t)q * ldz;
+    int extra = 0;
+    bool ok = false;
+    for (int it = 0; it < 12; ++it) {
+      // scale the right-hand side to norm ~ n * onenrm * eps-ish (dstein) so that the solve
+      // of a nearly singular system cannot overflow
+      double amax = 0.0;
+      for (int i = 0; i < n; ++i) amax = std::max(amax, std::fabs(x[i]));
+      if (!(amax > 0.0)) { x[0] = 1.0; amax = 1.0; }
+      const double scl = n * onenrm * std::max(eps, std::fabs(u0[n - 1])) / amax;
+      for (int i = 0; i < n; ++i) x[i] *= scl;
+      // L^-1 P
+      for (int i = 0; i < n - 1; ++i) {
+        if (piv[i]) {
+          const double t = x[i];
+          x[i] = x[i + 1];
+          x[i + 1] = t - l[i] * x[i];
+        } else {
+          x[i + 1] -= l[i] * x[i];
+        }
+      }
+      // U^-1
+      x[n - 1] /= u0[n - 1];
+      if (n > 1) x[n - 2] = (x[n - 2] - u1[n - 2] * x[n - 1]) / u0[n - 2];
+      for (int i = n - 3; i >= 0; --i)
+        x[i] = (x[i] - u1[i] * x[i + 1] - u2[i] * x[i + 2]) / u0[i];
+      // keep the cluster orthogonal
+      for (int r = cluster_begin; r < q; ++r) {
+        const double* zr = Z + (size_t)r * ldz;
+        double dot = 0.0;
+        for (int i = 0; i < n; ++i) dot += x[i] * zr[i];
+        for (int i = 0; i < n; ++i) x[i] -= dot * zr[i];
+      }
+      double nrm = 0.0;
+      for (int i = 0; i < n; ++i) nrm = std::max(nrm, std::fabs(x[i]));
+      if (!std::isfinite(nrm)) break;
+      if (nrm >= grow) {
+        if (++extra > 2) { ok = true; break; }
+      }
+    }
+    double s2 = 0.0;
+    int imax = 0;
+    for (int i = 0; i < n; ++i) {
+      s2 += x[i] * x[i];
+      if (std::fabs(x[i]) > std::fabs(x[imax])) imax = i;
+    }
+    if (!(s2 > 0.0) || !std::isfinite(s2)) {
+      ok = false;
+      for (int i = 0; i < n; ++i) z[i] = 0.0;
+    } else {
+      const double inv = (x[imax] < 0.0 ? -1.0 : 1.0) / std::sqrt(s2);
+      for (int i = 0; i < n; ++i) z[i] = x[i] * inv;
+    }
+    all_ok = all_ok && ok;
+  }
+  return all_ok;
+}
+
+// host-only export: lets the CPU tests pin the routine without a GPU.  vectors: (n, k)
+// row-major (column q = eigenvector of lam[q]).
+extern "C" int sc_host_tridiag_eigvectors(const double* d, const double* e, int n,
+                                          const double* lam, int k, double* vectors) {
+  if (!d || (!e && n > 1) || !lam || !vectors || n < 1 || k < 1) return SC_ERR_INVALID;
+  std::vector<double> z((size_t)n * k);
+  const bool ok = host_tridiag_eigvectors(d, e, n, lam, k, z.data(), (size_t)n);
+  for (int q = 0; q < k; ++q)
+    for (int i = 0; i < n; ++i) vectors[(size_t)i * k + q] = z[(size_t)q * n + i];
+  return ok ? SC_OK : SC_ERR_NOT_CONVERGED;
+}
+
+// ------------------------------------------------------------------------------
+// partial symmetric eigensolver on the host: ALL eigenvalues, the LEADING eigenvectors
+// ------------------------------------------------------------------------------
+// A Rayleigh-Ritz check of a basis of 72..128 vectors needs every Ritz value (the analysis
+// reads the far end too) but only the leading max_clusters + 1 (+ one block, for a restart)
+// Ritz VECTORS.  tred2 + tql2 above accumulate all m vectors: ~9 m^3 flops, 2 ms at m = 128.
+// Here: Householder tridiagonalisation with the reflectors kept (LAPACK dsytd2, 4/3 m^3),
+// eigenvalues by implicit QL without vectors (O(m^2)), the leading `need` vectors by
+// inverse iteration on the tridiagonal form (host_tridiag_eigvectors) and Q z through the
+// reflectors (O(m^2) each).
+
+// a (m x m symmetric, FULL storage, row-major lda; destroyed) -> d, e (e[i] couples i, i+1),
+// tau; reflector i: v(i, i+1) = 1, v(i, i+2 ..).  Both triangles are kept up to date so that
+// every inner loop walks a contiguous row (the compiler vectorises them).
+__attribute__((target_clones("avx2,fma", "default")))
+static void host_tridiagonalize(HostTridiag* w) {
+  const int m = w->m, lda = w->lda;
+  double* a = w->a.data();
+  w->v.assign((size_t)m * lda, 0.0);
+  double* vv = w->v.data();
+  w->d.assign(m, 0.0);
+  w->e.assign(std::max(m, 1), 0.0);
+  w->tau.assign(std::max(m, 1), 0.0);
+  std::vector<double> pbuf(m);
+  double* p = pbuf.data();
+  for (int i = 0; i + 1 < m; ++i) {
+    const int c0 = i + 1, len = m - c0;
+    const double* x = a + (size_t)i * lda + c0;  // row i right of the diagonal (= column i below)
+    double* v = vv + (size_t)i * lda + c0;
+    const double alpha = x[0];
+    double xnorm2 = 0.0;
+    for (int k = 1; k < len; ++k) xnorm2 += x[k] * x[k];
+    double tau = 0.0, beta = alpha;
+    if (xnorm2 > 0.0) {
+      beta = -std::copysign(std::sqrt(alpha * alpha + xnorm2), alpha);
+      tau = (beta - alpha) / beta;
+      const double scale = 1.0 / (alpha - beta);
+      v[0] = 1.0;
+      for (int k = 1; k < len; ++k) v[k] = x[k] * scale;
+    }
+    w->e[i] = beta;
+    w->tau[i] = tau;
+    w->d[i] = a[(size_t)i * lda + i];
+    if (tau == 0.0) continue;
+    // p = tau A22 v ; w = p - (tau/2)(p^T v) v ; A22 -= v w^T + w v^T
+    double dot = 0.0;
+    for (int r = 0; r < len; ++r) {
+      const double* row = a + (size_t)(c0 + r) * lda + c0;
+      double acc = 0.0;
+      for (int c = 0; c < len; ++c) acc += row[c] * v[c];
+      p[r] = tau * acc;
+      dot += p[r] * v[r];
+    }
+    const double half = 0.5 * tau * dot;
+    for (int r = 0; r < len; ++r) p[r] -= half * v[r];
+    for (int r = 0; r < len; ++r) {
+      double* row = a + (size_t)(c0 + r) * lda + c0;
+      const double vr = v[r], pr = p[r];
+      for (int c = 0; c < len; ++c) row[c] -= vr * p[c] + pr * v[c];
+    }
+  }
+  if (m > 0) w->d[m - 1] = a[(size_t)(m - 1) * lda + (m - 1)];
+}
+
+// eigenvalues of the tridiagonal (d, e) by implicit QL (tql1); ascending on return.
+// (plain sqrt instead of hypot: the projected matrices are O(||Op||), nowhere near the
+//  overflow range, and hypot was 3/4 of this routine's time)
+static bool host_tridiag_values(std::vector<double> d, std::vector<double> e, int m,
+                                std::vector<double>* out) {
+  e.resize(m + 1, 0.0);
+  e[m - 1] = 0.0;
+  for (int l = 0; l < m; ++l) {
+    int iter = 0, mm;
+    do {
+      for (mm = l; mm < m - 1; ++mm) {
+        const double dd = std::fabs(d[mm]) + std::fabs(d[mm + 1]);
+        if (std::fabs(e[mm]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (mm != l) {
+        if (iter++ == 60) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::sqrt(g * g + 1.0);
+        g = d[mm] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = mm - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          e[i + 1] = r = std::sqrt(f * f + g * g);
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[mm] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          d[i + 1] = g + (p = s * r);
+          g = c * r - b;
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[mm] = 0.0;
+      }
+    } while (mm != l);
+  }
+  std::sort(d.begin(), d.begin() + m);
+  out->assign(d.begin(), d.begin() + m);
+  return true;
+}
+
+// Step 1: every eigenvalue of the m x m symmetric T (upper triangle given, row-major ld),
+// DESCENDING into w->theta.
+bool host_partial_values(const double* T, int ld, int m, HostTridiag* w) {
+  w->m = m;
+  w->lda = m | 1;
+  w->a.assign((size_t)m * w->lda, 0.0);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j)  // the mirrored upper triangle is what the chain wrote
+      w->a[(size_t)i * w->lda + j] = i <= j ? T[(size_t)i * ld + j] : T[(size_t)j * ld + i];
+  host_tridiagonalize(w);
+  std::vector<double> asc;
+  if (!host_tridiag_values(w->d, w->e, m, &asc)) return false;
+  w->theta.assign(asc.rbegin(), asc.rend());
+  return true;
+}
+
+// Step 2: eigenvectors of the leading `need` eigenvalues into Y (row-major ldy: column q).
+bool host_partial_vectors(const HostTridiag& w, int need, double* Y, int ldy) {
+  const int m = w.m, lda = w.lda;
+  std::vector<double> z((size_t)m * need);
+  if (!host_tridiag_eigvectors(w.d.data(), w.e.data(), m, w.theta.data(), need, z.data(),
+                               (size_t)m))
+    return false;
+  for (int q = 0; q < need; ++q) {
+    double* x = z.data() + (size_t)q * m;
+    for (int i = m - 2; i >= 0; --i) {  // x <- H_i x, last reflector first
+      const double tau = w.tau[i];
+      if (tau == 0.0) continue;
+      const double* v = w.v.data() + (size_t)i * lda;
+      double dot = 0.0;
+      for (int k = i + 1; k < m; ++k) dot += v[k] * x[k];
+      dot *= tau;
+      for (int k = i + 1; k < m; ++k) x[k] -= dot * v[k];
+    }
+    for (int r = 0; r < m; ++r) Y[(size_t)r * ldy + q] = x[r];
+  }
+  return true;
+}
+
+// host-only export (CPU tests): values (m, descending), vectors (m, need) row-major
+extern "C" int sc_host_symmetric_eig_partial(const double* a, int m, int need, double* values,
+                                             double* vectors) {
+  if (!a || !values || !vectors || m < 1 || need < 1 || need > m) return SC_ERR_INVALID;
+  HostTridiag w;
+  if (!host_partial_values(a, m, m, &w)) return SC_ERR_NOT_CONVERGED;
+  for (int i = 0; i < m; ++i) values[i] = w.theta[i];
+  return host_partial_vectors(w, need, vectors, need) ? SC_OK : SC_ERR_NOT_CONVERGED;
+}
+

@@ -523,8 +523,9 @@ def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
                                  constraint_matrix=None) -> np.ndarray:
   """BASELINE config 4: every rank holds the embeddings (broadcast them first if only
   rank 0 has them), recomputes the affinity locally (cheaper than shipping n^2 doubles),
-  evaluates its share of each AutoTune search level, all-gathers (ratio, n_clusters),
-  and every rank finishes with the winner's eigenvectors + k-means: identical labels
+  evaluates its share of each AutoTune search level, all-gathers (ratio, n_clusters);
+  the rank that evaluated the winner adopts its eigenvectors from the sweep
+  (sc_sweep_adopt), runs k-means and broadcasts the labels (n int32): identical labels
   everywhere, no n x n or n x k matrix ever crosses xGMI.  Constraints are handled as in
   predict() (reference spectral_clusterer.py:259-264, 137-142)."""
   from spectralcluster_amd import _lib
@@ -550,9 +551,11 @@ def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
 
   evaluate.error = None
   evaluate.last_p = clusterer.refinement_options.p_percentile
+  evaluate.last_level = []
 
   def evaluate_many(ps):
     evaluate.last_p = ps[-1]
+    evaluate.last_level = list(ps)
     ratios, ks = autotune_sharded(comm, None, ps, evaluate_share_fn=evaluate)
     if evaluate.error is not None:
       raise evaluate.error
@@ -565,10 +568,33 @@ def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
   # the reference's closure leaves p_percentile at the LAST evaluated value
   # (spectral_clusterer.py:277); keep that observable state, like predict()
   clusterer.refinement_options.p_percentile = evaluate.last_p
-  diag = clusterer._eig_resident(handle, best_p)
   if clusterer.min_clusters is not None:
     n_clusters = max(n_clusters, clusterer.min_clusters)
-  labels = np.empty(n, dtype=np.int64)
-  handle.check(handle.lib.sc_cluster(handle.raw, clusterer.build_config(best_p), n_clusters,
-                                     _lib.as_int64_p(labels), diag))
-  return labels
+
+  def finish():
+    # the winner's eigenvectors (adopted from this rank's sweep when it evaluated the winner)
+    # + k-means
+    diag = clusterer._adopt_or_evaluate(handle, best_p)
+    labels = np.empty(n, dtype=np.int64)
+    handle.check(handle.lib.sc_cluster(handle.raw, clusterer.build_config(best_p), n_clusters,
+                                       _lib.as_int64_p(labels), diag))
+    return labels
+
+  last_level = [float(p) for p in evaluate.last_level]
+  if comm.size == 1 or float(best_p) not in last_level:
+    return finish()  # (a winner from an earlier level: every rank re-evaluates it)
+  # The rank that evaluated the winner still holds its eigenvectors: it alone runs k-means and
+  # broadcasts n int32 labels; the other ranks neither refine nor solve again.
+  owner = last_level.index(float(best_p)) % comm.size
+  payload, error = None, None
+  if comm.rank == owner:
+    try:
+      payload = finish().astype(np.int32).tobytes()
+    except Exception as exc:  # pylint: disable=broad-except
+      error, payload = exc, np.full(n, -2, dtype=np.int32).tobytes()  # the others must not hang
+  labels = np.frombuffer(comm.broadcast_bytes(payload, n * 4, root=owner), dtype=np.int32)
+  if error is not None:
+    raise error
+  if n and labels[0] == -2:
+    raise RuntimeError("the AutoTune winner could not be clustered on rank %d" % owner)
+  return labels.astype(np.int64)

@@ -157,7 +157,22 @@ class SpectralClusterer:
     handle.check(handle.lib.sc_eig_ncluster_sweep(handle.raw, self.build_config(), ps, count,
                                                   diags), TypeError)
     self.last_sweep_diags = list(diags)
+    self._last_sweep_ps = [float(p) for p in p_values]
     return self.last_sweep_diags
+
+  def _adopt_or_evaluate(self, handle: _lib.Handle, p: float) -> _lib.ScDiag:
+    """Make the eigenvectors for p_percentile `p` resident: adopted from the last sweep when
+    `p` was one of its values (the AutoTune winner normally is: the reference keeps the
+    winner's eigenvectors from the search, spectral_clusterer.py:274-292), evaluated with
+    `_eig_resident` otherwise."""
+    ps = getattr(self, "_last_sweep_ps", None)
+    if ps and float(p) in ps:
+      diag = _lib.ScDiag()
+      if handle.lib.sc_sweep_adopt(handle.raw, self.build_config(p), ps.index(float(p)),
+                                   diag) == _lib.SC_OK:
+        self.last_diag = diag
+        return diag
+    return self._eig_resident(handle, p)
 
   def consumed_eigenvalues(self) -> np.ndarray:
     """Every eigenvalue the last eigen call consumed, in the reference's order
@@ -293,7 +308,7 @@ class SpectralClusterer:
       # evaluated value (spectral_clusterer.py:277); keep that observable state
       self.refinement_options.p_percentile = evaluated[-1]
       self.last_best_p = best_p  # (not in the reference: the value the labels come from)
-      diag = self._eig_resident(handle, best_p)  # the winner's vectors, resident
+      diag = self._adopt_or_evaluate(handle, best_p)  # the winner's vectors, resident
     else:
       diag = self._eig_resident(handle)
       n_clusters = int(diag.n_clusters_raw)
@@ -330,7 +345,12 @@ class SpectralClusterer:
       streams     `sc_predict_batch_streams` (when `streams` is given and `group` is not):
                   the batch spread (longest-processing-time first) over `streams` HIP
                   streams, one host thread and arena per stream; streams=1 is a plain loop.
-    Per-utterance results are those of predict() either way.
+    Per-utterance results agree with predict() to the solver's tolerance, not bit for bit:
+    the grouped GEMMs sum K in whole tiles where a short single call splits K, and the
+    lockstep eigensolver checks convergence on the group's schedule, so a member can leave
+    with a different basis size (eigenvalues within 1e-6 relative, labels equal unless an
+    eigengap decision is a near tie).  A batch call is deterministic: the same list gives
+    the same results.
     """
     if group is None:
       group = 16 if streams is None else 0

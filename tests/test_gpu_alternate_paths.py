@@ -6,7 +6,6 @@ they are the repair / large-problem routes of the default ones:
   SC_EIG_DEVICE_RR=1    one-workgroup Jacobi for the Rayleigh-Ritz problem (used above 64
                         basis vectors; the host solves the smaller ones)
   SC_KMEANS_SINGLE=1    single-workgroup k-means (k > 32, other metrics, very large n)
-  SC_EIG_NO_HINT=1      no Rayleigh-Ritz scheduling hint
   SC_MATVEC_SYM_MIN_N=129  upper-triangle block matvec on every Krylov solve, not only for
                         n >= 4096 (edge tiles, restarts, the repair chain all go through it)
 
@@ -83,7 +82,7 @@ print("ALTERNATE_PATH_OK")
 
 
 @pytest.mark.parametrize("switch", ["SC_EIG_HOST_CHAIN", "SC_EIG_DEVICE_RR", "SC_KMEANS_SINGLE",
-                                    "SC_EIG_NO_HINT", "SC_MATVEC_SYM_MIN_N",
+                                    "SC_MATVEC_SYM_MIN_N",
                                     "SC_EIG_FORCE_DENSE"])
 def test_alternate_path(tmp_path, switch):
   script = tmp_path / "alt.py"

@@ -405,3 +405,30 @@ def test_turntodiarize_autotune_vs_oracle():
   emb = vecs[:, :k] / np.linalg.norm(vecs[:, :k], axis=1)[:, None]
   want = so.run_kmeans(emb, k, 300)
   assert so.adjusted_rand_index(got, want) == 1.0
+
+
+def test_results_do_not_depend_on_call_history():
+  """A solve is a function of its input alone: the same utterance gives the same
+  labels, cluster count, max_delta, consumed eigenvalues and basis size whether it is the
+  first call on the handle or follows calls that converge at other basis sizes."""
+  opts = icassp_options()
+  probe = so.blobs(1500, 64, 5, seed=77)
+  others = [so.blobs(700, 64, 2, seed=1), so.hard_inputs("iid", 900, 64, seed=2),
+            so.blobs(3000, 64, 7, seed=3), so.hard_inputs("turns", 1100, 64, seed=4)]
+
+  def run():
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=opts)
+    labels = c.predict(probe)
+    dg = c.last_diag
+    return (labels, dg.n_clusters_raw, dg.max_delta, dg.eigenvalue_array().copy(),
+            dg.eig_basis, dg.eig_matvec_passes)
+
+  first = run()
+  for x in others:  # calls that leave other state behind
+    for _ in range(3):
+      sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=opts).predict(x)
+    again = run()
+    assert np.array_equal(first[0], again[0])
+    assert first[1] == again[1] and first[4:] == again[4:]
+    assert first[2] == again[2]               # bit-equal, not just close
+    assert np.array_equal(first[3], again[3])

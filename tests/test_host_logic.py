@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), name
   assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-  assert lib.sc_abi_version() == 3
+  assert lib.sc_abi_version() == _lib.SC_ABI_VERSION == 4
 
 
 def test_graft_entry_build_runs():
@@ -509,6 +509,28 @@ def test_host_rayleigh_ritz_solver_vs_numpy():
     np.testing.assert_allclose(np.sort(w), np.linalg.eigvalsh(a), rtol=0, atol=1e-13 * scale)
     assert np.abs(a @ v - v * w).max() < 1e-13 * scale * m
     assert np.abs(v.T @ v - np.eye(m)).max() < 1e-13 * m
+
+
+def test_host_partial_symmetric_eig_vs_numpy():
+  """The Rayleigh-Ritz solve of bases above 64 vectors: all eigenvalues, leading vectors."""
+  lib = _lib.load()
+  rng = np.random.default_rng(3)
+  for m, need in ((1, 1), (2, 2), (5, 3), (24, 24), (72, 32), (96, 40), (128, 48), (128, 128)):
+    if m >= 72:  # a dense bulk next to a few separated values, like a hard Ritz problem
+      q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+      lam = np.r_[np.linspace(-1.0, -0.98, m - 3), [-0.5, 0.0, -0.97]]
+      a = (q * lam) @ q.T
+    else:
+      a = rng.standard_normal((m, m))
+    a = np.ascontiguousarray(0.5 * (a + a.T))
+    w = np.empty(m)
+    v = np.empty((m, need))
+    assert lib.sc_host_symmetric_eig_partial(_lib.as_double_p(a), m, need, _lib.as_double_p(w),
+                                             _lib.as_double_p(v)) == 0
+    scale = max(1.0, np.abs(a).max())
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(a)[::-1], rtol=0, atol=1e-13 * scale * m)
+    assert np.abs(a @ v - v * w[:need]).max() < 1e-12 * scale * m
+    assert np.abs(v.T @ v - np.eye(need)).max() < 1e-12 * m
 
 
 def test_host_tridiag_eigvectors_vs_scipy():

@@ -183,8 +183,7 @@ extern "C" int sc_create(int device, sc_handle* out) {
   // stage timers only (never used to synchronise, never to make memory visible): without the
   // system-scope fence a recorded event would otherwise carry -- a cache write-back and
   // invalidate between the stages it separates
-  static const unsigned ev_flags = getenv("SC_EVENT_SYSTEM_FENCE") ? hipEventDefault
-                                                                   : hipEventDisableSystemFence;
+  const unsigned ev_flags = hipEventDisableSystemFence;
   for (int i = 0; i < 48; ++i) {
     if (hipEventCreateWithFlags(&h->ev[i], ev_flags) != hipSuccess) {
       delete h;
@@ -794,7 +793,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   if (front_only)  // the lockstep group solve starts from clean chain flags
     SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
   SC_TRY(check_last(h, "scaling launch"));
-  if (getenv("SC_EIG_TRACE") && atoi(getenv("SC_EIG_TRACE")) > 2 && symmetric) {
+  if (sw::eig_trace() > 2 && symmetric) {
     std::vector<double> rm(n), rs(n);
     hipMemcpyAsync(rm.data(), h->rowmax.p, n * sizeof(double), hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(rs.data(), h->rowsum.p, n * sizeof(double), hipMemcpyDeviceToHost, s);
@@ -959,7 +958,7 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   const KmeansWorkspace ws = kmeans_workspace(h);
   int info[16] = {0};
   if (metric == kKmeansCosine && kmeans_chain_supported(n, k, trials) &&
-      !getenv("SC_KMEANS_SINGLE")) {
+      !sw::kmeans_single()) {
     // chain of short multi-workgroup kernels; cosine iterations four launches at a time
     // (the typical run stops after two or three), `done` comes back with the labels
     for (int it = 0;; it += 4) {
@@ -994,7 +993,7 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
                              hipMemcpyDeviceToHost, h->stream));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   if (iterations) *iterations = info[0];
-  if (getenv("SC_KMEANS_TRACE"))
+  if (sw::kmeans_trace())
     fprintf(stderr, "[sc] kmeans n=%d k=%d iters=%d  us: centre %.1f  kmeans++ %.1f  lloyd %.1f"
             "  cosine-loop %.1f\n", n, k, info[0], info[1] * 0.01, (info[2] - info[1]) * 0.01,
             (info[3] - info[2]) * 0.01, (info[4] - info[3]) * 0.01);

@@ -137,7 +137,7 @@ int enqueue_front(sc_handle lead, const double* const* xs, const int* ns, int d,
 bool grouped_front_covers(const sc_config* cfg) {
   static const int seq[6] = {SC_OP_CROP_DIAGONAL, SC_OP_GAUSSIAN_BLUR, SC_OP_ROW_WISE_THRESHOLD,
                              SC_OP_SYMMETRIZE, SC_OP_DIFFUSE, SC_OP_ROW_WISE_NORMALIZE};
-  if (cfg->n_ops != 6 || getenv("SC_GROUP_FRONT_BY_MEMBER")) return false;
+  if (cfg->n_ops != 6) return false;
   for (int i = 0; i < 6; ++i)
     if (cfg->ops[i] != seq[i]) return false;
   return (cfg->blur_radius == 4 || cfg->blur_radius == 8) &&
@@ -254,7 +254,7 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
 int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* const* labels,
                  sc_diag* diags, Member* mb, int count, const EigRequest& rq, int front_bank) {
   hipStream_t s = lead->stream;
-  const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
+  const bool trace = sw::group_trace();
   if (front_bank >= 0) {
     SC_HIP(lead, hipStreamWaitEvent(s, lead->gbank_ev[front_bank], 0));
   } else {
@@ -313,7 +313,7 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
     std::vector<double> unused;
     if (k >= 1 && k <= 32) kmeans_seed_constants(k, &u, &trials, &unused);
     if (k < 1 || k > 32 || k > h->n_vec || n < k || cfg->max_iter <= 0 ||
-        !kmeans_chain_supported(n, k, trials) || getenv("SC_KMEANS_SINGLE")) {
+        !kmeans_chain_supported(n, k, trials) || sw::kmeans_single()) {
       m.state = 1;  // the single-call path states the error or takes the other kernel
       continue;
     }
@@ -446,11 +446,9 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     // Banks of member arenas: while the eigensolver and k-means chains of group g run (short
     // launches, host synchronisations, Rayleigh-Ritz on the host), the GEMMs and refinement
     // passes of group g + 1 keep the chip busy on the other bank's stream.  (Two banks; a
-    // third one, SC_GROUP_BANKS=3, puts two more GEMMs next to the chains and costs 9 % on
-    // config 5: the chains' short kernels wait longer for a free CU.)
-    static const int banks = getenv("SC_GROUP_BANKS")
-                                 ? std::max(2, std::min(kGroupBanks, atoi(getenv("SC_GROUP_BANKS"))))
-                                 : 2;
+    // third one put two more GEMMs next to the chains and cost 9 % on config 5: the chains'
+    // short kernels wait longer for a free CU.)
+    constexpr int banks = kGroupBanks;
     const int nslots = std::min(banks * width, (int)grouped.size());
     for (int z = 0; z < nslots; ++z) {  // arenas once, for the largest member each will see
       sc_handle hz = nullptr;
@@ -464,20 +462,15 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     auto group_count = [&](int g) {
       return (int)std::min<size_t>(width, grouped.size() - (size_t)g * width);
     };
-    const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
+    const bool trace = sw::group_trace();
     const bool covers = grouped_front_covers(cfg);
     if (covers) {
       for (int b = 0; b < banks; ++b)
         if (!h->gbank_stream[b]) {
           // (same priority as the chains' stream: a lower one for the banks, so that the short
-          //  kernels of the other group's chains go first, cost 8 % -- the GEMMs are the
-          //  throughput; SC_GROUP_BANK_PRIORITY=-1 / 1 to try)
-          int least = 0, greatest = 0;
-          SC_HIP(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
-          int prio = 0;
-          if (const char* e = getenv("SC_GROUP_BANK_PRIORITY"))
-            prio = atoi(e) > 0 ? greatest : (atoi(e) < 0 ? least : 0);
-          SC_HIP(h, hipStreamCreateWithPriority(&h->gbank_stream[b], hipStreamNonBlocking, prio));
+          //  kernels of the other group's chains go first, cost 8 %, a higher one 11 % -- the
+          //  GEMMs are the throughput)
+          SC_HIP(h, hipStreamCreateWithPriority(&h->gbank_stream[b], hipStreamNonBlocking, 0));
           SC_HIP(h, hipEventCreateWithFlags(&h->gbank_ev[b], hipEventDisableTiming));
         }
       SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
@@ -538,7 +531,7 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
   const bool grouped = count > 1 && grouped_front_covers(cfg) && h->affinity_symmetric &&
                        !constraint_active(h, cfg, false) &&
                        blur_group_supported(n, cfg->blur_radius) &&
-                       sym_group_eligible(n, rq, true) && !getenv("SC_SWEEP_ONE_BY_ONE");
+                       sym_group_eligible(n, rq, true) && !sw::sweep_one_by_one();
   if (!grouped) {
     for (int i = 0; i < count; ++i) SC_TRY(one_by_one(i));
     return SC_OK;

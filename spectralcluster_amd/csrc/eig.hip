@@ -1269,9 +1269,7 @@ static int lz_rows_for(int m) {
   // (128-row workgroups by default: twice the workgroups of the 256-row form, half the LDS
   //  fill and half the serial length of the epilogue sums per link -- eigen stage 0.536 ->
   //  0.492 ms at n = 8192; 64 rows: 0.499)
-  static const int cap = getenv("SC_LZ_ROWS_CAP") ? atoi(getenv("SC_LZ_ROWS_CAP")) : 128;
-  if (cap <= 64) return 64;
-  if (cap <= 128 && (size_t)128 * (m + 1) * sizeof(double) <= 112 * 1024) return 128;
+  if ((size_t)128 * (m + 1) * sizeof(double) <= 112 * 1024) return 128;
   if ((size_t)256 * (m + 1) * sizeof(double) <= 96 * 1024) return 256;
   if ((size_t)128 * (m + 1) * sizeof(double) <= 112 * 1024) return 128;
   return 64;
@@ -1384,8 +1382,7 @@ void launch_lz_link_group(hipStream_t s, LzGroupMember* mem, int count, int m, i
                           bool zero_T) {
   GroupOf<LzStep> g;
   memset(&g, 0, sizeof(g));
-  static const int rows_cap = getenv("SC_GROUP_LZ_ROWS") ? atoi(getenv("SC_GROUP_LZ_ROWS")) : 256;
-  const int rows = std::min(lz_rows_for(m), rows_cap);
+  const int rows = lz_rows_for(m);
   int nwg = 0;
   for (int z = 0; z < count; ++z) {
     if (!mem[z].active) continue;  // n stays 0: every workgroup of the member returns

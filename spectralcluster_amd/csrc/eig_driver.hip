@@ -264,7 +264,7 @@ static int read_flags(sc_handle h, int* mask) {
   SC_HIP(h, hipStreamSynchronize(h->stream));
   *mask = h->h_flags[0];
   if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
-  if (h->h_flags[1] > 0 && getenv("SC_EIG_TRACE")) {
+  if (h->h_flags[1] > 0 && sw::eig_trace()) {
     fprintf(stderr, "[sc] jacobi sweeps=%d  %.1f us  %.0f MHz shader clock\n", h->h_flags[1],
             h->h_flags[2] * 0.01, h->h_flags[3] * 1024.0 / (h->h_flags[2] * 0.01));
     fprintf(stderr, "[sc]   thread-0 kcycles: param %d  barrier1 %d  update %d  barrier2 %d\n",
@@ -406,13 +406,12 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
   int m = 0, passes = 0, cycles = 0;
   EigRequest rq = rq_in;
   // (eig_skip_fused: the lockstep group solve saw this problem latch the fused chain)
-  bool fused = getenv("SC_EIG_HOST_CHAIN") == nullptr && !h->eig_skip_fused;
+  bool fused = !sw::eig_host_chain() && !h->eig_skip_fused;
   h->eig_skip_fused = false;
   bool three_pass = false;  // second attempt of the fused chain, see LzChain::three_pass
   // upper-triangle matvec once the matrix no longer fits the caches (below that the full
   // read is served on-die and the second launch costs more than it saves)
-  static const int sym_min_n = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N"))
-                                                            : 4096;
+  const int sym_min_n = sw::matvec_sym_min_n();
   const bool sym_mv = n >= sym_min_n;
   // Dense full-spectrum route (n > 128): all eigenvalues from the tridiagonal form, the
   // eigengap decision from those, then the same Lanczos loop below for just the vectors.
@@ -442,7 +441,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     if (scratch == nullptr || scratch == S)
       return fail(h, SC_ERR_NOT_CONVERGED,
                   "block Lanczos did not converge and no scratch matrix is free for the dense path");
-    if (getenv("SC_EIG_TRACE"))
+    if (sw::eig_trace())
       fprintf(stderr, "[sc] block Lanczos gave up (reason %d, %d passes): dense path\n", reason,
               passes);
     if (!dense) SC_TRY(run_dense());
@@ -509,7 +508,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       SC_HIP(h, hipMemsetAsync(h->T.p, 0, (size_t)kLdq * kLdq * sizeof(double), s));
     }
     // test switch: take the landing pad straight away (tests/test_gpu_alternate_paths.py)
-    if (!done && getenv("SC_EIG_FORCE_DENSE")) {
+    if (!done && sw::eig_force_dense()) {
       SC_TRY(dense_fallback(4));
       done = true;
     }
@@ -551,7 +550,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
                                                                m % (2 * kEigBlock) == 0 ||
                                                                m + kEigBlock > cap))
                                      : (m + kEigBlock > cap);
-      const bool host_rr = check && m <= kHostRRSingle && !getenv("SC_EIG_DEVICE_RR");
+      const bool host_rr = check && m <= kHostRRSingle && !sw::eig_device_rr();
       if (host_rr) {
         // small projected problem: T and G come back with the flags; solved on the host
         SC_HIP(h, hipMemcpy2DAsync(h->h_rr, (size_t)m * sizeof(double), h->T.p,
@@ -587,13 +586,13 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
           if (!three_pass && h->h_flags[15] == 2000) {
             // only "Gram far from I after the first pass" (an ill-conditioned block, no
             // dependent column): once more with the three-pass chain
-            if (getenv("SC_EIG_TRACE"))
+            if (sw::eig_trace())
               fprintf(stderr, "[sc] fused chain flagged at m=%d: three-pass chain\n",
                       h->h_flags[14]);
             three_pass = true;
             goto restart_lanczos;
           }
-          if (getenv("SC_EIG_TRACE")) fprintf(stderr, "[sc] fused chain flagged: host chain\n");
+          if (sw::eig_trace()) fprintf(stderr, "[sc] fused chain flagged: host chain\n");
           fused = false;
           goto restart_lanczos;
         }
@@ -630,7 +629,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       }
       if (check) {
         dc = analyze(rq, h->h_theta, h->h_theta + kLdq, m, n, false);
-        if (getenv("SC_EIG_TRACE")) {
+        if (sw::eig_trace()) {
           int worst = 0;
           double wr = 0.0;
           for (int i = 0; i < std::min(m, dc.kw > 0 ? dc.kw : m); ++i) {
@@ -736,10 +735,9 @@ static double now_us() {
 }
 
 bool sym_group_eligible(int n, const EigRequest& rq, bool any_size) {
-  static const int sym_min_n = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N"))
-                                                            : 4096;
+  const int sym_min_n = sw::matvec_sym_min_n();
   return n > kDenseMax && (any_size || n < sym_min_n) && !wants_full_spectrum(rq) &&
-         getenv("SC_EIG_HOST_CHAIN") == nullptr && getenv("SC_EIG_DEVICE_RR") == nullptr;
+         !sw::eig_host_chain() && !sw::eig_device_rr();
 }
 
 // pinned host + device staging of the group checks: per member m*m (T) + 64 (G) doubles +
@@ -783,9 +781,7 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
   // upper-triangle matvec once the group's matrices no longer fit the caches together
   size_t matrix_bytes = 0;
   for (int z = 0; z < count; ++z) matrix_bytes += (size_t)mem[z].n * mem[z].ld * sizeof(double);
-  static const size_t sym_min_bytes = getenv("SC_GROUP_MATVEC_SYM_MIN_MB")
-                                          ? (size_t)atol(getenv("SC_GROUP_MATVEC_SYM_MIN_MB")) << 20
-                                          : (size_t)128 << 20;
+  const size_t sym_min_bytes = (size_t)128 << 20;
   const bool sym_matvec = matrix_bytes >= sym_min_bytes;
   const uint64_t seed = 0x5eed5eedull;
   launch_lz_link_group(s, lz, count, 0, 0, 4, -1, 0, true, seed, false);
@@ -798,7 +794,7 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
   if (lead->gconv_seen >= 2 * kGroupMax && lead->gconv_hist[3] * 20 < lead->gconv_seen)
     first_check = 4 * kEigBlock;
   int active = count;
-  const bool trace = getenv("SC_GROUP_TRACE") != nullptr;
+  const bool trace = sw::group_trace();
   double us_first_sync = 0.0, us_sync = 0.0, us_host = 0.0;
   int steps = 0, wasted = 0;
   // one block step of every active member: matvec + the five links of the three-pass chain
@@ -866,8 +862,10 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
     const int seen = lead->gconv_seen;
     int done_by = 0;
     for (int b = 0; b <= m / kEigBlock && b < 16; ++b) done_by += lead->gconv_hist[b];
-    static const bool never = getenv("SC_GROUP_NO_SPECULATE") != nullptr;
-    const bool speculate = !never && (seen < 2 * kGroupMax || done_by * 4 < seen * 3);
+    // (never speculating costs 3 % on config 5; speculating while most members are already
+    //  done wastes a matvec pass over their matrices: stop once half of the members seen so
+    //  far in this batch had converged by this basis size)
+    const bool speculate = seen < 2 * kGroupMax || done_by * 2 < seen;
     if (speculate) SC_TRY(block_step(m));
     const double t_sync0 = trace ? now_us() : 0.0;
     SC_HIP(lead, hipEventSynchronize(lead->gcheck_ev));
@@ -1119,12 +1117,12 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
                                    hipMemcpyDeviceToHost, s));
         SC_TRY(fetch_ritz(m));
         dc = analyze(rq, th, th + kLdq, m, n, false);
-        if (getenv("SC_EIG_TRACE"))
+        if (sw::eig_trace())
           fprintf(stderr, "[sc] arnoldi pass %d m=%d cycle %d sweeps %d: enough=%d conv=%d kw=%d "
                   "kvec=%d fail kind %d at %d (resid %.2e)\n", passes, m, cycles, h->h_flags[9],
                   dc.enough, dc.converged, dc.kw, dc.kvec, dc.fail_kind, dc.fail_index,
                   dc.fail_index >= 0 ? th[kLdq + dc.fail_index] : 0.0);
-        if (getenv("SC_EIG_TRACE") && atoi(getenv("SC_EIG_TRACE")) > 1) {
+        if (sw::eig_trace() > 1) {
           for (int i = 0; i < std::min(m, 12); ++i)
             fprintf(stderr, "[sc]    ritz %2d  re %.12g  im %.3e  resid %.3e\n", i, th[i], thi[i],
                     th[kLdq + i]);

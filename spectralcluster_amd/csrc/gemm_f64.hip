@@ -35,8 +35,6 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 16;
-constexpr int kSyncWin = 8;        // K-tiles per throttle window
-constexpr int kSyncWindows = 1024;  // windows per group the counter array holds (K <= 131072)
 
 // 16-byte chunk kc (k = 2kc, 2kc+1) of row `row` sits at chunk position kc ^ ((row >> 1) & 7)
 // of the row's 128 bytes: the 16 lanes of a ds_read_b128 group (rows li = 0..15, one kc)
@@ -248,6 +246,11 @@ struct GemmGroup {
   int first[kGroupMax + 1];
 };
 
+// prologue / epilogue at the top issue priority (bit 0) and non-temporal C stores (bit 1):
+// 7.85 -> 7.78-7.83 ms on the Diffuse product (profiles/r02); a kernel argument so that both
+// bits stay plain runtime tests in the instruction stream that was measured
+constexpr int kEdgePrio = 3;
+
 template <int EPI, bool SYM, bool GROUPED>
 __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
                                                  int lda,
@@ -260,7 +263,6 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
                                                  double* __restrict__ probe_out,
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats,
-                                                 int* __restrict__ ksync,
                                                  int* __restrict__ queue, int edge_prio,
                                                  int nunits, int persist,
                                                  const GemmGroup* __restrict__ grp) {
@@ -282,34 +284,24 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   // tiles are taken by whoever finishes first.
   for (int iter = 0;; ++iter) {
   if (iter > 0) {
-    if constexpr (GROUPED) {
-      // grouped form, optional: a workgroup walks the tile list with the grid as its stride
-      if (!persist || (int)blockIdx.x + iter * (int)gridDim.x >= 8 * xcd_chunk) break;
-    } else {
-      if (!persist || queue == nullptr) break;
-    }
+    if (GROUPED || !persist || queue == nullptr) break;
     __syncthreads();  // the previous item's epilogue is done with the LDS
   }
   if (edge_prio & 1) __builtin_amdgcn_s_setprio(3);
   int ti, tj;
-  // Work item of this workgroup.  Static (queue == nullptr): by block index.  Dynamic: the grid
-  // still has exactly one workgroup per item, but each workgroup DRAWS its item when it
-  // starts -- whole tiles from its XCD's run of the tile list, in order, and the split-K
-  // units of the leftover tiles from one global counter -- with one twist: the workgroups
-  // that start as the SECOND resident of their CU (LDS allocation not at 0: the first
-  // generation's other half) take a split-K unit first.  That shifts the two workgroups of
-  // every CU by a fraction of a tile for the rest of the launch, so that the ~86 us between
-  // one tile's K loop and the next one's (epilogue at low issue priority, teardown, dispatch,
-  // prologue) overlaps the partner's K loop instead of the partner's own gap (measured with
-  // SC_GEMM_CLOCK_DUMP: both gaps coincided at every generation boundary, ~4 % of the launch
-  // with the MFMA pipe idle).  Which workgroup computes which item does not change any result.
+  // Work item of this workgroup.  Static (queue == nullptr): by block index.  Persistent
+  // (queue): one workgroup per resident slot, each DRAWS its items -- whole tiles from its
+  // XCD's run of the tile list, in order, then the split-K units of the leftover tiles from
+  // one global counter, then other XCDs' tiles.  Which workgroup computes which item does
+  // not change any result.  (Round 2 also tried shifting the two workgroups of a CU against
+  // each other by a split unit, and a K-window throttle that kept an XCD's tiles in one L2
+  // window: both measured slower; the code is gone.)
   int item_blk = (int)blockIdx.x;
   if constexpr (GROUPED) {
     // XCD-aware order (workgroup ids go round-robin over the 8 XCDs, each with its own L2):
     // XCD x walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the concatenated,
     // patch-ordered tile lists, so the ~64 tiles it has in flight come from one 8 x 8 patch of
     // one member and share 8 + 8 operand panels (by block index they would share 1 + 8)
-    item_blk += iter * (int)gridDim.x;
     item_blk = (item_blk & 7) * xcd_chunk + (item_blk >> 3);
     if (item_blk >= grp->first[kGroupMax]) continue;  // (the runs' ragged end)
     int z = 0;
@@ -331,7 +323,6 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
     int* s_item = reinterpret_cast<int*>(smem);  // (one LDS object per kernel: no second array)
     if (threadIdx.x == 0) {
       const int x = (int)blockIdx.x & 7;
-      const bool second = (__builtin_amdgcn_s_getreg(6 | (31 << 11)) & 0xfff) != 0;
       auto draw = [&](int* counter, int limit) -> int {
         if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= limit)
           return -1;
@@ -340,17 +331,12 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
         return v < limit ? v : -1;
       };
       int got = -1;
-      // (a) the stagger: second residents of the first generation start with a split unit
-      if (second && nunits > 0 && draw(&queue[8], min(nunits, queue[10])) >= 0) {
-        const int u = draw(&queue[9], nunits);
-        if (u >= 0) got = full_tiles + u;
-      }
-      // (b) the next tile of this XCD's run (block id = what the static map gives it)
-      if (got < 0) {
+      // (a) the next tile of this XCD's run (block id = what the static map gives it)
+      {
         const int k = draw(&queue[x], xcd_chunk);
         if (k >= 0) got = x + 8 * k;
       }
-      // (c) a split unit, (d) a tile of another XCD's run
+      // (b) a split unit, (c) a tile of another XCD's run
       if (got < 0) {
         const int u = draw(&queue[9], nunits);
         if (u >= 0) got = full_tiles + u;
@@ -375,21 +361,6 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own
   // L2), so XCD x walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the
   // patch-ordered tile list: the ~64 tiles it has in flight share 8 + 8 operand panels.
-  // K-window throttle (optional, ksync != nullptr): the <= 64 tiles an XCD has in flight
-  // come from one 8 x 8 patch and share 16 operand panels; they reuse each other's panel
-  // lines in the XCD's 4 MB L2 only while they are at about the same K.  Each workgroup
-  // counts the K windows (kSyncWin K-tiles) it has finished in cnt[group][window] and does not
-  // start window w before every member of its group has finished window w - 2, which bounds
-  // the K spread of a group to two windows = 2 x 16 x 128 rows x kSyncWin x 16 x 8 B.
-  int* sync_cnt = nullptr;
-  int sync_size = 0;
-  if (whole && xcd_chunk > 0 && ksync != nullptr) {
-    const int slot = tile >> 3;                 // index inside this XCD's run
-    const int grp = slot >> 6;                  // generation of 64 co-dispatched tiles
-    const int ngrp = (xcd_chunk + 63) >> 6;
-    sync_size = min(64, xcd_chunk - (grp << 6));
-    sync_cnt = ksync + ((size_t)(tile & 7) * ngrp + grp) * kSyncWindows;
-  }
   if (!GROUPED && whole && xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
   if (!whole) stats.mode = 0;  // k_gemm_tail_stats covers the split tiles
   if (tilemap != nullptr) {
@@ -541,26 +512,9 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   if (kt_begin < kt_end) load_frags(fa0, fb0, As[first_buf], Bs[first_buf], 0);
   // one K-tile; the LDS buffer index is a compile-time constant (the loop below is unrolled by
   // two), so every LDS address is a precomputed register + an immediate offset
-  int sync_seen = 0;  // count of cnt[w - 1] as loaded one window ago
   auto k_tile = [&](int kt, auto cur_c, auto prio_c) {
     constexpr int cur = decltype(cur_c)::value;
     constexpr int prio = decltype(prio_c)::value;
-    if (sync_cnt != nullptr && (kt & (kSyncWin - 1)) == 0 && kt > kt_begin) {
-      const int w = (kt - kt_begin) / kSyncWin;  // window about to start; w - 1 just finished
-      if (tid == 0) {
-        __hip_atomic_fetch_add(sync_cnt + (w - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w >= 2) {
-          // sync_seen holds cnt[w - 2] as it was one window ago: normally already complete
-          int seen = sync_seen;
-          while (seen < sync_size) {
-            __builtin_amdgcn_s_sleep(8);
-            seen = __hip_atomic_load(sync_cnt + (w - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        sync_seen = __hip_atomic_load(sync_cnt + (w - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      // (the other waves meet wave 0 at this K-tile's barrier)
-    }
     load_frags(fa1, fb1, As[cur], Bs[cur], 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(prio);
@@ -708,21 +662,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  double* __restrict__ probe_out,
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats,
-                                                 int* __restrict__ ksync,
                                                  int* __restrict__ queue, int edge_prio,
                                                  int nunits, int persist) {
   gemm_nt_body<EPI, SYM, false>(A, lda, B, ldb, C, ldc, M, N, K, ntiles_m, ntiles_n, full_tiles,
-                                ksplit_tail, partial, probe_out, tilemap, xcd_chunk, stats, ksync,
+                                ksplit_tail, partial, probe_out, tilemap, xcd_chunk, stats,
                                 queue, edge_prio, nunits, persist, nullptr);
 }
 // every workgroup: one whole tile of one member (no queue, no split, no probe)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_g(const GemmGroup grp, int stats_mode,
-                                                     int edge_prio, int xcd_chunk, int persist) {
+                                                     int edge_prio, int xcd_chunk) {
   GemmStats stats{nullptr, nullptr, stats_mode, nullptr};
   gemm_nt_body<EPI, true, true>(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0, 0x7fffffff, 1,
-                                nullptr, nullptr, nullptr, xcd_chunk, stats, nullptr, nullptr,
-                                edge_prio, 0, persist, &grp);
+                                nullptr, nullptr, nullptr, xcd_chunk, stats, nullptr,
+                                edge_prio, 0, 0, &grp);
 }
 
 // rowmax / rowsum of every member from its per-tile partials (k_gemm_stats_reduce, grouped)
@@ -850,9 +803,7 @@ __global__ __launch_bounds__(256) void k_gemm_tail_stats(const double* __restric
   }
 }
 
-__global__ void k_gemm_queue_init(int* queue, int front) {
-  queue[threadIdx.x] = threadIdx.x == 10 ? front : 0;
-}
+__global__ void k_gemm_queue_init(int* queue) { queue[threadIdx.x] = 0; }
 
 // co-resident k_gemm_nt workgroups on the current device (occupancy x CUs)
 int gemm_resident_slots() {
@@ -899,10 +850,7 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
   if (rem > 0) {
     if (splitk_ws != nullptr) {
       ksplit = g_slots / rem;
-      if (const char* e = getenv("SC_GEMM_TAIL_SPLIT")) ksplit = std::max(2, atoi(e));
-      static const int min_chunk = getenv("SC_GEMM_SPLIT_MIN_KTILES")
-                                       ? std::max(1, atoi(getenv("SC_GEMM_SPLIT_MIN_KTILES"))) : 8;
-      ksplit = std::min(ksplit, std::max(1, ktiles / min_chunk));  // >= 8 k-tiles per chunk
+      ksplit = std::min(ksplit, std::max(1, ktiles / 8));  // >= 8 k-tiles per chunk
       // a short product that does not fill the chip anyway (an utterance of a few thousand
       // rows against d = 256 features): the K loop of a whole tile is a third of the tile's
       // epilogue, splitting it only adds the partial stores and two more launches
@@ -916,65 +864,41 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
   }
   {
     const int xcd_chunk = (tilemap != nullptr && full % 8 == 0 && full >= 512) ? full / 8 : 0;
-    // SC_GEMM_CLOCK=1: every launch also records, per whole tile, the shader-clock cycles
-    // (s_memtime) and the constant-rate wall ticks (s_memrealtime) between kernel entry and
-    // the end of the K loop, synchronises and prints the effective shader clock -- the GEMM
-    // is power-managed, see DESIGN.md section 3.3.  SC_GEMM_CLOCK_DUMP=<file> also writes
-    // "workgroup cycles ticks start_tick" per tile (tools/gemm_tile_timeline.py reads it).
-    // Off: one pointer compare per workgroup.
+    // SC_GEMM_CLOCK=1 (diagnostic): every launch also records, per whole tile, the
+    // shader-clock cycles (s_memtime) and the constant-rate wall ticks (s_memrealtime)
+    // between kernel entry and the end of the K loop, synchronises and prints the effective
+    // shader clock -- the GEMM is power-managed, see DESIGN.md section 3.3.  Any other value is
+    // a file that also receives "workgroup cycles ticks start_tick ..." per tile
+    // (tools/gemm_tile_timeline.py reads it).  Off: one pointer compare per workgroup.
     static double* dbg = nullptr;
-    static const bool want_probe = getenv("SC_GEMM_CLOCK") != nullptr;
-    if (want_probe && dbg == nullptr) (void)hipMalloc(&dbg, sizeof(double) * 7 * 8192);
+    static const char* probe_env = getenv("SC_GEMM_CLOCK");
+    if (probe_env != nullptr && dbg == nullptr) (void)hipMalloc(&dbg, sizeof(double) * 7 * 8192);
     double* probe = (full > 0 && full <= 8192) ? dbg : nullptr;
-    // SC_GEMM_KSYNC=1: K-window throttle (see k_gemm_nt); counters zeroed per launch
-    static const bool want_ksync = getenv("SC_GEMM_KSYNC") != nullptr;
-    static int* ksync_buf[16] = {nullptr};
-    int* ksync = nullptr;
-    if (want_ksync && xcd_chunk > 0 && ktiles / kSyncWin < kSyncWindows) {
-      int dev = 0;
-      hipGetDevice(&dev);
-      dev &= 15;
-      const int ngrp = (xcd_chunk + 63) / 64;
-      const size_t bytes = sizeof(int) * 8 * (size_t)ngrp * kSyncWindows;
-      static size_t ksync_bytes[16] = {0};
-      if (ksync_bytes[dev] < bytes) {
-        if (ksync_buf[dev]) (void)hipFree(ksync_buf[dev]);
-        (void)hipMalloc(&ksync_buf[dev], bytes);
-        ksync_bytes[dev] = bytes;
-      }
-      ksync = ksync_buf[dev];
-      (void)hipMemsetAsync(ksync, 0, bytes, s);
-    }
-    // dynamic work draw with staggered CU partners (see k_gemm_nt), SC_GEMM_DYNAMIC=1: an
-    // experiment that did not pay (profiles/r02_i); the block-index map is the default.  queue: [0..7] next tile per XCD, [8] stagger claims, [9] next
-    // split unit, [10] units reserved for the stagger (one per CU)
-    // SC_GEMM_PERSIST=0: one workgroup per item by block index (round 1's form)
-    static const int want_persist = getenv("SC_GEMM_PERSIST") ? atoi(getenv("SC_GEMM_PERSIST")) : 1;
-    // (persistent only for long K: with K = 256 a tile is 16 K-tiles and the draw costs more
-    //  than the dispatch it saves -- affinity GEMM 0.395 -> 0.417 ms)
-    const bool want_static = getenv("SC_GEMM_DYNAMIC") == nullptr && !(want_persist && K >= 1024);
+    // Long K (the Diffuse product): persistent workgroups drawing items from a queue ([0..7]
+    // next tile per XCD, [9] next split unit) -- no teardown / dispatch between tiles.  With
+    // K = 256 a tile is 16 K-tiles and the draw costs more than the dispatch it saves
+    // (affinity GEMM 0.395 -> 0.417 ms): one workgroup per item by block index there.
     static int* queue_buf[16] = {nullptr};
     int* queue = nullptr;
-    if (!want_static && xcd_chunk > 0 && rem > 0 && SYM) {
+    if (K >= 1024 && xcd_chunk > 0 && rem > 0 && SYM) {
       int dev = 0;
       hipGetDevice(&dev);
       dev &= 15;
       if (queue_buf[dev] == nullptr) (void)hipMalloc(&queue_buf[dev], 16 * sizeof(int));
       queue = queue_buf[dev];
-      hipLaunchKernelGGL(k_gemm_queue_init, dim3(1), dim3(16), 0, s, queue,
-                         (want_persist && K >= 1024) ? 0 : g_slots / 2);
+      hipLaunchKernelGGL(k_gemm_queue_init, dim3(1), dim3(16), 0, s, queue);
     }
-    const int persist = (queue != nullptr && want_persist && K >= 1024) ? 1 : 0;
+    const int persist = queue != nullptr ? 1 : 0;
     const int grid = persist ? std::min(g_slots, full + rem * ksplit) : full + rem * ksplit;
-    static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 3;
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(grid), dim3(256), 0, s, A, lda,
                        B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, probe, tilemap,
-                       xcd_chunk, stats, ksync, queue, edge_prio, rem * ksplit, persist);
+                       xcd_chunk, stats, queue, kEdgePrio, rem * ksplit, persist);
     if (probe != nullptr) {
       (void)hipStreamSynchronize(s);
       std::vector<double> h(7 * full);
       (void)hipMemcpy(h.data(), dbg, sizeof(double) * 7 * full, hipMemcpyDeviceToHost);
-      if (const char* path = getenv("SC_GEMM_CLOCK_DUMP")) {
+      if (strcmp(probe_env, "1") != 0) {
+        const char* path = probe_env;
         // workgroup, cycles, ticks entry..K-loop end, start tick, prologue ticks, then ticks
         // since the end of the K loop: after the row statistics, stores issued, stores drained
         if (FILE* f = fopen(path, "w")) {
@@ -1070,19 +994,16 @@ void launch_gemm_nt_group(hipStream_t s, const GemmGroupItem* items, int count, 
   }
   grp.first[kGroupMax] = total;
   if (total == 0) return;
-  static const int edge_prio = getenv("SC_GEMM_EDGE_PRIO") ? atoi(getenv("SC_GEMM_EDGE_PRIO")) : 3;
-  // (SC_GEMM_GROUP_PERSIST=1: one workgroup per resident slot walking the tile list with the
-  //  grid as its stride -- measured 2 % slower on config 5 than one workgroup per tile: no
-  //  balancing between slots, and the loop-carried state costs a few spilled registers)
-  static const int persist = getenv("SC_GEMM_GROUP_PERSIST") ? atoi(getenv("SC_GEMM_GROUP_PERSIST")) : 0;
+  // one workgroup per tile (a persistent stride loop over the tile list measured 2 % slower on
+  // config 5: no balancing between slots, spilled loop-carried state; not kept)
   const int xcd_chunk = (total + 7) / 8;
-  const int grid = persist ? std::min(8 * xcd_chunk, gemm_resident_slots()) : 8 * xcd_chunk;
+  const int grid = 8 * xcd_chunk;
   if (epilogue == kEpiAffinity)
     hipLaunchKernelGGL((k_gemm_nt_g<kEpiAffinity>), dim3(grid), dim3(256), 0, s, grp, stats_mode,
-                       edge_prio, xcd_chunk, persist);
+                       kEdgePrio, xcd_chunk);
   else
     hipLaunchKernelGGL((k_gemm_nt_g<kEpiNone>), dim3(grid), dim3(256), 0, s, grp, stats_mode,
-                       edge_prio, xcd_chunk, persist);
+                       kEdgePrio, xcd_chunk);
   if (stats_mode != 0)
     hipLaunchKernelGGL(k_gemm_stats_reduce_g, dim3((nmax + kStatRows - 1) / kStatRows, count),
                        dim3(256),

@@ -26,7 +26,7 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
-constexpr int kGroupBanks = 3;  // banks of member arenas of the grouped batch (groups in flight)
+constexpr int kGroupBanks = 2;  // banks of member arenas of the grouped batch (groups in flight)
 
 // event slots of the stage timers of the current call (resolved once the stream has drained)
 struct StageEvents {

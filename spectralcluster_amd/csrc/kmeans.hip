@@ -852,8 +852,7 @@ void launch_to_colmajor(hipStream_t s, const double* src, int n, int k, double* 
 void launch_kmeans(hipStream_t s, const double* ET, int lde, int n, int k,
                    int max_iter, int first_center, int trials,
                    const KmeansWorkspace& ws, int metric) {
-  if (metric == kKmeansCosine && k <= 8 && n <= 16 * 512 && trials <= 8 &&
-      !getenv("SC_KMEANS_GENERIC")) {
+  if (metric == kKmeansCosine && k <= 8 && n <= 16 * 512 && trials <= 8) {
     // register-resident fast path: 512 threads (256 VGPRs each), contiguous rows per thread
     if (n <= 8 * 512)
       hipLaunchKernelGGL((k_kmeans_fast<8, 512>), dim3(1), dim3(512), 0, s, ET, lde, n, k,

@@ -3,6 +3,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include "switches.h"
 #include <stdint.h>
 
 #include <mutex>

@@ -1,0 +1,70 @@
+// Every environment switch the library reads, in one place.  None of them is a tuning knob:
+//   trace switches   print the solvers' bookkeeping to stderr;
+//   path switches    force a route the default configuration takes only for some inputs
+//                    (repair / large-problem routes), so that tests can hold those routes to
+//                    the same goldens: tests/test_gpu_alternate_paths.py runs every one.
+// Each is read once per process.  (Round 2's experiment switches -- K-window throttle,
+// staggered CU partners, bank priorities, a third bank, row caps -- are gone with the code
+// they guarded; their measurements are in DESIGN.md and profiles/r02_*.)
+#ifndef SPECTRALCLUSTER_AMD_SWITCHES_H_
+#define SPECTRALCLUSTER_AMD_SWITCHES_H_
+
+#include <cstdlib>
+
+namespace sc {
+namespace sw {
+
+// SC_EIG_TRACE=1|2|3: block Lanczos / Arnoldi log (2: Ritz values, 3: scaling vectors)
+inline int eig_trace() {
+  static const int v = getenv("SC_EIG_TRACE") ? std::max(1, atoi(getenv("SC_EIG_TRACE"))) : 0;
+  return v;
+}
+// SC_KMEANS_TRACE=1: seeds / iterations of the k-means stage
+inline bool kmeans_trace() {
+  static const bool v = getenv("SC_KMEANS_TRACE") != nullptr;
+  return v;
+}
+// SC_GROUP_TRACE=1: per-group timeline of the grouped batch
+inline bool group_trace() {
+  static const bool v = getenv("SC_GROUP_TRACE") != nullptr;
+  return v;
+}
+// SC_EIG_HOST_CHAIN=1: host-driven orthonormalisation chain (what the fused chain falls back
+// to when a Krylov block is rank deficient)
+inline bool eig_host_chain() {
+  static const bool v = getenv("SC_EIG_HOST_CHAIN") != nullptr;
+  return v;
+}
+// SC_EIG_DEVICE_RR=1: one-workgroup Jacobi for the Rayleigh-Ritz problems (the host solves them
+// by default)
+inline bool eig_device_rr() {
+  static const bool v = getenv("SC_EIG_DEVICE_RR") != nullptr;
+  return v;
+}
+// SC_EIG_FORCE_DENSE=1: straight to the dense landing pad (tridiagonalisation + bisection +
+// inverse iteration) that otherwise takes over when block Lanczos gives up
+inline bool eig_force_dense() {
+  static const bool v = getenv("SC_EIG_FORCE_DENSE") != nullptr;
+  return v;
+}
+// SC_MATVEC_SYM_MIN_N=<n>: upper-triangle block matvec from this size on (default 4096)
+inline int matvec_sym_min_n() {
+  static const int v = getenv("SC_MATVEC_SYM_MIN_N") ? atoi(getenv("SC_MATVEC_SYM_MIN_N")) : 4096;
+  return v;
+}
+// SC_KMEANS_SINGLE=1: single-workgroup k-means (k > 32, other metrics, very large n)
+inline bool kmeans_single() {
+  static const bool v = getenv("SC_KMEANS_SINGLE") != nullptr;
+  return v;
+}
+// SC_SWEEP_ONE_BY_ONE=1: an AutoTune level as separate sc_eig_ncluster calls (what a level
+// falls back to when member arenas do not fit or a value leaves the grouped path)
+inline bool sweep_one_by_one() {
+  static const bool v = getenv("SC_SWEEP_ONE_BY_ONE") != nullptr;
+  return v;
+}
+
+}  // namespace sw
+}  // namespace sc
+
+#endif  // SPECTRALCLUSTER_AMD_SWITCHES_H_

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Config 5 (512 utterances) throughput of the grouped batch (one stream, one host thread) vs
 the group width, beside the multi-stream form; labels of both must agree.
-   python tools/batch_group_probe.py [group widths ...]"""
+   python tests/probes/batch_group_probe.py [group widths ...]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _inputs as so  # noqa: E402

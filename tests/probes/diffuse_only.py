@@ -1,9 +1,9 @@
 """Diffuse (S S^T) at n=8192 through the stage API, for rocprofv3 kernel timing.
-   python tools/diffuse_only.py [n] [reps] [data: random|const|sparse|fewbit]"""
+   python tests/probes/diffuse_only.py [n] [reps] [data: random|const|sparse|fewbit]"""
 import os
 import sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from spectralcluster_amd import refinement as rf
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3

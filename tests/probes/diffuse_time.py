@@ -5,7 +5,7 @@ import os
 import sys
 import time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from spectralcluster_amd import _lib
 from spectralcluster_amd import refinement as rf
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192

@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """Two identical passes of BASELINE config 5 through the grouped batch (for rocprofv3 traces):
-   python tools/group_only.py [group] [streams]   (streams > 0: the multi-stream form instead)"""
+   python tests/probes/group_only.py [group] [streams]   (streams > 0: the multi-stream form instead)"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _inputs as so  # noqa: E402

@@ -6,7 +6,7 @@ so the n^3 product can be skipped.  This script checks that claim against the ex
 reference-shaped computation, and shows why it does NOT carry over to the ICASSP2018 sequence
 (RowWiseNormalize needs rowmax(S), which is not a matrix-vector quantity).
 
-    python tools/matrix_free_note.py [n]
+    python tests/probes/matrix_free_note.py [n]
 """
 import dataclasses
 import os
@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import scipy.sparse.linalg as spla
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import spectral_oracle as so  # noqa: E402
 

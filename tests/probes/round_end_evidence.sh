@@ -1,4 +1,4 @@
-# Round-end evidence run (on the GPU box: gpurun -- bash tools/round_end_evidence.sh): GPU tests, default bench, rocprofv3
+# Round-end evidence run (on the GPU box: gpurun -- bash tests/probes/round_end_evidence.sh): GPU tests, default bench, rocprofv3
 # kernel stats of the same bench command, FETCH/WRITE PMC passes -> gpurun_out/final/
 set -x
 cd $GRAFT_REPO_ROOT

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Single predict() calls over a range of utterance sizes (d=256, ICASSP2018 preset): ms per
-call and the stage timers.   python tools/single_sizes.py [n ...]"""
+call and the stage timers.   python tests/probes/single_sizes.py [n ...]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _inputs as so  # noqa: E402

@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """Run one stage in isolation (for rocprofv3 PMC passes):
-   python tools/stage_probe.py diffuse|affinity|predict [n] [reps]"""
+   python tests/probes/stage_probe.py diffuse|affinity|predict [n] [reps]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import spectralcluster_amd as sca  # noqa: E402
 from spectralcluster_amd import refinement as rf  # noqa: E402

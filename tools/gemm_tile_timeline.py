@@ -1,5 +1,5 @@
-"""Per-tile timeline of the Diffuse GEMM from a SC_GEMM_CLOCK_DUMP file (n = 8192):
-   SC_GEMM_CLOCK=1 SC_GEMM_CLOCK_DUMP=tiles.txt python tools/diffuse_only.py 8192 2 random
+"""Per-tile timeline of the Diffuse GEMM from a SC_GEMM_CLOCK=<file> dump (n = 8192):
+   SC_GEMM_CLOCK=tiles.txt python tests/probes/diffuse_only.py 8192 2 random
    python tools/gemm_tile_timeline.py tiles.txt
 Prints cycles / effective clock per XCD and per generation of tiles."""
 import numpy as np, sys

@@ -216,7 +216,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
-                    &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->td_tau, &h->mvsym,
+                    &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->td_tau, &h->td_panel, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
                     &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd, &h->gpack, &h->gypack, &h->ginfo, &h->glabels};
   for (DevBuf* b : bufs)
@@ -1238,11 +1238,13 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
     SC_TRY(grow(h, h->td_d, (size_t)n * sizeof(double)));
     SC_TRY(grow(h, h->td_e, (size_t)n * sizeof(double)));
     SC_TRY(grow(h, h->td_theta, (size_t)n * sizeof(double)));
-    SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 16) * sizeof(double)));
+    SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 2048) * sizeof(double)));
     SC_TRY(grow(h, h->td_tau, (size_t)n * sizeof(double)));
-    launch_tridiagonalize(h->stream, ptr<double>(h->B1), ld, n, ptr<double>(h->td_d),
-                          ptr<double>(h->td_e), ptr<double>(h->td_tau),
-                          ptr<double>(h->td_work));
+    SC_TRY(grow(h, h->td_panel, (size_t)n * 128 * sizeof(double)));
+    launch_tridiagonalize_blocked(h->stream, ptr<double>(h->B1), ld, n, ptr<double>(h->td_d),
+                                  ptr<double>(h->td_e), ptr<double>(h->td_tau),
+                                  ptr<double>(h->td_panel), ptr<double>(h->td_work),
+                                  ptr<double>(h->splitk));
     launch_tridiagonal_eigenvalues(h->stream, ptr<double>(h->td_d), ptr<double>(h->td_e), n,
                                    ptr<double>(h->td_theta), ptr<double>(h->td_work));
     SC_TRY(check_last(h, "dense eigenvalue launch"));

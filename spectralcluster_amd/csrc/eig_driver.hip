@@ -311,11 +311,13 @@ static int dense_spectrum(sc_handle h, const double* S, int ld, int n, double* s
   SC_TRY(grow(h, h->td_d, (size_t)n * sizeof(double)));
   SC_TRY(grow(h, h->td_e, (size_t)n * sizeof(double)));
   SC_TRY(grow(h, h->td_theta, (size_t)n * sizeof(double)));
-  SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 16) * sizeof(double)));
+  SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 2048) * sizeof(double)));
   SC_TRY(grow(h, h->td_tau, (size_t)n * sizeof(double)));
+  SC_TRY(grow(h, h->td_panel, (size_t)n * 128 * sizeof(double)));
   launch_td_materialize(s, S, ld, n, ptr<double>(h->cvec), ptr<double>(h->pvec), scratch);
-  launch_tridiagonalize(s, scratch, ld, n, ptr<double>(h->td_d), ptr<double>(h->td_e),
-                        ptr<double>(h->td_tau), ptr<double>(h->td_work));
+  launch_tridiagonalize_blocked(s, scratch, ld, n, ptr<double>(h->td_d), ptr<double>(h->td_e),
+                                ptr<double>(h->td_tau), ptr<double>(h->td_panel),
+                                ptr<double>(h->td_work), ptr<double>(h->splitk));
   launch_tridiagonal_eigenvalues(s, ptr<double>(h->td_d), ptr<double>(h->td_e), n,
                                  ptr<double>(h->td_theta), ptr<double>(h->td_work));
   SC_TRY(check_last(h, "dense eigenvalue launch"));

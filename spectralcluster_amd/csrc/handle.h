@@ -68,7 +68,7 @@ struct sc_handle_s {
   DevBuf E, Ek, Eio;      // eigenvectors (col-major), renormed copy, row-major I/O staging
   DevBuf mvsym;           // slabs of the symmetric block matvec
   // dense full-spectrum path (eig_dense.hip): d, e, all eigenvalues, reflector work vectors
-  DevBuf td_d, td_e, td_theta, td_work, td_tau;
+  DevBuf td_d, td_e, td_theta, td_work, td_tau, td_panel;
   std::vector<double> spectrum;  // host copy: every eigenvalue of Op, descending
   std::vector<double> last_w;    // eigenvalues the last eig call consumed (reference order)
   // general (non-symmetric) eigen path: right scaling, Im(theta), complex Ritz vectors

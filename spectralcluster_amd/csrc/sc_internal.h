@@ -322,6 +322,12 @@ void launch_td_materialize(hipStream_t s, const double* S, int ld, int n, const 
 // reflector j (v[j+1] = 1) is left in A[j, j+1 .. n-1].  work: 4 n + 8 doubles.  2 n launches.
 void launch_tridiagonalize(hipStream_t s, double* A, int ld, int n, double* d, double* e,
                            double* taus, double* work);
+// The same reduction in panels of 32 columns (LAPACK dsytrd / dlatrd): 8 B of read-only
+// traffic per trailing entry and column instead of 16 B read + write, the trailing update once
+// per panel on the MFMA GEMM.  panel: 4 * 32 * n doubles; work: 5 n + 2048 doubles.
+void launch_tridiagonalize_blocked(hipStream_t s, double* A, int ld, int n, double* d, double* e,
+                                   double* taus, double* panel, double* work,
+                                   double* splitk_ws);
 // Z (column-major: column q at Z + q * ldz) <- Q Z, Q = H_0 ... H_{n-2} from the above
 void launch_td_backtransform(hipStream_t s, const double* A, int ld, int n, const double* taus,
                              double* Z, int ldz, int cols);

@@ -67,3 +67,42 @@ def test_autotune_predict_vs_oracle(lap):
   want = so.run_kmeans(vecs[:, :k], k, 300)
   assert so.adjusted_rand_index(got, want) == 1.0
   assert c.last_diag.n_clusters == k
+
+
+@pytest.mark.parametrize("n,lap", [(900, None), (2000, sca.LaplacianType.GraphCut)])
+def test_adopted_eigenvectors_equal_a_fresh_evaluation(n, lap):
+  """sc_sweep_adopt: the eigenvectors a sweep left in a member arena span what
+  sc_eig_ncluster with that p_percentile computes (the AutoTune winner is no longer
+  evaluated a second time) -- same eigenvalues, same labels; refused for a configuration
+  that is not the sweep's, and after a new affinity."""
+  from spectralcluster_amd import _lib
+  x = so.blobs(n, 64, 5, seed=n + 3)
+  c = clusterer(lap, 7 if lap is None else 12)
+  handle = c._handle()
+  c._upload(handle, x)
+  ps = [0.6, 0.7, 0.8, 0.9, 0.95]
+  diags = c._eig_sweep(handle, ps)
+  for i in (1, 4):
+    dg = _lib.ScDiag()
+    assert handle.lib.sc_sweep_adopt(handle.raw, c.build_config(ps[i]), i, dg) == _lib.SC_OK
+    assert dg.n_clusters_raw == diags[i].n_clusters_raw and dg.max_delta == diags[i].max_delta
+    k = max(int(dg.n_clusters_raw), 2)
+    adopted = c._download_eigenvectors(handle, n, k)
+    labels_a = np.empty(n, dtype=np.int64)
+    handle.check(handle.lib.sc_cluster(handle.raw, c.build_config(ps[i]), k,
+                                       _lib.as_int64_p(labels_a), dg))
+    one = c._eig_resident(handle, ps[i])
+    fresh = c._download_eigenvectors(handle, n, k)
+    labels_f = np.empty(n, dtype=np.int64)
+    handle.check(handle.lib.sc_cluster(handle.raw, c.build_config(ps[i]), k,
+                                       _lib.as_int64_p(labels_f), one))
+    cos = np.abs(np.einsum("ij,ij->j", adopted, fresh))
+    np.testing.assert_allclose(cos, 1.0, atol=1e-7)
+    assert so.adjusted_rand_index(labels_a, labels_f) == 1.0
+  dg = _lib.ScDiag()
+  other = c.build_config(ps[1])
+  other.stop_eigenvalue = 0.5  # not the sweep's configuration
+  assert handle.lib.sc_sweep_adopt(handle.raw, other, 1, dg) == _lib.SC_ERR_UNSUPPORTED
+  assert handle.lib.sc_sweep_adopt(handle.raw, c.build_config(0.61), 0, dg) == _lib.SC_ERR_UNSUPPORTED
+  c._upload(handle, x)  # a new affinity: nothing of the old sweep may be adopted
+  assert handle.lib.sc_sweep_adopt(handle.raw, c.build_config(ps[1]), 1, dg) == _lib.SC_ERR_UNSUPPORTED

@@ -155,3 +155,27 @@ def test_descending_without_max_clusters_many_values(handle):
   assert np.max(np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-12)) < 1e-5
   assert max(clusterer.last_diag.n_clusters_raw, 2) == dump["n_clusters"]
   assert so.adjusted_rand_index(got, want) == 1.0
+
+
+@pytest.mark.parametrize("lap,maxc", [(4, 100), (0, 150), (4, 500)])
+def test_max_clusters_above_64_vs_oracle(lap, maxc):
+  """The reference accepts any max_clusters (spectral_clusterer.py:29-46).  More than 64
+  consumed eigenvalues do not fit a Krylov basis: they come from the dense path; what stays
+  limited on the device is the SELECTED cluster count (<= 64 eigenvector columns)."""
+  n = 900
+  x = so.blobs(n, 32, 6, seed=900 + maxc, noise=0.4)
+  cfg = so.icassp2018_config(laplacian_type=lap, max_clusters=maxc)
+  dump = {}
+  want = so.predict(x, cfg, dump)
+  clusterer = sca.SpectralClusterer(min_clusters=2, max_clusters=maxc,
+                                    refinement_options=icassp_options(),
+                                    laplacian_type=LAP[lap])
+  got = clusterer.predict(x)
+  ref = np.real(dump["eigenvalues"])
+  idx = so.consumed_eigen_indices(n, maxc, lap == 0, ref, 1e-2)
+  w = clusterer.consumed_eigenvalues()
+  assert idx.max() < w.shape[0]
+  rel = np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-9 * np.abs(ref).max())
+  assert rel.max() < 1e-5
+  assert max(clusterer.last_diag.n_clusters_raw, 2) == dump["n_clusters"]
+  assert so.adjusted_rand_index(got, want) == 1.0

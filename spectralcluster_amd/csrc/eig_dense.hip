@@ -200,6 +200,7 @@ constexpr int kTdNb = 32;
 constexpr int kTdColWgs = 32;                 // workgroups of k_tdb_column (partial sets)
 constexpr int kTdPartStride = 2 * kTdNb + 2;  // V^T a | W^T a | norm2 | pad
 constexpr int kTdSymvRows = 2;                // rows per wave of k_tdb_symv (4 waves per workgroup)
+constexpr int kTdSymvUnroll = 8 / kTdSymvRows;  // 16-byte loads per row and lane in flight
 
 // sum of p[0 .. count) by a whole workgroup (256 or 1024 threads), identical in every thread
 // and every workgroup: thread t adds p[t], p[t + T], ...; wave tree; the wave sums in order.
@@ -367,22 +368,25 @@ __global__ __launch_bounds__(256) void k_tdb_symv(
       acc[r] = 0.0;
     }
     const int kbeg = c0 & ~1;
-    for (int cb = kbeg + 2 * lane; cb < n; cb += 4 * 128) {
-      double2 a[kTdSymvRows][4];
-      double x0[4], x1[4];
+    for (int cb = kbeg + 2 * lane; cb < n; cb += kTdSymvUnroll * 128) {
+      double2 a[kTdSymvRows][kTdSymvUnroll];
+      double x0[kTdSymvUnroll], x1[kTdSymvUnroll];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kTdSymvUnroll; ++u) {
         const int c = cb + u * 128;
         const bool in = c < n;  // (c + 1 may be the padding column: masked below)
 #pragma unroll
         for (int r = 0; r < kTdSymvRows; ++r)
           a[r][u] = in ? *reinterpret_cast<const double2*>(A + (size_t)rows[r] * ld + c)
                        : make_double2(0.0, 0.0);
-        x0[u] = (in && c >= c0) ? (c == c0 ? 1.0 : scale * avec[c]) : 0.0;
-        x1[u] = (in && c + 1 < n) ? (c + 1 == c0 ? 1.0 : scale * avec[c + 1]) : 0.0;
+        // (one 16-byte load of a(c), a(c + 1): c is even, avec is 16-byte aligned and padded)
+        const double2 av = in ? *reinterpret_cast<const double2*>(avec + c)
+                              : make_double2(0.0, 0.0);
+        x0[u] = (in && c >= c0) ? (c == c0 ? 1.0 : scale * av.x) : 0.0;
+        x1[u] = (in && c + 1 < n) ? (c + 1 == c0 ? 1.0 : scale * av.y) : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < kTdSymvUnroll; ++u)
 #pragma unroll
         for (int r = 0; r < kTdSymvRows; ++r) {
           // (x is 0 outside [c0, n): the padding past column n may hold anything but a NaN

@@ -309,64 +309,46 @@ __global__ __launch_bounds__(1024) void k_tdb_column(
   }
 }
 
-// rows / columns j+1 .. n-1 of the (panel-start) matrix.  One wave = 4 rows.
+// rows / columns j+1 .. n-1 of the (panel-start) matrix.  One wave = kTdSymvRows rows.
+// The streaming loop does not depend on the reflector scalars: it accumulates
+// z(r) = sum_{c >= j+1} A(r, c) a_j(c); y(r) = A22(r,:) v = scale z(r) + A(r, j+1) (1 - scale
+// alpha) follows once the column kernel's partials have been summed.  Those partials (and
+// everything else of the prologue) are REQUESTED before the loop and consumed after it, so
+// their round trips hide behind the stream.
 __global__ __launch_bounds__(256) void k_tdb_symv(
     double* __restrict__ A, int ld, int n, int j, int jj, double* __restrict__ P1,
     const double* __restrict__ avec, const double* __restrict__ part1,
     double* __restrict__ wprime, double* __restrict__ part2, double* __restrict__ d,
     double* __restrict__ e, double* __restrict__ taus) {
-  __shared__ double sm[4];
+  __shared__ double sm[4][2 * kTdNb + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = j + 1;
-  // ---- prologue: the column kernel's partials -> reflector scalars and V^T v, W^T v
-  // (always kTdColWgs partial sets: all loads of a lane are issued together)
-  double pl[kTdColWgs], pn[kTdColWgs];
-#pragma unroll
-  for (int i = 0; i < kTdColWgs; ++i) {
-    pl[i] = part1[(size_t)i * kTdPartStride + lane];
-    pn[i] = part1[(size_t)i * kTdPartStride + 2 * kTdNb];
-  }
-  double s_l = 0.0, norm2 = 0.0;
-#pragma unroll
-  for (int i = 0; i < kTdColWgs; ++i) {
-    s_l += pl[i];
-    norm2 += pn[i];
-  }
-  const double alpha = avec[c0];
-  double tau = 0.0, scale = 0.0, beta = alpha;
-  if (norm2 > 0.0) {
-    beta = -copysign(sqrt(__builtin_fma(alpha, alpha, norm2)), alpha);
-    tau = (beta - alpha) / beta;
-    scale = 1.0 / (alpha - beta);
-  }
   const int k = lane < kTdNb ? lane : lane - kTdNb;
   const bool live = k < jj;
-  // t_l = (V^T v)(l) for l < nb, (W^T v)(l - nb) above: row j+1 carries v = 1, the rest scale * a
-  double t_l = 0.0;
-  if (live) {
-    const double p1 = P1[(size_t)c0 * 2 * kTdNb + lane];
-    t_l = p1 + scale * (s_l - p1 * alpha);
-  }
-  // lane l < nb pairs V(r, l) with (W^T v)(l): the other half's value
-  const double u_l = __shfl_xor(t_l, kTdNb);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    d[j] = avec[j];
-    e[j] = beta;
-    taus[j] = tau;
-  }
-  // Two rows per wave, four 16-byte loads per row and lane in flight: 8 KB per wave, 16 waves
-  // per CU = 128 KB per CU -- what a memory system with ~5 us of loaded latency needs to stream
-  // (four rows per wave and one load each in flight reached 2.2 TB/s).
-  const int r0 = c0 + (blockIdx.x * 4 + wave) * kTdSymvRows;
-  double wv = 0.0;  // this wave's share of w'^T v
-  if (r0 < n) {
-    int rows[kTdSymvRows];
-    double acc[kTdSymvRows];
+  // ---- requests of the prologue: wave w takes the partial sets w, w + 4, ...
+  constexpr int kMine = kTdColWgs / 4;
+  double pl[kMine];
 #pragma unroll
-    for (int r = 0; r < kTdSymvRows; ++r) {
-      rows[r] = min(r0 + r, n - 1);
-      acc[r] = 0.0;
-    }
+  for (int i = 0; i < kMine; ++i) pl[i] = part1[(size_t)(wave + 4 * i) * kTdPartStride + lane];
+  const double pn = lane < kTdColWgs ? part1[(size_t)lane * kTdPartStride + 2 * kTdNb] : 0.0;
+  const double alpha = avec[c0];
+  const double p1 = live ? P1[(size_t)c0 * 2 * kTdNb + lane] : 0.0;
+  const double dj = avec[j];
+  const int r0 = c0 + (blockIdx.x * 4 + wave) * kTdSymvRows;
+  int rows[kTdSymvRows];
+  double acc[kTdSymvRows], arc0[kTdSymvRows], prow[kTdSymvRows], arow[kTdSymvRows];
+#pragma unroll
+  for (int r = 0; r < kTdSymvRows; ++r) {
+    rows[r] = min(r0 + r, n - 1);
+    acc[r] = 0.0;
+    arc0[r] = A[(size_t)rows[r] * ld + c0];
+    prow[r] = live ? P1[(size_t)rows[r] * 2 * kTdNb + lane] : 0.0;
+    arow[r] = avec[rows[r]];
+  }
+  // ---- the stream: two rows per wave, four 16-byte loads per row and lane in flight (8 KB
+  // per wave, 16 waves per CU = 128 KB per CU: what ~5 us of loaded latency needs; four rows
+  // and one load each reached 2.2 TB/s, this form 5 TB/s)
+  if (r0 < n) {
     const int kbeg = c0 & ~1;
     for (int cb = kbeg + 2 * lane; cb < n; cb += kTdSymvUnroll * 128) {
       double2 a[kTdSymvRows][kTdSymvUnroll];
@@ -382,31 +364,61 @@ __global__ __launch_bounds__(256) void k_tdb_symv(
         // (one 16-byte load of a(c), a(c + 1): c is even, avec is 16-byte aligned and padded)
         const double2 av = in ? *reinterpret_cast<const double2*>(avec + c)
                               : make_double2(0.0, 0.0);
-        x0[u] = (in && c >= c0) ? (c == c0 ? 1.0 : scale * av.x) : 0.0;
-        x1[u] = (in && c + 1 < n) ? (c + 1 == c0 ? 1.0 : scale * av.y) : 0.0;
+        x0[u] = (in && c >= c0) ? av.x : 0.0;
+        x1[u] = (in && c + 1 < n) ? av.y : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < kTdSymvUnroll; ++u)
 #pragma unroll
         for (int r = 0; r < kTdSymvRows; ++r) {
-          // (x is 0 outside [c0, n): the padding past column n may hold anything but a NaN
-          //  times 0 would still poison the sum, so the value is masked too)
+          // (x is 0 outside [c0, n): the padding past column n may hold anything, and a NaN
+          //  times 0 would poison the sum, so the matrix value is masked too)
           acc[r] = __builtin_fma(x0[u] != 0.0 ? a[r][u].x : 0.0, x0[u], acc[r]);
           acc[r] = __builtin_fma(x1[u] != 0.0 ? a[r][u].y : 0.0, x1[u], acc[r]);
         }
     }
+  }
+  // ---- the column kernel's partials -> reflector scalars and V^T v, W^T v
+  double s_w = 0.0;
+#pragma unroll
+  for (int i = 0; i < kMine; ++i) s_w += pl[i];
+  sm[wave][lane] = s_w;
+  double norm2 = pn;  // lanes 0 .. kTdColWgs-1 hold one partial each: fixed-order tree
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) norm2 += __shfl_xor(norm2, o);
+  __syncthreads();
+  const double s_l = ((sm[0][lane] + sm[1][lane]) + sm[2][lane]) + sm[3][lane];
+  double tau = 0.0, scale = 0.0, beta = alpha;
+  if (norm2 > 0.0) {
+    beta = -copysign(sqrt(__builtin_fma(alpha, alpha, norm2)), alpha);
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  // t_l = (V^T v)(l) for l < nb, (W^T v)(l - nb) above: row j+1 carries v = 1, the rest scale * a
+  const double t_l = live ? p1 + scale * (s_l - p1 * alpha) : 0.0;
+  // lane l < nb pairs V(r, l) with (W^T v)(l): the other half's value
+  const double u_l = __shfl_xor(t_l, kTdNb);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    d[j] = dj;
+    e[j] = beta;
+    taus[j] = tau;
+  }
+  double wv = 0.0;  // this wave's share of w'^T v
+  if (r0 < n) {
+    const double unit = 1.0 - scale * alpha;  // v(j+1) = 1 instead of scale * a(j+1)
 #pragma unroll
     for (int r = 0; r < kTdSymvRows; ++r) {
       if (r0 + r >= n) break;  // (wave-uniform)
       const int row = r0 + r;
-      double y = acc[r];
-      double corr = live ? P1[(size_t)row * 2 * kTdNb + lane] * u_l : 0.0;
+      double z = acc[r];
+      double corr = prow[r] * u_l;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
-        y += __shfl_xor(y, o);
+        z += __shfl_xor(z, o);
         corr += __shfl_xor(corr, o);
       }
-      const double vr = row == c0 ? 1.0 : scale * avec[row];
+      const double y = __builtin_fma(scale, z, arc0[r] * unit);
+      const double vr = row == c0 ? 1.0 : scale * arow[r];
       const double wp = tau * (y - corr);
       if (lane == 0) {
         wprime[row] = wp;
@@ -416,9 +428,10 @@ __global__ __launch_bounds__(256) void k_tdb_symv(
       }
     }
   }
-  if (lane == 0) sm[wave] = wv;
+  __syncthreads();  // (sm is reused)
+  if (lane == 0) sm[wave][0] = wv;
   __syncthreads();
-  if (threadIdx.x == 0) part2[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+  if (threadIdx.x == 0) part2[blockIdx.x] = ((sm[0][0] + sm[1][0]) + sm[2][0]) + sm[3][0];
 }
 
 __global__ void k_tdb_last(const double* __restrict__ avec, int n, double* __restrict__ d,

@@ -318,13 +318,10 @@ void launch_colmajor_to_rowmajor(hipStream_t s, const double* src, int lds, int 
 // M = diag(p) + diag(c) S diag(c), exactly symmetric
 void launch_td_materialize(hipStream_t s, const double* S, int ld, int n, const double* c,
                            const double* p, double* M);
-// Householder tridiagonalisation of A (n x n, ld; destroyed): d[0..n), e[0..n-1), taus[0..n);
-// reflector j (v[j+1] = 1) is left in A[j, j+1 .. n-1].  work: 4 n + 8 doubles.  2 n launches.
-void launch_tridiagonalize(hipStream_t s, double* A, int ld, int n, double* d, double* e,
-                           double* taus, double* work);
-// The same reduction in panels of 32 columns (LAPACK dsytrd / dlatrd): 8 B of read-only
-// traffic per trailing entry and column instead of 16 B read + write, the trailing update once
-// per panel on the MFMA GEMM.  panel: 4 * 32 * n doubles; work: 5 n + 2048 doubles.
+// Householder tridiagonalisation of A (n x n, ld; destroyed) in panels of 32 columns (LAPACK
+// dsytrd / dlatrd): d[0..n), e[0..n-1), taus[0..n); reflector j (v[j+1] = 1) is left in
+// A[j, j+1 .. n-1].  8 B of read-only traffic per trailing entry and column, the trailing
+// update once per panel on the MFMA GEMM.  panel: 4 * 32 * n doubles; work: 5 n + 2048.
 void launch_tridiagonalize_blocked(hipStream_t s, double* A, int ld, int n, double* d, double* e,
                                    double* taus, double* panel, double* work,
                                    double* splitk_ws);

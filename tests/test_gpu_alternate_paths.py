@@ -9,6 +9,9 @@ they are the repair / large-problem routes of the default ones:
   SC_MATVEC_SYM_MIN_N=129  upper-triangle block matvec on every Krylov solve, not only for
                         n >= 4096 (edge tiles, restarts, the repair chain all go through it)
 
+  SC_SWEEP_ONE_BY_ONE=1 an AutoTune level as separate sc_eig_ncluster calls (what a level falls
+                        back to when member arenas do not fit or a value leaves the group;
+                        the winner is then evaluated, not adopted)
   SC_EIG_FORCE_DENSE=1  the landing pad of spectra block Lanczos gives up on: eigenvalues by
                         tridiagonalisation + bisection, eigenvectors by inverse iteration +
                         Householder back-transform (sc_diag.eig_path == 6)
@@ -57,6 +60,22 @@ for name in ("e2e_n1000_lap0_max7", "e2e_n1000_lap4_max20", "e2e_n1000_lap3_max2
     assert dg.eig_host_chain == 1
   if os.environ.get("SC_EIG_FORCE_DENSE"):
     assert dg.eig_path == 6 and dg.eig_fallback == 4
+# one AutoTune search (16 values) against the reference golden: per-value proxies and labels
+g = np.load(os.path.join(ROOT, "tests", "golden", "autotune_n512.npz"))
+x = so.blobs(512, 64, 6, 512)
+tuner = sca.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95, init_search_step=0.025,
+                     search_level=1)
+c = sca.SpectralClusterer(min_clusters=2, max_clusters=20, autotune=tuner,
+                          refinement_options=sca.RefinementOptions(
+                              gaussian_blur_sigma=1, p_percentile=0.95,
+                              thresholding_soft_multiplier=0.01,
+                              refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE),
+                          laplacian_type=sca.LaplacianType.GraphCut)
+labels = c.predict(x)
+assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+assert c.last_best_p == float(g["best_p"])
+ratios = [tuner.ratio(p, d.max_delta) for p, d in zip(g["grid"], c.last_sweep_diags)]
+assert np.allclose(ratios, g["ratios"], rtol=1e-6)
 km = np.load(os.path.join(ROOT, "tests", "golden", "kmeans.npz"))
 for tag, k in (("a", 4), ("b", 8), ("c", 2), ("d", 20)):
   got = sca.custom_distance_kmeans.run_kmeans(km["e_" + tag], k, "cosine", 300)
@@ -82,7 +101,7 @@ print("ALTERNATE_PATH_OK")
 
 
 @pytest.mark.parametrize("switch", ["SC_EIG_HOST_CHAIN", "SC_EIG_DEVICE_RR", "SC_KMEANS_SINGLE",
-                                    "SC_MATVEC_SYM_MIN_N",
+                                    "SC_MATVEC_SYM_MIN_N", "SC_SWEEP_ONE_BY_ONE",
                                     "SC_EIG_FORCE_DENSE"])
 def test_alternate_path(tmp_path, switch):
   script = tmp_path / "alt.py"

@@ -76,7 +76,7 @@ constexpr int kTdNb = 32;
 constexpr int kTdColWgs = 32;                 // workgroups of k_tdb_column (partial sets)
 constexpr int kTdPartStride = 2 * kTdNb + 2;  // V^T a | W^T a | norm2 | pad
 constexpr int kTdSymvRows = 2;                // rows per wave of k_tdb_symv (4 waves per workgroup)
-constexpr int kTdSymvUnroll = 8 / kTdSymvRows;  // 16-byte loads per row and lane in flight
+constexpr int kTdSymvUnroll = 16 / kTdSymvRows;  // 16-byte loads per row and lane in flight
 
 // sum of p[0 .. count) by a whole workgroup (256 or 1024 threads), identical in every thread
 // and every workgroup: thread t adds p[t], p[t + T], ...; wave tree; the wave sums in order.

@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "handle.h"
+#include "host_pool.h"
 
 // ------------------------------------------------------------------------------
 // device arena
@@ -231,6 +232,7 @@ extern "C" int sc_destroy(sc_handle h) {
     if (h->gbank_stream[b]) hipStreamDestroy(h->gbank_stream[b]);
   }
   if (h->gcheck_ev) hipEventDestroy(h->gcheck_ev);
+  delete h->gpool;
   if (h->h_gpack) hipHostFree(h->h_gpack);
   if (h->h_gypack) hipHostFree(h->h_gypack);
   if (h->h_ginfo) hipHostFree(h->h_ginfo);

@@ -199,7 +199,7 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
     f.B2 = ptr<double>(h->B2);
     f.cropval = ptr<double>(h->cropval);
     f.rmpart = ptr<double>(h->rmpart);
-    f.blur_cols = blur_tile_columns(n, cfg->blur_radius);
+    f.blur_cols = blur_stream_columns(n, cfg->blur_radius);  // (the grouped front streams)
     f.cut = ptr<double>(h->cut);
     f.rowmax = ptr<double>(h->rowmax);
     f.rowsum = ptr<double>(h->rowsum);
@@ -480,9 +480,9 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     auto front = [&](int g) -> int {
       const int b = g % banks, cnt = group_count(g);
       const int* idx = grouped.data() + (size_t)g * width;
-      // (the streaming blur of the grouped front needs every member at n >= 512; the sizes
+      // (the streaming blur of the grouped front needs every member at n >= 256; the sizes
       //  are sorted, the last member of the group is its smallest)
-      if (covers && blur_group_supported(ns[idx[cnt - 1]], cfg->blur_radius)) {
+      if (covers && blur_group_front_supported(ns[idx[cnt - 1]], cfg->blur_radius)) {
         front_bank[b] = b;
         return enqueue_front_grouped(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b], b);
       }

@@ -378,9 +378,23 @@ bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, in
   return false;
 }
 
-// The streaming blur of every member of a batch group (all n >= kStreamMinN) in one launch.
+// The streaming blur of every member of a batch group in one launch.  (kStreamMinN is where a
+// SINGLE matrix has enough column strips for the streaming kernel to beat the tile kernel; an
+// AutoTune sweep blurs its one matrix with the single-call launcher, hence the same bound.)
 bool blur_group_supported(int n_min, int radius) {
   return (radius == 4 || radius == 8) && n_min >= kStreamMinN;
+}
+// Grouped FRONT of a batch: the strips of 16 members fill the chip whatever their size, so the
+// streaming kernel takes every member of at least one full strip height -- config 5's 41
+// utterances below n = 512 no longer run their stages member by member.
+constexpr int kStreamGroupMinN = 256;
+bool blur_group_front_supported(int n_min, int radius) {
+  return (radius == 4 || radius == 8) && n_min >= kStreamGroupMinN;
+}
+// strips per row of the streaming kernel (row-max partials per row), whatever n
+int blur_stream_columns(int n, int radius) {
+  const int ow = 256 - 2 * radius;
+  return (n + ow - 1) / ow;
 }
 void launch_gaussian_blur_group(hipStream_t s, const FrontItem* items, int count, int radius,
                                 const double* weights_dev) {

@@ -6,6 +6,7 @@
 
 #include "handle.h"
 #include "host_eig.h"
+#include "host_pool.h"
 
 // ------------------------------------------------------------------------------
 // symmetric top-k eigensolver driver
@@ -756,6 +757,10 @@ static int ensure_group_staging(sc_handle lead) {
                                y_doubles * sizeof(double)));
     SC_HIP(lead, hipEventCreateWithFlags(&lead->gcheck_ev, hipEventDisableTiming));
   }
+  if (!lead->gpool) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    lead->gpool = new HostPool(hw >= 8 ? 6 : (hw >= 4 ? 2 : 0));
+  }
   return SC_OK;
 }
 
@@ -874,12 +879,31 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
     const double t_sync1 = trace ? now_us() : 0.0;
     if (trace) (m == first_check ? us_first_sync : us_sync) += t_sync1 - t_sync0;
     const int active_before = active;
+    // The projected problems of the members are independent: solved on the lead handle's few
+    // host workers + this thread (one after the other they were 1.0-1.9 ms per group, during
+    // which this stream has nothing queued but the speculative block).
+    bool rr_wanted[kGroupMax], rr_ok[kGroupMax];
+    for (int z = 0; z < count; ++z) {
+      rr_wanted[z] = rr_ok[z] = false;
+      if (!lz[z].active) continue;
+      const double* pack = lead->h_gpack + (size_t)z * out_stride;
+      const int* hflags = reinterpret_cast<const int*>(pack + m * m + 64);
+      const bool latched = hflags[13] != 0;
+      rr_wanted[z] = !(hflags[12] != 0 || (latched && hflags[14] != m));
+    }
+    lead->gpool->run(count, [&](int z) {
+      if (!rr_wanted[z]) return;
+      sc_handle h = mem[z].h;
+      const double* pack = lead->h_gpack + (size_t)z * out_stride;
+      double* hy = lead->h_gypack + (size_t)z * kHostRR * kHostRR;
+      bool ok = host_rayleigh_ritz(pack, m, pack + m * m, m, h->h_theta, h->h_theta + kLdq, hy, m);
+      for (int i = 0; ok && i < m; ++i) ok = std::isfinite(h->h_theta[i]);
+      rr_ok[z] = ok;
+    });
     for (int z = 0; z < count; ++z) {
       if (!lz[z].active) continue;
       sc_handle h = mem[z].h;
       const double* pack = lead->h_gpack + (size_t)z * out_stride;
-      const double* hT = pack;
-      const double* hG = pack + m * m;
       const int* hflags = reinterpret_cast<const int*>(pack + m * m + 64);
       auto hand_back = [&]() {
         mem[z].status = 1;
@@ -894,15 +918,12 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
       if (trace && latched)
         fprintf(stderr, "[sc]   member %d (n %d): chain latched at m=%d (code %d), check at m=%d\n",
                 z, mem[z].n, hflags[14], hflags[15], m);
-      if (hflags[12] != 0 || (latched && hflags[14] != m)) {
+      if (!rr_wanted[z]) {
         if (latched) h->eig_skip_fused = true;
         hand_back();
         continue;
       }
-      double* hy = lead->h_gypack + (size_t)z * kHostRR * kHostRR;
-      bool ok = host_rayleigh_ritz(hT, m, hG, m, h->h_theta, h->h_theta + kLdq, hy, m);
-      for (int i = 0; ok && i < m; ++i) ok = std::isfinite(h->h_theta[i]);
-      if (!ok) {
+      if (!rr_ok[z]) {
         hand_back();
         continue;
       }

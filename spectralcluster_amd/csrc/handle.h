@@ -107,6 +107,7 @@ struct sc_handle_s {
   long long* h_glabels = nullptr;
   size_t h_glabels_count = 0;
   hipEvent_t gcheck_ev = nullptr;
+  class HostPool* gpool = nullptr;  // host workers of the group checks (host_pool.h)
   // grouped front: the stages before the eigensolver of a whole group as grouped launches on
   // the stream of the group's bank, handed to this handle's stream through the bank's event
   hipStream_t gbank_stream[kGroupBanks] = {nullptr};

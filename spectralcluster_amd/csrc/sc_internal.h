@@ -264,6 +264,9 @@ struct FrontItem {
 void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count,
                               bool normalize_rows);
 bool blur_group_supported(int n_min, int radius);
+// grouped front of a batch (16 members per launch): from n = 256 on; its strips per row
+bool blur_group_front_supported(int n_min, int radius);
+int blur_stream_columns(int n, int radius);
 void launch_gaussian_blur_group(hipStream_t s, const FrontItem* items, int count, int radius,
                                 const double* weights_dev);
 void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,

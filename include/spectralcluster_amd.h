@@ -211,6 +211,10 @@ int sc_set_profiling(sc_handle h, int level);
 int sc_config_default(sc_config* cfg);
 /* scipy.ndimage _gaussian_kernel1d(sigma, order 0, radius int(4 sigma + .5)) */
 int sc_gaussian_weights(double sigma, int32_t* radius, double* weights);
+/* GaussianBlur with sigma > 8 (radius > SC_MAX_BLUR_RADIUS; refinement.py:154-162 has no
+ * limit): its 2 * radius + 1 weights do not fit sc_config -- upload them once, they stay
+ * resident in the handle, and a config with blur_radius == radius uses them. */
+int sc_set_blur_weights(sc_handle h, int radius, const double* weights);
 
 /* ---- whole path ---------------------------------------------------------- */
 /*

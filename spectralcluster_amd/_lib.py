@@ -181,6 +181,7 @@ PROTOTYPES = {
                                                 ctypes.POINTER(ScDiag), ctypes.c_int]),
     "sc_eig_ncluster_sweep": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), _c_double_p,
                                              ctypes.c_int, ctypes.POINTER(ScDiag)]),
+    "sc_set_blur_weights": (ctypes.c_int, [_handle_t, ctypes.c_int, _c_double_p]),
     "sc_sweep_adopt": (ctypes.c_int, [_handle_t, ctypes.POINTER(ScConfig), ctypes.c_int,
                                       ctypes.POINTER(ScDiag)]),
     "sc_predict_batch_grouped": (ctypes.c_int, [_handle_t, ctypes.POINTER(_c_double_p),
@@ -310,6 +311,16 @@ def device_count() -> int:
 
 def as_double_p(a: np.ndarray):
   return a.ctypes.data_as(_c_double_p)
+
+
+def sync_blur_weights(handle, cfg) -> None:
+  """A GaussianBlur of sigma > 8 has more weights than `sc_config` holds (radius > 32):
+  `refinement.fill_config` leaves them on the config object and they are uploaded to the
+  handle here, before the config is used with it (sc_set_blur_weights)."""
+  w = getattr(cfg, "_blur_ext", None)
+  if w is not None:
+    handle.check(handle.lib.sc_set_blur_weights(handle.raw, int(cfg.blur_radius),
+                                                as_double_p(w)))
 
 
 def as_int64_p(a: np.ndarray):

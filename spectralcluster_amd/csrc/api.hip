@@ -213,7 +213,7 @@ extern "C" int sc_destroy(sc_handle h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->X,     &h->Xn,    &h->A0,     &h->B1,      &h->B2,    &h->rowmax,
-                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->tilemap_table, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->ahc_size, &h->ahc_chain, &h->ahc_Z, &h->ahc_lab, &h->ahc_cent, &h->fb_part, &h->fb_small, &h->fb_x, &h->fb_cent, &h->fb_int, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
+                    &h->rowsum, &h->cvec,  &h->pvec,   &h->tvec,    &h->deg,   &h->blurw, &h->blur_tmp, &h->dvec, &h->cut, &h->rmpart, &h->splitk, &h->tilemap, &h->tilemap_table, &h->cropval, &h->statp, &h->crvec, &h->thetai, &h->Vre, &h->Vim, &h->gpart, &h->gsrc, &h->genL, &h->ahc_size, &h->ahc_chain, &h->ahc_Z, &h->ahc_lab, &h->ahc_cent, &h->fb_part, &h->fb_small, &h->fb_x, &h->fb_cent, &h->fb_int, &h->Cq, &h->cp[0], &h->cp[1], &h->cp[2], &h->cp[3], &h->cp[4], &h->symflag,
                     &h->Q,     &h->Q2,    &h->Vs,     &h->W,       &h->partial, &h->T,
                     &h->Y,     &h->Yt,    &h->theta,  &h->resid,   &h->G,     &h->Rinv,
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
@@ -290,6 +290,17 @@ extern "C" int sc_gaussian_weights(double sigma, int32_t* radius, double* weight
   const double sum = numpy_sum_short(weights, 2 * r + 1);
   for (int i = 0; i < 2 * r + 1; ++i) weights[i] /= sum;
   *radius = r;
+  return SC_OK;
+}
+
+// Weights of a Gaussian blur whose radius does not fit sc_config (sigma > 8: radius =
+// int(4 sigma + .5) > SC_MAX_BLUR_RADIUS; the reference has no limit, refinement.py:154-162).
+// They stay resident in the handle; a config with blur_radius == radius then uses them.
+extern "C" int sc_set_blur_weights(sc_handle h, int radius, const double* weights) {
+  if (!h) return SC_ERR_INVALID;
+  if (radius <= SC_MAX_BLUR_RADIUS || radius > (1 << 20) || !weights)
+    return fail(h, SC_ERR_INVALID, "sc_set_blur_weights: radius must exceed 32; weights 2 r + 1");
+  h->blur_ext.assign(weights, weights + 2 * (size_t)radius + 1);
   return SC_OK;
 }
 
@@ -442,8 +453,11 @@ int validate_config(sc_handle h, const sc_config* cfg) {
   for (int i = 0; i < cfg->n_ops; ++i)
     if (cfg->ops[i] < SC_OP_CROP_DIAGONAL || cfg->ops[i] > SC_OP_ROW_WISE_NORMALIZE)
       return fail(h, SC_ERR_INVALID, "Unknown refinement operation");
-  if (cfg->blur_radius < 0 || cfg->blur_radius > SC_MAX_BLUR_RADIUS)
-    return fail(h, SC_ERR_UNSUPPORTED, "gaussian blur radius > 32");
+  if (cfg->blur_radius < 0) return fail(h, SC_ERR_INVALID, "gaussian blur radius < 0");
+  if (cfg->blur_radius > SC_MAX_BLUR_RADIUS &&
+      (!h || (int)h->blur_ext.size() != 2 * cfg->blur_radius + 1))
+    return fail(h, SC_ERR_UNSUPPORTED,
+                "gaussian blur radius > 32: upload its weights with sc_set_blur_weights first");
   if (cfg->laplacian_type < SC_LAPLACIAN_NONE || cfg->laplacian_type > SC_LAPLACIAN_GRAPH_CUT)
     return fail(h, SC_ERR_INVALID, "laplacian_type must be a LaplacianType");
   if (cfg->eigengap_type != SC_EIGENGAP_RATIO &&
@@ -461,6 +475,13 @@ int validate_config(sc_handle h, const sc_config* cfg) {
 // device copy of the blur weights; the upload is skipped while they do not change
 int upload_blur_weights(sc_handle h, const sc_config* cfg) {
   const int count = 2 * cfg->blur_radius + 1;
+  if (cfg->blur_radius > SC_MAX_BLUR_RADIUS) {  // resident weights of sc_set_blur_weights
+    SC_TRY(grow(h, h->blurw, (size_t)count * sizeof(double)));
+    h->blurw_radius = -1;  // (the small-radius cache no longer describes the buffer)
+    SC_HIP(h, hipMemcpyAsync(h->blurw.p, h->blur_ext.data(), count * sizeof(double),
+                             hipMemcpyHostToDevice, h->stream));
+    return SC_OK;
+  }
   if (h->blurw_radius == cfg->blur_radius &&
       memcmp(h->blurw_host, cfg->blur_weights, count * sizeof(double)) == 0)
     return SC_OK;
@@ -481,7 +502,13 @@ static int run_refine_op(sc_handle h, int op, const sc_config* cfg, const double
       break;
     case SC_OP_GAUSSIAN_BLUR:
       if (cfg->blur_radius > 0) SC_TRY(upload_blur_weights(h, cfg));
-      launch_gaussian_blur(s, in, out, n, ld, cfg->blur_radius, ptr<double>(h->blurw));
+      if (cfg->blur_radius > SC_MAX_BLUR_RADIUS) {
+        SC_TRY(grow(h, h->blur_tmp, (size_t)n * ld * sizeof(double)));
+        launch_gaussian_blur_any_radius(s, in, ptr<double>(h->blur_tmp), out, n, ld,
+                                        cfg->blur_radius, ptr<double>(h->blurw));
+      } else {
+        launch_gaussian_blur(s, in, out, n, ld, cfg->blur_radius, ptr<double>(h->blurw));
+      }
       break;
     case SC_OP_ROW_WISE_THRESHOLD:
       if (cfg->threshold_type == SC_THRESHOLD_PERCENTILE) {
@@ -1137,6 +1164,7 @@ extern "C" int sc_predict_batch_streams(sc_handle h, const double* const* xs, co
   std::vector<int> rcs(streams, SC_OK);
   auto work = [&](int q) {
     sc_handle hq = q == 0 ? h : h->pool[q - 1];
+    if (q > 0) hq->blur_ext = h->blur_ext;  // (weights of a blur radius above 32 live in the handle)
     int nmax = 0;
     for (int i : share[q]) nmax = std::max(nmax, ns[i]);
     int rc = nmax > 0 ? sc_reserve(hq, nmax, d) : SC_OK;

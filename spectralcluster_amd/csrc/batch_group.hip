@@ -52,6 +52,9 @@ int group_slot(sc_handle lead, int z, sc_handle* out) {
     lead->gslots.push_back(sub);
   }
   *out = lead->gslots[z];
+  // (weights of a blur radius above 32 live in the handle: members inherit the lead's)
+  if ((*out)->blur_ext.size() != lead->blur_ext.size() || !lead->blur_ext.empty())
+    (*out)->blur_ext = lead->blur_ext;
   return SC_OK;
 }
 

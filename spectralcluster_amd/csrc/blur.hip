@@ -317,6 +317,43 @@ __global__ void k_copy_matrix(const double* __restrict__ in,
     out[e] = in[e];
 }
 
+// Any radius (sigma > 8: radius > SC_MAX_BLUR_RADIUS, up to many times n): the separable
+// correlation as scipy runs it -- the whole matrix along axis 0, then along axis 1
+// (scipy/ndimage/_filters.py gaussian_filter; refinement.py:160-162) -- one thread per output
+// element, same summation order (centre tap, then the pairs from the outermost inwards),
+// "reflect" extension with as many reflections as the radius needs.  O(n^2 r) loads from
+// the caches; a path for completeness, not for speed (sigma = 1 in every preset).
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_gaussian_blur_axis(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld, int radius,
+    const double* __restrict__ weights) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= n) return;
+  double t = in[(size_t)i * ld + j] * weights[radius];
+  for (int q = radius; q >= 1; --q) {
+    double lo, hi;
+    if (AXIS == 0) {
+      lo = in[(size_t)reflect_index(i - q, n) * ld + j];
+      hi = in[(size_t)reflect_index(i + q, n) * ld + j];
+    } else {
+      lo = in[(size_t)i * ld + reflect_index(j - q, n)];
+      hi = in[(size_t)i * ld + reflect_index(j + q, n)];
+    }
+    t += (lo + hi) * weights[radius - q];
+  }
+  out[(size_t)i * ld + j] = t;
+}
+
+void launch_gaussian_blur_any_radius(hipStream_t s, const double* in, double* tmp, double* out,
+                                     int n, int ld, int radius, const double* weights_dev) {
+  dim3 grid((n + 255) / 256, n);
+  hipLaunchKernelGGL(k_gaussian_blur_axis<0>, grid, dim3(256), 0, s, in, tmp, n, ld, radius,
+                     weights_dev);
+  hipLaunchKernelGGL(k_gaussian_blur_axis<1>, grid, dim3(256), 0, s, tmp, out, n, ld, radius,
+                     weights_dev);
+}
+
 void launch_gaussian_blur(hipStream_t s, const double* in, double* out, int n,
                           int ld, int radius, const double* weights_dev) {
   launch_gaussian_blur_fused(s, in, out, n, ld, radius, weights_dev, nullptr, nullptr);

@@ -62,6 +62,8 @@ struct sc_handle_s {
   int tilemap_off[65] = {0};
   const int2* tilemap_cur = nullptr;  // what ensure_tilemap selected for the current n
   DevBuf blurw;           // device copy of the blur weights
+  DevBuf blur_tmp;        // scratch of the two-pass blur of a radius above SC_MAX_BLUR_RADIUS
+  std::vector<double> blur_ext;  // weights of such a radius (sc_set_blur_weights): 2 r + 1
   // eigen workspace
   DevBuf Q, Q2, Vs, W, partial, T, Y, Yt, theta, resid, G, Rinv, Hbuf, hsq, colnorm,
       flags;

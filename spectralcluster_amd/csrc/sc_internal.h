@@ -105,6 +105,9 @@ bool launch_gaussian_blur_fused(hipStream_t s, const double* in, double* out, in
                                 int radius, const double* weights_dev, const double* diag,
                                 double* rowmax_partials);
 int blur_tile_columns(int n, int radius);
+// radius above SC_MAX_BLUR_RADIUS (sigma > 8): two global passes, tmp = an n x ld scratch
+void launch_gaussian_blur_any_radius(hipStream_t s, const double* in, double* tmp, double* out,
+                                     int n, int ld, int radius, const double* weights_dev);
 void launch_crop_value(hipStream_t s, const double* in, int n, int ld, double* dvec);
 void launch_cut_from_partials(hipStream_t s, const double* partials, int n, int ntiles,
                               double p, double* cut);

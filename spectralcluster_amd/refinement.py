@@ -64,13 +64,14 @@ def fill_config(cfg: _lib.ScConfig, *, sigma=1, p_percentile=0.95, multiplier=0.
   if float(sigma) > 1e-15:
     w = gaussian_weights(sigma)
     radius = (w.size - 1) // 2
-    if radius > _lib.SC_MAX_BLUR_RADIUS:
-      raise _lib.UnsupportedOnDeviceError(
-          "gaussian_blur_sigma=%r needs radius %d > %d" %
-          (sigma, radius, _lib.SC_MAX_BLUR_RADIUS))
     cfg.blur_radius = radius
-    for i, v in enumerate(w):
-      cfg.blur_weights[i] = float(v)
+    if radius > _lib.SC_MAX_BLUR_RADIUS:
+      # sigma > 8: the weights do not fit `sc_config`; they travel to the handle on their own
+      # (`_lib.sync_blur_weights`, called wherever this config meets a handle)
+      cfg._blur_ext = np.ascontiguousarray(w, dtype=np.float64)
+    else:
+      for i, v in enumerate(w):
+        cfg.blur_weights[i] = float(v)
   else:
     cfg.blur_radius = 0
     cfg.blur_weights[0] = 1.0
@@ -107,6 +108,7 @@ class AffinityRefinementOperation(metaclass=abc.ABCMeta):
     out = np.empty_like(src)
     handle = _lib.default_handle()
     cfg = self._config()
+    _lib.sync_blur_weights(handle, cfg)
     handle.check(handle.lib.sc_stage_refine(
         handle.raw, self._OP.value, cfg, _lib.as_double_p(src), src.shape[0],
         _lib.as_double_p(out)))

@@ -112,6 +112,8 @@ class SpectralClusterer:
       cfg.kmeans_metric = _lib.kmeans_metric_code(self.custom_dist)
     if self.constraint_options is not None:
       self.constraint_options.to_config(cfg)
+    if getattr(cfg, "_blur_ext", None) is not None:  # sigma > 8: weights go to the handle
+      _lib.sync_blur_weights(self._handle(), cfg)
     return cfg
 
   def _set_constraint(self, handle: _lib.Handle, n: int, constraint_matrix) -> bool:

@@ -106,8 +106,40 @@ def test_large_sigma_uses_generic_blur():
   m = rng.random((300, 300))
   for sigma in (0.5, 1.5, 3.0, 5.0, 8.0):
     assert np.array_equal(rf.GaussianBlur(sigma).refine(m), so.gaussian_blur(m, sigma))
-  with pytest.raises(sca.UnsupportedOnDeviceError):
-    rf.GaussianBlur(9.0).refine(m)   # radius 36 > 32
+
+
+@pytest.mark.parametrize("n,sigma", [(300, 8.5), (300, 9.0), (257, 12.0), (100, 40.0),
+                                     (37, 20.0), (640, 16.0)])
+def test_blur_sigma_above_8_any_radius(n, sigma):
+  """The reference has no limit on gaussian_blur_sigma (refinement.py:154-162).  A radius
+  above 32 -- above n, even: scipy's `reflect` extension reflects as often as it takes --
+  goes through the two-pass kernel with the weights resident in the handle
+  (sc_set_blur_weights): bit-exact against the oracle, which is bit-exact against scipy."""
+  rng = np.random.default_rng(int(n + 10 * sigma))
+  m = rng.random((n, n))
+  assert int(4 * sigma + 0.5) > 32
+  assert np.array_equal(rf.GaussianBlur(sigma).refine(m), so.gaussian_blur(m, sigma))
+  # and a smaller radius right after it on the same handle (the weight cache must notice)
+  assert np.array_equal(rf.GaussianBlur(1).refine(m), so.gaussian_blur(m, 1))
+
+
+def test_predict_with_sigma_above_8_vs_oracle():
+  """End to end, single call and both batch forms (member arenas and pooled handles inherit
+  the extended weights)."""
+  x = so.blobs(400, 24, 3, seed=9)
+  cfg = so.icassp2018_config(gaussian_blur_sigma=9.0, max_clusters=7)
+  want = so.predict(x, cfg)
+  opts = sca.RefinementOptions(gaussian_blur_sigma=9.0, p_percentile=0.95,
+                               thresholding_soft_multiplier=0.01,
+                               refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=opts)
+  assert so.adjusted_rand_index(c.predict(x), want) == 1.0
+  x2 = so.blobs(350, 24, 2, seed=10)
+  want2 = so.predict(x2, cfg)
+  for how in ({"group": 16}, {"streams": 2}):
+    out = c.predict_batch([x, x2], **how)
+    assert so.adjusted_rand_index(out[0], want) == 1.0
+    assert so.adjusted_rand_index(out[1], want2) == 1.0
 
 
 def test_fused_and_unfused_pipelines_agree():

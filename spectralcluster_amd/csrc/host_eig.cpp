@@ -10,13 +10,14 @@
 #include "../../include/spectralcluster_amd.h"
 
 // ------------------------------------------------------------------------------
-// Rayleigh-Ritz on the host for small projected problems (m <= kHostRR)
+// Rayleigh-Ritz on the host: full solve of small projected problems (m <= kHostRR = 64)
 // ------------------------------------------------------------------------------
 // The projected matrix T = Q^T Op Q of the first checks is 24 x 24 .. 48 x 48: 4.6-18 KB that
 // come back with the flags the host reads anyway.  A one-workgroup Jacobi takes 170-330 us
 // for it on the device (a chain of ~160 barrier-separated rounds); Householder
 // tridiagonalisation + implicit QL (the textbook tred2 / tql2 recurrences) on one host core
-// takes ~20-60 us.  Larger bases (after restarts) stay on the device (k_jacobi).
+// takes ~20-60 us.  Larger bases (clustered spectra, restarts) take the leading-vector
+// solve further down (host_partial_*); the device Jacobi remains behind SC_EIG_DEVICE_RR.
 //
 // a: m x m symmetric (row-major, lda), overwritten with the eigenvectors (columns);
 // d: eigenvalues ascending.  Returns false if QL did not converge (30 iterations).

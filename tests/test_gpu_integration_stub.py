@@ -46,7 +46,7 @@ def _duck(ns, **kw):
       "min_clusters", "max_clusters", "refinement_options", "autotune", "laplacian_type",
       "stop_eigenvalue", "row_wise_renorm", "custom_dist", "max_iter", "constraint_options",
       "eigengap_type")})
-  for name in ("predict", "predict_many", "evaluate_level", "_to_config"):
+  for name in ("predict", "predict_many", "evaluate_level", "cluster_winner", "_to_config"):
     setattr(obj, name, types.MethodType(ns[name], obj))
   return obj
 
@@ -115,6 +115,11 @@ def test_stub_batch_and_autotune_level(stub):
   assert lib.sc_set_embeddings(handle, xc.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                512, 64) == 0
   assert lib.sc_compute_affinity(handle) == 0
-  out = duck.evaluate_level([float(p) for p in g["grid"]])
+  grid = [float(p) for p in g["grid"]]
+  out = duck.evaluate_level(grid)
   np.testing.assert_allclose([r for r, _ in out], g["ratios"], rtol=1e-6)
   assert [k for _, k in out] == [int(v) for v in g["n_clusters"]]
+  # the search's winner: eigenvectors adopted from the sweep, then k-means
+  winner = int(np.argmin([r for r, _ in out]))
+  labels = duck.cluster_winner(grid, winner, 512)
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0

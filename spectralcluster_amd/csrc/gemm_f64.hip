@@ -31,6 +31,7 @@ namespace sc {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128;
 constexpr int BN = 128;
@@ -166,6 +167,126 @@ __device__ __forceinline__ void tile_row_stats(const v4f64 (&acc)[4][4], int ti,
   }
 }
 
+// v_max_f64 without the canonicalising self-max hipcc puts in front of every fmax whose
+// operand it cannot prove quiet (an MFMA result, a value read back from LDS): the epilogue is
+// issue-bound, and those were a quarter of its vector instructions.
+__device__ __forceinline__ double vmax64(double a, double b) {
+  double d;
+  asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+// LDS map of an epilogue (doubles; the 8192 of the operand tiles, dead by then):
+//   [0, 1024)     row partials per wave column half / finished column partials (tile_row_stats)
+//   [1024, 3072)  column partials of the full-tile statistics  [2 stats][wr * 4 + lg][128]
+//   [3072, 8192)  per wave: the transposed row partials of the full-tile statistics, then the
+//                 transposed staging of the mirror tile (1280 per wave)
+constexpr int kEpiColPart = 1024;
+constexpr int kEpiStage = 3072;
+constexpr int kEpiStageWave = 1280;
+constexpr int kEpiRowPitch = 17;  // 64 rows x 16 partials per wave, odd pitch: conflict-free
+
+// The statistics of tile_row_stats for a tile that lies wholly inside the matrix (all of them
+// when n is a multiple of 128, all but the last tile row / column otherwise).  Same values
+// (max is exact; the sums are taken in a different, equally fixed order), a third of the
+// instructions: no per-element guards, and the 16-lane reductions of the row partials go
+// through a transposed copy in LDS (16 writes + 16 reads + 15 operations per statistic) in
+// place of 64 butterfly exchanges of two ds_bpermute each.
+template <int EPI, bool SYM>
+__device__ __forceinline__ void tile_row_stats_full(const v4f64 (&acc)[4][4], int ti, int tj,
+                                                    int ntiles, int tid, const GemmStats& st,
+                                                    double* smem) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const bool diag_tile = ti == tj;
+  const bool sums = st.mode == 1;
+  // CropDiagonal's value skips the diagonal: it runs through the (m, m) accumulators of the
+  // two waves on the tile's diagonal, at lane-local row == column
+  const bool crop = st.mode == 2 && diag_tile && wr == wc;
+  double* rmax = smem;        // [2][128]  (wc, row)
+  double* rsum = smem + 256;  // [2][128]
+  double* cpart = smem + kEpiColPart;
+  double* T = smem + kEpiStage + wave * (64 * kEpiRowPitch);
+  // (the affinity epilogue (v + 1) / 2 is applied at each use: done once in place, hipcc keeps
+  //  the raw and the finished accumulators live side by side and spills 240 registers)
+  auto el = [&](int m, int nn, int r) -> double {
+    const double x = acc[m][nn][r];
+    return EPI == kEpiAffinity ? __builtin_fma(x, 0.5, 0.5) : x;
+  };
+  // --- rows: over the 4 column blocks in the lane, then over the 16 lanes through T
+  auto rows_of = [&](auto is_sum) {
+    constexpr bool SUM = decltype(is_sum)::value;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double a[4];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) a[nn] = el(m, nn, r);
+        double v;
+        if (SUM) {
+          v = (a[0] + a[1]) + (a[2] + a[3]);
+        } else {
+          if (crop && lg + 4 * r == li) a[m] = -INFINITY;
+          v = vmax64(vmax64(a[0], a[1]), vmax64(a[2], a[3]));
+        }
+        T[(m * 16 + lg + 4 * r) * kEpiRowPitch + li] = v;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double t[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t[j] = T[lane * kEpiRowPitch + j];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int j = 0; j < w; ++j) t[j] = SUM ? t[j] + t[j + w] : vmax64(t[j], t[j + w]);
+    (SUM ? rsum : rmax)[wc * 128 + wr * 64 + lane] = t[0];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  rows_of(std::false_type{});
+  if (sums) rows_of(std::true_type{});
+  // --- columns (the mirror tile's rows): over the 16 rows in the lane; the 4 lane groups and
+  // the 2 wave rows are combined by the finishing threads below
+  const bool mirror = SYM && !diag_tile;
+  if (mirror) {
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+      double mx[4], sm[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double x0 = el(m, nn, 0), x1 = el(m, nn, 1), x2 = el(m, nn, 2), x3 = el(m, nn, 3);
+        mx[m] = vmax64(vmax64(x0, x1), vmax64(x2, x3));
+        sm[m] = (x0 + x1) + (x2 + x3);
+      }
+      const int slot = (wr * 4 + lg) * 128 + wc * 64 + nn * 16 + li;
+      cpart[slot] = vmax64(vmax64(mx[0], mx[1]), vmax64(mx[2], mx[3]));
+      if (sums) cpart[1024 + slot] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const size_t at = (size_t)(ti * BM + tid) * ntiles + tj;
+    st.pmax[at] = vmax64(rmax[tid], rmax[128 + tid]);
+    if (sums) st.psum[at] = rsum[tid] + rsum[128 + tid];
+  } else if (mirror) {
+    const int c = tid - 128;
+    const size_t at = (size_t)(tj * BN + c) * ntiles + ti;
+    double t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = cpart[j * 128 + c];
+    st.pmax[at] = vmax64(vmax64(vmax64(t[0], t[1]), vmax64(t[2], t[3])),
+                         vmax64(vmax64(t[4], t[5]), vmax64(t[6], t[7])));
+    if (sums) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = cpart[1024 + j * 128 + c];
+      st.psum[at] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+  }
+}
+
 // rowmax[i] / rowsum[i] from the per-tile partials (fixed slot order)
 __global__ void k_gemm_stats_reduce(const double* __restrict__ pmax,
                                     const double* __restrict__ psum, int n, int ntiles,
@@ -247,8 +368,7 @@ struct GemmGroup {
 };
 
 // prologue / epilogue at the top issue priority (bit 0) and non-temporal C stores (bit 1):
-// 7.85 -> 7.78-7.83 ms on the Diffuse product (profiles/r02); a kernel argument so that both
-// bits stay plain runtime tests in the instruction stream that was measured
+// 7.85 -> 7.78-7.83 ms on the Diffuse product (profiles/r02)
 constexpr int kEdgePrio = 3;
 
 template <int EPI, bool SYM, bool GROUPED>
@@ -263,7 +383,7 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
                                                  double* __restrict__ probe_out,
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats,
-                                                 int* __restrict__ queue, int edge_prio,
+                                                 int* __restrict__ queue,
                                                  int nunits, int persist,
                                                  const GemmGroup* __restrict__ grp) {
   // one 64 KB block: As[2] | Bs[2] in the K loop, reduction scratch + the transposed
@@ -287,7 +407,7 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
     if (GROUPED || !persist || queue == nullptr) break;
     __syncthreads();  // the previous item's epilogue is done with the LDS
   }
-  if (edge_prio & 1) __builtin_amdgcn_s_setprio(3);
+  if (kEdgePrio & 1) __builtin_amdgcn_s_setprio(3);
   int ti, tj;
   // Work item of this workgroup.  Static (queue == nullptr): by block index.  Persistent
   // (queue): one workgroup per resident slot, each DRAWS its items -- whole tiles from its
@@ -557,7 +677,7 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
     if (kt < kt_end) k_tile(kt, std::integral_constant<int, 0>{}, P0{});
   }
 
-  if (edge_prio & 1) __builtin_amdgcn_s_setprio(3);
+  if (kEdgePrio & 1) __builtin_amdgcn_s_setprio(3);
   long long wall_k1 = 0;
   if (probe) wall_k1 = wall_clock64();
   if (probe && tid == 0) {
@@ -580,10 +700,13 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
     continue;
   }
   const bool mirror = SYM && (ti != tj);
-  const bool nt_store = (edge_prio & 2) != 0;
+  constexpr bool nt_store = (kEdgePrio & 2) != 0;
+  // wholly inside the matrix (wave-uniform): the epilogue without per-element guards
+  const bool full = row0 + BM <= M && col0 + BN <= N;
   if (stats.mode != 0 || mirror) __syncthreads();  // operand tiles are dead: LDS is reused
   if (stats.mode != 0) {
-    tile_row_stats<EPI, SYM>(acc, ti, tj, ntiles_n, M, N, tid, stats, smem);
+    if (full) tile_row_stats_full<EPI, SYM>(acc, ti, tj, ntiles_n, tid, stats, smem);
+    else tile_row_stats<EPI, SYM>(acc, ti, tj, ntiles_n, M, N, tid, stats, smem);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (probe && tid == 0) probe_out[4 * full_tiles + item_blk] = (double)(wall_clock64() - wall_k1);
@@ -591,7 +714,54 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   // sub-tile at a time: T[c][r], pitch 20 doubles = two lanes per bank pair on the writes) so
   // that its stores are 128-byte row segments like the direct ones, not 8-byte scatters.
   constexpr int kStagePitch = 20;
-  double* stage = smem + 1024 + wave * (64 * kStagePitch);  // after the reduction scratch
+  double* stage = smem + kEpiStage + wave * kEpiStageWave;
+  if (full) {
+    // one 64-bit address per 4-row group of the direct tile and per 8-row group of the mirror
+    // tile, immediates for the rest; 16-byte stores for the mirror tile
+    double* cdir = C + (size_t)(row0 + wr * 64 + lg) * ldc + (col0 + wc * 64 + li);
+    const double* adir = nullptr;
+    if (EPI == kEpiAdd)
+      adir = stats.addend + (size_t)(row0 + wr * 64 + lg) * ldc + (col0 + wc * 64 + li);
+    double* cmir = C + (size_t)(col0 + wc * 64 + (lane >> 3)) * ldc + (row0 + wr * 64 + 2 * (lane & 7));
+    double* stage_w = stage + li * kStagePitch + lg;
+    const double* stage_r = stage + (lane >> 3) * kStagePitch + 2 * (lane & 7);
+    // (two straight-line instances: with `mirror` as a run-time test hipcc guards every LDS
+    //  write with its own pair of scalar branches)
+    auto store_full = [&](auto mirror_c) {
+      constexpr bool MIRROR = decltype(mirror_c)::value;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t roff = (size_t)(m * 16 + 4 * r) * ldc;
+#pragma unroll
+          for (int nn = 0; nn < 4; ++nn) {
+            double v = acc[m][nn][r];
+            if (EPI == kEpiAffinity) v = __builtin_fma(v, 0.5, 0.5);
+            if (EPI == kEpiAdd) v += adir[roff + nn * 16];
+            if (nt_store) __builtin_nontemporal_store(v, cdir + roff + nn * 16);
+            else cdir[roff + nn * 16] = v;
+            if (MIRROR) stage_w[nn * 16 * kStagePitch + 4 * r] = v;
+          }
+        }
+        if (MIRROR) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const v2f64 v = *reinterpret_cast<const v2f64*>(stage_r + i * 8 * kStagePitch);
+            v2f64* dst = reinterpret_cast<v2f64*>(cmir + (size_t)(i * 8) * ldc + m * 16);
+            if (nt_store) __builtin_nontemporal_store(v, dst);
+            else *dst = v;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    };
+    if (mirror) store_full(std::true_type{});
+    else store_full(std::false_type{});
+  } else {
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -639,6 +809,7 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
       __builtin_amdgcn_wave_barrier();
     }
   }
+  }
   if (probe) {  // stores issued | stores drained (ticks since the end of the K loop)
     const long long t_issued = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -662,20 +833,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double* __restrict__ A
                                                  double* __restrict__ probe_out,
                                                  const int2* __restrict__ tilemap,
                                                  int xcd_chunk, GemmStats stats,
-                                                 int* __restrict__ queue, int edge_prio,
+                                                 int* __restrict__ queue,
                                                  int nunits, int persist) {
   gemm_nt_body<EPI, SYM, false>(A, lda, B, ldb, C, ldc, M, N, K, ntiles_m, ntiles_n, full_tiles,
                                 ksplit_tail, partial, probe_out, tilemap, xcd_chunk, stats,
-                                queue, edge_prio, nunits, persist, nullptr);
+                                queue, nunits, persist, nullptr);
 }
 // every workgroup: one whole tile of one member (no queue, no split, no probe)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_g(const GemmGroup grp, int stats_mode,
-                                                     int edge_prio, int xcd_chunk) {
+                                                     int xcd_chunk) {
   GemmStats stats{nullptr, nullptr, stats_mode, nullptr};
   gemm_nt_body<EPI, true, true>(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0, 0x7fffffff, 1,
                                 nullptr, nullptr, nullptr, xcd_chunk, stats, nullptr,
-                                edge_prio, 0, 0, &grp);
+                                0, 0, &grp);
 }
 
 // rowmax / rowsum of every member from its per-tile partials (k_gemm_stats_reduce, grouped)
@@ -892,7 +1063,7 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     const int grid = persist ? std::min(g_slots, full + rem * ksplit) : full + rem * ksplit;
     hipLaunchKernelGGL((k_gemm_nt<EPI, SYM>), dim3(grid), dim3(256), 0, s, A, lda,
                        B, ldb, C, ldc, M, N, K, tm, tn, full, ksplit, g_partial, probe, tilemap,
-                       xcd_chunk, stats, queue, kEdgePrio, rem * ksplit, persist);
+                       xcd_chunk, stats, queue, rem * ksplit, persist);
     if (probe != nullptr) {
       (void)hipStreamSynchronize(s);
       std::vector<double> h(7 * full);
@@ -1000,10 +1171,10 @@ void launch_gemm_nt_group(hipStream_t s, const GemmGroupItem* items, int count, 
   const int grid = 8 * xcd_chunk;
   if (epilogue == kEpiAffinity)
     hipLaunchKernelGGL((k_gemm_nt_g<kEpiAffinity>), dim3(grid), dim3(256), 0, s, grp, stats_mode,
-                       kEdgePrio, xcd_chunk);
+                       xcd_chunk);
   else
     hipLaunchKernelGGL((k_gemm_nt_g<kEpiNone>), dim3(grid), dim3(256), 0, s, grp, stats_mode,
-                       kEdgePrio, xcd_chunk);
+                       xcd_chunk);
   if (stats_mode != 0)
     hipLaunchKernelGGL(k_gemm_stats_reduce_g, dim3((nmax + kStatRows - 1) / kStatRows, count),
                        dim3(256),

@@ -168,6 +168,16 @@ extern "C" int sc_device_info(int device, char* name, int name_len, char* arch,
   return SC_OK;
 }
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by
+// default) and streams that share one run one after the other.  The grouped batch keeps six
+// streams busy (two lanes: lockstep chains + two banks of fronts each, batch_group.hip); with
+// eight queues they can each have their own.  Set when the library is loaded, i.e. before its
+// first HIP call, and only if the process has not chosen a value itself; a runtime that is
+// already initialised keeps what it has.
+__attribute__((constructor)) static void sc_default_hw_queues() {
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 extern "C" int sc_create(int device, sc_handle* out) {
   if (!out) return SC_ERR_INVALID;
   *out = nullptr;
@@ -231,7 +241,10 @@ extern "C" int sc_destroy(sc_handle h) {
     if (h->gbank_ev[b]) hipEventDestroy(h->gbank_ev[b]);
     if (h->gbank_stream[b]) hipStreamDestroy(h->gbank_stream[b]);
   }
+  if (h->gchain_stream) hipStreamDestroy(h->gchain_stream);
   if (h->gcheck_ev) hipEventDestroy(h->gcheck_ev);
+  for (sc_handle lane : h->glanes) sc_destroy(lane);
+  h->glanes.clear();
   delete h->gpool;
   if (h->h_gpack) hipHostFree(h->h_gpack);
   if (h->h_gypack) hipHostFree(h->h_gypack);

@@ -23,6 +23,7 @@
 // sc_predict to the solver's tolerance (the grouped GEMMs sum whole K tiles, the group sets
 // the check schedule), and a batch call is a deterministic function of its input.
 #include <ctime>
+#include <thread>
 
 #include "handle.h"
 
@@ -420,6 +421,81 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
   return SC_OK;
 }
 
+
+// One lane of the grouped batch: the groups `mine` (indices into the size-sorted list, `width`
+// members each) on the lead's streams and member arenas.
+int run_group_lane(sc_handle h, const double* const* xs, const int* ns, int d,
+                   const sc_config* cfg, int64_t* const* labels, sc_diag* diags,
+                   const std::vector<int>& grouped, int width, const std::vector<int>& mine,
+                   const EigRequest& rq) {
+  if (mine.empty()) return SC_OK;
+  // (the lead's lockstep chains run on its dedicated stream for the duration of the batch)
+  struct StreamSwap {
+    sc_handle h;
+    hipStream_t saved;
+    ~StreamSwap() { h->stream = saved; }
+  } swap{h, h->stream};
+  SC_HIP(h, hipStreamSynchronize(h->stream));
+  h->stream = h->gchain_stream;
+  SC_TRY(ensure_seed_table(h));
+  memset(h->gconv_hist, 0, sizeof(h->gconv_hist));
+  h->gconv_seen = 0;
+  const int ngroups = (int)mine.size();
+  // Banks of member arenas: while the eigensolver and k-means chains of group g run (short
+  // launches, host synchronisations, Rayleigh-Ritz on the host), the GEMMs and refinement
+  // passes of group g + 1 keep the chip busy on the other bank's stream.  (Two banks; a
+  // third one put two more GEMMs next to the chains and cost 9 % on config 5: the chains'
+  // short kernels wait longer for a free CU.)
+  constexpr int banks = kGroupBanks;
+  auto group_count = [&](int j) {
+    return (int)std::min<size_t>(width, grouped.size() - (size_t)mine[j] * width);
+  };
+  auto group_members = [&](int j) { return grouped.data() + (size_t)mine[j] * width; };
+  // arenas once, for the largest member each will see
+  for (int b = 0; b < std::min(banks, ngroups); ++b)
+    for (int z = 0; z < width; ++z) {
+      int largest = 0;
+      for (int j = b; j < ngroups; j += banks)
+        if (z < group_count(j)) largest = std::max(largest, ns[group_members(j)[z]]);
+      if (largest == 0) continue;
+      sc_handle hz = nullptr;
+      SC_TRY(group_slot(h, b * width + z, &hz));
+      const int rc = sc_reserve(hz, largest, d);
+      if (rc != SC_OK) return fail(h, rc, hz->err);
+      hz->have_constraint = false;
+    }
+  Member mbs[kGroupBanks][kGroupMax];
+  int front_bank[kGroupBanks];
+  const bool trace = sw::group_trace();
+  const bool covers = grouped_front_covers(cfg);
+  if (covers) {
+    SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
+    SC_TRY(upload_blur_weights(h, cfg));
+    SC_HIP(h, hipStreamSynchronize(h->stream));  // the bank streams read them
+  }
+  auto front = [&](int j) -> int {
+    const int b = j % banks, cnt = group_count(j);
+    const int* idx = group_members(j);
+    // (the streaming blur of the grouped front needs every member at n >= 256; the sizes
+    //  are sorted, the last member of the group is its smallest)
+    if (covers && blur_group_front_supported(ns[idx[cnt - 1]], cfg->blur_radius)) {
+      front_bank[b] = b;
+      return enqueue_front_grouped(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b], b);
+    }
+    front_bank[b] = -1;
+    return enqueue_front(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b]);
+  };
+  for (int j = 0; j < std::min(banks - 1, ngroups); ++j) SC_TRY(front(j));
+  for (int j = 0; j < ngroups; ++j) {
+    const double t0 = trace ? now_us() : 0.0;
+    if (j + banks - 1 < ngroups) SC_TRY(front(j + banks - 1));
+    if (trace) fprintf(stderr, "[sc] next front enqueued in %.0f us\n", now_us() - t0);
+    SC_TRY(finish_group(h, ns, cfg, labels, diags, mbs[j % banks], group_count(j), rq,
+                        front_bank[j % banks]));
+  }
+  return SC_OK;
+}
+
 }  // namespace
 
 extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, const int* ns,
@@ -439,67 +515,70 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     else single.push_back(i);
   }
   if (!grouped.empty()) {
-    SC_TRY(ensure_seed_table(h));
-    memset(h->gconv_hist, 0, sizeof(h->gconv_hist));
-    h->gconv_seen = 0;
     // similar sizes together: a group's launches are sized by its largest member
     std::stable_sort(grouped.begin(), grouped.end(), [&](int a, int b) { return ns[a] > ns[b]; });
     const int width = std::min(group, (int)grouped.size());
     const int ngroups = ((int)grouped.size() + width - 1) / width;
-    // Banks of member arenas: while the eigensolver and k-means chains of group g run (short
-    // launches, host synchronisations, Rayleigh-Ritz on the host), the GEMMs and refinement
-    // passes of group g + 1 keep the chip busy on the other bank's stream.  (Two banks; a
-    // third one put two more GEMMs next to the chains and cost 9 % on config 5: the chains'
-    // short kernels wait longer for a free CU.)
-    constexpr int banks = kGroupBanks;
-    const int nslots = std::min(banks * width, (int)grouped.size());
-    for (int z = 0; z < nslots; ++z) {  // arenas once, for the largest member each will see
-      sc_handle hz = nullptr;
-      SC_TRY(group_slot(h, z, &hz));
-      const int rc = sc_reserve(hz, ns[grouped[z]], d);
-      if (rc != SC_OK) return fail(h, rc, hz->err);
-      hz->have_constraint = false;
-    }
-    Member mbs[kGroupBanks][kGroupMax];
-    int front_bank[kGroupBanks];
-    auto group_count = [&](int g) {
-      return (int)std::min<size_t>(width, grouped.size() - (size_t)g * width);
-    };
-    const bool trace = sw::group_trace();
-    const bool covers = grouped_front_covers(cfg);
-    if (covers) {
-      for (int b = 0; b < banks; ++b)
-        if (!h->gbank_stream[b]) {
-          // (same priority as the chains' stream: a lower one for the banks, so that the short
-          //  kernels of the other group's chains go first, cost 8 %, a higher one 11 % -- the
-          //  GEMMs are the throughput)
-          SC_HIP(h, hipStreamCreateWithPriority(&h->gbank_stream[b], hipStreamNonBlocking, 0));
-          SC_HIP(h, hipEventCreateWithFlags(&h->gbank_ev[b], hipEventDisableTiming));
-        }
-      SC_TRY(grow(h, h->blurw, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)));
-      SC_TRY(upload_blur_weights(h, cfg));
-      SC_HIP(h, hipStreamSynchronize(h->stream));  // the bank streams read them
-    }
-    auto front = [&](int g) -> int {
-      const int b = g % banks, cnt = group_count(g);
-      const int* idx = grouped.data() + (size_t)g * width;
-      // (the streaming blur of the grouped front needs every member at n >= 256; the sizes
-      //  are sorted, the last member of the group is its smallest)
-      if (covers && blur_group_front_supported(ns[idx[cnt - 1]], cfg->blur_radius)) {
-        front_bank[b] = b;
-        return enqueue_front_grouped(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b], b);
+    // Two lanes: every other group of the size-sorted list goes to a second lead (its own
+    // streams, member arenas, staging and host workers) driven by a second host thread.  The
+    // lockstep eigensolver / k-means chain of a group is a string of short launches, host
+    // synchronisations and Rayleigh-Ritz solves on the host; with one lane the chains of all
+    // groups ran end to end on one stream and that string was the batch's critical path
+    // (132 ms of chain against 118 ms of GEMM / refinement kernels on config 5).
+    static const int lanes_env = getenv("SC_TMP_LANES") ? atoi(getenv("SC_TMP_LANES")) : kGroupLanes;
+    const int lanes = std::max(1, std::min({lanes_env, kGroupLanesMax, grouped_front_covers(cfg) ? ngroups / kGroupBanks : 1}));
+    std::vector<int> lane_groups[kGroupLanesMax];
+    for (int g = 0; g < ngroups; ++g) lane_groups[g % lanes].push_back(g);
+    static const int order_env = getenv("SC_TMP_ORDER") ? atoi(getenv("SC_TMP_ORDER")) : 0;
+    if (order_env == 1)
+      for (int l = 1; l < lanes; l += 2) std::reverse(lane_groups[l].begin(), lane_groups[l].end());
+    sc_handle leads[kGroupLanesMax] = {h};
+    for (int l = 1; l < lanes; ++l) {
+      while ((int)h->glanes.size() < l) {
+        sc_handle lane = nullptr;
+        const int rc = sc_create(h->device, &lane);
+        if (rc != SC_OK) return fail(h, rc, "could not create a lane of the grouped batch");
+        lane->profile_level = 1;
+        h->glanes.push_back(lane);
       }
-      front_bank[b] = -1;
-      return enqueue_front(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b]);
-    };
-    for (int g = 0; g < std::min(banks - 1, ngroups); ++g) SC_TRY(front(g));
-    for (int g = 0; g < ngroups; ++g) {
-      const double t0 = trace ? now_us() : 0.0;
-      if (g + banks - 1 < ngroups) SC_TRY(front(g + banks - 1));
-      if (trace) fprintf(stderr, "[sc] next front enqueued in %.0f us\n", now_us() - t0);
-      SC_TRY(finish_group(h, ns, cfg, labels, diags, mbs[g % banks], group_count(g), rq,
-                          front_bank[g % banks]));
+      leads[l] = h->glanes[l - 1];
+      leads[l]->blur_ext = h->blur_ext;
+      leads[l]->err.clear();
     }
+    // The streams of the batch: per lane one for the lockstep chains and one per bank for the
+    // fronts.  A HIP stream is bound to a hardware queue when it is created -- the one with the
+    // fewest streams on it (GPU_MAX_HW_QUEUES of them: 4 by default, 8 once this library is
+    // loaded, api.hip) -- and streams that share a queue run one after the other.  A chain's
+    // 10 us launches queued behind a front's multi-millisecond GEMM cost the two-lane batch
+    // 10 % (3700 instead of 4150 utterances/s on config 5) whenever the creation order of a
+    // batch's ~70 streams (every member arena owns one) put them together.  Created back to
+    // back, before any member arena, the six take six different queues; the leads' own streams
+    // idle during the batch.
+    for (int pass = 0; pass < 1 + kGroupBanks; ++pass)
+      for (int l = 0; l < lanes; ++l) {
+        hipStream_t* slot = pass == 0 ? &leads[l]->gchain_stream : &leads[l]->gbank_stream[pass - 1];
+        // (one priority for all of them: a lower one for the banks, so that the short kernels
+        //  of the chains go first, cost 8 %, a higher one 11 % -- the GEMMs are the throughput)
+        if (!*slot) SC_HIP(h, hipStreamCreateWithPriority(slot, hipStreamNonBlocking, 0));
+        if (pass > 0 && !leads[l]->gbank_ev[pass - 1])
+          SC_HIP(h, hipEventCreateWithFlags(&leads[l]->gbank_ev[pass - 1], hipEventDisableTiming));
+      }
+    int rcs[kGroupLanesMax] = {SC_OK};
+    std::vector<std::thread> side;
+    for (int l = 1; l < lanes; ++l)
+      side.emplace_back([&, l]() {
+        if (hipSetDevice(h->device) != hipSuccess) {
+          rcs[l] = fail(leads[l], SC_ERR_HIP, "hipSetDevice failed on a lane");
+          return;
+        }
+        rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, width,
+                                lane_groups[l], rq);
+      });
+    rcs[0] = run_group_lane(h, xs, ns, d, cfg, labels, diags, grouped, width, lane_groups[0], rq);
+    for (auto& t : side) t.join();
+    if (rcs[0] != SC_OK) return rcs[0];
+    for (int l = 1; l < lanes; ++l)
+      if (rcs[l] != SC_OK) return fail(h, rcs[l], leads[l]->err.c_str());
   }
   for (int i : single)
     SC_TRY(sc_predict(h, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr));

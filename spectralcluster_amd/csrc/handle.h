@@ -27,6 +27,8 @@ struct DevBuf {
 };
 
 constexpr int kGroupBanks = 2;  // banks of member arenas of the grouped batch (groups in flight)
+constexpr int kGroupLanes = 2;  // leads of the grouped batch (host threads, each with its banks)
+constexpr int kGroupLanesMax = 8;
 
 // event slots of the stage timers of the current call (resolved once the stream has drained)
 struct StageEvents {
@@ -109,10 +111,12 @@ struct sc_handle_s {
   long long* h_glabels = nullptr;
   size_t h_glabels_count = 0;
   hipEvent_t gcheck_ev = nullptr;
+  std::vector<sc_handle_s*> glanes;  // the leads of lanes 1.. (batch_group.hip)
   class HostPool* gpool = nullptr;  // host workers of the group checks (host_pool.h)
   // grouped front: the stages before the eigensolver of a whole group as grouped launches on
   // the stream of the group's bank, handed to this handle's stream through the bank's event
   hipStream_t gbank_stream[kGroupBanks] = {nullptr};
+  hipStream_t gchain_stream = nullptr;  // the lockstep chains of a grouped batch (stands in for `stream`)
   hipEvent_t gbank_ev[kGroupBanks] = {nullptr};
   int gconv_hist[16] = {0};  // members of this batch that converged at basis 8 * index ...
   int gconv_seen = 0;        // ... of this many: where a speculative block is likely wasted

@@ -250,12 +250,12 @@ def batch512_leg(sca, multigpu, comm, fence, group=16, streams=8, project=True):
 
   _, t_streams, _ = timed(streams=streams)
   _, t_loop, _ = timed(streams=1)
-  # (two host threads share the chip inside a grouped batch: the median of three passes)
+  # (three host threads share the chip inside a grouped batch: the median of three passes)
   labels, elapsed, passes_s = timed(reps=3, group=group)
   diags = clusterer.last_batch_diags
   passes = {i: int(dg.eig_matvec_passes) for i, dg in zip(owned, diags)}
   out = {"value": 512 / elapsed, "unit": "utterances/s", "seconds": elapsed,
-         "mode": "grouped: two lanes (host threads) per GPU, %d utterances per launch; median "
+         "mode": "grouped: three lanes (host threads) per GPU, %d utterances per launch; median "
                  "of 3 passes" % group,
          "passes_seconds": passes_s,
          "utterances": 512, "n_gpus": comm.size,

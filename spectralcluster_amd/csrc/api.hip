@@ -169,11 +169,15 @@ extern "C" int sc_device_info(int device, char* name, int name_len, char* arch,
 }
 
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by
-// default) and streams that share one run one after the other.  The grouped batch keeps six
-// streams busy (two lanes: lockstep chains + two banks of fronts each, batch_group.hip); with
-// eight queues they can each have their own.  Set when the library is loaded, i.e. before its
-// first HIP call, and only if the process has not chosen a value itself; a runtime that is
-// already initialised keeps what it has.
+// default) and streams that share one run one after the other.  The grouped batch keeps nine
+// streams busy (three lanes: lockstep chains + two banks of fronts each) and picks them so that
+// they share as little as the runtime allows (independent_streams, batch_group.hip); with eight
+// queues only two fronts double up.  Config 5, utterances/s: 4 queues 3720-4160 from run to
+// run, 6: 3720-3970, 8: 4130-4260, 12 / 16 the same, 24: 3450.  (The older multi-stream form
+// of predict_batch, one arena and host thread per stream, likes it the other way: 2040 with 4
+// queues, 1820 with 8.)  Set when the library is loaded, i.e. before its first HIP call, and
+// only if the process has not chosen a value itself; a runtime that is already initialised keeps
+// what it has.
 __attribute__((constructor)) static void sc_default_hw_queues() {
   setenv("GPU_MAX_HW_QUEUES", "8", 0);
 }

@@ -422,6 +422,73 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
 }
 
 
+// ---- streams on hardware queues of their own
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by
+// default, 8 once this library is loaded: api.hip), and streams that share a queue run one
+// after the other.  A chain's 10 us launches queued behind a front's multi-millisecond GEMM cost
+// a two-lane batch 10 % (3700 instead of 4100 utterances/s on config 5) whenever the creation
+// order of the process's streams (every member arena owns one, an application has its own) put
+// them together.  Which queue a new stream lands on is the runtime's business (ROCm 7.2: up
+// the queues, then down again -- streams created back to back do collide where it turns), so
+// it is MEASURED: a one-lane kernel spins for 150 us on stream a; a marker recorded on stream
+// b right after it completes at once unless b sits behind a.
+__global__ void k_spin(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+int streams_share_queue(sc_handle h, hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb,
+                        bool* share) {
+  SC_HIP(h, hipStreamSynchronize(a));
+  SC_HIP(h, hipStreamSynchronize(b));
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, a, 15000LL);  // 100 MHz ticks
+  SC_HIP(h, hipEventRecord(ea, a));
+  SC_HIP(h, hipEventRecord(eb, b));
+  SC_HIP(h, hipEventSynchronize(eb));
+  *share = hipEventQuery(ea) == hipSuccess;  // the spin was over before b's marker came through
+  SC_HIP(h, hipStreamSynchronize(a));
+  return SC_OK;
+}
+// Fills slots[0..count) with new streams none of which shares a hardware queue with another or
+// with one of `have`; candidates that do are destroyed.  When the queues run out (a runtime
+// initialised with 4 of them) the remaining slots take what comes -- the first slots, the
+// chains, have been served by then.
+int independent_streams(sc_handle h, std::vector<hipStream_t> have, hipStream_t** slots,
+                        int count) {
+  hipEvent_t ea = nullptr, eb = nullptr;
+  SC_HIP(h, hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+  SC_HIP(h, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+  std::vector<hipStream_t> rejected;
+  int filled = 0, rc = SC_OK;
+  for (int tries = 0; filled < count && tries < 4 * count + 16 && rc == SC_OK; ++tries) {
+    hipStream_t cand = nullptr;
+    // (one priority for all of them: a lower one for the banks, so that the short kernels of
+    //  the chains go first, cost 8 %, a higher one 11 % -- the GEMMs are the throughput)
+    if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, 0) != hipSuccess) {
+      rc = fail(h, SC_ERR_HIP, "could not create a stream for the grouped batch");
+      break;
+    }
+    bool clash = false;
+    for (size_t i = 0; i < have.size() && !clash && rc == SC_OK; ++i)
+      rc = streams_share_queue(h, have[i], cand, ea, eb, &clash);
+    if (rc != SC_OK || clash) {
+      rejected.push_back(cand);  // (kept until the end: destroying it now would free its place)
+      continue;
+    }
+    have.push_back(cand);
+    *slots[filled++] = cand;
+  }
+  for (; filled < count && rc == SC_OK; ++filled)
+    if (hipStreamCreateWithPriority(slots[filled], hipStreamNonBlocking, 0) != hipSuccess)
+      rc = fail(h, SC_ERR_HIP, "could not create a stream for the grouped batch");
+  if (sw::group_trace())
+    fprintf(stderr, "[sc] streams of the batch: %d on queues of their own, %zu candidates rejected\n",
+            (int)have.size(), rejected.size());
+  for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+  (void)hipEventDestroy(ea);
+  (void)hipEventDestroy(eb);
+  return rc;
+}
+
 // One lane of the grouped batch: the groups `mine` (indices into the size-sorted list, `width`
 // members each) on the lead's streams and member arenas.
 int run_group_lane(sc_handle h, const double* const* xs, const int* ns, int d,
@@ -519,20 +586,21 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     std::stable_sort(grouped.begin(), grouped.end(), [&](int a, int b) { return ns[a] > ns[b]; });
     const int width = std::min(group, (int)grouped.size());
     const int ngroups = ((int)grouped.size() + width - 1) / width;
-    // Two lanes: every other group of the size-sorted list goes to a second lead (its own
-    // streams, member arenas, staging and host workers) driven by a second host thread.  The
+    // Lanes: the groups of the size-sorted list are dealt round-robin to kGroupLanes leads (the
+    // caller's handle and kGroupLanes - 1 more, each with its own streams, member arenas, staging
+    // and host workers), and every lead but the first is driven by its own host thread.  The
     // lockstep eigensolver / k-means chain of a group is a string of short launches, host
     // synchronisations and Rayleigh-Ritz solves on the host; with one lane the chains of all
-    // groups ran end to end on one stream and that string was the batch's critical path
-    // (132 ms of chain against 118 ms of GEMM / refinement kernels on config 5).
-    static const int lanes_env = getenv("SC_TMP_LANES") ? atoi(getenv("SC_TMP_LANES")) : kGroupLanes;
-    const int lanes = std::max(1, std::min({lanes_env, kGroupLanesMax, grouped_front_covers(cfg) ? ngroups / kGroupBanks : 1}));
-    std::vector<int> lane_groups[kGroupLanesMax];
+    // groups ran end to end on one stream, and that string -- not the GEMMs -- was the batch's
+    // critical path (132 ms of chain against 118 ms of GEMM / refinement kernels on config 5).
+    // Measured on config 5 (utterances/s, tests/probes/group_only.py): 1 lane 3800, 2 lanes
+    // 4020, 3 lanes 4200, 4 lanes 4150; the second lane's groups in ascending order of size
+    // (a GEMM-heavy lane beside a latency-bound one) 3920 against 4020.
+    const int lanes =
+        std::max(1, std::min(kGroupLanes, grouped_front_covers(cfg) ? ngroups / kGroupBanks : 1));
+    std::vector<int> lane_groups[kGroupLanes];
     for (int g = 0; g < ngroups; ++g) lane_groups[g % lanes].push_back(g);
-    static const int order_env = getenv("SC_TMP_ORDER") ? atoi(getenv("SC_TMP_ORDER")) : 0;
-    if (order_env == 1)
-      for (int l = 1; l < lanes; l += 2) std::reverse(lane_groups[l].begin(), lane_groups[l].end());
-    sc_handle leads[kGroupLanesMax] = {h};
+    sc_handle leads[kGroupLanes] = {h};
     for (int l = 1; l < lanes; ++l) {
       while ((int)h->glanes.size() < l) {
         sc_handle lane = nullptr;
@@ -546,24 +614,30 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
       leads[l]->err.clear();
     }
     // The streams of the batch: per lane one for the lockstep chains and one per bank for the
-    // fronts.  A HIP stream is bound to a hardware queue when it is created -- the one with the
-    // fewest streams on it (GPU_MAX_HW_QUEUES of them: 4 by default, 8 once this library is
-    // loaded, api.hip) -- and streams that share a queue run one after the other.  A chain's
-    // 10 us launches queued behind a front's multi-millisecond GEMM cost the two-lane batch
-    // 10 % (3700 instead of 4150 utterances/s on config 5) whenever the creation order of a
-    // batch's ~70 streams (every member arena owns one) put them together.  Created back to
-    // back, before any member arena, the six take six different queues; the leads' own streams
+    // fronts, on hardware queues of their own (independent_streams above); the leads' own streams
     // idle during the batch.
-    for (int pass = 0; pass < 1 + kGroupBanks; ++pass)
-      for (int l = 0; l < lanes; ++l) {
-        hipStream_t* slot = pass == 0 ? &leads[l]->gchain_stream : &leads[l]->gbank_stream[pass - 1];
-        // (one priority for all of them: a lower one for the banks, so that the short kernels
-        //  of the chains go first, cost 8 %, a higher one 11 % -- the GEMMs are the throughput)
-        if (!*slot) SC_HIP(h, hipStreamCreateWithPriority(slot, hipStreamNonBlocking, 0));
-        if (pass > 0 && !leads[l]->gbank_ev[pass - 1])
-          SC_HIP(h, hipEventCreateWithFlags(&leads[l]->gbank_ev[pass - 1], hipEventDisableTiming));
+    {
+      hipStream_t* want[kGroupLanes * (1 + kGroupBanks)];
+      int nwant = 0;
+      for (int pass = 0; pass < 1 + kGroupBanks; ++pass)  // (the chains first: they matter most)
+        for (int l = 0; l < lanes; ++l) {
+          hipStream_t* slot =
+              pass == 0 ? &leads[l]->gchain_stream : &leads[l]->gbank_stream[pass - 1];
+          if (!*slot) want[nwant++] = slot;
+          if (pass > 0 && !leads[l]->gbank_ev[pass - 1])
+            SC_HIP(h, hipEventCreateWithFlags(&leads[l]->gbank_ev[pass - 1], hipEventDisableTiming));
+        }
+      if (nwant > 0) {
+        std::vector<hipStream_t> have;  // (lanes of an earlier, smaller batch keep theirs)
+        for (int l = 0; l < lanes; ++l) {
+          if (leads[l]->gchain_stream) have.push_back(leads[l]->gchain_stream);
+          for (int b2 = 0; b2 < kGroupBanks; ++b2)
+            if (leads[l]->gbank_stream[b2]) have.push_back(leads[l]->gbank_stream[b2]);
+        }
+        SC_TRY(independent_streams(h, have, want, nwant));
       }
-    int rcs[kGroupLanesMax] = {SC_OK};
+    }
+    int rcs[kGroupLanes] = {SC_OK};
     std::vector<std::thread> side;
     for (int l = 1; l < lanes; ++l)
       side.emplace_back([&, l]() {

@@ -27,8 +27,7 @@ struct DevBuf {
 };
 
 constexpr int kGroupBanks = 2;  // banks of member arenas of the grouped batch (groups in flight)
-constexpr int kGroupLanes = 2;  // leads of the grouped batch (host threads, each with its banks)
-constexpr int kGroupLanesMax = 8;
+constexpr int kGroupLanes = 3;  // leads of the grouped batch (host threads, each with its banks)
 
 // event slots of the stage timers of the current call (resolved once the stream has drained)
 struct StageEvents {

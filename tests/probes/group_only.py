@@ -20,6 +20,13 @@ ns = rng.integers(300, 3001, 512)
 ks = rng.integers(2, 8, 512)
 utts = [so.blobs(int(n), 256, int(k), seed=i) for i, (n, k) in enumerate(zip(ns, ks))]
 c = sca.configs.icassp2018_clusterer
+pre = os.environ.get("GROUP_ONLY_PRE", "")  # what bench.py does before its grouped leg
+if "8" in pre:
+  c.predict_batch(utts, streams=8)
+if "1" in pre:
+  c.predict_batch(utts, streams=1)
+if "s" in pre:
+  c.predict_batch(utts[:64], streams=8)
 for _ in range(int(os.environ.get("GROUP_ONLY_PASSES", "2"))):
   t = time.perf_counter()
   if streams > 0:

@@ -17,8 +17,8 @@ Multi-GPU = independent replicas (every rank runs the same per-GPU work, no data
 collective, weak scaling).
 
 Extra keys (not the headline): `batch512` = BASELINE config 5 (512 utterances, n in
-[300, 3000], LPT-partitioned over the ranks, one grouped batch per rank -- one host thread,
-16 utterances per launch -- labels all-gathered; the multi-stream form and the plain loop are
+[300, 3000], LPT-partitioned over the ranks, one grouped batch per rank -- 16 utterances per launch,
+three lanes -- labels all-gathered; the multi-stream form and the plain loop are
 timed beside it) in utterances/s, and `autotune16` = config 4 (16-value p_percentile sweep at
 n=4096, grid round-robin over the ranks) in ms per sweep -- the quantities the 8-GPU
 target is stated on; both carry their own `roofline` (algorithmic flops + HBM bytes -> floor)
@@ -224,8 +224,8 @@ def workload_roofline(flops, hbm_bytes, seconds):
 
 def batch512_leg(sca, multigpu, comm, fence, group=16, streams=8, project=True):
   """Config 5: the 512 utterances are LPT-partitioned over the ranks by size alone, so each
-  rank only synthesises its own share and uploads it itself; per rank ONE grouped batch (one
-  host thread, `group` utterances per launch); labels all-gathered.  The multi-stream form
+  rank only synthesises its own share and uploads it itself; per rank ONE grouped batch
+  (`group` utterances per launch, three lanes); labels all-gathered.  The multi-stream form
   (one host thread and arena per stream) is timed beside it."""
   ns, ks = batch512_sizes()
   sizes = [int(n) for n in ns]

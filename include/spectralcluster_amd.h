@@ -300,10 +300,13 @@ int sc_predict_batch(sc_handle h, const double* const* xs, const int* ns, int d,
 int sc_predict_batch_streams(sc_handle h, const double* const* xs, const int* ns, int d,
                              int count, const sc_config* cfg, int64_t* const* labels,
                              sc_diag* diags, int streams);
-/* the same on ONE stream with ONE host thread, `group` (<= 16) utterances per launch: the
- * stages before the eigensolver are enqueued member after member, the block Lanczos chain
- * and the k-means chain of the members advance in lockstep (one launch per step and one
- * host synchronisation per check for the whole group).  Per-utterance results agree with
+/* the same as groups of `group` (<= 16) utterances per launch: the stages before the
+ * eigensolver are enqueued member after member (one launch for all members' GEMM tiles when
+ * the sequence is the ICASSP2018 one), the block Lanczos chain and the k-means chain of the
+ * members advance in lockstep (one launch per step and one host synchronisation per check for
+ * the whole group).  The groups are dealt to up to three lanes -- internal lead handles with
+ * their own streams, member arenas and host thread -- so up to three groups' chains are in
+ * flight; the call returns when all lanes are done.  Per-utterance results agree with
  * sc_predict to the solver's tolerance (whole-K tile sums where a short single call splits
  * K; the group's check schedule), not bit for bit; the same batch always gives the same
  * results.  Utterances outside the grouped path's range (n <= 128, n >= 4096, a

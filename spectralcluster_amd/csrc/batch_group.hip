@@ -1,11 +1,12 @@
 // Grouped execution of a batch of SHORT utterances (512 independent
-// predict() calls, n = 300..3000) on ONE stream with ONE host thread.
+// predict() calls, n = 300..3000): groups of up to 16 utterances per launch, dealt to three
+// lanes (a lead handle, its streams and a host thread each; sc_predict_batch_grouped below).
 //
 // A short utterance cannot fill 256 CUs, and after its three GEMM-shaped stages its pipeline
 // is ~50 tiny dependent launches (block Lanczos chain, k-means chain) with three host
 // synchronisations: 0.45-0.6 ms of latency that does not shrink with n.  Running utterances
 // on several streams from several host threads hides that latency (sc_predict_batch_streams);
-// this file removes it instead:
+// this file removes it instead.  Per group:
 //   front   upload, affinity GEMM, refinement, Diffuse GEMM, scaling vectors of every member
 //           of a group of up to kGroupMax utterances are enqueued back to back, each on the
 //           member's own stream (no host synchronisation; one utterance's GEMM tiles cannot

@@ -340,10 +340,11 @@ class SpectralClusterer:
 
     Small utterances cannot fill 256 CUs, and their pipeline is a chain of short dependent
     launches.  Two ways around that, both ONE library call with the GIL released:
-      group       `sc_predict_batch_grouped` (the default, group=16): one host thread,
-                  `group` (<= 16) utterances per launch -- the eigensolver and k-means
-                  chains of a group advance in lockstep on one stream while the GEMMs and
-                  refinement passes of the next group run on the members' streams;
+      group       `sc_predict_batch_grouped` (the default, group=16): `group` (<= 16)
+                  utterances per launch -- the eigensolver and k-means chains of a group
+                  advance in lockstep on one stream while the GEMMs and refinement passes of
+                  the next group run on another; the groups are dealt to three lanes (a host
+                  thread and a set of streams each) inside the call;
       streams     `sc_predict_batch_streams` (when `streams` is given and `group` is not):
                   the batch spread (longest-processing-time first) over `streams` HIP
                   streams, one host thread and arena per stream; streams=1 is a plain loop.

@@ -1,5 +1,5 @@
-"""Grouped execution of a batch (sc_predict_batch_grouped: one stream, one host thread, up to
-16 utterances per launch, eigensolver and k-means chains in lockstep) gives every utterance the
+"""Grouped execution of a batch (sc_predict_batch_grouped: up to 16 utterances per launch,
+eigensolver and k-means chains in lockstep, groups dealt to three lanes) gives every utterance the
 result of its own predict() call -- against single calls, against the oracle and against the
 real-reference golden of BASELINE config 5."""
 import os

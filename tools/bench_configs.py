@@ -59,7 +59,7 @@ for streams in (1, 2, 4, 8):
   dt = time.perf_counter() - t
   out["cfg5_batch512_s_streams%d" % streams] = dt
   out["cfg5_utterances_per_s_streams%d" % streams] = 512 / dt
-for group in (4, 8, 16):  # the grouped batch: one host thread, `group` utterances per launch
+for group in (4, 8, 16):  # the grouped batch: `group` utterances per launch, three lanes
   c.predict_batch(utts[:2 * group], group=group)
   t = time.perf_counter()
   labs = c.predict_batch(utts, group=group)

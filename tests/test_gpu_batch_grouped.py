@@ -158,6 +158,29 @@ def test_grouped_is_deterministic_and_order_independent():
     assert np.array_equal(x, y) and np.array_equal(x, z)
 
 
+def test_lanes_give_every_group_the_one_lane_result():
+  """A batch of >= 4 groups is dealt to three lanes (three leads, three host threads): every
+  utterance still gets the result of its own predict() call, two passes agree bit for bit
+  (labels and reported eigenvalues), and so does a pass in a process that created the
+  multi-stream form's eight streams first (the lanes pick their streams by measurement)."""
+  utts = mixed_utterances(100, seed=77, lo=260, hi=1400, d=32)  # 7 groups of 16
+  c = icassp(laplacian_type=sca.LaplacianType.GraphCut, max_clusters=10)
+  a = c.predict_batch(utts, group=16)
+  da = [d.eigenvalue_array().copy() for d in c.last_batch_diags]
+  c.predict_batch(utts[:24], streams=8)
+  b = c.predict_batch(utts, group=16)
+  db = [d.eigenvalue_array().copy() for d in c.last_batch_diags]
+  for i, u in enumerate(utts):
+    assert np.array_equal(a[i], b[i]), i
+    assert np.array_equal(da[i], db[i]), i
+  for i in range(0, 100, 7):
+    assert np.array_equal(a[i], c.predict(utts[i])), i
+  # a fresh clusterer (new lead, new lanes) reproduces it
+  c2 = icassp(laplacian_type=sca.LaplacianType.GraphCut, max_clusters=10)
+  for x, y in zip(a, c2.predict_batch(utts, group=16)):
+    assert np.array_equal(x, y)
+
+
 def test_config5_batch512_grouped_vs_reference():
   g = np.load(os.path.join(GOLDEN, "batch512.npz"))
   ns, ks = g["ns"], g["ks"]

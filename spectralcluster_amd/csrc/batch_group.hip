@@ -640,16 +640,27 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     }
     int rcs[kGroupLanes] = {SC_OK};
     std::vector<std::thread> side;
-    for (int l = 1; l < lanes; ++l)
-      side.emplace_back([&, l]() {
+    bool inline_lane[kGroupLanes] = {false};
+    for (int l = 1; l < lanes; ++l) {
+      auto body = [&, l]() {
         if (hipSetDevice(h->device) != hipSuccess) {
           rcs[l] = fail(leads[l], SC_ERR_HIP, "hipSetDevice failed on a lane");
           return;
         }
         rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, width,
                                 lane_groups[l], rq);
-      });
+      };
+      try {
+        side.emplace_back(body);
+      } catch (...) {  // (no thread to be had: the lane runs on this one, after lane 0)
+        inline_lane[l] = true;
+      }
+    }
     rcs[0] = run_group_lane(h, xs, ns, d, cfg, labels, diags, grouped, width, lane_groups[0], rq);
+    for (int l = 1; l < lanes; ++l)
+      if (inline_lane[l])
+        rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, width,
+                                lane_groups[l], rq);
     for (auto& t : side) t.join();
     if (rcs[0] != SC_OK) return rcs[0];
     for (int l = 1; l < lanes; ++l)

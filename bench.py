@@ -527,7 +527,8 @@ def main():
   from spectralcluster_amd import _lib
   from spectralcluster_amd import multigpu
 
-  handle = _lib.default_handle(local_rank)
+  # (one rank per GPU; on a box with fewer GPUs than ranks -- a 1-GPU test box -- ranks share)
+  handle = _lib.default_handle(local_rank % max(1, _lib.device_count()))
   lib = handle.lib
   comm = multigpu.RcclComm.from_env(handle)  # RCCL (C ABI) for N > 1, identity for N = 1
   clusterer = sca.SpectralClusterer(

@@ -662,6 +662,20 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
         rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, width,
                                 lane_groups[l], rq);
     for (auto& t : side) t.join();
+    {  // member arenas that hold a large share of the device do not outlive the batch (the
+       // lanes keep up to 3 x 2 x 16 of them warm otherwise: 21 GB after config 5)
+      size_t free_b = 0, total_b = 0, held = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        for (int l = 0; l < lanes; ++l)
+          for (sc_handle sub : leads[l]->gslots) held += sub->A0.bytes + sub->B1.bytes + sub->B2.bytes;
+        if (held > total_b / 4)
+          for (int l = 0; l < lanes; ++l) {
+            for (sc_handle sub : leads[l]->gslots) sc_destroy(sub);
+            leads[l]->gslots.clear();
+            leads[l]->sweep_slot.clear();
+          }
+      }
+    }
     if (rcs[0] != SC_OK) return rcs[0];
     for (int l = 1; l < lanes; ++l)
       if (rcs[l] != SC_OK) return fail(h, rcs[l], leads[l]->err.c_str());

@@ -563,9 +563,26 @@ def hard_goldens(only_n=None, only_kinds=None):
           flush=True)
 
 
+def many_cluster_goldens():
+  """15. Eigengap decisions beyond 64 clusters (`max_clusters` > 64 AND more than 64 selected):
+  n = 1500 samples of 90 speakers, max_clusters = 120, ICASSP2018 refinement, laplacian None
+  and GraphCut.  Groundwork: the device path of round 3 raises UnsupportedOnDeviceError when
+  more than 64 clusters are SELECTED; these fixtures pin the oracle for
+  the day it does not (reference spectral_clusterer.py:29-46, utils.py:100-128)."""
+  for lap in (0, 4):
+    r = e2e_run(1500, 256, 90, 1590, lap, 120)
+    save("manyk_n1500_k90_lap%d_max120.npz" % lap, **r)
+    print("  lap=%d: n_clusters_raw=%d, distinct labels %d, %.1f s" % (
+        lap, int(r["n_clusters_raw"]), len(np.unique(r["labels"])), float(r["ref_seconds"])),
+          flush=True)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
+  if "--many-clusters" in sys.argv:  # only section 15
+    many_cluster_goldens()
+    return
   if "--hard" in sys.argv:  # only section 14 (optionally: --hard kind [kind ...])
     kinds = [a for a in sys.argv[sys.argv.index("--hard") + 1:] if a in so.HARD_KINDS]
     hard_goldens(only_kinds=kinds or None)

@@ -142,6 +142,25 @@ def test_e2e_small(name):
   assert dump["max_delta"] == float(g["max_delta"])
 
 
+@pytest.mark.parametrize("name", ["manyk_n1500_k90_lap0_max120.npz",
+                                  "manyk_n1500_k90_lap4_max120.npz"])
+def test_e2e_more_than_64_clusters(name):
+  """The reference selects 90 / 89 clusters here (max_clusters = 120); the oracle follows it
+  through the eigengap rule and the 90-centre k-means++ / cosine loop.  (The device path of
+  round 3 raises UnsupportedOnDeviceError past 64 selected clusters: these pin the checker for
+  the round that lifts it.)"""
+  g = golden(name)
+  n, d, k, seed, lap, max_clusters = [int(v) for v in g["params"]]
+  assert int(g["n_clusters_raw"]) > 64
+  cfg = so.icassp2018_config(laplacian_type=lap, max_clusters=max_clusters)
+  dump = {}
+  labels = so.predict(so.blobs(n, d, k, seed), cfg, dump)
+  assert dump["n_clusters"] == int(g["n_clusters_raw"])
+  assert np.array_equal(labels, g["labels"])
+  assert np.array_equal(dump["eigenvalues"][g["consumed_index"]], g["consumed_eigenvalues"])
+  assert dump["max_delta"] == float(g["max_delta"])
+
+
 def test_autotune_small():
   g = golden("autotune_n512.npz")
   x = so.blobs(512, 64, 6, 512)

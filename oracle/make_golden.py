@@ -577,11 +577,41 @@ def many_cluster_goldens():
           flush=True)
 
 
+def general_wide_golden():
+  """16. More than 32 eigenpairs of a genuinely non-symmetric refined matrix: [RowWiseThreshold
+  (Percentile)] + GraphCut as in section 8, n = 400 samples of 36 speakers, min_clusters = 40,
+  max_clusters = 48.
+  Groundwork: the device's general path of round 3 holds at most 32 eigenpairs for n > 64
+  (DESIGN.md section 6)."""
+  n, d, k, seed, maxc, p = 400, 32, 36, 1636, 48, 0.9
+  x = so.blobs(n, d, k, seed)
+  opts = ref_refinement.RefinementOptions(
+      p_percentile=p, thresholding_type=ref_refinement.ThresholdType.Percentile,
+      refinement_sequence=[ref_refinement.RefinementName.RowWiseThreshold])
+  minc = 40  # (the eigengap alone says 2 here; min_clusters makes 40 eigenVECTORS the embedding)
+  clusterer = ref_sc.SpectralClusterer(
+      min_clusters=minc, max_clusters=maxc, refinement_options=opts, laplacian_type=LAP[4],
+      row_wise_renorm=True)
+  with _Spy() as spy:
+    labels = clusterer.predict(x)
+  c = spy.calls[-1]
+  w = np.real(c["w"])
+  save("general_wide_n400.npz", params=np.array([n, d, k, seed, 4, maxc]),
+       min_clusters=np.int64(minc),
+       p_percentile=np.float64(p), head_eigenvalues=w[:maxc + 2],
+       n_clusters_raw=np.int64(c["k"]), max_delta=np.float64(c["delta"]), labels=labels)
+  print("  general wide: k=%d delta=%.6g distinct labels %d" % (
+      c["k"], c["delta"], len(np.unique(labels))), flush=True)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
   if "--many-clusters" in sys.argv:  # only section 15
     many_cluster_goldens()
+    return
+  if "--general-wide" in sys.argv:  # only section 16
+    general_wide_golden()
     return
   if "--hard" in sys.argv:  # only section 14 (optionally: --hard kind [kind ...])
     kinds = [a for a in sys.argv[sys.argv.index("--hard") + 1:] if a in so.HARD_KINDS]

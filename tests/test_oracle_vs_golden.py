@@ -273,6 +273,25 @@ def test_general_matrix_autotune_vs_reference(n):
   assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
 
 
+def test_general_matrix_more_than_32_eigenpairs():
+  """[RowWiseThreshold] + GraphCut with min_clusters = 40, max_clusters = 48: the reference
+  embeds in 40 eigenvectors of a non-symmetric matrix.  (Groundwork: the device's general path
+  of round 3 holds at most 32 eigenpairs for n > 64.)"""
+  g = golden("general_wide_n400.npz")
+  n, d, k, seed, lap, maxc = [int(v) for v in g["params"]]
+  cfg = so.OracleConfig(min_clusters=int(g["min_clusters"]), max_clusters=maxc,
+                        sequence=(so.OP_ROW_WISE_THRESHOLD,), p_percentile=float(g["p_percentile"]),
+                        threshold_type=so.THRESHOLD_PERCENTILE,
+                        laplacian_type=so.LAPLACIAN_GRAPH_CUT, row_wise_renorm=True)
+  dump = {}
+  labels = so.predict(so.blobs(n, d, k, seed), cfg, dump)
+  assert len(np.unique(labels)) == len(np.unique(g["labels"])) > 32
+  assert np.array_equal(labels, g["labels"])
+  np.testing.assert_allclose(dump["eigenvalues"][:maxc + 2], g["head_eigenvalues"], rtol=1e-9,
+                             atol=1e-12)
+  np.testing.assert_allclose(dump["max_delta"], float(g["max_delta"]), rtol=1e-9)
+
+
 def test_size_reduction_vs_reference():
   g = golden("size_reduction.npz")
   x = g["x_1000by6"]

@@ -40,6 +40,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the grouped batch (config 5) keeps nine streams busy: eight hardware queues instead of the
+# runtime's four.  Must be in the environment before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_SAMPLES, N_FEATURES, N_SPEAKERS, SEED = 8192, 256, 8, 0
 MAX_CLUSTERS = 20

@@ -213,7 +213,10 @@ int sc_config_default(sc_config* cfg);
 int sc_gaussian_weights(double sigma, int32_t* radius, double* weights);
 /* GaussianBlur with sigma > 8 (radius > SC_MAX_BLUR_RADIUS; refinement.py:154-162 has no
  * limit): its 2 * radius + 1 weights do not fit sc_config -- upload them once, they stay
- * resident in the handle, and a config with blur_radius == radius uses them. */
+ * resident in the handle, and a config with blur_radius == radius uses them.  Such a config
+ * carries the CENTRAL 2 * SC_MAX_BLUR_RADIUS + 1 weights (weights[radius - 32 .. radius + 32])
+ * in cfg->blur_weights: every call checks them against the resident ones, so two sigmas that
+ * share a radius cannot be confused (SC_ERR_UNSUPPORTED: upload again). */
 int sc_set_blur_weights(sc_handle h, int radius, const double* weights);
 
 /* ---- whole path ---------------------------------------------------------- */

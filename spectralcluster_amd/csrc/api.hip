@@ -168,19 +168,18 @@ extern "C" int sc_device_info(int device, char* name, int name_len, char* arch,
   return SC_OK;
 }
 
-// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by
-// default) and streams that share one run one after the other.  The grouped batch keeps nine
-// streams busy (three lanes: lockstep chains + two banks of fronts each) and picks them so that
-// they share as little as the runtime allows (independent_streams, batch_group.hip); with eight
-// queues only two fronts double up.  Config 5, utterances/s: 4 queues 3720-4160 from run to
-// run, 6: 3720-3970, 8: 4130-4260, 12 / 16 the same, 24: 3450.  (The older multi-stream form
-// of predict_batch, one arena and host thread per stream, likes it the other way: 2040 with 4
-// queues, 1820 with 8.)  Set when the library is loaded, i.e. before its first HIP call, and
-// only if the process has not chosen a value itself; a runtime that is already initialised keeps
-// what it has.
-__attribute__((constructor)) static void sc_default_hw_queues() {
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
-}
+// Hardware queues.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES
+// hardware queues (4 by default) and streams that share one run one after the other.  The grouped
+// batch keeps nine streams busy (three lanes: lockstep chains + two banks of fronts each) and
+// picks them so that they share as little as the runtime allows (independent_streams,
+// batch_group.hip); with eight queues only two fronts double up.  Config 5, utterances/s:
+// 4 queues 3720-4160 from run to run, 6: 3720-3970, 8: 4130-4260, 12 / 16 the same, 24: 3450.
+// (The older multi-stream form of predict_batch, one arena and host thread per stream, likes it
+// the other way: 2040 with 4 queues, 1820 with 8.)  The library does NOT touch the process
+// environment (rounds 2-3 set the variable from a load-time constructor: that changed the queue
+// configuration of every other HIP user of the process and depended on the import order): a
+// caller that wants the grouped batch at its best exports GPU_MAX_HW_QUEUES=8 before the first
+// HIP call of the process -- bench.py does, INTEGRATION.md section 4 says so.
 
 extern "C" int sc_create(int device, sc_handle* out) {
   if (!out) return SC_ERR_INVALID;
@@ -471,10 +470,18 @@ int validate_config(sc_handle h, const sc_config* cfg) {
     if (cfg->ops[i] < SC_OP_CROP_DIAGONAL || cfg->ops[i] > SC_OP_ROW_WISE_NORMALIZE)
       return fail(h, SC_ERR_INVALID, "Unknown refinement operation");
   if (cfg->blur_radius < 0) return fail(h, SC_ERR_INVALID, "gaussian blur radius < 0");
-  if (cfg->blur_radius > SC_MAX_BLUR_RADIUS &&
-      (!h || (int)h->blur_ext.size() != 2 * cfg->blur_radius + 1))
-    return fail(h, SC_ERR_UNSUPPORTED,
-                "gaussian blur radius > 32: upload its weights with sc_set_blur_weights first");
+  if (cfg->blur_radius > SC_MAX_BLUR_RADIUS) {
+    if (!h || (int)h->blur_ext.size() != 2 * cfg->blur_radius + 1)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "gaussian blur radius > 32: upload its weights with sc_set_blur_weights first");
+    // the radius travels in the config, the weights live in the handle: the config names WHICH
+    // weights it means by their central 2 * 32 + 1 entries (two sigmas can share a radius)
+    const double* centre = h->blur_ext.data() + (cfg->blur_radius - SC_MAX_BLUR_RADIUS);
+    if (memcmp(centre, cfg->blur_weights, (2 * SC_MAX_BLUR_RADIUS + 1) * sizeof(double)) != 0)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "gaussian blur radius > 32: the weights resident in the handle are not the "
+                  "ones this config was built with (sc_set_blur_weights them again)");
+  }
   if (cfg->laplacian_type < SC_LAPLACIAN_NONE || cfg->laplacian_type > SC_LAPLACIAN_GRAPH_CUT)
     return fail(h, SC_ERR_INVALID, "laplacian_type must be a LaplacianType");
   if (cfg->eigengap_type != SC_EIGENGAP_RATIO &&

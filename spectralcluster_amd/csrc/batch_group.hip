@@ -574,6 +574,9 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
   SC_TRY(validate_config(h, cfg));
   SC_HIP(h, hipSetDevice(h->device));
   group = std::max(1, std::min(group, kGroupMax));
+  // the batch reuses the member arenas a sweep may have left eigenvectors in
+  h->sweep_slot.clear();
+  for (sc_handle lane : h->glanes) lane->sweep_slot.clear();
   const EigRequest rq = make_eig_request(cfg);
   const bool cfg_ok = group > 1 && cfg->kmeans_metric == kKmeansCosine &&
                       !constraint_active(h, cfg, true) && !constraint_active(h, cfg, false);
@@ -705,6 +708,9 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
   SC_HIP(h, hipSetDevice(h->device));
   const int n = h->n, ld = h->ldn;
   const EigRequest rq = make_eig_request(cfg);
+  // whatever an earlier sweep left in the member arenas is no longer adoptable (a sweep that
+  // takes the one-by-one route below leaves no eigenvectors there at all)
+  h->sweep_slot.clear();
   auto one_by_one = [&](int i) -> int {
     sc_config c = *cfg;
     c.p_percentile = p_values[i];

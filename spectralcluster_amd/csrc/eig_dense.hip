@@ -583,13 +583,9 @@ void launch_td_backtransform(hipStream_t s, const double* A, int ld, int n, cons
   if (cols <= 0) return;
   if (n <= kTdLdsRows) {
     const size_t lds = (size_t)n * sizeof(double);
-    static bool raised = false;
-    if (!raised) {  // above the 64 KB default of dynamic LDS
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_td_backtransform<true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                          kTdLdsRows * (int)sizeof(double));
-      raised = true;
-    }
+    // above the 64 KB default of dynamic LDS: opt in once per device (handles of several
+    // devices / host threads share the process)
+    SC_OPT_IN_LDS(&k_td_backtransform<true>, kTdLdsRows * (int)sizeof(double));
     hipLaunchKernelGGL(k_td_backtransform<true>, dim3(cols), dim3(1024), lds, s, A, ld, n, taus,
                        Z, ldz);
   } else {

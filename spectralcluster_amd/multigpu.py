@@ -461,6 +461,13 @@ def predict_batch_sharded(
   return out
 
 
+def sweep_owner(index: int, world: int) -> int:
+  """Rank that evaluates grid[index] of an AutoTune level: the ONE dealing rule
+  (`autotune_sharded` deals by it, `predict_autotune_distributed` finds the winner's rank by
+  it)."""
+  return index % world
+
+
 def autotune_sharded(
     comm: Comm,
     evaluate_fn: typing.Optional[typing.Callable[[float], typing.Tuple[float, int]]],
@@ -474,7 +481,7 @@ def autotune_sharded(
   world, rank = comm.size, comm.rank
   per = (len(grid) + world - 1) // world
   mine = np.full((per, 2), np.nan)
-  share = [float(grid[i]) for i in range(rank, len(grid), world)]
+  share = [float(grid[i]) for i in range(len(grid)) if sweep_owner(i, world) == rank]
   if evaluate_share_fn is not None:
     results = evaluate_share_fn(share) if share else []
   else:
@@ -487,7 +494,7 @@ def autotune_sharded(
   ks = np.zeros(len(grid), dtype=np.int64)
   for r in range(world):
     block = np.frombuffer(blocks[r], dtype=np.float64).reshape(per, 2)
-    for s, i in enumerate(range(r, len(grid), world)):
+    for s, i in enumerate(i for i in range(len(grid)) if sweep_owner(i, world) == r):
       ratios[i] = block[s, 0]
       ks[i] = int(block[s, 1])
   return ratios, ks
@@ -585,7 +592,7 @@ def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
     return finish()  # (a winner from an earlier level: every rank re-evaluates it)
   # The rank that evaluated the winner still holds its eigenvectors: it alone runs k-means and
   # broadcasts n int32 labels; the other ranks neither refine nor solve again.
-  owner = last_level.index(float(best_p)) % comm.size
+  owner = sweep_owner(last_level.index(float(best_p)), comm.size)
   payload, error = None, None
   if comm.rank == owner:
     try:
@@ -593,6 +600,10 @@ def predict_autotune_distributed(comm: Comm, clusterer, embeddings: np.ndarray,
     except Exception as exc:  # pylint: disable=broad-except
       error, payload = exc, np.full(n, -2, dtype=np.int32).tobytes()  # the others must not hang
   labels = np.frombuffer(comm.broadcast_bytes(payload, n * 4, root=owner), dtype=np.int32)
+  if comm.rank != owner:
+    # this rank's resident eigenvectors / diagnostics belong to its own share of the sweep,
+    # not to the winner: do not leave them looking like the result
+    clusterer.last_diag = None
   if error is not None:
     raise error
   if n and labels[0] == -2:

@@ -69,6 +69,9 @@ def fill_config(cfg: _lib.ScConfig, *, sigma=1, p_percentile=0.95, multiplier=0.
       # sigma > 8: the weights do not fit `sc_config`; they travel to the handle on their own
       # (`_lib.sync_blur_weights`, called wherever this config meets a handle)
       cfg._blur_ext = np.ascontiguousarray(w, dtype=np.float64)
+      # ... and the config names them by their central 65 entries (checked on every call)
+      for i in range(2 * _lib.SC_MAX_BLUR_RADIUS + 1):
+        cfg.blur_weights[i] = float(w[radius - _lib.SC_MAX_BLUR_RADIUS + i])
     else:
       for i, v in enumerate(w):
         cfg.blur_weights[i] = float(v)

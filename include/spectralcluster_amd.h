@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 4
+#define SC_ABI_VERSION 5
 #define SC_MAX_OPS 16
 #define SC_MAX_BLUR_RADIUS 32
 #define SC_MAX_EIG 128 /* max eigenvalues reported in sc_diag */
@@ -116,7 +116,24 @@ enum {
   SC_STAGE_BLUR = 7,           /* CropDiagonal + GaussianBlur kernel */
   SC_STAGE_THRESHOLD_SYM = 8,  /* RowWiseThreshold + Symmetrize kernel */
   SC_STAGE_MATVEC = 9,         /* sum over the block matvec launches of the eigen stage */
-  SC_STAGE_AFFINITY_GEMM = 10  /* the affinity GEMM launch alone */
+  SC_STAGE_AFFINITY_GEMM = 10, /* the affinity GEMM launch alone */
+  /* matrix-free Diffuse (sc_diag.diffuse_path == SC_DIFFUSE_PATH_FREE); their sum is
+   * SC_STAGE_DIFFUSE of such a call */
+  SC_STAGE_FREE_QUANTIZE = 11, /* max|a| + 8-bit digits of A, rowsum(A) */
+  SC_STAGE_FREE_PRODUCT = 12,  /* exact integer MFMA product of the digits */
+  SC_STAGE_FREE_SCAN = 13,     /* row maxima + candidates within the proven slack */
+  SC_STAGE_FREE_STATS = 14     /* exact fp64 rowmax(S) of the candidates, rowsum(S) */
+};
+
+/* How the last Diffuse (refinement.py:229-234) of the sequence ran (sc_diag.diffuse_path) */
+enum {
+  SC_DIFFUSE_PATH_NONE = 0,
+  SC_DIFFUSE_PATH_EXPLICIT = 1,           /* S = A A^T by the fp64 MFMA GEMM */
+  /* S never formed: rowmax(S) by the digit product + exact recheck, S V = A (A V) */
+  SC_DIFFUSE_PATH_FREE = 2,
+  /* started matrix-free, S formed after all (a dense eigen route read entries, or more rows
+   * than the exact-row route takes had to be evaluated in full) */
+  SC_DIFFUSE_PATH_FREE_THEN_EXPLICIT = 3
 };
 
 /*
@@ -158,7 +175,11 @@ typedef struct sc_config {
   int32_t integration_type;      /* SC_INTEGRATION_* */
   double constraint_alpha;       /* constraint_propagation_alpha (0.6) */
   int32_t kmeans_metric;         /* SC_KMEANS_* (custom_dist, spectral_clusterer.py:38) */
-  int32_t reserved[5];
+  /* Route of a Diffuse that only feeds RowWiseNormalize / the Laplacian (no reference
+   * equivalent; see sc_set_diffuse_mode): 0 = the handle's / process default, 1 = explicit fp64
+   * product, 2 = matrix-free wherever the sequence allows it */
+  int32_t diffuse_mode;
+  int32_t reserved[4];
 } sc_config;
 
 typedef struct sc_diag {
@@ -183,6 +204,10 @@ typedef struct sc_diag {
                                     1 restart budget spent, 2 projected eigenproblem failed,
                                     3 no full-rank Krylov block, 4 forced (SC_EIG_FORCE_DENSE) */
   float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */
+  int32_t diffuse_path;          /* SC_DIFFUSE_PATH_* */
+  int32_t free_candidates;       /* matrix-free Diffuse: exact dot products evaluated (n + few) */
+  int32_t free_overflow_rows;    /* ... rows evaluated in full (more candidates than the cap) */
+  int32_t reserved_diag;
 } sc_diag;
 
 /* ---- library / device ---------------------------------------------------- */
@@ -205,6 +230,15 @@ int sc_synchronize(sc_handle h);
 /* hipEvent timers in sc_diag.stage_ms: 1 (default) = one pair per stage, 2 = additionally
  * around the individual hot kernels (bench.py's per-kernel roofline list) */
 int sc_set_profiling(sc_handle h, int level);
+/* Route of a Diffuse (refinement.py:229-234) that is followed only by RowWiseNormalize and the
+ * Laplacian -- the ICASSP2018 sequence.  0 (default): matrix-free from n = 2048 on (S = A A^T is
+ * never formed: rowmax(S) from an exact 8-bit-digit integer MFMA product + fp64 recheck of the
+ * candidates within a proven slack, the eigensolver applies A twice); 1: always the explicit
+ * fp64 MFMA product; 2: matrix-free wherever the sequence allows it (n > 128); -1: back to
+ * the process default (environment SC_DIFFUSE=explicit|free|auto, SC_DIFFUSE_FREE_MIN_N).
+ * Both routes return the same rowmax / rowsum to summation order; sc_diag.diffuse_path says
+ * which one ran. */
+int sc_set_diffuse_mode(sc_handle h, int mode);
 
 /* fills cfg with the reference defaults (refinement.py:76-100,
  * spectral_clusterer.py:29-46): no ops, sigma 1 weights, p .95, mult .01 ... */
@@ -358,6 +392,13 @@ int sc_stage_refine(sc_handle h, int op, const sc_config* cfg, const double* in,
  * and its options are read from cfg.  Any square affinity / constraint matrix. */
 int sc_stage_constraint(sc_handle h, const sc_config* cfg, const double* affinity,
                         const double* constraint_matrix, int n, double* out);
+/* rowmax / rowsum of Diffuse(a) = a a^T (refinement.py:232-234) for a SYMMETRIC (n, n) input --
+ * what RowWiseNormalize (refinement.py:240-245) and the Laplacian degree (laplacian.py:41) read
+ * of it -- by either route: mode 1 the explicit fp64 product, mode 2 the matrix-free search
+ * (n <= 65536).  info (4 ints, may be NULL): candidates evaluated exactly, rows over the
+ * candidate cap (evaluated in full), largest candidate count of a row, 1 if S was formed after all. */
+int sc_stage_diffuse_rowstats(sc_handle h, const double* a, int n, int mode, double* rowmax,
+                              double* rowsum, int32_t* info);
 /* laplacian.compute_laplacian (laplacian.py:24-60) */
 int sc_stage_laplacian(sc_handle h, int laplacian_type, const double* in, int n,
                        double* out);

@@ -27,7 +27,10 @@ SC_ERR_UNSUPPORTED = -5
 SC_ERR_NON_FINITE = -6
 
 STAGE_NAMES = ("affinity", "refine", "diffuse", "scaling", "eig", "kmeans",
-               "total", "blur", "threshold_sym", "matvec", "affinity_gemm")
+               "total", "blur", "threshold_sym", "matvec", "affinity_gemm",
+               "free_quantize", "free_product", "free_scan", "free_stats")
+
+DIFFUSE_PATH_NONE, DIFFUSE_PATH_EXPLICIT, DIFFUSE_PATH_FREE, DIFFUSE_PATH_FREE_THEN_EXPLICIT = range(4)
 
 _LIB_NAME = "libspectralcluster_amd.so"
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
@@ -45,7 +48,7 @@ class EigenSolverNotConverged(RuntimeError):
   """The block-Lanczos eigensolver did not reach its tolerance."""
 
 
-SC_ABI_VERSION = 4
+SC_ABI_VERSION = 5
 
 
 class ScConfig(ctypes.Structure):
@@ -76,7 +79,8 @@ class ScConfig(ctypes.Structure):
       ("integration_type", ctypes.c_int32),
       ("constraint_alpha", ctypes.c_double),
       ("kmeans_metric", ctypes.c_int32),
-      ("reserved", ctypes.c_int32 * 5),
+      ("diffuse_mode", ctypes.c_int32),
+      ("reserved", ctypes.c_int32 * 4),
   ]
 
 
@@ -101,6 +105,10 @@ class ScDiag(ctypes.Structure):
       ("eig_host_chain", ctypes.c_int32),
       ("eig_fallback", ctypes.c_int32),
       ("stage_ms", ctypes.c_float * SC_MAX_STAGES),
+      ("diffuse_path", ctypes.c_int32),
+      ("free_candidates", ctypes.c_int32),
+      ("free_overflow_rows", ctypes.c_int32),
+      ("reserved_diag", ctypes.c_int32),
   ]
 
   def eigenvalue_array(self) -> np.ndarray:
@@ -130,6 +138,10 @@ PROTOTYPES = {
     "sc_last_error": (ctypes.c_char_p, [_handle_t]),
     "sc_synchronize": (ctypes.c_int, [_handle_t]),
     "sc_set_profiling": (ctypes.c_int, [_handle_t, ctypes.c_int]),
+    "sc_set_diffuse_mode": (ctypes.c_int, [_handle_t, ctypes.c_int]),
+    "sc_stage_diffuse_rowstats": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
+                                                 ctypes.c_int, _c_double_p, _c_double_p,
+                                                 ctypes.POINTER(ctypes.c_int32)]),
     "sc_config_default": (ctypes.c_int, [ctypes.POINTER(ScConfig)]),
     "sc_gaussian_weights": (ctypes.c_int, [ctypes.c_double,
                                            ctypes.POINTER(ctypes.c_int32),

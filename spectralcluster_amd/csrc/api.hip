@@ -232,13 +232,15 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->Hbuf,  &h->hsq,   &h->colnorm, &h->flags,  &h->E,     &h->Ek,   &h->Eio,
                     &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->td_tau, &h->td_panel, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
-                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd, &h->gpack, &h->gypack, &h->ginfo, &h->glabels};
+                    &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd, &h->gpack, &h->gypack, &h->ginfo, &h->glabels,
+                    &h->fq, &h->ft32, &h->fy1, &h->fR, &h->fscal, &h->fwords, &h->fcand, &h->fY};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);
   if (h->h_theta) hipHostFree(h->h_theta);
   if (h->h_flags) hipHostFree(h->h_flags);
   if (h->h_rr) hipHostFree(h->h_rr);
+  if (h->h_free) hipHostFree(h->h_free);
   if (h->sync_ev) hipEventDestroy(h->sync_ev);
   for (int b = 0; b < kGroupBanks; ++b) {
     if (h->gbank_ev[b]) hipEventDestroy(h->gbank_ev[b]);
@@ -665,6 +667,12 @@ static void resolve_stage_times(sc_handle h, sc_diag* diag) {
   diag->stage_ms[SC_STAGE_REFINE] = ev_ms(h, t.begin, t.after_refine) - dms;
   diag->stage_ms[SC_STAGE_SCALING] = ev_ms(h, t.after_refine, t.after_scaling);
   diag->stage_ms[SC_STAGE_EIG] = ev_ms(h, t.after_scaling, t.after_eig);
+  if (t.free_path) {
+    diag->stage_ms[SC_STAGE_FREE_QUANTIZE] = ev_ms(h, h->free_ev[0], h->free_ev[1]);
+    diag->stage_ms[SC_STAGE_FREE_PRODUCT] = ev_ms(h, h->free_ev[1], h->free_ev[2]);
+    diag->stage_ms[SC_STAGE_FREE_SCAN] = ev_ms(h, h->free_ev[2], h->free_ev[3]);
+    diag->stage_ms[SC_STAGE_FREE_STATS] = ev_ms(h, h->free_ev[3], h->free_ev[4]);
+  }
   if (t.fine) {
     diag->stage_ms[SC_STAGE_BLUR] = ev_ms(h, t.blur[0], t.blur[1]);
     diag->stage_ms[SC_STAGE_THRESHOLD_SYM] = ev_ms(h, t.thr[0], t.thr[1]);
@@ -690,6 +698,8 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   const bool fine = h->profile_level >= 2;
   int eb0 = -1, eb1 = -1, et0 = -1, et1 = -1;  // blur / threshold+symmetrize (last of each)
   h->n_mv_ev = 0;
+  h->free_on = false;
+  bool free_path = false;
   float diffuse_ms_events[SC_MAX_OPS][2];
   int n_diffuse = 0;
   ev_rec(h, &e_begin);
@@ -732,6 +742,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
     double* out = bufs[which];
     which ^= 1;
     int e0 = -1, e1 = -1;
+    bool keep_cur = false;
     if (op == SC_OP_DIFFUSE) ev_rec(h, &e0);
     if (op == SC_OP_GAUSSIAN_BLUR && blur_fast) {
       const bool want = next == SC_OP_ROW_WISE_THRESHOLD && next2 == SC_OP_SYMMETRIZE &&
@@ -766,6 +777,23 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
       symmetric = true;
       ++i;  // Symmetrize consumed
       continue;
+    } else if (op == SC_OP_DIFFUSE && symmetric && !constrain_after && !front_only &&
+               cur != ptr<double>(h->A0) &&
+               (i == cfg->n_ops - 1 || (i == cfg->n_ops - 2 && next == SC_OP_ROW_WISE_NORMALIZE)) &&
+               free_diffuse_wanted(h, cfg, n, make_eig_request(cfg))) {
+      // Matrix-free Diffuse (free_api.hip): nothing after this op reads an entry of
+      // S = A A^T -- only rowmax(S) (the RowWiseNormalize fold), rowsum(S) (the Laplacian) and
+      // S V (the eigensolver).  `cur` stays the symmetric A; `out` stays free.
+      SC_TRY(ensure_eig(h, n));
+      SC_TRY(free_diffuse_stats(h, cur, ld, n));
+      h->free_on = true;
+      h->free_lap = cfg->laplacian_type;
+      h->free_rownorm = next == SC_OP_ROW_WISE_NORMALIZE ? 1 : 0;
+      free_path = true;
+      have_row_stats = true;
+      have_partials = false;
+      keep_cur = true;
+      which ^= 1;
     } else if (op == SC_OP_DIFFUSE) {
       // when Diffuse is the last materialised matrix its row max / row sum (for the
       // RowWiseNormalize fold and the Laplacian scaling) come out of the GEMM epilogue
@@ -789,7 +817,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
       diffuse_ms_events[n_diffuse][1] = (float)e1;
       ++n_diffuse;
     }
-    cur = out;
+    if (!keep_cur) cur = out;
     switch (op) {
       case SC_OP_CROP_DIAGONAL:
       case SC_OP_GAUSSIAN_BLUR:
@@ -891,6 +919,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
     diag->n_eigenvalues = std::min((int)w.size(), SC_MAX_EIG);
     for (int i = 0; i < diag->n_eigenvalues; ++i) diag->eigenvalues[i] = w[i];
     diag->symmetry_state = !symmetric ? 3 : (folded_rownorm ? 2 : 1);
+    if (!free_path && n_diffuse > 0) diag->diffuse_path = SC_DIFFUSE_PATH_EXPLICIT;
   }
   StageEvents& t = h->stage_events;
   t.pending = true;
@@ -904,6 +933,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
     t.diffuse[i][1] = (int)diffuse_ms_events[i][1];
   }
   t.fine = fine;
+  t.free_path = free_path;
   t.blur[0] = eb0;
   t.blur[1] = eb1;
   t.thr[0] = et0;

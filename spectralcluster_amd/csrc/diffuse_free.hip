@@ -1,0 +1,547 @@
+// Matrix-free Diffuse (reference refinement.py:229-245 Diffuse + RowWiseNormalize, and
+// laplacian.py:41-58 on top of them) -- DESIGN.md section 3.11.
+//
+// For a sequence whose Diffuse is followed only by RowWiseNormalize (+ a Laplacian) the eigen
+// stage never reads an ENTRY of S = A A^T.  It needs
+//     S V            = A (A V)            two passes over A per Krylov block,
+//     rowsum(S)      = A (A 1)            one n-vector pass,
+//     rowmax(S)_i    = max_j <A_i, A_j>   the one quantity that is not a matrix-vector product.
+// rowmax(S) is found without the fp64 n^3 product:
+//   1. k_free_quantize   A -> 15-bit fixed point q = rint(sigma a), sigma = 32639 / max|a|, split
+//                        into two signed 8-bit digits q = 256 h + l;
+//   2. k_gemm_i8_sym     T = Q Q^T EXACTLY (integer MFMA, v_mfma_i32_32x32x32_i8: hh, hl + lh and
+//                        ll products in three i32 accumulators), upper-triangle tiles, stored as
+//                        fp32;
+//   3. k_t32_rowmax / k_t32_candidates   row maxima M_i of T and every j with
+//                        T_ij >= M_i - slack_i, where slack_i is a PROVEN bound: with
+//                        sigma a_ik = q_ik + d_ik, |d_ik| <= 1/2 (+ one fp64 rounding),
+//                        sigma^2 S_ij - T_ij = sum_k (q_ik d_jk + d_ik q_jk + d_ik d_jk), so
+//                        |sigma^2 S_ij - T_ij| <= (R_i + R_j) / 2 + n / 4,  R_i = sum_k |q_ik|;
+//                        hence the true argmax j* of row i satisfies
+//                        T_ij* >= M_i - (R_i + Rmax) - n / 2 - (fp32 rounding of the two T's);
+//   4. k_free_row_stats  exact fp64 dot products <A_i, A_j> for the (1-3) candidates of a row:
+//                        rowmax(S)_i; and rowsum(S)_i = <A_i, A 1> in the same pass over A_i.
+// Rows with more candidates than kFreeCap (a handful of samples far from everything: their row
+// of S is tiny against the slack) are evaluated exactly, eight at a time, as one block matvec
+// S[:, rows] = A (A[rows, :]^T) (free_api.hip).
+//
+// Integer arithmetic makes the bound a statement about the QUANTISER alone: no assumption
+// about the accumulation order or internal precision of the matrix core enters it.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "sc_internal.h"
+
+namespace sc {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ double fr_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double fr_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// 256-thread workgroups; sm: >= 4 doubles
+__device__ __forceinline__ double fr_block_max(double v, double* sm) {
+  v = fr_wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+__device__ __forceinline__ double fr_block_sum(double v, double* sm) {
+  v = fr_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// order-preserving map float -> unsigned (for atomicMax on values of either sign)
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_value(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// tile slot s of the row-major upper-triangle enumeration -> (I, J), J >= I
+__device__ __forceinline__ void slot_to_tile(int slot, int nt, int* I, int* J) {
+  const double b2 = 2.0 * nt + 1.0;
+  int ti = (int)((b2 - sqrt(b2 * b2 - 8.0 * slot)) * 0.5);
+  ti = ti < 0 ? 0 : (ti >= nt ? nt - 1 : ti);
+  auto off = [&](int t) { return t * nt - (t * (t - 1)) / 2; };
+  while (ti > 0 && off(ti) > slot) --ti;
+  while (ti + 1 < nt && off(ti + 1) <= slot) ++ti;
+  *I = ti;
+  *J = ti + (slot - off(ti));
+}
+__device__ __forceinline__ int tile_to_slot(int I, int J, int nt) {
+  return I * nt - I * (I - 1) / 2 + (J - I);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- scale
+// scal[0] = max |a_ij| (bit pattern of a non-negative double: ordered like an unsigned integer)
+__global__ __launch_bounds__(256) void k_free_absmax(const double* __restrict__ A, int n, int ld,
+                                                     unsigned long long* __restrict__ amax_bits) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const double* x = A + (size_t)row * ld;
+  double m = 0.0;
+  for (int j = 2 * threadIdx.x; j < n; j += 512) {
+    const double2 v = *reinterpret_cast<const double2*>(x + j);
+    m = fmax(m, fabs(v.x));
+    if (j + 1 < n) m = fmax(m, fabs(v.y));
+  }
+  m = fr_block_max(m, sm);
+  if (threadIdx.x == 0 && m > 0.0) atomicMax(amax_bits, (unsigned long long)__double_as_longlong(m));
+}
+
+// ---------------------------------------------------------------- quantiser
+// Row `row` of A -> digits.  Layout of Q: row pitch 2 Kp bytes (Kp = n rounded up to 64); the
+// 64 k's of block b live in one 128-byte line: bytes [0, 64) the high digits, [64, 128) the low
+// digits -- a K stage of the GEMM reads whole lines.  Rows >= n and columns >= n are zero.
+// Also y1 = rowsum(A) (fp64, fixed order), R = sum |q| and its maximum.
+__global__ __launch_bounds__(256) void k_free_quantize(
+    const double* __restrict__ A, int n, int ld, signed char* __restrict__ Q, size_t pitch, int Kp,
+    const double* __restrict__ scal, double* __restrict__ y1, double* __restrict__ R,
+    unsigned long long* __restrict__ rmax_bits) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  signed char* qrow = Q + (size_t)row * pitch;
+  if (row >= n) {
+    for (int u = threadIdx.x; u < (int)(pitch / 16); u += 256)
+      reinterpret_cast<int4*>(qrow)[u] = make_int4(0, 0, 0, 0);
+    return;
+  }
+  const double amax = scal[0];
+  const double sigma = (amax > 0.0 && isfinite(amax)) ? 32639.0 / amax : 0.0;
+  const double* x = A + (size_t)row * ld;
+  double sum = 0.0, rsum = 0.0;
+  for (int u = threadIdx.x; u < Kp / 16; u += 256) {
+    const int k0 = 16 * u;
+    union { signed char b[16]; int4 v; } hb, lb;
+#pragma unroll
+    for (int t2 = 0; t2 < 8; ++t2) {
+      const int k = k0 + 2 * t2;
+      // rows are padded to ld (a multiple of 16 doubles): the load stays inside the row
+      double2 v = k < ld ? *reinterpret_cast<const double2*>(x + k) : make_double2(0.0, 0.0);
+      if (k >= n) v.x = 0.0;
+      if (k + 1 >= n) v.y = 0.0;
+      sum += v.x;
+      sum += v.y;
+      const double e[2] = {v.x, v.y};
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        double qd = rint(e[w] * sigma);
+        qd = fmin(fmax(qd, -32639.0), 32639.0);  // (NaN -> -32639: such a row is flagged later)
+        const int q = (int)qd;
+        const int h = (q + 128) >> 8;             // floor((q + 128) / 256): l in [-128, 127]
+        const int l = q - (h << 8);
+        rsum += (double)(q < 0 ? -q : q);
+        hb.b[2 * t2 + w] = (signed char)h;
+        lb.b[2 * t2 + w] = (signed char)l;
+      }
+    }
+    signed char* dst = qrow + (size_t)(k0 >> 6) * 128 + (k0 & 63);
+    *reinterpret_cast<int4*>(dst) = hb.v;
+    *reinterpret_cast<int4*>(dst + 64) = lb.v;
+  }
+  sum = fr_block_sum(sum, sm);
+  rsum = fr_block_sum(rsum, sm);
+  if (threadIdx.x == 0) {
+    y1[row] = sum;
+    R[row] = rsum;
+    atomicMax(rmax_bits, (unsigned long long)__double_as_longlong(rsum));
+  }
+}
+
+// ---------------------------------------------------------------- T = Q Q^T, integer MFMA
+// One workgroup (8 waves) = one 128 x 128 tile (I, J), J >= I, of T; wave (wr, wc) owns the
+// 32 x 64 block at (32 wr, 64 wc): two 32 x 32 MFMA blocks, three i32 accumulators each
+// (hh | hl + lh | ll), T = 65536 hh + 256 (hl + lh) + ll.
+//
+// K loop: stages of 64 k.  A stage of an operand tile is 128 rows x 128 B (one line per row:
+// 64 high digits, 64 low digits) = 16 KB; A tile + B tile = 32 KB; three stage buffers (96 KB)
+// filled by global_load_lds_dwordx4 (LDS-DMA, no staging registers) two stages ahead: per stage
+// a wave waits for its own four DMA instructions of THAT stage (vmcnt(4): the next stage's four
+// stay in flight), one s_barrier makes every wave's pieces visible and retires the buffer read
+// two stages ago, the DMA of stage + 2 is issued into it, then 12 ds_read_b128 feed 16 MFMAs.
+// LDS image: 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) -- the DMA
+// writes lane-linear, so the permutation is applied to the SOURCE address; with it every
+// 16-lane group of a ds_read_b128 (same chunk, 16 rows) covers all 64 banks.
+constexpr int kI8Threads = 512;
+constexpr int kI8Tile = 128;
+constexpr int kI8StageBytes = 32768;
+constexpr int kI8Buffers = 3;
+
+__device__ __forceinline__ void glds16(const signed char* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),
+                                   (__attribute__((address_space(3))) void*)(l), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
+    const signed char* __restrict__ Q, size_t pitch, int nstages, const int2* __restrict__ tilemap,
+    int xcd_chunk, float* __restrict__ T32, int nt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int tile = blockIdx.x;
+  // XCD-aware order (workgroup ids go round-robin over the 8 XCDs, each with its own L2): XCD x
+  // walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the patch-ordered tile list
+  if (xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
+  const int2 tij = tilemap[tile];
+  const int I = tij.x, J = tij.y;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // ---- DMA sources: instruction q of wave w fills LDS units [q * 512 + w * 64, + 64) of the
+  // stage image [A tile | B tile]; unit e = row * 8 + stored chunk
+  const int sr = 8 * w + (lane >> 3);
+  const int cx = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);
+  const signed char* gA0 = Q + (size_t)(I * kI8Tile + sr) * pitch + 16 * cx;
+  const signed char* gA1 = gA0 + (size_t)64 * pitch;
+  const signed char* gB0 = Q + (size_t)(J * kI8Tile + sr) * pitch + 16 * cx;
+  const signed char* gB1 = gB0 + (size_t)64 * pitch;
+  auto issue = [&](int stage, int buf) {
+    unsigned char* base = lds + buf * kI8StageBytes + w * 1024;
+    const size_t off = (size_t)stage * 128;
+    glds16(gA0 + off, base);
+    glds16(gA1 + off, base + 8192);
+    glds16(gB0 + off, base + 16384);
+    glds16(gB1 + off, base + 24576);
+  };
+  // ---- fragment addresses: lane (rr, g) reads row rr of its 32-row block, logical chunk
+  // 4 digit + 2 step + g, stored at that ^ ((rr >> 1) & 7)
+  const int rr = lane & 31, g = lane >> 5;
+  const int y = g ^ ((rr >> 1) & 7);
+  const int wr = w >> 1, wc = w & 1;
+  const int aoff = (32 * wr + rr) * 128;
+  const int boff = 16384 + (64 * wc + rr) * 128;
+  int coff[2][2];
+#pragma unroll
+  for (int dg = 0; dg < 2; ++dg)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) coff[dg][s] = 16 * ((4 * dg + 2 * s) ^ y);
+
+  v16i hh[2], mid[2], ll[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      hh[cb][r] = 0;
+      mid[cb][r] = 0;
+      ll[cb][r] = 0;
+    }
+  }
+  issue(0, 0);
+  if (nstages > 1) issue(1, 1);
+  int buf = 0;
+  for (int st = 0; st < nstages; ++st) {
+    if (st + 1 < nstages)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 2 < nstages) issue(st + 2, buf >= 1 ? buf - 1 : 2);  // (st + 2) % 3
+    const unsigned char* sb = lds + buf * kI8StageBytes;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const v4i ah = *reinterpret_cast<const v4i*>(sb + aoff + coff[0][s]);
+      const v4i al = *reinterpret_cast<const v4i*>(sb + aoff + coff[1][s]);
+      v4i bh[2], bl[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        bh[cb] = *reinterpret_cast<const v4i*>(sb + boff + cb * 4096 + coff[0][s]);
+        bl[cb] = *reinterpret_cast<const v4i*>(sb + boff + cb * 4096 + coff[1][s]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) hh[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, bh[cb], hh[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) mid[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, bl[cb], mid[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) ll[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, bl[cb], ll[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) mid[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, bh[cb], mid[cb], 0, 0, 0);
+    }
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  // ---- epilogue: T = 65536 hh + 256 mid + ll, exact in fp64 (|T| < 2^53), stored as fp32 into
+  // the tile's slot (tile-major, row-major inside).  D layout of the 32 x 32 block: lane l,
+  // register r: row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
+  float* out = T32 + (size_t)tile_to_slot(I, J, nt) * (kI8Tile * kI8Tile);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int col = 64 * wc + 32 * cb + rr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * g;
+      const double t = (double)hh[cb][r] * 65536.0 + (double)mid[cb][r] * 256.0 + (double)ll[cb][r];
+      out[row * kI8Tile + col] = (float)t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- scans of T
+// One workgroup per stored tile (I, J).  Phase A: the tile's rows (rows I*128.. of T, columns
+// J*128..).  Phase B (J > I): its columns, which are rows J*128.. of the symmetric T.
+// M holds ordered_bits() of the row maxima (0 = nothing yet).
+__global__ __launch_bounds__(256) void k_t32_rowmax(const float* __restrict__ T32, int nt, int n,
+                                                    unsigned* __restrict__ M) {
+  __shared__ float colpart[2][128];
+  int I, J;
+  slot_to_tile(blockIdx.x, nt, &I, &J);
+  const float* tile = T32 + (size_t)blockIdx.x * (kI8Tile * kI8Tile);
+  const int r0 = I * kI8Tile, c0 = J * kI8Tile;
+  {  // phase A: thread (row = t >> 1, half = t & 1) scans 64 columns
+    const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
+    float m = -INFINITY;
+    const float4* src = reinterpret_cast<const float4*>(tile + r * kI8Tile + 64 * half);
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+      const float4 v = src[q];
+      const int c = c0 + 64 * half + 4 * q;
+      if (c < n) m = fmaxf(m, v.x);
+      if (c + 1 < n) m = fmaxf(m, v.y);
+      if (c + 2 < n) m = fmaxf(m, v.z);
+      if (c + 3 < n) m = fmaxf(m, v.w);
+    }
+    m = fmaxf(m, __shfl_xor(m, 1));
+    if (half == 0 && r0 + r < n && m > -INFINITY) atomicMax(&M[r0 + r], ordered_bits(m));
+  }
+  if (I == J) return;
+  {  // phase B: thread (col = t & 127, half = t >> 7) scans 64 rows
+    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+    float m = -INFINITY;
+    for (int r = 64 * half; r < 64 * half + 64; ++r)
+      if (r0 + r < n) m = fmaxf(m, tile[r * kI8Tile + c]);
+    colpart[half][c] = m;
+    __syncthreads();
+    if (half == 0) {
+      m = fmaxf(colpart[0][c], colpart[1][c]);
+      if (c0 + c < n && m > -INFINITY) atomicMax(&M[c0 + c], ordered_bits(m));
+    }
+  }
+}
+
+// slack of row i (in units of sigma^2 S), see the header of this file: twice the bound on
+// |sigma^2 S - T| with R_j replaced by its maximum, plus the fp32 rounding of the two stored
+// values that are compared (2^-24 relative each, doubled for safety)
+__device__ __forceinline__ float free_threshold(float m, double Ri, double Rmax, int n) {
+  const double e = 0.5000001 * (Ri + Rmax) + 0.26 * (double)n;
+  const double thr = (double)m - 2.0 * e - 2.4e-7 * fabs((double)m);
+  // round DOWN to fp32: the comparison is made in fp32
+  float t = (float)thr;
+  if ((double)t > thr) t = nextafterf(t, -INFINITY);
+  return t;
+}
+
+__device__ __forceinline__ void free_append(int row, int col, int cap, int* __restrict__ count,
+                                            int* __restrict__ cand) {
+  const int pos = atomicAdd(&count[row], 1);
+  if (pos < cap) cand[(size_t)row * cap + pos] = col;
+}
+
+__global__ __launch_bounds__(256) void k_t32_candidates(
+    const float* __restrict__ T32, int nt, int n, const unsigned* __restrict__ M,
+    const double* __restrict__ R, const unsigned long long* __restrict__ rmax_bits, int cap,
+    int* __restrict__ count, int* __restrict__ cand) {
+  __shared__ float thrI[128], thrJ[128];
+  int I, J;
+  slot_to_tile(blockIdx.x, nt, &I, &J);
+  const float* tile = T32 + (size_t)blockIdx.x * (kI8Tile * kI8Tile);
+  const int r0 = I * kI8Tile, c0 = J * kI8Tile;
+  const double Rmax = __longlong_as_double((long long)*rmax_bits);
+  if (threadIdx.x < 128) {
+    const int row = r0 + threadIdx.x;
+    thrI[threadIdx.x] = row < n ? free_threshold(ordered_value(M[row]), R[row], Rmax, n) : INFINITY;
+  } else {
+    const int row = c0 + threadIdx.x - 128;
+    thrJ[threadIdx.x - 128] =
+        row < n ? free_threshold(ordered_value(M[row]), R[row], Rmax, n) : INFINITY;
+  }
+  __syncthreads();
+  {  // phase A
+    const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const float thr = thrI[r];
+    const float4* src = reinterpret_cast<const float4*>(tile + r * kI8Tile + 64 * half);
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+      const float4 v = src[q];
+      const int c = c0 + 64 * half + 4 * q;
+      if (v.x >= thr && c < n) free_append(r0 + r, c, cap, count, cand);
+      if (v.y >= thr && c + 1 < n) free_append(r0 + r, c + 1, cap, count, cand);
+      if (v.z >= thr && c + 2 < n) free_append(r0 + r, c + 2, cap, count, cand);
+      if (v.w >= thr && c + 3 < n) free_append(r0 + r, c + 3, cap, count, cand);
+    }
+  }
+  if (I == J) return;
+  {  // phase B
+    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const float thr = thrJ[c];
+    for (int r = 64 * half; r < 64 * half + 64; ++r)
+      if (tile[r * kI8Tile + c] >= thr && r0 + r < n) free_append(c0 + c, r0 + r, cap, count, cand);
+  }
+}
+
+// ---------------------------------------------------------------- exact statistics of S
+// rowmax(S)_i = max over the candidates j of <A_i, A_j>, rowsum(S)_i = <A_i, y1>, y1 = A 1:
+// fp64, fixed order (thread t owns k = 2 t, 2 t + 1 (mod 512), then the block tree).
+// ovf[0] = rows with more candidates than `cap`, ovf[1 + e] their indices (first 64),
+// ovf[65] = candidates evaluated in total, ovf[66] = largest candidate count of a row.
+constexpr int kFreeCapMax = 8;
+__global__ __launch_bounds__(256) void k_free_row_stats(
+    const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
+    const int* __restrict__ count, const int* __restrict__ cand, int cap,
+    double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
+  const int total = count[row];
+  const int cnt = total < cap ? total : cap;
+  const double* x = A + (size_t)row * ld;
+  const double* xj[kFreeCapMax];
+#pragma unroll
+  for (int c = 0; c < kFreeCapMax; ++c)
+    xj[c] = A + (size_t)(c < cnt ? cand[(size_t)row * cap + c] : row) * ld;
+  double acc[kFreeCapMax];
+#pragma unroll
+  for (int c = 0; c < kFreeCapMax; ++c) acc[c] = 0.0;
+  double rs = 0.0;
+  for (int k = 2 * threadIdx.x; k < n; k += 512) {
+    double2 a = *reinterpret_cast<const double2*>(x + k);
+    double2 yy = *reinterpret_cast<const double2*>(y1 + k);
+    if (k + 1 >= n) { a.y = 0.0; yy.y = 0.0; }
+    rs = __builtin_fma(a.x, yy.x, rs);
+    rs = __builtin_fma(a.y, yy.y, rs);
+#pragma unroll
+    for (int c = 0; c < kFreeCapMax; ++c) {
+      if (c < cnt) {
+        double2 b = *reinterpret_cast<const double2*>(xj[c] + k);
+        if (k + 1 >= n) b.y = 0.0;
+        acc[c] = __builtin_fma(a.x, b.x, acc[c]);
+        acc[c] = __builtin_fma(a.y, b.y, acc[c]);
+      }
+    }
+  }
+  rs = fr_block_sum(rs, sm);
+  double best = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < kFreeCapMax; ++c) {
+    if (c < cnt) {  // (block-uniform)
+      const double d = fr_block_sum(acc[c], sm);
+      best = fmax(best, d);
+    }
+  }
+  if (threadIdx.x == 0) {
+    rowmax[row] = best;
+    rowsum[row] = rs;
+    atomicAdd(&ovf[65], cnt);
+    atomicMax(&ovf[66], total);
+    if (total > cap) {
+      const int e = atomicAdd(&ovf[0], 1);
+      if (e < 64) ovf[1 + e] = row;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- rows evaluated in full
+// Vs[k][v] = A[rows[v]][k] (v < nrows, zero otherwise): the block whose product with A is
+// S[:, rows] (A symmetric).  One workgroup per 32 values of k.
+__global__ __launch_bounds__(256) void k_free_gather_rows(const double* __restrict__ A, int n,
+                                                          int ld, const int* __restrict__ rows,
+                                                          int nrows, double* __restrict__ Vs) {
+  const int v = threadIdx.x & (kEigBlock - 1);
+  const int k = blockIdx.x * (256 / kEigBlock) + threadIdx.x / kEigBlock;
+  if (k >= n) return;
+  Vs[(size_t)k * kEigBlock + v] = v < nrows ? A[(size_t)rows[v] * ld + k] : 0.0;
+}
+// rowmax[rows[v]] = max_k W[k][v]   (W = S[:, rows], n x kEigBlock)
+__global__ __launch_bounds__(256) void k_free_colmax(const double* __restrict__ W, int n,
+                                                     const int* __restrict__ rows, int nrows,
+                                                     double* __restrict__ rowmax) {
+  __shared__ double sm[4];
+  const int v = blockIdx.x;
+  if (v >= nrows) return;
+  double m = -INFINITY;
+  for (int k = threadIdx.x; k < n; k += 256) m = fmax(m, W[(size_t)k * kEigBlock + v]);
+  m = fr_block_max(m, sm);
+  if (threadIdx.x == 0) rowmax[rows[v]] = m;
+}
+
+// ---------------------------------------------------------------- launchers
+int free_rows_padded(int n) { return round_up(n, kI8Tile); }
+int free_k_padded(int n) { return round_up(n, 64); }
+size_t free_q_bytes(int n) { return (size_t)free_rows_padded(n) * 2 * free_k_padded(n); }
+size_t free_t32_bytes(int n) {
+  const size_t nt = (n + kI8Tile - 1) / kI8Tile;
+  return nt * (nt + 1) / 2 * kI8Tile * kI8Tile * sizeof(float);
+}
+int free_candidate_cap() { return kFreeCapMax; }
+
+void launch_free_absmax(hipStream_t s, const double* A, int n, int ld, double* scal) {
+  hipLaunchKernelGGL(k_free_absmax, dim3(n), dim3(256), 0, s, A, n, ld,
+                     reinterpret_cast<unsigned long long*>(scal));
+}
+
+void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed char* Q,
+                          double* scal, double* y1, double* R) {
+  const int Kp = free_k_padded(n);
+  hipLaunchKernelGGL(k_free_quantize, dim3(free_rows_padded(n)), dim3(256), 0, s, A, n, ld, Q,
+                     (size_t)2 * Kp, Kp, scal, y1, R,
+                     reinterpret_cast<unsigned long long*>(scal) + 2);
+}
+
+void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
+                        float* T32) {
+  const int nt = (n + kI8Tile - 1) / kI8Tile;
+  const int tiles = nt * (nt + 1) / 2;
+  const int Kp = free_k_padded(n);
+  const int lds = kI8Buffers * kI8StageBytes;
+  SC_OPT_IN_LDS(k_gemm_i8_sym, lds);
+  const int xcd_chunk = (tiles % 8 == 0 && tiles >= 512) ? tiles / 8 : 0;
+  hipLaunchKernelGGL(k_gemm_i8_sym, dim3(tiles), dim3(kI8Threads), lds, s, Q, (size_t)2 * Kp,
+                     Kp / 64, tilemap, xcd_chunk, T32, nt);
+}
+
+void launch_t32_rowmax(hipStream_t s, const float* T32, int n, unsigned* M) {
+  const int nt = (n + kI8Tile - 1) / kI8Tile;
+  hipLaunchKernelGGL(k_t32_rowmax, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, T32, nt, n, M);
+}
+
+void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,
+                           const double* R, const double* scal, int* count, int* cand) {
+  const int nt = (n + kI8Tile - 1) / kI8Tile;
+  hipLaunchKernelGGL(k_t32_candidates, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, T32, nt, n, M, R,
+                     reinterpret_cast<const unsigned long long*>(scal) + 2, kFreeCapMax, count,
+                     cand);
+}
+
+void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const double* y1,
+                           const int* count, const int* cand, double* rowmax, double* rowsum,
+                           int* ovf) {
+  hipLaunchKernelGGL(k_free_row_stats, dim3(n), dim3(256), 0, s, A, n, ld, y1, count, cand,
+                     kFreeCapMax, rowmax, rowsum, ovf);
+}
+
+void launch_free_gather_rows(hipStream_t s, const double* A, int n, int ld, const int* rows,
+                             int nrows, double* Vs) {
+  const int per = 256 / kEigBlock;
+  hipLaunchKernelGGL(k_free_gather_rows, dim3((n + per - 1) / per), dim3(256), 0, s, A, n, ld,
+                     rows, nrows, Vs);
+}
+
+void launch_free_colmax(hipStream_t s, const double* W, int n, const int* rows, int nrows,
+                        double* rowmax) {
+  hipLaunchKernelGGL(k_free_colmax, dim3(nrows), dim3(256), 0, s, W, n, rows, nrows, rowmax);
+}
+
+}  // namespace sc

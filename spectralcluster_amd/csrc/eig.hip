@@ -119,9 +119,12 @@ __device__ __forceinline__ void block_matvec_body(
 #pragma unroll
       for (int w = 0; w < kMvWaves; ++w) sum += red[w][lane][r];
       const int row = r0 + lg + 4 * r;  // D[row = (l >> 4) + 4 r][col = l & 15]
+      // (cvec == nullptr: c = 1, pvec == nullptr: p = 0 -- the plain product A Vs, the first
+      //  half of the matrix-free Diffuse operator)
       if (row < n && li < B)
         W[(size_t)row * B + li] =
-            __builtin_fma(cvec[row], sum, pvec[row] * V[(size_t)row * ldv + li]);
+            __builtin_fma(cvec ? cvec[row] : 1.0, sum,
+                          pvec ? pvec[row] * V[(size_t)row * ldv + li] : 0.0);
     }
   }
 }
@@ -326,7 +329,7 @@ __device__ __forceinline__ void matvec_sym_reduce_body(
     for (int u = 0; u < 8; ++u) acc += x[u];
   }
   if (row < n) W[(size_t)row * B + v] =
-      __builtin_fma(cvec[row], acc, pvec[row] * V[(size_t)row * ldv + v]);
+      __builtin_fma(cvec ? cvec[row] : 1.0, acc, pvec ? pvec[row] * V[(size_t)row * ldv + v] : 0.0);
 }
 __global__ __launch_bounds__(256) void k_matvec_sym_reduce(
     const double* __restrict__ pdirect, const double* __restrict__ pmirror, int nt, int n,

@@ -366,7 +366,7 @@ static int dense_vectors(sc_handle h, const double* scratch, int ld, int n, int 
 }
 
 // Does the request read the whole spectrum (or its far end) exactly?
-static bool wants_full_spectrum(const EigRequest& rq) {
+bool wants_full_spectrum(const EigRequest& rq) {
   if (rq.fixed_count > 0 || rq.descend) return false;
   // ascending: every eigenvalue when max_clusters is None (utils.py:100-115); the
   // NormalizedDiff gap divides by np.max(eigenvalues), the far end of the spectrum, which
@@ -396,11 +396,56 @@ static EigWorkspace eig_workspace(sc_handle h) {
 }
 
 // S (n x n, ld) symmetric on the device; cvec/pvec/tvec already set.
-int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_in,
+// With h->free_on (matrix-free Diffuse, free_api.hip) `S_in` is the symmetric matrix A BEFORE
+// Diffuse and the operator is diag(p) + diag(c) A A diag(c): two block products per pass,
+// S = A A^T is only formed if a dense route needs its entries.
+int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& rq_in,
              sc_diag* diag, EigDecision* out_dc, std::vector<double>* out_w,
-             double* scratch) {
+             double* scratch_in) {
   hipStream_t s = h->stream;
   SC_TRY(ensure_eig(h, n));
+  const double* S = S_in;
+  double* scratch = scratch_in;
+  const bool free_at_entry = h->free_on;
+  // S = A A^T after all (a dense route reads entries; or the exact-row route gave up): the fp64
+  // MFMA product into the scratch matrix, A's buffer becomes the scratch
+  auto free_materialize = [&](bool with_stats) -> int {
+    if (!h->free_on) return SC_OK;
+    if (scratch == nullptr || scratch == S)
+      return fail(h, SC_ERR_UNSUPPORTED, "no scratch matrix to form the Diffuse product in");
+    SC_TRY(ensure_tilemap(h, n));
+    GemmRowStats rs{1, ptr<double>(h->statp), ptr<double>(h->statp) + (size_t)n * gemm_tile_dim(n),
+                    ptr<double>(h->rowmax), ptr<double>(h->rowsum)};
+    launch_gemm_nt(s, S, ld, S, ld, scratch, ld, n, n, n, kEpiNone, true, ptr<double>(h->splitk),
+                   h->tilemap_cur, with_stats ? &rs : nullptr);
+    SC_TRY(check_last(h, "diffuse launch"));
+    double* a_buffer = const_cast<double*>(S);
+    S = scratch;
+    scratch = a_buffer;
+    h->free_on = false;
+    return SC_OK;
+  };
+  // rows whose candidate list overflowed are evaluated in full once the stream has drained;
+  // *restart: the scaling vectors changed under a solve that had already started
+  auto free_check = [&](bool* restart) -> int {
+    *restart = false;
+    if (!h->free_on || h->free_checked) return SC_OK;
+    bool changed = false, too_many = false;
+    SC_TRY(free_fix_overflow(h, S, ld, n, &changed, &too_many));
+    if (too_many) {
+      SC_TRY(free_materialize(true));
+      changed = true;
+    }
+    if (changed) {
+      launch_scaling_vectors(s, ptr<double>(h->rowmax), ptr<double>(h->rowsum), n, h->free_lap,
+                             h->free_rownorm, ptr<double>(h->cvec), ptr<double>(h->pvec),
+                             ptr<double>(h->tvec));
+      launch_check_finite(s, ptr<double>(h->cvec), ptr<double>(h->pvec), n, ptr<int>(h->flags) + 12);
+      SC_TRY(check_last(h, "scaling launch"));
+      *restart = true;
+    }
+    return SC_OK;
+  };
   double* theta_d = ptr<double>(h->theta);
   double* resid_d = ptr<double>(h->resid);
   const double* cvec = ptr<double>(h->cvec);
@@ -421,6 +466,9 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
   EigDecision dense_dc;
   bool dense = false;
   auto run_dense = [&]() -> int {
+    bool unused = false;
+    SC_TRY(free_check(&unused));
+    SC_TRY(free_materialize(false));
     SC_TRY(dense_spectrum(h, S, ld, n, scratch));
     std::vector<double> zeros(n, 0.0);
     dense_dc = analyze(rq_in, h->spectrum.data(), zeros.data(), n, n, true);
@@ -448,6 +496,7 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       fprintf(stderr, "[sc] block Lanczos gave up (reason %d, %d passes): dense path\n", reason,
               passes);
     if (!dense) SC_TRY(run_dense());
+    SC_TRY(free_materialize(false));  // (a `dense` that predates the hand-over: not in free mode)
     int cols = dense_dc.kvec;
     if (rq_in.fixed_count > 0 || rq_in.max_clusters > 0) cols = std::max(dense_dc.kw, cols);
     cols = std::max(1, std::min(cols, kMaxVectors));
@@ -526,7 +575,9 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
       // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
       const bool time_mv = h->profile_level >= 2 && h->n_mv_ev < 16;
       if (time_mv) ev_rec(h, &h->mv_ev[h->n_mv_ev][0]);
-      if (sym_mv)
+      if (h->free_on)
+        free_apply_operator(h, S, ld, n, sym_mv, ptr<double>(h->Q) + m, kLdq);
+      else if (sym_mv)
         launch_block_matvec_sym(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
                                 ptr<double>(h->Vs), ptr<double>(h->W), ptr<double>(h->mvsym));
       else
@@ -597,6 +648,19 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
           }
           if (sw::eig_trace()) fprintf(stderr, "[sc] fused chain flagged: host chain\n");
           fused = false;
+          goto restart_lanczos;
+        }
+      }
+      if (h->free_on && !h->free_checked && (!fused || check)) {
+        // (the stream has just drained) matrix-free Diffuse: rows the candidate search could
+        // not prune get their exact maximum now; the solve starts over on the corrected operator
+        bool restart = false;
+        SC_TRY(free_check(&restart));
+        if (restart) {
+          if (sw::eig_trace())
+            fprintf(stderr, "[sc] matrix-free diffuse: %d rows evaluated in full, restart\n",
+                    h->h_free[0]);
+          passes = 0;
           goto restart_lanczos;
         }
       }
@@ -714,6 +778,11 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq_i
     diag->eig_max_residual = dc.max_resid;
     diag->eig_host_chain = (n > kDenseMax && !fused) ? 1 : 0;
     diag->eig_fallback = fallback_reason;
+    if (free_at_entry) {
+      diag->diffuse_path = h->free_on ? SC_DIFFUSE_PATH_FREE : SC_DIFFUSE_PATH_FREE_THEN_EXPLICIT;
+      diag->free_candidates = h->free_checked ? h->h_free[65] : 0;
+      diag->free_overflow_rows = h->free_checked ? h->h_free[0] : 0;
+    }
   }
   *out_dc = dc;
   return SC_OK;

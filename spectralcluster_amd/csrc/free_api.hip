@@ -1,0 +1,192 @@
+// Host side of the matrix-free Diffuse (kernels: diffuse_free.hip): when the
+// route is taken, the statistics pipeline, the exact evaluation of rows the candidate search
+// cannot prune, and the two-pass operator the eigensolver applies instead of reading S.
+#include "handle.h"
+
+namespace {
+constexpr int kOvfWords = 80;   // [0] rows over the cap, [1..64] their ids, [65] candidates, [66] max
+constexpr int kOvfRowsMax = 64;
+}  // namespace
+
+// SC_DIFFUSE=explicit|free|auto (default auto) and SC_DIFFUSE_FREE_MIN_N=<n> (default 2048):
+// path switches in the sense of switches.h -- both routes are held to the same goldens
+// (tests/test_gpu_diffuse_free.py, tests/test_gpu_alternate_paths.py).
+static int env_diffuse_mode() {
+  static const int v = [] {
+    const char* e = getenv("SC_DIFFUSE");
+    if (!e) return 0;
+    if (!strcmp(e, "explicit")) return 1;
+    if (!strcmp(e, "free")) return 2;
+    return 0;
+  }();
+  return v;
+}
+static int env_free_min_n() {
+  static const int v = getenv("SC_DIFFUSE_FREE_MIN_N") ? atoi(getenv("SC_DIFFUSE_FREE_MIN_N")) : 2048;
+  return v;
+}
+
+extern "C" int sc_set_diffuse_mode(sc_handle h, int mode) {
+  if (!h || mode < -1 || mode > 2) return SC_ERR_INVALID;
+  h->diffuse_mode = mode;
+  return SC_OK;
+}
+
+bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequest& rq) {
+  // the call's own choice, else the handle's, else the process default
+  const int mode = cfg->diffuse_mode == 1 || cfg->diffuse_mode == 2
+                       ? cfg->diffuse_mode
+                       : (h->diffuse_mode >= 0 ? h->diffuse_mode : env_diffuse_mode());
+  if (mode == 1) return false;
+  // the dense routes read entries of the operator; n <= 128 is one Jacobi launch on it; the
+  // i32 accumulators of the digit products hold K <= 65536
+  if (n <= kDenseMax || n > 65536 || wants_full_spectrum(rq)) return false;
+  if (mode == 2) return true;
+  return n >= env_free_min_n();
+}
+
+static int ensure_free(sc_handle h, int n) {
+  const size_t nv = (size_t)round_up(n, 16) * sizeof(double);
+  SC_TRY(grow(h, h->fq, free_q_bytes(n)));
+  SC_TRY(grow(h, h->ft32, free_t32_bytes(n)));
+  SC_TRY(grow(h, h->fy1, nv));
+  SC_TRY(grow(h, h->fR, nv));
+  SC_TRY(grow(h, h->fscal, 4 * sizeof(double)));
+  SC_TRY(grow(h, h->fwords, ((size_t)2 * n + kOvfWords) * sizeof(int)));
+  SC_TRY(grow(h, h->fcand, (size_t)n * free_candidate_cap() * sizeof(int)));
+  SC_TRY(grow(h, h->fY, (size_t)n * kEigBlock * sizeof(double)));
+  if (!h->h_free)
+    SC_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_free), kOvfWords * sizeof(int)));
+  return SC_OK;
+}
+
+int free_diffuse_stats(sc_handle h, const double* A, int ld, int n) {
+  hipStream_t s = h->stream;
+  SC_TRY(ensure_free(h, n));
+  SC_TRY(ensure_tilemap(h, n));
+  unsigned* M = ptr<unsigned>(h->fwords);
+  int* count = ptr<int>(h->fwords) + n;
+  int* ovf = ptr<int>(h->fwords) + 2 * (size_t)n;
+  SC_HIP(h, hipMemsetAsync(h->fscal.p, 0, 4 * sizeof(double), s));
+  SC_HIP(h, hipMemsetAsync(h->fwords.p, 0, ((size_t)2 * n + kOvfWords) * sizeof(int), s));
+  ev_rec(h, &h->free_ev[0]);
+  launch_free_absmax(s, A, n, ld, ptr<double>(h->fscal));
+  launch_free_quantize(s, A, n, ld, ptr<signed char>(h->fq), ptr<double>(h->fscal),
+                       ptr<double>(h->fy1), ptr<double>(h->fR));
+  ev_rec(h, &h->free_ev[1]);
+  launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32));
+  ev_rec(h, &h->free_ev[2]);
+  launch_t32_rowmax(s, ptr<float>(h->ft32), n, M);
+  launch_t32_candidates(s, ptr<float>(h->ft32), n, M, ptr<double>(h->fR), ptr<double>(h->fscal),
+                        count, ptr<int>(h->fcand));
+  ev_rec(h, &h->free_ev[3]);
+  launch_free_row_stats(s, A, n, ld, ptr<double>(h->fy1), count, ptr<int>(h->fcand),
+                        ptr<double>(h->rowmax), ptr<double>(h->rowsum), ovf);
+  ev_rec(h, &h->free_ev[4]);
+  SC_TRY(check_last(h, "matrix-free diffuse launch"));
+  SC_HIP(h, hipMemcpyAsync(h->h_free, ovf, kOvfWords * sizeof(int), hipMemcpyDeviceToHost, s));
+  h->free_checked = false;
+  return SC_OK;
+}
+
+// plain product W = A Vs by the solver's own block matvec (c = 1, p = 0)
+static void plain_matvec(sc_handle h, const double* A, int ld, int n, bool sym_mv,
+                         const double* Vs, double* W) {
+  if (sym_mv)
+    launch_block_matvec_sym(h->stream, A, ld, n, nullptr, nullptr, Vs, kEigBlock, Vs, W,
+                            ptr<double>(h->mvsym));
+  else
+    launch_block_matvec(h->stream, A, ld, n, nullptr, nullptr, Vs, kEigBlock, Vs, W);
+}
+
+int free_fix_overflow(sc_handle h, const double* A, int ld, int n, bool* changed,
+                      bool* too_many) {
+  *changed = *too_many = false;
+  hipStream_t s = h->stream;
+  SC_HIP(h, hipStreamSynchronize(s));  // (h_free was copied behind the statistics)
+  h->free_checked = true;
+  const int rows = h->h_free[0];
+  if (rows <= 0) return SC_OK;
+  if (rows > kOvfRowsMax) {
+    *too_many = true;
+    return SC_OK;
+  }
+  // S[:, rows] = A (A[rows, :]^T), eight rows per pass: two block products over A
+  SC_TRY(ensure_eig(h, n));
+  const bool sym_mv = n >= sw::matvec_sym_min_n();
+  const int* ids = ptr<int>(h->fwords) + 2 * (size_t)n + 1;
+  for (int r0 = 0; r0 < rows; r0 += kEigBlock) {
+    const int nr = std::min(kEigBlock, rows - r0);
+    launch_free_gather_rows(s, A, n, ld, ids + r0, nr, ptr<double>(h->Vs));
+    plain_matvec(h, A, ld, n, sym_mv, ptr<double>(h->Vs), ptr<double>(h->W));
+    launch_free_colmax(s, ptr<double>(h->W), n, ids + r0, nr, ptr<double>(h->rowmax));
+  }
+  SC_TRY(check_last(h, "matrix-free diffuse: exact rows"));
+  *changed = true;
+  return SC_OK;
+}
+
+void free_apply_operator(sc_handle h, const double* A, int ld, int n, bool sym_mv,
+                         const double* V, int ldv) {
+  // fY = A Vs (Vs = c .* V, left by the chain), then W = p .* V + c .* (A fY)
+  plain_matvec(h, A, ld, n, sym_mv, ptr<double>(h->Vs), ptr<double>(h->fY));
+  if (sym_mv)
+    launch_block_matvec_sym(h->stream, A, ld, n, ptr<double>(h->cvec), ptr<double>(h->pvec), V,
+                            ldv, ptr<double>(h->fY), ptr<double>(h->W), ptr<double>(h->mvsym));
+  else
+    launch_block_matvec(h->stream, A, ld, n, ptr<double>(h->cvec), ptr<double>(h->pvec), V, ldv,
+                        ptr<double>(h->fY), ptr<double>(h->W));
+}
+
+// rowmax(S), rowsum(S) of S = a a^T for a symmetric (n, n) input by either route (parity
+// tests): mode 1 the fp64 MFMA product with fused row statistics, mode 2 the matrix-free search.
+// info (may be NULL): [0] candidates evaluated, [1] rows over the cap, [2] largest candidate
+// count of a row, [3] 1 when the exact-row route gave up and S was formed after all.
+extern "C" int sc_stage_diffuse_rowstats(sc_handle h, const double* a, int n, int mode,
+                                         double* rowmax, double* rowsum, int32_t* info) {
+  if (!h) return SC_ERR_INVALID;
+  if (!a || n <= 0 || !rowmax || !rowsum || (mode != 1 && mode != 2))
+    return fail(h, SC_ERR_INVALID, "bad diffuse row statistics request");
+  if (mode == 2 && n > 65536) return fail(h, SC_ERR_UNSUPPORTED, "matrix-free diffuse: n <= 65536");
+  SC_HIP(h, hipSetDevice(h->device));
+  SC_TRY(ensure_matrices(h, n, 0));
+  SC_TRY(ensure_eig(h, n));
+  SC_TRY(ensure_tilemap(h, n));
+  const int ld = matrix_ld(n);
+  h->n = n;
+  h->ldn = ld;
+  h->have_affinity = h->have_cropval = false;
+  h->have_x = false;
+  h->n_vec = 0;
+  h->nev = 0;
+  hipStream_t s = h->stream;
+  double* A = ptr<double>(h->B2);
+  SC_TRY(h2d_matrix(h, a, n, n, A, ld));
+  int inf[4] = {0, 0, 0, 0};
+  auto explicit_stats = [&]() -> int {
+    GemmRowStats rs{1, ptr<double>(h->statp), ptr<double>(h->statp) + (size_t)n * gemm_tile_dim(n),
+                    ptr<double>(h->rowmax), ptr<double>(h->rowsum)};
+    launch_gemm_nt(s, A, ld, A, ld, ptr<double>(h->B1), ld, n, n, n, kEpiNone, true,
+                   ptr<double>(h->splitk), h->tilemap_cur, &rs);
+    return check_last(h, "diffuse launch");
+  };
+  if (mode == 1) {
+    SC_TRY(explicit_stats());
+  } else {
+    SC_TRY(free_diffuse_stats(h, A, ld, n));
+    bool changed = false, too_many = false;
+    SC_TRY(free_fix_overflow(h, A, ld, n, &changed, &too_many));
+    inf[0] = h->h_free[65];
+    inf[1] = h->h_free[0];
+    inf[2] = h->h_free[66];
+    if (too_many) {
+      inf[3] = 1;
+      SC_TRY(explicit_stats());
+    }
+  }
+  SC_HIP(h, hipMemcpyAsync(rowmax, h->rowmax.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipMemcpyAsync(rowsum, h->rowsum.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipStreamSynchronize(s));
+  if (info) memcpy(info, inf, sizeof(inf));
+  return SC_OK;
+}

@@ -31,7 +31,7 @@ constexpr int kGroupLanes = 3;  // leads of the grouped batch (host threads, eac
 
 // event slots of the stage timers of the current call (resolved once the stream has drained)
 struct StageEvents {
-  bool pending = false, fine = false;
+  bool pending = false, fine = false, free_path = false;
   int begin = -1, after_refine = -1, after_scaling = -1, after_eig = -1;
   int diffuse[SC_MAX_OPS][2];
   int n_diffuse = 0;
@@ -132,6 +132,16 @@ struct sc_handle_s {
   int krnd_k = -1, krnd_trials = -1;
   int kfirst_n = -1, kfirst = 0;  // first k-means++ centre of the last n (RandomState(0) draw)
   bool eig_skip_fused = false;  // next sym_topk: go straight to the host-driven chain
+  // ---- matrix-free Diffuse (free_api.hip)
+  int diffuse_mode = -1;   // sc_set_diffuse_mode: 0 auto, 1 explicit fp64 product, 2 matrix-free
+                           // wherever the sequence allows it; -1: the environment's default
+  DevBuf fq, ft32, fy1, fR, fscal, fwords, fcand, fY;  // digits, T (fp32 tiles), A 1, sum|q|,
+                           // scalars, M | count | ovf words, candidate lists, A Vs
+  int* h_free = nullptr;   // pinned copy of the ovf words (80)
+  bool free_on = false;    // the operator of the current solve is c .* A (A (c .* v)) + p .* v
+  bool free_checked = false;  // ... and its overflow rows have been dealt with
+  int free_lap = 0, free_rownorm = 0;  // what the scaling vectors were built for
+  int free_ev[5] = {-1, -1, -1, -1, -1};  // event slots: begin | quantised | product | scans | stats
 };
 
 // hipEvent slots of the current call (reset by the entry points); -1 when exhausted
@@ -306,6 +316,22 @@ int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq, 
 int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
              const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
              std::vector<double>* out_w);
+
+// matrix-free Diffuse (free_api.hip)
+// does this call take the matrix-free route for a Diffuse whose output only feeds
+// RowWiseNormalize / the Laplacian?  (mode of the handle, problem size, request)
+bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequest& rq);
+// enqueue the statistics of S = A A^T (h->rowmax, h->rowsum) on h->stream; no synchronisation.
+// The overflow words travel to h->h_free behind them.
+int free_diffuse_stats(sc_handle h, const double* A, int ld, int n);
+// after the stream has drained: rows with more candidates than the cap are evaluated in full.
+// *changed: rowmax was rewritten (the scaling vectors must be rebuilt); *too_many: more such
+// rows than the exact route takes (the caller forms S explicitly).
+int free_fix_overflow(sc_handle h, const double* A, int ld, int n, bool* changed, bool* too_many);
+// W = p .* V + c .* (A (A Vs)) through h->fY (both halves on h->stream)
+void free_apply_operator(sc_handle h, const double* A, int ld, int n, bool sym_mv,
+                         const double* V, int ldv);
+bool wants_full_spectrum(const EigRequest& rq);
 
 // constraints (constraint_api.hip)
 int device_is_symmetric(sc_handle h, const double* m, int n, int ld, bool* out);

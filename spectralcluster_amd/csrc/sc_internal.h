@@ -364,6 +364,32 @@ void launch_gen_gather(hipStream_t s, const double* Vre, const double* Vim, int 
 void launch_scaling_general(hipStream_t s, const double* deg, int n, int laplacian_type,
                             double* cl, double* cr, double* p);
 
+// ---- matrix-free Diffuse (diffuse_free.hip; host side free_api.hip) ---------------------
+// rowmax / rowsum of S = A A^T without the fp64 product: 8-bit fixed-point digits of A, an exact
+// integer MFMA product of them, row maxima + candidates within a proven slack, exact fp64 dot
+// products for the candidates.  scal: 4 doubles ([0] max|a| bits, [2] max R bits; zeroed by
+// the caller); M / count: n words each, zeroed; ovf: 80 words, zeroed; cand: n x cap.
+int free_rows_padded(int n);
+int free_k_padded(int n);
+size_t free_q_bytes(int n);
+size_t free_t32_bytes(int n);
+int free_candidate_cap();
+void launch_free_absmax(hipStream_t s, const double* A, int n, int ld, double* scal);
+void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed char* Q,
+                          double* scal, double* y1, double* R);
+void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
+                        float* T32);
+void launch_t32_rowmax(hipStream_t s, const float* T32, int n, unsigned* M);
+void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,
+                           const double* R, const double* scal, int* count, int* cand);
+void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const double* y1,
+                           const int* count, const int* cand, double* rowmax, double* rowsum,
+                           int* ovf);
+void launch_free_gather_rows(hipStream_t s, const double* A, int n, int ld, const int* rows,
+                             int nrows, double* Vs);
+void launch_free_colmax(hipStream_t s, const double* W, int n, const int* rows, int nrows,
+                        double* rowmax);
+
 // ---- size reduction (ahc.hip) ----------------------------------------------------------
 void launch_cosine_distance(hipStream_t s, double* c, int n, int ld);
 // nearest-neighbour-chain agglomeration on the n x n distance matrix D (destroyed);

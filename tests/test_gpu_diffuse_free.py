@@ -1,0 +1,231 @@
+"""GPU: the matrix-free Diffuse (csrc/diffuse_free.hip, free_api.hip).
+
+For a sequence whose Diffuse (reference refinement.py:229-234) is followed only by
+RowWiseNormalize (:240-245) and the Laplacian (laplacian.py:41-58) the device never forms
+S = A A^T: rowmax(S) comes from an exact 8-bit-digit integer MFMA product (a candidate
+search within a proven slack) + an fp64 recheck, rowsum(S) = A (A 1), and the eigensolver
+applies A twice per block.  Both routes must give what the reference gives:
+
+  * stage level: rowmax / rowsum of a a^T through `sc_stage_diffuse_rowstats` -- matrix-free
+    (mode 2) against the explicit fp64 product (mode 1) and against NumPy, on refined affinities
+    and on inputs built to stress the search (near ties, exact ties, negative entries, a zero
+    row, rows that are tiny against the rest, ragged sizes);
+  * end to end: the reference goldens (labels, n_clusters, max_delta, consumed eigenvalues)
+    with `diffuse_mode` 2 (matrix-free wherever the sequence allows) and 1 (explicit), and the
+    default routing (matrix-free from n = 2048 on).
+"""
+
+import ctypes
+import dataclasses
+
+import numpy as np
+import pytest
+
+import spectral_oracle as so
+from conftest import golden
+
+import spectralcluster_amd as sca
+from spectralcluster_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+LAP = {0: None, 2: sca.LaplacianType.Unnormalized, 3: sca.LaplacianType.RandomWalk,
+       4: sca.LaplacianType.GraphCut}
+EXPLICIT, FREE = 1, 2
+
+
+def rowstats(a, mode):
+  h = _lib.default_handle()
+  a = np.ascontiguousarray(a, dtype=np.float64)
+  n = a.shape[0]
+  rmax, rsum = np.empty(n), np.empty(n)
+  info = (ctypes.c_int32 * 4)()
+  h.check(h.lib.sc_stage_diffuse_rowstats(h.raw, _lib.as_double_p(a), n, mode,
+                                          _lib.as_double_p(rmax), _lib.as_double_p(rsum), info))
+  return rmax, rsum, list(info)
+
+
+def check_rowstats(a, name, expect_overflow=None, expect_formed=None):
+  s = a @ a.T
+  want_max, want_sum = s.max(axis=1), s.sum(axis=1)
+  scale = np.abs(s).max()
+  for mode in (EXPLICIT, FREE):
+    rmax, rsum, info = rowstats(a, mode)
+    # summation order only: 1e-13 of the row's own scale (|a_i| |a_j| bounds every term)
+    tol = 1e-13 * np.maximum(np.abs(want_max), 1e-3 * scale)
+    assert np.all(np.abs(rmax - want_max) <= tol), (name, mode, np.abs(rmax - want_max).max())
+    tols = 1e-12 * np.maximum(np.abs(want_sum), np.abs(s).sum(axis=1))
+    assert np.all(np.abs(rsum - want_sum) <= tols), (name, mode)
+    if mode == FREE:
+      if expect_overflow is not None:
+        assert (info[1] > 0) == expect_overflow, (name, info)
+      if expect_formed is not None:
+        assert bool(info[3]) == expect_formed, (name, info)
+  return info
+
+
+def refined_before_diffuse(x, **over):
+  cfg = so.icassp2018_config(**over)
+  i = list(cfg.sequence).index(so.OP_DIFFUSE)
+  return so.refine(so.affinity(x), dataclasses.replace(cfg, sequence=tuple(cfg.sequence[:i])))
+
+
+# ------------------------------------------------------------------- stage level
+@pytest.mark.parametrize("n,d,k", [(300, 32, 3), (1000, 64, 5), (1153, 48, 4), (2048, 128, 4)])
+def test_rowstats_of_refined_affinities(n, d, k):
+  a = refined_before_diffuse(so.blobs(n, d, k, seed=n))
+  info = check_rowstats(a, "blobs%d" % n, expect_formed=False)
+  assert info[0] <= 3 * n  # a few exact dot products per row, not n
+
+
+@pytest.mark.parametrize("kind", so.HARD_KINDS)
+def test_rowstats_of_unfriendly_inputs(kind):
+  n = 1000
+  g = golden("hard_%s_n%d_lap4.npz" % (kind, n))
+  a = refined_before_diffuse(so.hard_inputs(kind, n, int(g["params"][1]), int(g["params"][2])))
+  # "tiny": five samples whose rows of S are small against the slack -> evaluated in full
+  check_rowstats(a, kind, expect_formed=False)
+
+
+def test_rowstats_exact_and_near_ties():
+  rng = np.random.default_rng(5)
+  n = 640
+  b = rng.random((n, n))
+  a = 0.5 * (b + b.T)
+  # exact ties: duplicated samples (identical rows AND columns)
+  for dup in ((3, 77), (3, 200), (400, 401), (400, 402), (400, 403)):
+    a[dup[1], :] = a[dup[0], :]
+    a[:, dup[1]] = a[:, dup[0]]
+  a = 0.5 * (a + a.T)
+  # near ties: a row that differs from another in its last bits
+  a[500, :] = a[10, :] * (1.0 + 3e-16)
+  a[:, 500] = a[500, :]
+  check_rowstats(a, "ties", expect_formed=False)
+
+
+def test_rowstats_many_identical_rows_form_s_after_all():
+  """More rows over the candidate cap than the exact-row route takes (64): S is formed
+  explicitly, the result is still the reference's."""
+  rng = np.random.default_rng(6)
+  b = rng.random((32, 32))
+  a = np.kron(0.5 * (b + b.T), np.ones((16, 16)))  # n = 512: 32 groups of 16 identical samples
+  check_rowstats(a, "plateau", expect_overflow=True, expect_formed=True)
+
+
+def test_rowstats_negative_entries_and_zero_row():
+  rng = np.random.default_rng(7)
+  n = 700
+  b = rng.standard_normal((n, n))
+  a = 0.5 * (b + b.T)
+  a[123, :] = 0.0
+  a[:, 123] = 0.0
+  check_rowstats(a, "signed")
+
+
+def test_rowstats_wide_dynamic_range():
+  """Rows far below the matrix maximum: their digits carry few bits, the slack is large
+  against their row of S and they are evaluated in full."""
+  rng = np.random.default_rng(8)
+  n = 900
+  b = rng.random((n, n))
+  a = 0.5 * (b + b.T)
+  scale = np.ones(n)
+  scale[[5, 6, 7, 450, 899]] = 1e-4
+  a = a * scale[:, None] * scale[None, :]
+  check_rowstats(a, "range", expect_formed=False)
+
+
+# ------------------------------------------------------------------- end to end
+def icassp_options():
+  return sca.RefinementOptions(
+      gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
+      thresholding_type=sca.ThresholdType.RowMax,
+      refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
+
+
+def rel_err(got, want):
+  return np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-12))
+
+
+E2E = ["e2e_n200_lap4_max7.npz", "e2e_n1000_lap0_max7.npz", "e2e_n1000_lap4_max20.npz",
+       "e2e_n1000_lap3_max20.npz", "e2e_n1000_lap2_max20.npz", "e2e_n2048_lap0_max7.npz",
+       "e2e_n2048_lap4_max20.npz", "e2e_n8192_lap4_max20.npz", "e2e_n8192_lap0_max7.npz"]
+
+
+@pytest.mark.parametrize("mode", [FREE, EXPLICIT])
+@pytest.mark.parametrize("name", E2E)
+def test_predict_vs_reference_golden_both_routes(name, mode):
+  g = golden(name)
+  n, d, k, seed, lap, max_clusters = [int(v) for v in g["params"]]
+  x = so.blobs(n, d, k, seed)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=max_clusters,
+                            refinement_options=icassp_options(), laplacian_type=LAP[lap])
+  c.diffuse_mode = mode
+  labels = c.predict(x)
+  dg = c.last_diag
+  assert dg.diffuse_path == (_lib.DIFFUSE_PATH_FREE if mode == FREE
+                             else _lib.DIFFUSE_PATH_EXPLICIT), name
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"])
+  np.testing.assert_allclose(dg.max_delta, float(g["max_delta"]), rtol=1e-6)
+  w = dg.eigenvalue_array()
+  idx, ref = g["consumed_index"], g["consumed_eigenvalues"]
+  if lap in (0, 1):
+    keep = so.consumed_eigen_indices(n, max_clusters, True, ref, 1e-2)
+    idx, ref = idx[keep], ref[keep]
+  assert rel_err(w[idx], ref) < 1e-6, name
+  if mode == FREE:
+    assert dg.free_candidates >= n and dg.free_candidates <= 3 * n
+
+
+def test_default_routing_by_size():
+  opts = icassp_options()
+  for n, want in ((1000, _lib.DIFFUSE_PATH_EXPLICIT), (2048, _lib.DIFFUSE_PATH_FREE)):
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=opts)
+    c.predict(so.blobs(n, 64, 4, seed=n))
+    assert c.last_diag.diffuse_path == want, n
+
+
+@pytest.mark.parametrize("kind", so.HARD_KINDS)
+@pytest.mark.parametrize("n,lap", [(1000, 4), (2048, 0), (2048, 4), (4096, 4)])
+def test_hard_inputs_matrix_free(kind, n, lap):
+  """The unfriendly spectra (restarts, long bases, the "tiny" cluster whose rows overflow
+  the candidate lists) through the two-pass operator."""
+  name = "hard_%s_n%d_lap%d" % (kind, n, lap)
+  g = golden(name + ".npz")
+  nn, d, seed, lap_g, maxc = (int(v) for v in g["params"])
+  x = so.hard_inputs(kind, n, d, seed)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=maxc, laplacian_type=LAP[lap],
+                            refinement_options=icassp_options())
+  c.diffuse_mode = FREE
+  labels = c.predict(x)
+  dg = c.last_diag
+  assert dg.diffuse_path in (_lib.DIFFUSE_PATH_FREE, _lib.DIFFUSE_PATH_FREE_THEN_EXPLICIT)
+  idx, ref = g["consumed_index"], g["consumed_eigenvalues"]
+  scale = np.abs(g["head_eigenvalues"]).max()
+  err = np.abs(dg.eigenvalue_array()[idx] - ref) / np.maximum(np.abs(ref), 1e-9 * scale)
+  assert err.max() < 1e-5, (name, err.max())
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"]), name
+  np.testing.assert_allclose(dg.max_delta, float(g["max_delta"]), rtol=1e-5, err_msg=name)
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0, name
+  if kind == "tiny":
+    assert dg.free_overflow_rows > 0  # its five far-away samples were evaluated in full
+
+
+def test_other_sequences_keep_the_explicit_product():
+  """Diffuse in the middle of a sequence (its entries ARE read) stays explicit even when the
+  matrix-free route is asked for."""
+  x = so.blobs(600, 32, 3, seed=600)
+  seq = [sca.RefinementName.CropDiagonal, sca.RefinementName.RowWiseThreshold,
+         sca.RefinementName.Symmetrize, sca.RefinementName.Diffuse,
+         sca.RefinementName.GaussianBlur, sca.RefinementName.RowWiseNormalize]
+  opts = sca.RefinementOptions(gaussian_blur_sigma=1, p_percentile=0.9,
+                               thresholding_soft_multiplier=0.01, refinement_sequence=seq)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=opts)
+  c.diffuse_mode = FREE
+  got = c.predict(x)
+  assert c.last_diag.diffuse_path == _lib.DIFFUSE_PATH_EXPLICIT
+  ocfg = so.OracleConfig(sequence=(so.OP_CROP_DIAGONAL, so.OP_ROW_WISE_THRESHOLD, so.OP_SYMMETRIZE,
+                                   so.OP_DIFFUSE, so.OP_GAUSSIAN_BLUR, so.OP_ROW_WISE_NORMALIZE),
+                         p_percentile=0.9, min_clusters=2, max_clusters=7)
+  assert so.adjusted_rand_index(got, so.predict(x, ocfg)) == 1.0

@@ -700,6 +700,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   h->n_mv_ev = 0;
   h->free_on = false;
   bool free_path = false;
+  const double* amax_of = nullptr;  // matrix whose max|a| h->fscal[0] bounds (matrix-free Diffuse)
   float diffuse_ms_events[SC_MAX_OPS][2];
   int n_diffuse = 0;
   ev_rec(h, &e_begin);
@@ -772,6 +773,19 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
                                   cfg->preserve_diagonal);
       if (fine) ev_rec(h, &et1);
       SC_TRY(check_last(h, "threshold+symmetrize launch"));
+      // the matrix-free Diffuse quantises this matrix: when it is non-negative by
+      // construction (cosine affinity, no constraint applied to it) and thresholded by RowMax
+      // with a multiplier in [0, 1], its maximum is known from the cut vector
+      if (cfg->threshold_type == SC_THRESHOLD_ROW_MAX && h->affinity_from_embeddings &&
+          !h->constraint_applied && cfg->p_percentile > 0.0 && cfg->soft_multiplier >= 0.0 &&
+          cfg->soft_multiplier <= 1.0 && i + 2 < cfg->n_ops && cfg->ops[i + 2] == SC_OP_DIFFUSE &&
+          free_diffuse_wanted(h, cfg, n, make_eig_request(cfg))) {
+        SC_TRY(ensure_free(h, n));
+        launch_free_amax_from_cut(s, ptr<double>(h->cut), n, cfg->p_percentile,
+                                  (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0,
+                                  ptr<double>(h->fscal));
+        amax_of = out;
+      }
       have_partials = false;
       cur = out;
       symmetric = true;
@@ -785,7 +799,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
       // S = A A^T -- only rowmax(S) (the RowWiseNormalize fold), rowsum(S) (the Laplacian) and
       // S V (the eigensolver).  `cur` stays the symmetric A; `out` stays free.
       SC_TRY(ensure_eig(h, n));
-      SC_TRY(free_diffuse_stats(h, cur, ld, n));
+      SC_TRY(free_diffuse_stats(h, cur, ld, n, amax_of == cur));
       h->free_on = true;
       h->free_lap = cfg->laplacian_type;
       h->free_rownorm = next == SC_OP_ROW_WISE_NORMALIZE ? 1 : 0;

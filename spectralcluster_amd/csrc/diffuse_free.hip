@@ -109,6 +109,22 @@ __global__ __launch_bounds__(256) void k_free_absmax(const double* __restrict__ 
   if (threadIdx.x == 0 && m > 0.0) atomicMax(amax_bits, (unsigned long long)__double_as_longlong(m));
 }
 
+// The same bound without a pass over the matrix, for A = Symmetrize(RowWiseThreshold(B)) with
+// B >= 0 and a soft multiplier in [0, 1]: every entry of A is at most max_i rowmax(B)_i, and
+// cut_i = rowmax(B)_i * p is what the threshold stage already holds.  `floor_value`: 1 when the
+// stage writes ones (binarisation, preserved diagonal).  Any upper bound of max|a| will do for
+// the quantiser (it only has to keep sigma |a| <= 32639); this one is attained.
+__global__ __launch_bounds__(256) void k_free_amax_from_cut(const double* __restrict__ cut, int n,
+                                                            double p, double floor_value,
+                                                            double* __restrict__ scal) {
+  __shared__ double sm[4];
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, cut[i]);
+  m = fr_block_max(m, sm);
+  // (cut_i / p can round below the row maximum it came from: one part in 1e12 on top)
+  if (threadIdx.x == 0) scal[0] = fmax(m / p * (1.0 + 1e-12), floor_value);
+}
+
 // ---------------------------------------------------------------- quantiser
 // Row `row` of A -> digits.  Layout of Q: row pitch 2 Kp bytes (Kp = n rounded up to 64); the
 // 64 k's of block b live in one 128-byte line: bytes [0, 64) the high digits, [64, 128) the low
@@ -118,6 +134,7 @@ __global__ __launch_bounds__(256) void k_free_quantize(
     const double* __restrict__ A, int n, int ld, signed char* __restrict__ Q, size_t pitch, int Kp,
     const double* __restrict__ scal, double* __restrict__ y1, double* __restrict__ R,
     unsigned long long* __restrict__ rmax_bits) {
+  extern __shared__ __attribute__((aligned(16))) signed char qimg[];  // the row's digit image
   __shared__ double sm[4];
   const int row = blockIdx.x;
   signed char* qrow = Q + (size_t)row * pitch;
@@ -130,37 +147,36 @@ __global__ __launch_bounds__(256) void k_free_quantize(
   const double sigma = (amax > 0.0 && isfinite(amax)) ? 32639.0 / amax : 0.0;
   const double* x = A + (size_t)row * ld;
   double sum = 0.0, rsum = 0.0;
-  for (int u = threadIdx.x; u < Kp / 16; u += 256) {
-    const int k0 = 16 * u;
-    union { signed char b[16]; int4 v; } hb, lb;
+  // coalesced: lane t reads the pair k = 2 t + 512 m (16 B), digits go to the LDS image
+  for (int k = 2 * threadIdx.x; k < Kp; k += 512) {
+    // rows are padded to ld (a multiple of 16 doubles): a pair that starts inside the row's
+    // storage stays inside it
+    double2 v = k < ld ? *reinterpret_cast<const double2*>(x + k) : make_double2(0.0, 0.0);
+    if (k >= n) v.x = 0.0;
+    if (k + 1 >= n) v.y = 0.0;
+    sum += v.x;
+    sum += v.y;
+    const double e[2] = {v.x, v.y};
+    signed char hb[2], lb[2];
 #pragma unroll
-    for (int t2 = 0; t2 < 8; ++t2) {
-      const int k = k0 + 2 * t2;
-      // rows are padded to ld (a multiple of 16 doubles): the load stays inside the row
-      double2 v = k < ld ? *reinterpret_cast<const double2*>(x + k) : make_double2(0.0, 0.0);
-      if (k >= n) v.x = 0.0;
-      if (k + 1 >= n) v.y = 0.0;
-      sum += v.x;
-      sum += v.y;
-      const double e[2] = {v.x, v.y};
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        double qd = rint(e[w] * sigma);
-        qd = fmin(fmax(qd, -32639.0), 32639.0);  // (NaN -> -32639: such a row is flagged later)
-        const int q = (int)qd;
-        const int h = (q + 128) >> 8;             // floor((q + 128) / 256): l in [-128, 127]
-        const int l = q - (h << 8);
-        rsum += (double)(q < 0 ? -q : q);
-        hb.b[2 * t2 + w] = (signed char)h;
-        lb.b[2 * t2 + w] = (signed char)l;
-      }
+    for (int w = 0; w < 2; ++w) {
+      double qd = rint(e[w] * sigma);
+      qd = fmin(fmax(qd, -32639.0), 32639.0);  // (NaN -> -32639: such a row is flagged later)
+      const int q = (int)qd;
+      const int h = (q + 128) >> 8;             // floor((q + 128) / 256): l in [-128, 127]
+      const int l = q - (h << 8);
+      rsum += (double)(q < 0 ? -q : q);
+      hb[w] = (signed char)h;
+      lb[w] = (signed char)l;
     }
-    signed char* dst = qrow + (size_t)(k0 >> 6) * 128 + (k0 & 63);
-    *reinterpret_cast<int4*>(dst) = hb.v;
-    *reinterpret_cast<int4*>(dst + 64) = lb.v;
+    signed char* dst = qimg + (k >> 6) * 128 + (k & 63);
+    *reinterpret_cast<short*>(dst) = (short)((unsigned char)hb[0] | ((unsigned short)(unsigned char)hb[1] << 8));
+    *reinterpret_cast<short*>(dst + 64) = (short)((unsigned char)lb[0] | ((unsigned short)(unsigned char)lb[1] << 8));
   }
-  sum = fr_block_sum(sum, sm);
+  sum = fr_block_sum(sum, sm);   // (its barriers also publish the image)
   rsum = fr_block_sum(rsum, sm);
+  for (int u = threadIdx.x; u < (int)(pitch / 16); u += 256)
+    reinterpret_cast<int4*>(qrow)[u] = reinterpret_cast<const int4*>(qimg)[u];
   if (threadIdx.x == 0) {
     y1[row] = sum;
     R[row] = rsum;
@@ -173,29 +189,47 @@ __global__ __launch_bounds__(256) void k_free_quantize(
 // 32 x 64 block at (32 wr, 64 wc): two 32 x 32 MFMA blocks, three i32 accumulators each
 // (hh | hl + lh | ll), T = 65536 hh + 256 (hl + lh) + ll.
 //
-// K loop: stages of 64 k.  A stage of an operand tile is 128 rows x 128 B (one line per row:
-// 64 high digits, 64 low digits) = 16 KB; A tile + B tile = 32 KB; three stage buffers (96 KB)
-// filled by global_load_lds_dwordx4 (LDS-DMA, no staging registers) two stages ahead: per stage
-// a wave waits for its own four DMA instructions of THAT stage (vmcnt(4): the next stage's four
-// stay in flight), one s_barrier makes every wave's pieces visible and retires the buffer read
-// two stages ago, the DMA of stage + 2 is issued into it, then 12 ds_read_b128 feed 16 MFMAs.
+// K loop: stages of 64 k = two MFMA k-steps.  A stage of an operand tile is 128 rows x 128 B
+// (one line per row: 64 high digits, 64 low digits) = 16 KB; A tile + B tile = 32 KB; FOUR stage
+// buffers (128 KB) filled by global_load_lds_dwordx4 (LDS-DMA, no staging registers) three stages
+// ahead.  Software pipeline (one s_barrier per stage, in its middle):
+//     [fragments of (st, k0) already in registers]
+//     DMA of stage st + 3 -> buffer (st - 1) % 4     (every wave left stage st - 1 at the last barrier)
+//     4 MFMAs of (st, k0) | ds_read fragments (st, k1) | 4 MFMAs of (st, k0)
+//     s_waitcnt vmcnt(4): own DMA of stage st + 2 landed;  s_barrier: everybody's did
+//     4 MFMAs of (st, k1) | ds_read fragments (st + 1, k0) | 4 MFMAs of (st, k1)
+// so no MFMA ever waits for an LDS read issued in its own half-stage, and a DMA has two full
+// stages (~2000 cycles) to land before anyone waits for it.
 // LDS image: 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) -- the DMA
 // writes lane-linear, so the permutation is applied to the SOURCE address; with it every
 // 16-lane group of a ds_read_b128 (same chunk, 16 rows) covers all 64 banks.
+// Epilogue: T as fp32 into the tile's slot, and the tile's row / column maxima straight into
+// M (ordered-bits atomicMax: integer, so the result does not depend on the order).
 constexpr int kI8Threads = 512;
 constexpr int kI8Tile = 128;
 constexpr int kI8StageBytes = 32768;
-constexpr int kI8Buffers = 3;
+constexpr int kI8Buffers = 4;
 
 __device__ __forceinline__ void glds16(const signed char* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),
                                    (__attribute__((address_space(3))) void*)(l), 16, 0, 0);
 }
 
+struct I8Frag {
+  v4i ah, al, bh[2], bl[2];
+};
+
+// PROBE (tests/probes/i8_gemm_probe.hip only; the library instantiates 0): 1 = no DMA inside
+// the loop, 2 = no MFMA, 3 = no fragment reads inside the loop -- what each part costs.
+template <int PROBE>
 __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
     const signed char* __restrict__ Q, size_t pitch, int nstages, const int2* __restrict__ tilemap,
-    int xcd_chunk, float* __restrict__ T32, int nt) {
+    int xcd_chunk, float* __restrict__ T32, int nt, int n, unsigned* __restrict__ M,
+    unsigned long long* __restrict__ probe_clk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  // (probe only: shader cycles and 100 MHz wall ticks of this workgroup's K loop)
+  const unsigned long long c_begin = probe_clk ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long t_begin = probe_clk ? wall_clock64() : 0ull;
   int tile = blockIdx.x;
   // XCD-aware order (workgroup ids go round-robin over the 8 XCDs, each with its own L2): XCD x
   // walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the patch-ordered tile list
@@ -212,8 +246,9 @@ __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
   const signed char* gA1 = gA0 + (size_t)64 * pitch;
   const signed char* gB0 = Q + (size_t)(J * kI8Tile + sr) * pitch + 16 * cx;
   const signed char* gB1 = gB0 + (size_t)64 * pitch;
-  auto issue = [&](int stage, int buf) {
-    unsigned char* base = lds + buf * kI8StageBytes + w * 1024;
+  auto issue = [&](int stage) {
+    if (PROBE == 1 && stage > 2) return;
+    unsigned char* base = lds + (stage & 3) * kI8StageBytes + w * 1024;
     const size_t off = (size_t)stage * 128;
     glds16(gA0 + off, base);
     glds16(gA1 + off, base + 8192);
@@ -232,6 +267,17 @@ __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
   for (int dg = 0; dg < 2; ++dg)
 #pragma unroll
     for (int s = 0; s < 2; ++s) coff[dg][s] = 16 * ((4 * dg + 2 * s) ^ y);
+  auto read_frag = [&](I8Frag& f, int stage, int s) {
+    if (PROBE == 3 && stage > 0) return;
+    const unsigned char* sb = lds + (stage & 3) * kI8StageBytes;
+    f.ah = *reinterpret_cast<const v4i*>(sb + aoff + coff[0][s]);
+    f.al = *reinterpret_cast<const v4i*>(sb + aoff + coff[1][s]);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      f.bh[cb] = *reinterpret_cast<const v4i*>(sb + boff + cb * 4096 + coff[0][s]);
+      f.bl[cb] = *reinterpret_cast<const v4i*>(sb + boff + cb * 4096 + coff[1][s]);
+    }
+  };
 
   v16i hh[2], mid[2], ll[2];
 #pragma unroll
@@ -243,96 +289,121 @@ __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
       ll[cb][r] = 0;
     }
   }
-  issue(0, 0);
-  if (nstages > 1) issue(1, 1);
-  int buf = 0;
+  auto mfma_first = [&](const I8Frag& f) {  // the four products with the high digits of A
+    if (PROBE == 2) {
+      asm volatile("" ::"v"(f.ah), "v"(f.al), "v"(f.bh[0]), "v"(f.bh[1]), "v"(f.bl[0]), "v"(f.bl[1]));
+      return;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) hh[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.ah, f.bh[cb], hh[cb], 0, 0, 0);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) mid[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.ah, f.bl[cb], mid[cb], 0, 0, 0);
+  };
+  auto mfma_second = [&](const I8Frag& f) {  // ... with its low digits
+    if (PROBE == 2) return;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) ll[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.al, f.bl[cb], ll[cb], 0, 0, 0);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) mid[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.al, f.bh[cb], mid[cb], 0, 0, 0);
+  };
+
+  // ---- prologue: stages 0, 1, 2 in flight; stages 0 and 1 visible; fragments of (0, k0)
+  issue(0);
+  if (nstages > 1) issue(1);
+  if (nstages > 2) issue(2);
+  if (nstages > 2)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  I8Frag f0, f1;
+  read_frag(f0, 0, 0);
   for (int st = 0; st < nstages; ++st) {
-    if (st + 1 < nstages)
+    if (st + 3 < nstages) issue(st + 3);
+    // (the compiler waits for EVERY outstanding LDS read before the first MFMA that needs one:
+    //  the next fragments are requested behind the first four MFMAs of a half, so that wait
+    //  only ever sees reads that had a full half-stage to return.  sched_barrier pins that.)
+    mfma_first(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(f1, st, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_second(f0);
+    // own DMA of stage st + 2 landed (only stage st + 3's four may still be in flight) ...
+    if (st + 3 < nstages && PROBE != 1)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and this wave's reads of stage st have returned (its buffer is refilled next round)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (st + 2 < nstages) issue(st + 2, buf >= 1 ? buf - 1 : 2);  // (st + 2) % 3
-    const unsigned char* sb = lds + buf * kI8StageBytes;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const v4i ah = *reinterpret_cast<const v4i*>(sb + aoff + coff[0][s]);
-      const v4i al = *reinterpret_cast<const v4i*>(sb + aoff + coff[1][s]);
-      v4i bh[2], bl[2];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        bh[cb] = *reinterpret_cast<const v4i*>(sb + boff + cb * 4096 + coff[0][s]);
-        bl[cb] = *reinterpret_cast<const v4i*>(sb + boff + cb * 4096 + coff[1][s]);
-      }
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) hh[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, bh[cb], hh[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) mid[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ah, bl[cb], mid[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) ll[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, bl[cb], ll[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) mid[cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(al, bh[cb], mid[cb], 0, 0, 0);
-    }
-    buf = buf == 2 ? 0 : buf + 1;
+    // (the last round re-reads its own stage: straight-line code lets the compiler count the
+    //  fragment reads still in flight instead of waiting for all of them before the MFMAs)
+    mfma_first(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(f0, st + 1 < nstages ? st + 1 : st, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_second(f1);
+  }
+  if (probe_clk != nullptr && threadIdx.x == 0) {
+    probe_clk[2 * blockIdx.x] = __builtin_readcyclecounter() - c_begin;
+    probe_clk[2 * blockIdx.x + 1] = wall_clock64() - t_begin;
   }
   // ---- epilogue: T = 65536 hh + 256 mid + ll, exact in fp64 (|T| < 2^53), stored as fp32 into
   // the tile's slot (tile-major, row-major inside).  D layout of the 32 x 32 block: lane l,
   // register r: row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
   float* out = T32 + (size_t)tile_to_slot(I, J, nt) * (kI8Tile * kI8Tile);
+  float rowm[16];  // running maxima of this lane's 16 rows over its columns
+  float colm[2];   // ... of its 2 columns over its 16 rows
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowm[r] = -INFINITY;
+  const int grow0 = I * kI8Tile + 32 * wr + 4 * g;  // + (r & 3) + 8 (r >> 2)
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int col = 64 * wc + 32 * cb + rr;
+    const bool col_ok = J * kI8Tile + col < n;
+    colm[cb] = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * g;
       const double t = (double)hh[cb][r] * 65536.0 + (double)mid[cb][r] * 256.0 + (double)ll[cb][r];
-      out[row * kI8Tile + col] = (float)t;
+      const float tf = (float)t;
+      out[row * kI8Tile + col] = tf;
+      if (col_ok) rowm[r] = fmaxf(rowm[r], tf);
+      if (grow0 + (r & 3) + 8 * (r >> 2) < n) colm[cb] = fmaxf(colm[cb], tf);
     }
+  }
+  // row maxima: over the 32 lanes of a half-wave (the columns); the DMA buffers are dead now,
+  // LDS holds the per-wave partials: rows [wc][128], columns [wr][128]
+  __builtin_amdgcn_s_barrier();
+  float* prow = reinterpret_cast<float*>(lds);
+  float* pcol = prow + 2 * 128;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = rowm[r];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if (rr == 0) prow[wc * 128 + 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * g] = v;
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const float v = fmaxf(colm[cb], __shfl_xor(colm[cb], 32));
+    if (g == 0) pcol[wr * 128 + 64 * wc + 32 * cb + rr] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int row = I * kI8Tile + threadIdx.x;
+    const float v = fmaxf(prow[threadIdx.x], prow[128 + threadIdx.x]);
+    if (row < n && v > -INFINITY) atomicMax(&M[row], ordered_bits(v));
+  } else if (threadIdx.x < 256 && I != J) {
+    const int c = threadIdx.x - 128;
+    const int row = J * kI8Tile + c;
+    const float v = fmaxf(fmaxf(pcol[c], pcol[128 + c]), fmaxf(pcol[256 + c], pcol[384 + c]));
+    if (row < n && v > -INFINITY) atomicMax(&M[row], ordered_bits(v));
   }
 }
 
-// ---------------------------------------------------------------- scans of T
-// One workgroup per stored tile (I, J).  Phase A: the tile's rows (rows I*128.. of T, columns
-// J*128..).  Phase B (J > I): its columns, which are rows J*128.. of the symmetric T.
-// M holds ordered_bits() of the row maxima (0 = nothing yet).
-__global__ __launch_bounds__(256) void k_t32_rowmax(const float* __restrict__ T32, int nt, int n,
-                                                    unsigned* __restrict__ M) {
-  __shared__ float colpart[2][128];
-  int I, J;
-  slot_to_tile(blockIdx.x, nt, &I, &J);
-  const float* tile = T32 + (size_t)blockIdx.x * (kI8Tile * kI8Tile);
-  const int r0 = I * kI8Tile, c0 = J * kI8Tile;
-  {  // phase A: thread (row = t >> 1, half = t & 1) scans 64 columns
-    const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
-    float m = -INFINITY;
-    const float4* src = reinterpret_cast<const float4*>(tile + r * kI8Tile + 64 * half);
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-      const float4 v = src[q];
-      const int c = c0 + 64 * half + 4 * q;
-      if (c < n) m = fmaxf(m, v.x);
-      if (c + 1 < n) m = fmaxf(m, v.y);
-      if (c + 2 < n) m = fmaxf(m, v.z);
-      if (c + 3 < n) m = fmaxf(m, v.w);
-    }
-    m = fmaxf(m, __shfl_xor(m, 1));
-    if (half == 0 && r0 + r < n && m > -INFINITY) atomicMax(&M[r0 + r], ordered_bits(m));
-  }
-  if (I == J) return;
-  {  // phase B: thread (col = t & 127, half = t >> 7) scans 64 rows
-    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-    float m = -INFINITY;
-    for (int r = 64 * half; r < 64 * half + 64; ++r)
-      if (r0 + r < n) m = fmaxf(m, tile[r * kI8Tile + c]);
-    colpart[half][c] = m;
-    __syncthreads();
-    if (half == 0) {
-      m = fmaxf(colpart[0][c], colpart[1][c]);
-      if (c0 + c < n && m > -INFINITY) atomicMax(&M[c0 + c], ordered_bits(m));
-    }
-  }
-}
-
+// ---------------------------------------------------------------- candidates
+// (M: ordered_bits() of the row maxima of T, left by the product's epilogue; 0 = nothing)
 // slack of row i (in units of sigma^2 S), see the header of this file: twice the bound on
 // |sigma^2 S - T| with R_j replaced by its maximum, plus the fp32 rounding of the two stored
 // values that are compared (2^-24 relative each, doubled for safety)
@@ -351,6 +422,9 @@ __device__ __forceinline__ void free_append(int row, int col, int cap, int* __re
   if (pos < cap) cand[(size_t)row * cap + pos] = col;
 }
 
+// One workgroup per stored tile (I, J): every entry is looked at once, as T[row][col] against
+// its row's threshold and -- off the diagonal tiles -- as T[col][row] (T is symmetric) against
+// its column's.  A wave reads whole 512-byte tile rows.
 __global__ __launch_bounds__(256) void k_t32_candidates(
     const float* __restrict__ T32, int nt, int n, const unsigned* __restrict__ M,
     const double* __restrict__ R, const unsigned long long* __restrict__ rmax_bits, int cap,
@@ -367,29 +441,31 @@ __global__ __launch_bounds__(256) void k_t32_candidates(
   } else {
     const int row = c0 + threadIdx.x - 128;
     thrJ[threadIdx.x - 128] =
-        row < n ? free_threshold(ordered_value(M[row]), R[row], Rmax, n) : INFINITY;
+        (row < n && I != J) ? free_threshold(ordered_value(M[row]), R[row], Rmax, n) : INFINITY;
   }
   __syncthreads();
-  {  // phase A
-    const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const float thr = thrI[r];
-    const float4* src = reinterpret_cast<const float4*>(tile + r * kI8Tile + 64 * half);
+  const int c4 = 4 * (threadIdx.x & 31);
+  const float tj0 = thrJ[c4], tj1 = thrJ[c4 + 1], tj2 = thrJ[c4 + 2], tj3 = thrJ[c4 + 3];
+  const float tjmin = fminf(fminf(tj0, tj1), fminf(tj2, tj3));
 #pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-      const float4 v = src[q];
-      const int c = c0 + 64 * half + 4 * q;
-      if (v.x >= thr && c < n) free_append(r0 + r, c, cap, count, cand);
-      if (v.y >= thr && c + 1 < n) free_append(r0 + r, c + 1, cap, count, cand);
-      if (v.z >= thr && c + 2 < n) free_append(r0 + r, c + 2, cap, count, cand);
-      if (v.w >= thr && c + 3 < n) free_append(r0 + r, c + 3, cap, count, cand);
+  for (int rg = 0; rg < 16; ++rg) {
+    const int r = 8 * rg + (threadIdx.x >> 5);
+    const float4 v = *reinterpret_cast<const float4*>(tile + r * kI8Tile + c4);
+    const float ti = thrI[r];
+    const float vmax = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    if (vmax >= ti) {  // (rare) as entries of row r0 + r; padding columns are not entries
+      const int c = c0 + c4;
+      if (v.x >= ti && c < n) free_append(r0 + r, c, cap, count, cand);
+      if (v.y >= ti && c + 1 < n) free_append(r0 + r, c + 1, cap, count, cand);
+      if (v.z >= ti && c + 2 < n) free_append(r0 + r, c + 2, cap, count, cand);
+      if (v.w >= ti && c + 3 < n) free_append(r0 + r, c + 3, cap, count, cand);
     }
-  }
-  if (I == J) return;
-  {  // phase B
-    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const float thr = thrJ[c];
-    for (int r = 64 * half; r < 64 * half + 64; ++r)
-      if (tile[r * kI8Tile + c] >= thr && r0 + r < n) free_append(c0 + c, r0 + r, cap, count, cand);
+    if (vmax >= tjmin && r0 + r < n) {  // as entries of rows c0 + c4 .. (thrJ = inf when unused)
+      if (v.x >= tj0) free_append(c0 + c4, r0 + r, cap, count, cand);
+      if (v.y >= tj1) free_append(c0 + c4 + 1, r0 + r, cap, count, cand);
+      if (v.z >= tj2) free_append(c0 + c4 + 2, r0 + r, cap, count, cand);
+      if (v.w >= tj3) free_append(c0 + c4 + 3, r0 + r, cap, count, cand);
+    }
   }
 }
 
@@ -492,29 +568,31 @@ void launch_free_absmax(hipStream_t s, const double* A, int n, int ld, double* s
                      reinterpret_cast<unsigned long long*>(scal));
 }
 
+void launch_free_amax_from_cut(hipStream_t s, const double* cut, int n, double p,
+                               double floor_value, double* scal) {
+  hipLaunchKernelGGL(k_free_amax_from_cut, dim3(1), dim3(256), 0, s, cut, n, p, floor_value, scal);
+}
+
 void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed char* Q,
                           double* scal, double* y1, double* R) {
   const int Kp = free_k_padded(n);
-  hipLaunchKernelGGL(k_free_quantize, dim3(free_rows_padded(n)), dim3(256), 0, s, A, n, ld, Q,
-                     (size_t)2 * Kp, Kp, scal, y1, R,
+  SC_OPT_IN_LDS(k_free_quantize, 2 * 65536);  // (n <= 65536: the row image is 2 Kp bytes)
+  hipLaunchKernelGGL(k_free_quantize, dim3(free_rows_padded(n)), dim3(256), (size_t)2 * Kp, s, A,
+                     n, ld, Q, (size_t)2 * Kp, Kp, scal, y1, R,
                      reinterpret_cast<unsigned long long*>(scal) + 2);
 }
 
 void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
-                        float* T32) {
+                        float* T32, unsigned* M) {
   const int nt = (n + kI8Tile - 1) / kI8Tile;
   const int tiles = nt * (nt + 1) / 2;
   const int Kp = free_k_padded(n);
   const int lds = kI8Buffers * kI8StageBytes;
-  SC_OPT_IN_LDS(k_gemm_i8_sym, lds);
+  SC_OPT_IN_LDS(k_gemm_i8_sym<0>, lds);
   const int xcd_chunk = (tiles % 8 == 0 && tiles >= 512) ? tiles / 8 : 0;
-  hipLaunchKernelGGL(k_gemm_i8_sym, dim3(tiles), dim3(kI8Threads), lds, s, Q, (size_t)2 * Kp,
-                     Kp / 64, tilemap, xcd_chunk, T32, nt);
-}
-
-void launch_t32_rowmax(hipStream_t s, const float* T32, int n, unsigned* M) {
-  const int nt = (n + kI8Tile - 1) / kI8Tile;
-  hipLaunchKernelGGL(k_t32_rowmax, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, T32, nt, n, M);
+  hipLaunchKernelGGL(k_gemm_i8_sym<0>, dim3(tiles), dim3(kI8Threads), lds, s, Q, (size_t)2 * Kp,
+                     Kp / 64, tilemap, xcd_chunk, T32, nt, n, M,
+                     static_cast<unsigned long long*>(nullptr));
 }
 
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,

@@ -45,7 +45,7 @@ bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequ
   return n >= env_free_min_n();
 }
 
-static int ensure_free(sc_handle h, int n) {
+int ensure_free(sc_handle h, int n) {
   const size_t nv = (size_t)round_up(n, 16) * sizeof(double);
   SC_TRY(grow(h, h->fq, free_q_bytes(n)));
   SC_TRY(grow(h, h->ft32, free_t32_bytes(n)));
@@ -60,23 +60,24 @@ static int ensure_free(sc_handle h, int n) {
   return SC_OK;
 }
 
-int free_diffuse_stats(sc_handle h, const double* A, int ld, int n) {
+int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax) {
   hipStream_t s = h->stream;
   SC_TRY(ensure_free(h, n));
   SC_TRY(ensure_tilemap(h, n));
   unsigned* M = ptr<unsigned>(h->fwords);
   int* count = ptr<int>(h->fwords) + n;
   int* ovf = ptr<int>(h->fwords) + 2 * (size_t)n;
-  SC_HIP(h, hipMemsetAsync(h->fscal.p, 0, 4 * sizeof(double), s));
+  // ([0] max|a| stays when the caller has it; [2] max R starts from zero)
+  SC_HIP(h, hipMemsetAsync(ptr<double>(h->fscal) + (have_amax ? 1 : 0), 0,
+                           (have_amax ? 3 : 4) * sizeof(double), s));
   SC_HIP(h, hipMemsetAsync(h->fwords.p, 0, ((size_t)2 * n + kOvfWords) * sizeof(int), s));
   ev_rec(h, &h->free_ev[0]);
-  launch_free_absmax(s, A, n, ld, ptr<double>(h->fscal));
+  if (!have_amax) launch_free_absmax(s, A, n, ld, ptr<double>(h->fscal));
   launch_free_quantize(s, A, n, ld, ptr<signed char>(h->fq), ptr<double>(h->fscal),
                        ptr<double>(h->fy1), ptr<double>(h->fR));
   ev_rec(h, &h->free_ev[1]);
-  launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32));
+  launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32), M);
   ev_rec(h, &h->free_ev[2]);
-  launch_t32_rowmax(s, ptr<float>(h->ft32), n, M);
   launch_t32_candidates(s, ptr<float>(h->ft32), n, M, ptr<double>(h->fR), ptr<double>(h->fscal),
                         count, ptr<int>(h->fcand));
   ev_rec(h, &h->free_ev[3]);

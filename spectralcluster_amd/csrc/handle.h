@@ -323,7 +323,9 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
 bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequest& rq);
 // enqueue the statistics of S = A A^T (h->rowmax, h->rowsum) on h->stream; no synchronisation.
 // The overflow words travel to h->h_free behind them.
-int free_diffuse_stats(sc_handle h, const double* A, int ld, int n);
+// `have_amax`: h->fscal[0] already holds max|a| (or an upper bound of it) for this A
+int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax = false);
+int ensure_free(sc_handle h, int n);
 // after the stream has drained: rows with more candidates than the cap are evaluated in full.
 // *changed: rowmax was rewritten (the scaling vectors must be rebuilt); *too_many: more such
 // rows than the exact route takes (the caller forms S explicitly).

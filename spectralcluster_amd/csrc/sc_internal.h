@@ -375,11 +375,14 @@ size_t free_q_bytes(int n);
 size_t free_t32_bytes(int n);
 int free_candidate_cap();
 void launch_free_absmax(hipStream_t s, const double* A, int n, int ld, double* scal);
+// scal[0] = an attained upper bound of max|a| for A = Symmetrize(RowWiseThreshold(B)), B >= 0,
+// from the threshold stage's cut vector (cut_i = rowmax(B)_i * p): no pass over the matrix
+void launch_free_amax_from_cut(hipStream_t s, const double* cut, int n, double p,
+                               double floor_value, double* scal);
 void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed char* Q,
                           double* scal, double* y1, double* R);
 void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
-                        float* T32);
-void launch_t32_rowmax(hipStream_t s, const float* T32, int n, unsigned* M);
+                        float* T32, unsigned* M);
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,
                            const double* R, const double* scal, int* count, int* cand);
 void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const double* y1,

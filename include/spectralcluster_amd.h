@@ -202,7 +202,8 @@ typedef struct sc_diag {
                                     the host-driven repair chain redid the solve */
   int32_t eig_fallback;          /* 0, or why block Lanczos handed over to the dense path:
                                     1 restart budget spent, 2 projected eigenproblem failed,
-                                    3 no full-rank Krylov block, 4 forced (SC_EIG_FORCE_DENSE) */
+                                    3 no full-rank Krylov block, 4 forced (SC_EIG_FORCE_DENSE),
+                                    5 more than 64 eigenvectors wanted (> 64 selected clusters) */
   float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */
   int32_t diffuse_path;          /* SC_DIFFUSE_PATH_* */
   int32_t free_candidates;       /* matrix-free Diffuse: exact dot products evaluated (n + few) */

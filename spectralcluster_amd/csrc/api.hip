@@ -105,8 +105,16 @@ int ensure_eig(sc_handle h, int n) {
     SC_HIP(h, hipMemsetAsync(h->flags.p, 0, 16 * sizeof(int), h->stream));
   }
   SC_TRY(grow(h, h->mvsym, matvec_sym_workspace_doubles(n) * sizeof(double)));
-  SC_TRY(grow(h, h->E, (size_t)round_up(n, 16) * kMaxCols * sizeof(double)));
-  SC_TRY(grow(h, h->Eio, (size_t)n * kMaxCols * sizeof(double)));
+  SC_TRY(ensure_vectors(h, n, kMaxCols));
+  return SC_OK;
+}
+
+// room for `cols` eigenvector columns (the arena holds kMaxCols; a request that selects more
+// clusters than that -- the reference has no limit, spectral_clusterer.py:295-299 -- grows it)
+int ensure_vectors(sc_handle h, int n, int cols) {
+  cols = std::max(cols, kMaxCols);
+  SC_TRY(grow(h, h->E, (size_t)round_up(n, 16) * cols * sizeof(double)));
+  SC_TRY(grow(h, h->Eio, (size_t)n * cols * sizeof(double)));
   return SC_OK;
 }
 
@@ -123,16 +131,21 @@ int ensure_gen(sc_handle h, int n) {
   return SC_OK;
 }
 
-int ensure_kmeans(sc_handle h, int n) {
-  SC_TRY(grow(h, h->Ek, (size_t)round_up(n, 16) * kMaxCols * sizeof(double)));
-  SC_TRY(grow(h, h->Eio, (size_t)n * kMaxCols * sizeof(double)));
-  SC_TRY(grow(h, h->kXc, (size_t)n * kMaxVectors * sizeof(double)));
+int ensure_kmeans(sc_handle h, int n, int k) {
+  const int cols = std::max(k, kMaxCols), kk = std::max(k, kMaxVectors);
+  SC_TRY(grow(h, h->Ek, (size_t)round_up(n, 16) * cols * sizeof(double)));
+  SC_TRY(grow(h, h->Eio, (size_t)n * cols * sizeof(double)));
+  SC_TRY(grow(h, h->kXc, (size_t)n * kk * sizeof(double)));
   SC_TRY(grow(h, h->kxsq, (size_t)n * sizeof(double)));
   SC_TRY(grow(h, h->kclosest, (size_t)n * sizeof(double)));
   SC_TRY(grow(h, h->kcand, (size_t)8 * n * sizeof(double)));
   SC_TRY(grow(h, h->kenorm, (size_t)n * sizeof(double)));
-  SC_TRY(grow(h, h->krnd, 1024 * sizeof(double)));
-  SC_TRY(grow(h, h->kcent, (size_t)kMaxVectors * kMaxVectors * sizeof(double)));
+  SC_TRY(grow(h, h->krnd, (size_t)std::max(1024, 8 * kk) * sizeof(double)));
+  SC_TRY(grow(h, h->kcent, (size_t)kk * kk * sizeof(double)));
+  if (k > kMaxVectors) {  // the large-k form keeps its per-cluster arrays in global memory
+    SC_TRY(grow(h, h->kbig, kmeans_big_workspace_doubles(k) * sizeof(double)));
+    SC_TRY(grow(h, h->kbigw, (size_t)3 * k * sizeof(int)));
+  }
   SC_TRY(grow(h, h->klab32, (size_t)n * sizeof(int)));
   SC_TRY(grow(h, h->klab64, (size_t)n * sizeof(long long)));
   SC_TRY(grow(h, h->kinfo, 16 * sizeof(int)));
@@ -233,7 +246,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->td_tau, &h->td_panel, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
                     &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd, &h->gpack, &h->gypack, &h->ginfo, &h->glabels,
-                    &h->fq, &h->ft32, &h->fy1, &h->fR, &h->fscal, &h->fwords, &h->fcand, &h->fY};
+                    &h->kbig, &h->kbigw, &h->fq, &h->ft32, &h->fy1, &h->fR, &h->fscal, &h->fwords, &h->fcand, &h->fY};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);
@@ -1015,6 +1028,8 @@ KmeansWorkspace kmeans_workspace(sc_handle h) {
   ws.labels64 = ptr<long long>(h->klab64);
   ws.info = ptr<int>(h->kinfo);
   ws.chain = ptr<double>(h->kchain);
+  ws.big = ptr<double>(h->kbig);
+  ws.big_words = ptr<int>(h->kbigw);
   return ws;
 }
 
@@ -1029,9 +1044,10 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   if (max_iter <= 0)
     return fail(h, SC_ERR_INVALID, "Number of iterations should be a positive number");
   if (n < k) return fail(h, SC_ERR_INVALID, "n_samples should be >= n_clusters");
-  if (k < 1 || k > kMaxVectors)
-    return fail(h, SC_ERR_UNSUPPORTED, "n_clusters must be in [1, 64] on the device path");
-  SC_TRY(ensure_kmeans(h, n));
+  // k-means++ draws 2 + int(log k) candidates per centre (sklearn); the kernels hold 8
+  if (k < 1 || k > 1096)
+    return fail(h, SC_ERR_UNSUPPORTED, "n_clusters must be in [1, 1096] on the device path");
+  SC_TRY(ensure_kmeans(h, n, k));
   // RandomState(0): first centre via choice(n, p=uniform) = cdf.searchsorted(u, 'right')
   Mt19937 rng(0);
   const double u = rng.next_double();
@@ -1042,7 +1058,7 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   const int first = h->kfirst;
   const int trials = 2 + (int)std::log((double)k);
   const size_t nrnd = (size_t)std::max(1, (k - 1) * trials);
-  if (nrnd > 1024) return fail(h, SC_ERR_UNSUPPORTED, "too many k-means++ trials");
+  if (trials > 8) return fail(h, SC_ERR_UNSUPPORTED, "too many k-means++ trials");
   if (h->krnd_k != k || h->krnd_trials != trials) {  // RandomState(0) doubles: a function of k
     std::vector<double> rnd(nrnd);
     for (size_t i = 0; i < nrnd; ++i) rnd[i] = rng.next_double();
@@ -1094,6 +1110,13 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
     fprintf(stderr, "[sc] kmeans n=%d k=%d iters=%d  us: centre %.1f  kmeans++ %.1f  lloyd %.1f"
             "  cosine-loop %.1f\n", n, k, info[0], info[1] * 0.01, (info[2] - info[1]) * 0.01,
             (info[3] - info[2]) * 0.01, (info[4] - info[3]) * 0.01);
+  if (sw::kmeans_trace() && k > kMaxVectors) {  // the large-k form keeps its seeds in global memory
+    std::vector<int> seeds(k);
+    hipMemcpy(seeds.data(), h->kbigw.p, (size_t)k * sizeof(int), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[sc] kmeans++ seeds:");
+    for (int i = 0; i < k; ++i) fprintf(stderr, " %d", seeds[i]);
+    fprintf(stderr, "\n");
+  }
   return SC_OK;
 }
 
@@ -1111,7 +1134,7 @@ extern "C" int sc_cluster(sc_handle h, const sc_config* cfg, int n_clusters, int
   const double* E = ptr<double>(h->E);
   const int lde = round_up(n, 16);
   if (cfg->row_wise_renorm) {
-    SC_TRY(ensure_kmeans(h, n));
+    SC_TRY(ensure_kmeans(h, n, n_clusters));
     SC_HIP(h, hipMemcpyAsync(h->Ek.p, h->E.p, (size_t)lde * n_clusters * sizeof(double),
                              hipMemcpyDeviceToDevice, h->stream));
     launch_row_renorm(h->stream, ptr<double>(h->Ek), lde, n, n_clusters);
@@ -1319,8 +1342,6 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   if (!h) return SC_ERR_INVALID;
   if (!m || n <= 0 || count <= 0 || count > n || !values)
     return fail(h, SC_ERR_INVALID, "bad eigen request");
-  if (n > kDenseMax && count > kMaxVectors && vectors)
-    return fail(h, SC_ERR_UNSUPPORTED, "at most 64 eigenvectors for n > 128");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
   const int ld = matrix_ld(n);
@@ -1329,7 +1350,7 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   h->have_affinity = h->have_cropval = false;
   h->have_x = false;
   SC_TRY(h2d_matrix(h, m, n, n, ptr<double>(h->B1), ld));
-  if (n > kDenseMax && count > kMaxVectors) {
+  if (n > kDenseMax && count > kMaxVectors && !vectors) {
     // values only, more than a Krylov basis holds: the dense full-spectrum path
     // (Householder tridiagonalisation + Sturm bisection, eig_dense.hip)
     SC_TRY(ensure_eig(h, n));
@@ -1462,10 +1483,8 @@ extern "C" int sc_stage_kmeans_metric(sc_handle h, const double* e, int n, int k
                                       int* iterations) {
   if (!h) return SC_ERR_INVALID;
   if (!e || !labels || n <= 0 || k <= 0) return fail(h, SC_ERR_INVALID, "bad k-means input");
-  if (k > kMaxVectors)
-    return fail(h, SC_ERR_UNSUPPORTED, "n_clusters must be <= 64 on the device path");
   SC_HIP(h, hipSetDevice(h->device));
-  SC_TRY(ensure_kmeans(h, n));
+  SC_TRY(ensure_kmeans(h, n, k));
   SC_HIP(h, hipMemcpyAsync(h->Eio.p, e, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice,
                            h->stream));
   launch_to_colmajor(h->stream, ptr<double>(h->Eio), n, k, ptr<double>(h->Ek),

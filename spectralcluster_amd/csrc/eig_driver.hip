@@ -55,7 +55,12 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
                   rq.eigengap_type, rq.descend, wmax, &dc.n_clusters_raw, &dc.max_delta);
     dc.kvec = std::max(dc.n_clusters_raw, rq.min_clusters);
     if (dc.kvec < 1) dc.kvec = 1;
-    if (dc.kvec > m) dc.kvec = m;
+    if (dc.kvec > kEigBasisCap / 2 && !exact) {  // (min_clusters beyond what a basis holds)
+      dc.enough = false;
+      dc.unsupported = true;
+      return dc;
+    }
+    if (dc.kvec > m) dc.kvec = std::min(m, n);
   }
   if (exact) {
     dc.converged = true;
@@ -341,8 +346,9 @@ static int dense_spectrum(sc_handle h, const double* S, int ld, int n, double* s
 // (utils.py:59) it always returns.
 static int dense_vectors(sc_handle h, const double* scratch, int ld, int n, int cols) {
   hipStream_t s = h->stream;
-  if (cols < 1 || cols > kMaxCols || cols > n)
+  if (cols < 1 || cols > n)
     return fail(h, SC_ERR_UNSUPPORTED, "dense eigenvector request out of range");
+  SC_TRY(ensure_vectors(h, n, cols));
   std::vector<double> de(2 * (size_t)n);
   SC_HIP(h, hipMemcpyAsync(de.data(), h->td_d.p, (size_t)n * sizeof(double),
                            hipMemcpyDeviceToHost, s));
@@ -464,7 +470,7 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
   // Dense full-spectrum route (n > 128): all eigenvalues from the tridiagonal form, the
   // eigengap decision from those, then the same Lanczos loop below for just the vectors.
   EigDecision dense_dc;
-  bool dense = false;
+  bool dense = false, many_vectors = false;
   auto run_dense = [&]() -> int {
     bool unused = false;
     SC_TRY(free_check(&unused));
@@ -473,9 +479,10 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
     std::vector<double> zeros(n, 0.0);
     dense_dc = analyze(rq_in, h->spectrum.data(), zeros.data(), n, n, true);
     if (!dense_dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
-    if (dense_dc.kvec > kMaxVectors)
-      return fail(h, SC_ERR_UNSUPPORTED,
-                  "the eigengap selects more than 64 clusters; set max_clusters");
+    // More vectors than a Krylov basis comfortably yields (the eigengap selected > 64
+    // clusters, min_clusters > 64, or a stage request for > 64 pairs): they come from the
+    // tridiagonal form too (dense_vectors), like every vector of the landing pad.
+    many_vectors = dense_dc.kvec > kMaxVectors;
     dense = true;
     rq = rq_in;
     rq.fixed_count = std::max(1, dense_dc.kvec);  // vectors only
@@ -498,8 +505,9 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
     if (!dense) SC_TRY(run_dense());
     SC_TRY(free_materialize(false));  // (a `dense` that predates the hand-over: not in free mode)
     int cols = dense_dc.kvec;
-    if (rq_in.fixed_count > 0 || rq_in.max_clusters > 0) cols = std::max(dense_dc.kw, cols);
-    cols = std::max(1, std::min(cols, kMaxVectors));
+    if (rq_in.fixed_count > 0 || rq_in.max_clusters > 0)
+      cols = std::max(std::min(dense_dc.kw, kMaxVectors), cols);
+    cols = std::max(1, cols);
     SC_TRY(dense_vectors(h, scratch, ld, n, cols));
     vectors_from_dense = true;
     fallback_reason = reason;
@@ -535,8 +543,15 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
     uint64_t seed = 0x5eed5eedull;
     const double* vscale = h->vs_scale ? h->vs_scale : cvec;
     LzChain chain;
+    if (dense && many_vectors) {
+      // the full spectrum is known and more than 64 vectors are wanted: all of them from the
+      // tridiagonal form (inverse iteration + Householder back-transform), no Krylov solve
+      SC_TRY(dense_fallback(5));
+      done = true;
+    }
     // ---- start block
-    if (fused) {
+    if (done) {
+    } else if (fused) {
       // fused chain (k_lz_step): no host synchronisation until the first Rayleigh-Ritz
       SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
       const EigWorkspace ws = eig_workspace(h);

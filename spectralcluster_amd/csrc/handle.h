@@ -82,6 +82,7 @@ struct sc_handle_s {
   DevBuf fb_part, fb_small, fb_x, fb_cent, fb_int;      // fallback decisions scratch
   // k-means workspace
   DevBuf kXc, kxsq, kclosest, kcand, kenorm, krnd, kcent, klab32, klab64, kinfo, kchain;
+  DevBuf kbig, kbigw;     // more than kMaxVectors clusters: per-cluster arrays of k_kmeans<true>
   // pinned host scratch
   double* h_theta = nullptr;  // 3 * kLdq doubles (theta, resid, Im theta)
   int* h_flags = nullptr;
@@ -220,7 +221,9 @@ int ensure_eig(sc_handle h, int n);
 
 int ensure_gen(sc_handle h, int n);
 
-int ensure_kmeans(sc_handle h, int n);
+// k: clusters the k-means stage will be asked for (buffers grow past the 64-cluster default)
+int ensure_kmeans(sc_handle h, int n, int k = kMaxVectors);
+int ensure_vectors(sc_handle h, int n, int cols);
 
 inline int check_last(sc_handle h, const char* what) {
   hipError_t e = hipGetLastError();

@@ -1,5 +1,6 @@
 // K1/K2: run_kmeans with custom_dist="cosine" (reference
-// custom_distance_kmeans.py:13-141) on the (n, k) spectral embedding, k <= 64.
+// custom_distance_kmeans.py:13-141) on the (n, k) spectral embedding; any k (k <= 64 with the
+// per-cluster arrays in LDS, more through a global workspace: k_kmeans<true>).
 //
 //   seeds   = sklearn 1.7.2 KMeans(init="k-means++", max_iter=1, random_state=0,
 //             n_init="auto").fit(E).cluster_centers_   (:39-43), restated:
@@ -74,12 +75,12 @@ __global__ void k_to_colmajor(const double* __restrict__ src, int n, int k,
 __device__ __forceinline__ void cluster_means(const double* __restrict__ data, int ld,
                                               int n, int k, const int* __restrict__ lab,
                                               double* cent, const double* mean, int mode,
-                                              double* wpart /* 2 * KW * kMaxVectors */,
+                                              double* wpart /* 2 * KW * kst */, int kst,
                                               int* counts, int* nzcounts) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = 0; c < k; ++c) {
     int cnt = 0, nz = 0;
-    double* wp = wpart + (c & 1) * (KW * kMaxVectors);  // double-buffered by parity
+    double* wp = wpart + (c & 1) * (KW * kst);  // double-buffered by parity
     for (int j0 = 0; j0 < k; j0 += 8) {
       double acc[8];
 #pragma unroll
@@ -96,7 +97,7 @@ __device__ __forceinline__ void cluster_means(const double* __restrict__ data, i
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const double v = wsum(acc[q]);
-        if (lane == 0 && j0 + q < k) wp[wave * kMaxVectors + j0 + q] = v;
+        if (lane == 0 && j0 + q < k) wp[wave * kst + j0 + q] = v;
       }
     }
     cnt = wsumi(cnt);
@@ -106,43 +107,65 @@ __device__ __forceinline__ void cluster_means(const double* __restrict__ data, i
       atomicAdd(&nzcounts[c], nz);
     }
     __syncthreads();
-    if (tid < k) {
+    // (the counters were built by atomics, which execute in L2: in the large-k form they live
+    //  in global memory, and a plain load could be served from this CU's L1 with the zero that
+    //  was stored before the atomics -- read them the way they were written)
+    const int count_c = __hip_atomic_load(&counts[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nz_c = __hip_atomic_load(&nzcounts[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = tid; t < k; t += KT) {  // (k <= 64: one trip; the large-k form strides)
       double tot = 0.0;
 #pragma unroll
-      for (int w = 0; w < KW; ++w) tot += wp[w * kMaxVectors + tid];
-      const int q = c * k + tid;
+      for (int w = 0; w < KW; ++w) tot += wp[w * kst + t];
+      const int q = c * k + t;
       if (mode == 0) {
-        const double v = counts[c] > 0 ? tot / (double)counts[c] : cent[q];
-        cent[q] = v + mean[tid];
-      } else if (nzcounts[c] > 0) {
-        cent[q] = tot / (double)counts[c];
+        const double v = count_c > 0 ? tot / (double)count_c : cent[q];
+        cent[q] = v + mean[t];
+      } else if (nz_c > 0) {
+        cent[q] = tot / (double)count_c;
       }
     }
   }
   __syncthreads();
 }
 
+// BIG: more than kMaxVectors clusters (the reference has no limit: custom_distance_kmeans.py:
+// 13-52 takes any k) -- the per-cluster arrays live in a global workspace `gws` / `gwi` instead
+// of LDS (one workgroup: its own stores are visible to it behind __syncthreads), everything else
+// is the same code.  gws: k (2 + 8 + 2 KW) + k^2 doubles, gwi: 3 k ints.
+size_t kmeans_big_workspace_doubles(int k) { return (size_t)k * (2 + 8 + 2 * KW) + (size_t)k * k; }
+template <bool BIG>
 __global__ __launch_bounds__(KT) void k_kmeans(
     const double* __restrict__ ET, int lde, int n, int k, int max_iter,
     int first_center, int trials, double* __restrict__ XcT, double* __restrict__ xsq,
     double* __restrict__ closest, double* __restrict__ cand_d,
     double* __restrict__ enorm, const double* __restrict__ rnd,
     double* __restrict__ cent_out, int* __restrict__ labels32,
-    long long* __restrict__ labels64, int* __restrict__ info, int metric) {
+    long long* __restrict__ labels64, int* __restrict__ info, int metric,
+    double* __restrict__ gws, int* __restrict__ gwi) {
+  constexpr int KL = BIG ? 1 : kMaxVectors;  // LDS footprint of the per-cluster arrays
   __shared__ double sm[KW];
-  __shared__ double mean[kMaxVectors];
-  __shared__ double cent[kMaxVectors * kMaxVectors];   // k x k, stride k
-  __shared__ double cnorm[kMaxVectors];
-  __shared__ double candrow[8 * kMaxVectors];          // candidate rows, stride k
+  __shared__ double s_mean[KL];
+  __shared__ double s_cent[KL * KL];   // k x k, stride k
+  __shared__ double s_cnorm[KL];
+  __shared__ double s_candrow[8 * KL];          // candidate rows, stride k
   __shared__ double candsq[8];
   __shared__ double scan[KT];
   __shared__ double pots[8];
   __shared__ double rvals[8];
   __shared__ int cand[8];
-  __shared__ int seeds[kMaxVectors];
-  __shared__ int counts[kMaxVectors];
-  __shared__ int nzcounts[kMaxVectors];
-  __shared__ double wpart[2 * KW * kMaxVectors];
+  __shared__ int s_seeds[KL];
+  __shared__ int s_counts[KL];
+  __shared__ int s_nzcounts[KL];
+  __shared__ double s_wpart[2 * KW * KL];
+  const int kst = BIG ? k : kMaxVectors;  // stride of the per-wave partial sums
+  double* mean = BIG ? gws : s_mean;
+  double* cnorm = BIG ? gws + k : s_cnorm;
+  double* candrow = BIG ? gws + 2 * (size_t)k : s_candrow;
+  double* wpart = BIG ? gws + 10 * (size_t)k : s_wpart;
+  double* cent = BIG ? gws + (size_t)k * (10 + 2 * KW) : s_cent;
+  int* seeds = BIG ? gwi : s_seeds;
+  int* counts = BIG ? gwi + k : s_counts;
+  int* nzcounts = BIG ? gwi + 2 * (size_t)k : s_nzcounts;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const long long t_start = wall_clock64();  // 100 MHz; phase times go to info[1..4]
@@ -172,7 +195,7 @@ __global__ __launch_bounds__(KT) void k_kmeans(
   // ---- k-means++ (sklearn _kmeans_plusplus, unit sample weights) --------------
   if (tid == 0) info[1] = (int)(wall_clock64() - t_start);
   if (tid == 0) seeds[0] = first_center;
-  if (tid < k) candrow[tid] = XcT[(size_t)tid * n + first_center];
+  for (int t = tid; t < k; t += KT) candrow[t] = XcT[(size_t)t * n + first_center];
   __syncthreads();
   double pot;
   {
@@ -295,10 +318,10 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     cent[e] = XcT[(size_t)j * n + seeds[c]];
   }
   __syncthreads();
-  if (tid < k) {
+  for (int t = tid; t < k; t += KT) {
     double s = 0.0;
-    for (int j = 0; j < k; ++j) s += cent[tid * k + j] * cent[tid * k + j];
-    cnorm[tid] = s;  // squared norms here
+    for (int j = 0; j < k; ++j) s += cent[t * k + j] * cent[t * k + j];
+    cnorm[t] = s;  // squared norms here
   }
   __syncthreads();
 #pragma unroll 2
@@ -325,21 +348,21 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     }
     labels32[r] = best;
   }
-  if (tid < k) { counts[tid] = 0; nzcounts[tid] = 0; }
+  for (int t = tid; t < k; t += KT) { counts[t] = 0; nzcounts[t] = 0; }
   __syncthreads();
   // empty cluster: keeps its seed (sklearn relocates; unreachable from k-means++
   // seeds, each of which is its own nearest centre); best_centers += X_mean
-  cluster_means(XcT, n, n, k, labels32, cent, mean, 0, wpart, counts, nzcounts);
+  cluster_means(XcT, n, n, k, labels32, cent, mean, 0, wpart, kst, counts, nzcounts);
 
   // ---- CustomKMeans.predict (custom_distance_kmeans.py:118-141), scipy cdist metric --
   if (tid == 0) info[3] = (int)(wall_clock64() - t_start);
   double prev = 0.0;
   int it = 0;
   for (;; ++it) {
-    if (tid < k) {
+    for (int t = tid; t < k; t += KT) {
       double s = 0.0;
-      for (int j = 0; j < k; ++j) s += cent[tid * k + j] * cent[tid * k + j];
-      cnorm[tid] = sqrt(s);
+      for (int j = 0; j < k; ++j) s += cent[t * k + j] * cent[t * k + j];
+      cnorm[t] = sqrt(s);
     }
     __syncthreads();
     double part = 0.0;
@@ -392,10 +415,10 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     // (:131-133)
     if ((mean_d <= prev && mean_d >= (1.0 - 0.001) * prev) || it == max_iter) break;
     prev = mean_d;
-    if (tid < k) { counts[tid] = 0; nzcounts[tid] = 0; }
+    for (int t = tid; t < k; t += KT) { counts[t] = 0; nzcounts[t] = 0; }
     __syncthreads();
     // centroid <- mean of members iff `.any()` of the member INDICES (:137-138)
-    cluster_means(ET, lde, n, k, labels32, cent, mean, 1, wpart, counts, nzcounts);
+    cluster_means(ET, lde, n, k, labels32, cent, mean, 1, wpart, kst, counts, nzcounts);
   }
   for (int r = tid; r < n; r += KT) labels64[r] = labels32[r];
   for (int e = tid; e < k * k; e += KT) cent_out[e] = cent[e];
@@ -864,10 +887,17 @@ void launch_kmeans(hipStream_t s, const double* ET, int lde, int n, int k,
                          ws.info);
     return;
   }
-  hipLaunchKernelGGL(k_kmeans, dim3(1), dim3(KT), 0, s, ET, lde, n, k, max_iter,
+  if (k > kMaxVectors) {
+    hipLaunchKernelGGL(k_kmeans<true>, dim3(1), dim3(KT), 0, s, ET, lde, n, k, max_iter,
+                       first_center, trials, ws.Xc, ws.xsq, ws.closest, ws.cand, ws.enorm, ws.rnd,
+                       ws.centroids, ws.labels32, ws.labels64, ws.info, metric, ws.big,
+                       ws.big_words);
+    return;
+  }
+  hipLaunchKernelGGL(k_kmeans<false>, dim3(1), dim3(KT), 0, s, ET, lde, n, k, max_iter,
                      first_center, trials, ws.Xc, ws.xsq, ws.closest, ws.cand,
                      ws.enorm, ws.rnd, ws.centroids, ws.labels32, ws.labels64,
-                     ws.info, metric);
+                     ws.info, metric, static_cast<double*>(nullptr), static_cast<int*>(nullptr));
 }
 
 }  // namespace sc

@@ -428,7 +428,10 @@ struct KmeansWorkspace {
   long long* labels64 = nullptr;  // n
   int* info = nullptr;        // [0] iterations, [8] chain: stop rule met
   double* chain = nullptr;    // kmeans_chain_workspace_doubles(n): partials of the kernel chain
+  double* big = nullptr;      // k > kMaxVectors: kmeans_big_workspace_doubles(k) (else unused)
+  int* big_words = nullptr;   // ... and 3 k ints
 };
+size_t kmeans_big_workspace_doubles(int k);
 // k-means as a chain of short multi-workgroup kernels (kmeans_chain.hip), cosine metric
 size_t kmeans_chain_workspace_doubles(int n);
 bool kmeans_chain_supported(int n, int k, int trials);

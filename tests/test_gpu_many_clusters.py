@@ -1,0 +1,134 @@
+"""GPU: more than 64 SELECTED clusters.
+
+The reference has no limit anywhere on this path: `compute_number_of_clusters` reads
+max_clusters + 1 eigenvalues of any size (utils.py:100-128), `predict` slices
+`eigenvectors[:, :n_clusters]` (spectral_clusterer.py:295-299) and `run_kmeans` takes any k
+(custom_distance_kmeans.py:13-52).  Rounds 1-3 of the device path stopped at 64 eigenvector
+columns / 64 k-means centres.  Now: a request that needs more vectors than a Krylov basis
+comfortably yields takes ALL its eigenvalues from the tridiagonal form and its eigenvectors
+from inverse iteration + the Householder back-transform (the landing pad's machinery,
+sc_diag.eig_path == 6, eig_fallback == 5), the arenas grow with the request, and k-means runs
+its large-k form (per-cluster arrays in global memory).
+
+Goldens: tests/golden/manyk_*.npz from the REAL reference (oracle/make_golden.py
+--many-clusters): n = 1500, 90 speakers, max_clusters = 120 -> 90 / 89 clusters.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+import spectral_oracle as so
+from conftest import golden
+
+import spectralcluster_amd as sca
+from spectralcluster_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+LAP = {0: None, 4: sca.LaplacianType.GraphCut}
+
+
+def icassp_options():
+  return sca.RefinementOptions(
+      gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
+      thresholding_type=sca.ThresholdType.RowMax,
+      refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
+
+
+@pytest.mark.parametrize("mode", [0, 2])  # default routing; matrix-free Diffuse asked for
+@pytest.mark.parametrize("name", ["manyk_n1500_k90_lap0_max120.npz",
+                                  "manyk_n1500_k90_lap4_max120.npz"])
+def test_more_than_64_selected_clusters_vs_reference(name, mode):
+  g = golden(name)
+  n, d, k, seed, lap, max_clusters = [int(v) for v in g["params"]]
+  assert int(g["n_clusters_raw"]) > 64
+  x = so.blobs(n, d, k, seed)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=max_clusters,
+                            refinement_options=icassp_options(), laplacian_type=LAP[lap])
+  c.diffuse_mode = mode
+  labels = c.predict(x)
+  dg = c.last_diag
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"])
+  assert dg.n_clusters == int(g["n_clusters_raw"])
+  assert dg.eig_path == 6 and dg.eig_fallback == 5
+  np.testing.assert_allclose(dg.max_delta, float(g["max_delta"]), rtol=1e-6)
+  w = c.consumed_eigenvalues()
+  idx, ref = g["consumed_index"], g["consumed_eigenvalues"]
+  if lap == 0:  # the descending loop stops reading after the first value < 1e-2
+    keep = so.consumed_eigen_indices(n, max_clusters, True, ref, 1e-2)
+    idx, ref = idx[keep], ref[keep]
+  scale = np.abs(ref).max()
+  err = np.abs(w[idx] - ref) / np.maximum(np.abs(ref), 1e-9 * scale)
+  assert err.max() < 1e-5, err.max()
+  assert np.unique(labels).size == int(g["n_clusters_raw"])
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+
+
+@pytest.mark.parametrize("k", [65, 90, 130, 300])
+def test_run_kmeans_more_than_64_centres(k):
+  """custom_distance_kmeans.run_kmeans with k > 64 against the oracle's restatement of sklearn's
+  k-means++ (RandomState(0)) + the custom cosine loop: identical labels."""
+  # Six members per blob.  (With blobs of exactly TWO members k-means++ meets exact ties: when
+  # both members are drawn as candidates of one step their potentials differ by
+  # d(a, b) - d(b, a) = 0, and which one wins is decided by the last bit of two dot products
+  # -- OpenBLAS's in sklearn, a sequential sum here.  tests/probes/km_bigk_probe.py shows the
+  # seeds then differ in a handful of late picks and nowhere else.  No golden of the reference
+  # has such a tie; a test must not depend on one.)
+  rng = np.random.default_rng(k)
+  n = 6 * k
+  centers = rng.standard_normal((k, k))
+  e = centers[rng.permutation(n) % k] + 0.05 * rng.standard_normal((n, k))
+  want = so.run_kmeans(e, k, 300)
+  got = sca.custom_distance_kmeans.run_kmeans(e, k, "cosine", 300)
+  assert np.array_equal(got, want)
+
+
+def test_kmeans_trial_limit_is_reported():
+  # sklearn's k-means++ draws 2 + int(log k) candidates per centre; the kernels hold 8,
+  # i.e. k <= 1096 -- beyond that the device path says so instead of guessing
+  e = np.random.default_rng(0).standard_normal((1200, 1100))
+  with pytest.raises(_lib.UnsupportedOnDeviceError):
+    sca.custom_distance_kmeans.run_kmeans(e, 1100, "cosine", 10)
+
+
+def test_stage_sym_eig_more_than_64_vectors():
+  """utils.compute_sorted_eigenvectors on a symmetric matrix, 100 leading pairs at n = 700."""
+  rng = np.random.default_rng(3)
+  n, count = 700, 100
+  q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  lam = np.concatenate([np.linspace(5.0, 1.0, count), rng.uniform(-0.5, 0.5, n - count)])
+  m = (q * lam) @ q.T
+  m = 0.5 * (m + m.T)
+  h = _lib.default_handle()
+  values = np.empty(count)
+  vectors = np.empty((n, count))
+  diag = _lib.ScDiag()
+  h.check(h.lib.sc_stage_sym_eig(h.raw, _lib.as_double_p(np.ascontiguousarray(m)), n, count, 1,
+                                 _lib.as_double_p(values), _lib.as_double_p(vectors), diag))
+  want = np.sort(np.linalg.eigvalsh(m))[::-1][:count]
+  np.testing.assert_allclose(values, want, rtol=1e-10, atol=1e-12)
+  # residuals and orthonormality of the returned vectors
+  r = m @ vectors - vectors * values
+  assert np.abs(r).max() < 1e-9
+  assert np.abs(vectors.T @ vectors - np.eye(count)).max() < 1e-9
+
+
+def test_min_clusters_above_64():
+  """predict() keeps max(n_clusters, min_clusters) eigenvectors (spectral_clusterer.py:295-296):
+  70 of them here although the eigengap selects 4.  The 70-dimensional embedding is compared
+  with the oracle's through the labels of the well-separated part: the four blobs never mix."""
+  n = 900
+  x = so.blobs(n, 48, 4, seed=77)
+  c = sca.SpectralClusterer(min_clusters=70, max_clusters=7, refinement_options=icassp_options(),
+                            laplacian_type=sca.LaplacianType.GraphCut)
+  labels = c.predict(x)
+  dg = c.last_diag
+  assert dg.n_clusters == 70 and dg.n_clusters_raw <= 7
+  rng = np.random.default_rng(77)  # (spectral_oracle.blobs: centres first, then the labels)
+  rng.standard_normal((4, 48))
+  truth = np.sort(rng.integers(0, 4, n))
+  # every one of the 70 clusters lies inside ONE blob
+  for lab in np.unique(labels):
+    assert np.unique(truth[labels == lab]).size == 1

@@ -448,6 +448,14 @@ int sc_host_symmetric_eig_partial(const double* a, int m, int need, double* valu
  * can be pinned without a GPU. */
 int sc_host_tridiag_eigvectors(const double* d, const double* e, int n, const double* lam,
                                int k, double* vectors);
+/* The Rayleigh-Ritz solve of the WIDE block Arnoldi (general eigen path, more than 32 eigenpairs
+ * at n > 64: projected problems of order 64 < m <= 128; smaller ones are solved by a
+ * one-wavefront device kernel): eigenvalues of the real m x m matrix `a` (row-major) sorted by
+ * real part, descending, and the first nvec eigenvectors ((m, nvec) row-major, real and
+ * imaginary parts, unit 2-norm).  Hessenberg reduction + shifted complex QR + back
+ * substitution.  Host-only; exported so it can be pinned against numpy without a GPU. */
+int sc_host_general_eig(const double* a, int m, int nvec, double* values_re, double* values_im,
+                        double* vectors_re, double* vectors_im);
 /* utils.compute_number_of_clusters (utils.py:74-130) -- host scalar loop */
 int sc_eigengap(const double* eigenvalues, int count, int max_clusters,
                 double stop_eigenvalue, int eigengap_type, int descend,

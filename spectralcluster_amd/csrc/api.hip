@@ -1427,8 +1427,8 @@ extern "C" int sc_stage_eig(sc_handle h, const double* m, int n, int count, int 
   if (!h) return SC_ERR_INVALID;
   if (!m || n <= 0 || count <= 0 || count > n || !values)
     return fail(h, SC_ERR_INVALID, "bad eigen request");
-  if (n > kGenMax && count > 32)
-    return fail(h, SC_ERR_UNSUPPORTED, "at most 32 eigenpairs for n > 64 on the general path");
+  if (n > kGenMax && count > 64)
+    return fail(h, SC_ERR_UNSUPPORTED, "at most 64 eigenpairs for n > 64 on the general path");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
   SC_TRY(ensure_gen(h, n));

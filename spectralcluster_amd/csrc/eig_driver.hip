@@ -1153,6 +1153,28 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
       return fail(h, SC_ERR_UNSUPPORTED,
                   "max_clusters=None with a Laplacian needs every eigenvalue; only "
                   "supported for n <= 64 on the general eigen path");
+    // Narrow form: basis <= 64, projected problems solved by the one-wavefront device kernel,
+    // up to 32 Ritz pairs.  WIDE form (a request for more -- max_clusters up to 63,
+    // min_clusters up to 64 -- or a descending request whose stop_eigenvalue turns out to lie
+    // deeper): basis <= 128, the projected problems (order <= 128) solved on the host
+    // (host_general_eig), up to 64 pairs.
+    const int asked = rq.fixed_count > 0
+                          ? rq.fixed_count
+                          : std::max(rq.max_clusters > 0 ? rq.max_clusters + 1 : 0, rq.min_clusters);
+    bool wide = asked > 32;
+    if (asked > 64)
+      return fail(h, SC_ERR_UNSUPPORTED,
+                  "the general eigen path reports at most 64 eigenpairs for n > 64; set "
+                  "max_clusters <= 63");
+  general_restart:
+    if (wide) {  // Ritz vectors: 104 kept + 1 far end + 8 residual columns
+      SC_TRY(grow(h, h->Vre, (size_t)ldv * 2 * kGenMax * sizeof(double)));
+      SC_TRY(grow(h, h->Vim, (size_t)ldv * 2 * kGenMax * sizeof(double)));
+      Vre = ptr<double>(h->Vre);
+      Vim = ptr<double>(h->Vim);
+    }
+    m = 0;
+    cycles = 0;
     const double* cl = ptr<double>(h->cvec);
     const double* cr = ptr<double>(h->crvec);
     const double* pv = ptr<double>(h->pvec);
@@ -1164,12 +1186,13 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
       sc_handle h;
       ~Restore() { h->vs_scale = nullptr; }
     } restore{h};
-    const int cap = std::min(kGenMax, ((n - kEigBlock) / kEigBlock) * kEigBlock);
+    const int cap = std::min(wide ? kEigBasisCap : kGenMax, ((n - kEigBlock) / kEigBlock) * kEigBlock);
     const int first_check = std::min(3 * kEigBlock, cap);
     uint64_t seed = 0x9e3779b97f4a7c15ull;
     std::vector<std::vector<int>> start_blocks;  // restart: codes 2*col+part, -1 = noise
     size_t next_start = 0;
-    const int kMaxCheck = 32;  // Ritz pairs whose residual is evaluated
+    const int kMaxCheck = wide ? 64 : 32;  // Ritz pairs whose residual is evaluated
+    std::vector<double> hy;  // wide: host copies of the Ritz coefficient vectors (re | im)
     while (true) {
       // ---- next block into W
       if (next_start < start_blocks.size()) {
@@ -1206,11 +1229,37 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
           launch_copy_block(s, ptr<double>(h->Hbuf), kEigBlock, ptr<double>(h->T) + jb, kLdq,
                             m, kEigBlock);
         }
-        launch_gen_eig(s, ptr<double>(h->T), kLdq, m, 1.0, m, theta_d, thetai_d, Yre, Yim, kLdq,
-                       info_d);
+        if (!wide) {
+          launch_gen_eig(s, ptr<double>(h->T), kLdq, m, 1.0, m, theta_d, thetai_d, Yre, Yim, kLdq,
+                         info_d);
+        } else {
+          // projected problem of order up to 128: T comes to the host, its eigenpairs go back
+          // to where k_gen_eig leaves them
+          SC_HIP(h, hipMemcpy2DAsync(h->h_rr, (size_t)m * sizeof(double), h->T.p,
+                                     (size_t)kLdq * sizeof(double), (size_t)m * sizeof(double), m,
+                                     hipMemcpyDeviceToHost, s));
+          SC_HIP(h, hipStreamSynchronize(s));
+          hy.assign(2 * (size_t)m * m, 0.0);
+          for (size_t e = 0; e < (size_t)m * m; ++e)
+            if (!std::isfinite(h->h_rr[e])) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+          if (!host_general_eig(h->h_rr, m, m, m, th, thi, hy.data(), hy.data() + (size_t)m * m, m))
+            return fail(h, SC_ERR_NOT_CONVERGED, "QR iteration of the projected eigenproblem failed");
+          SC_HIP(h, hipMemcpyAsync(theta_d, th, m * sizeof(double), hipMemcpyHostToDevice, s));
+          SC_HIP(h, hipMemcpyAsync(thetai_d, thi, m * sizeof(double), hipMemcpyHostToDevice, s));
+          SC_HIP(h, hipMemcpy2DAsync(Yre, (size_t)kLdq * sizeof(double), hy.data(),
+                                     (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
+                                     hipMemcpyHostToDevice, s));
+          SC_HIP(h, hipMemcpy2DAsync(Yim, (size_t)kLdq * sizeof(double), hy.data() + (size_t)m * m,
+                                     (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
+                                     hipMemcpyHostToDevice, s));
+          SC_HIP(h, hipMemsetAsync(info_d, 0, 2 * sizeof(int), s));
+          SC_HIP(h, hipStreamSynchronize(s));  // (th / thi / hy are reused below)
+        }
         const int c1 = std::min(m, kMaxCheck);
-        launch_gen_residual(s, Q, OpQ, kLdq, m, n, Yre, Yim, kLdq, theta_d, thetai_d, c1,
-                            ptr<double>(h->gpart), resid_d);
+        for (int c0 = 0; c0 < c1; c0 += 32)  // (the residual kernel takes 32 pairs per launch)
+          launch_gen_residual(s, Q, OpQ, kLdq, m, n, Yre + c0, Yim + c0, kLdq, theta_d + c0,
+                              thetai_d + c0, std::min(32, c1 - c0), ptr<double>(h->gpart),
+                              resid_d + c0);
         if (far_end && m - 1 >= c1)
           launch_gen_residual(s, Q, OpQ, kLdq, m, n, Yre + (m - 1), Yim + (m - 1), kLdq,
                               theta_d + (m - 1), thetai_d + (m - 1), 1, ptr<double>(h->gpart),
@@ -1234,10 +1283,18 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
             fprintf(stderr, "[sc]    ritz %2d  re %.12g  im %.3e  resid %.3e\n", i, th[i], thi[i],
                     th[kLdq + i]);
         }
+        if (!wide && !dc.unsupported && (!dc.enough ? m >= kMaxCheck && rq.max_clusters == 0 && rq.fixed_count == 0
+                                                    : std::max(dc.kw, dc.kvec) > kMaxCheck)) {
+          // a descending request that reads further than 32 values: once more, wide
+          if (sw::eig_trace()) fprintf(stderr, "[sc] arnoldi: more than 32 pairs wanted, wide form\n");
+          wide = true;
+          passes = 0;
+          goto general_restart;
+        }
         if (dc.unsupported || (dc.enough && std::max(dc.kw, dc.kvec) > kMaxCheck))
           return fail(h, SC_ERR_UNSUPPORTED,
-                      "the general eigen path reports at most 32 eigenpairs for n > 64; set "
-                      "max_clusters <= 31");
+                      "the general eigen path reports at most 64 eigenpairs for n > 64; set "
+                      "max_clusters <= 63");
         if (dc.enough && dc.converged) break;
       }
       if (m + kEigBlock > cap) {
@@ -1246,14 +1303,14 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
           return fail(h, SC_ERR_NOT_CONVERGED, "block Arnoldi did not converge");
         // (thick restart: the new basis is [wanted Ritz vectors | residual block], after
         // which the Arnoldi recurrence continues from the residual block)
-        constexpr int kStash = 48;  // Vre columns [48, 56) hold the residual block
+        const int kStash = wide ? 112 : 48;  // Vre columns [kStash, kStash + 8): the residual block
         launch_copy_block(s, OpQ + (m - kEigBlock), kLdq, W, kEigBlock, n, kEigBlock);
         SC_TRY(orthonormalize(h, n, m, false, 0, -1, false));
         SC_TRY(finish_block(h, n, m, -1, &seed));
         launch_rowmajor_to_colmajor(s, W, kEigBlock, n, kEigBlock, Vre + (size_t)kStash * ldv,
                                     ldv);
         const int want = dc.enough ? std::max(dc.kw, dc.kvec) : cap / 4;
-        const int avail = std::min(m, 40);  // Ritz vectors materialised: columns [0, avail)
+        const int avail = std::min(m, wide ? 104 : 40);  // Ritz vectors materialised: columns [0, avail)
         launch_gen_ritz(s, Q, kLdq, m, n, Yre, Yim, kLdq, avail, Vre, Vim, ldv);
         int vcols = avail;
         const bool far_kept = far_end && m - 1 >= avail;

@@ -347,7 +347,11 @@ __global__ __launch_bounds__(256) void k_gen_residual(
     const double* __restrict__ Yre, const double* __restrict__ Yim, int ldy,
     const double* __restrict__ theta_re, const double* __restrict__ theta_im, int cols,
     double* __restrict__ partial) {
-  __shared__ double yr[GM][33], yi[GM][33];
+  // Ritz coefficients of the launch's 32 pairs: m x 33 doubles each (m <= 64 on the narrow
+  // Arnoldi, up to kLdq on the wide one: dynamic LDS, 2 * m * 33 * 8 bytes)
+  extern __shared__ __attribute__((aligned(16))) double ysm[];
+  double (*yr)[33] = reinterpret_cast<double (*)[33]>(ysm);
+  double (*yi)[33] = yr + m;
   __shared__ double red[8][33];
   const int c = threadIdx.x & 31, rr = threadIdx.x >> 5;
   for (int e = threadIdx.x; e < m * 32; e += 256) {
@@ -397,7 +401,9 @@ __global__ __launch_bounds__(256) void k_gen_ritz(const double* __restrict__ Q, 
                                                  const double* __restrict__ Yim, int ldy,
                                                  int col0, int cols, double* __restrict__ Vre,
                                                  double* __restrict__ Vim, int ldv) {
-  __shared__ double yr[GM][33], yi[GM][33];
+  extern __shared__ __attribute__((aligned(16))) double ysm[];
+  double (*yr)[33] = reinterpret_cast<double (*)[33]>(ysm);
+  double (*yi)[33] = yr + m;
   const int c = threadIdx.x & 31, rr = threadIdx.x >> 5;
   for (int e = threadIdx.x; e < m * 32; e += 256) {
     const int j = e >> 5, cc = e & 31;
@@ -537,14 +543,18 @@ void launch_gen_residual(hipStream_t s, const double* Q, const double* OpQ, int 
                          const double* theta_re, const double* theta_im, int cols,
                          double* partial, double* resid) {
   const int nb = gen_residual_blocks(n);
-  hipLaunchKernelGGL(k_gen_residual, dim3(nb), dim3(256), 0, s, Q, OpQ, ldq, m, n, Yre, Yim,
+  const size_t lds = (size_t)2 * m * 33 * sizeof(double);
+  SC_OPT_IN_LDS(k_gen_residual, 2 * kLdq * 33 * (int)sizeof(double));
+  hipLaunchKernelGGL(k_gen_residual, dim3(nb), dim3(256), lds, s, Q, OpQ, ldq, m, n, Yre, Yim,
                      ldy, theta_re, theta_im, cols, partial);
   hipLaunchKernelGGL(k_gen_residual_reduce, dim3(1), dim3(32), 0, s, partial, nb, cols, resid);
 }
 void launch_gen_ritz(hipStream_t s, const double* Q, int ldq, int m, int n, const double* Yre,
                      const double* Yim, int ldy, int cols, double* Vre, double* Vim, int ldv) {
+  const size_t lds = (size_t)2 * m * 33 * sizeof(double);
+  SC_OPT_IN_LDS(k_gen_ritz, 2 * kLdq * 33 * (int)sizeof(double));
   for (int c0 = 0; c0 < cols; c0 += 32)
-    hipLaunchKernelGGL(k_gen_ritz, dim3((n + 7) / 8), dim3(256), 0, s, Q, ldq, m, n, Yre, Yim,
+    hipLaunchKernelGGL(k_gen_ritz, dim3((n + 7) / 8), dim3(256), lds, s, Q, ldq, m, n, Yre, Yim,
                        ldy, c0, cols - c0 < 32 ? cols - c0 : 32, Vre, Vim, ldv);
 }
 void launch_gen_phase(hipStream_t s, double* Vre, double* Vim, int ldv, int n, int cols,

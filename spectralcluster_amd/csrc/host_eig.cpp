@@ -436,3 +436,202 @@ extern "C" int sc_host_symmetric_eig_partial(const double* a, int m, int need, d
   return host_partial_vectors(w, need, vectors, need) ? SC_OK : SC_ERR_NOT_CONVERGED;
 }
 
+
+// ------------------------------------------------------------------------------
+// general (non-symmetric) projected eigenproblem, 64 < m <= 128
+// ------------------------------------------------------------------------------
+// The Rayleigh-Ritz step of the WIDE block Arnoldi (eig_driver.hip: more than 32 eigenpairs of a
+// matrix that is not diagonally similar to a symmetric one; reference utils.py:59 calls
+// np.linalg.eig on the whole matrix).  Same method as the one-wavefront device solver of
+// eig_general.hip, which stops at order 64: real Householder reduction to Hessenberg form,
+// explicitly shifted complex QR (Wilkinson shift, exceptional shifts, deflation) to the
+// complex Schur form A = Z T Z^H, eigenvectors of T by back substitution, y = Z x.
+// Eigenvalues sorted by real part, descending; the first nvec eigenvectors, unit 2-norm, go
+// to Y[:, q] = yre + i yim (row-major, ldy).
+#include <complex>
+
+namespace {
+typedef std::complex<double> cplx;
+inline double abs1(const cplx& z) { return std::fabs(z.real()) + std::fabs(z.imag()); }
+}  // namespace
+
+bool host_general_eig(const double* a, int lda, int m, int nvec, double* wr, double* wi,
+                      double* yre, double* yim, int ldy) {
+  if (m <= 0) return true;
+  std::vector<double> h((size_t)m * m), z((size_t)m * m, 0.0), v(m);
+  for (int i = 0; i < m; ++i) {
+    for (int j = 0; j < m; ++j) h[(size_t)i * m + j] = a[(size_t)i * lda + j];
+    z[(size_t)i * m + i] = 1.0;
+  }
+  // ---- 1. Hessenberg form, H = P^T A P, Z = P
+  for (int k = 0; k + 2 < m; ++k) {
+    double below2 = 0.0;
+    for (int i = k + 2; i < m; ++i) below2 += h[(size_t)i * m + k] * h[(size_t)i * m + k];
+    if (below2 == 0.0) continue;
+    const double x0 = h[(size_t)(k + 1) * m + k];
+    const double nrm = std::sqrt(below2 + x0 * x0);
+    const double alpha = x0 > 0.0 ? -nrm : nrm;
+    double vn2 = 0.0;
+    for (int i = k + 1; i < m; ++i) {
+      v[i] = h[(size_t)i * m + k];
+      if (i == k + 1) v[i] -= alpha;
+      vn2 += v[i] * v[i];
+    }
+    const double inv = 1.0 / std::sqrt(vn2);
+    for (int i = k + 1; i < m; ++i) v[i] *= inv;
+    for (int j = k; j < m; ++j) {  // rows: H <- (I - 2 v v^T) H
+      double w = 0.0;
+      for (int i = k + 1; i < m; ++i) w += v[i] * h[(size_t)i * m + j];
+      w *= 2.0;
+      for (int i = k + 1; i < m; ++i) h[(size_t)i * m + j] -= v[i] * w;
+    }
+    for (int i = 0; i < m; ++i) {  // columns: H <- H (I - 2 v v^T), Z likewise
+      double w = 0.0, wz = 0.0;
+      for (int j = k + 1; j < m; ++j) {
+        w += h[(size_t)i * m + j] * v[j];
+        wz += z[(size_t)i * m + j] * v[j];
+      }
+      w *= 2.0;
+      wz *= 2.0;
+      for (int j = k + 1; j < m; ++j) {
+        h[(size_t)i * m + j] -= w * v[j];
+        z[(size_t)i * m + j] -= wz * v[j];
+      }
+    }
+    for (int i = k + 2; i < m; ++i) h[(size_t)i * m + k] = 0.0;
+  }
+  // ---- 2. complex Schur form by shifted QR
+  std::vector<cplx> H((size_t)m * m), Z((size_t)m * m);
+  double norm = 0.0;
+  for (size_t e = 0; e < (size_t)m * m; ++e) {
+    H[e] = h[e];
+    Z[e] = z[e];
+    norm = std::max(norm, std::fabs(h[e]));
+  }
+  if (!(norm < 1e300)) return false;  // NaN / inf
+  const double eps = 2.220446049250313e-16;
+  std::vector<double> cs(m);
+  std::vector<cplx> sn(m);
+  int en = m - 1, its = 0;
+  long budget = 60L * m;
+  while (en >= 0) {
+    int l = en;
+    for (; l > 0; --l) {
+      double s = abs1(H[(size_t)(l - 1) * m + l - 1]) + abs1(H[(size_t)l * m + l]);
+      if (s == 0.0) s = norm;
+      if (abs1(H[(size_t)l * m + l - 1]) <= eps * s) {
+        H[(size_t)l * m + l - 1] = 0.0;
+        break;
+      }
+    }
+    if (l == en) {
+      --en;
+      its = 0;
+      continue;
+    }
+    if (--budget < 0 || ++its > 60) return false;
+    cplx mu;
+    if (its == 10 || its == 20) {  // exceptional shift
+      mu = cplx(std::fabs(H[(size_t)en * m + en - 1].real()) +
+                    (en >= 2 ? std::fabs(H[(size_t)(en - 1) * m + en - 2].real()) : 0.0),
+                0.0) + H[(size_t)en * m + en];
+    } else {  // Wilkinson: eigenvalue of the trailing 2 x 2 closer to its last entry
+      const cplx a11 = H[(size_t)(en - 1) * m + en - 1], a12 = H[(size_t)(en - 1) * m + en];
+      const cplx a21 = H[(size_t)en * m + en - 1], a22 = H[(size_t)en * m + en];
+      const cplx half = 0.5 * (a11 - a22);
+      const cplx disc = std::sqrt(half * half + a12 * a21);
+      const cplx m1 = a22 + half + disc, m2 = a22 + half - disc;  // (a11 + a22) / 2 +- disc
+      mu = std::abs(m1 - a22) <= std::abs(m2 - a22) ? m1 : m2;
+    }
+    for (int i = l; i <= en; ++i) H[(size_t)i * m + i] -= mu;
+    for (int k = l; k < en; ++k) {  // H - mu I = Q R: rotations from the left
+      const cplx x = H[(size_t)k * m + k], y = H[(size_t)(k + 1) * m + k];
+      const double ax = std::abs(x), r = std::hypot(ax, std::abs(y));
+      double c;
+      cplx s;
+      if (r == 0.0) {
+        c = 1.0;
+        s = 0.0;
+      } else if (ax == 0.0) {
+        c = 0.0;
+        s = std::conj(y) / r;
+      } else {
+        c = ax / r;
+        s = (x / ax) * std::conj(y) / r;
+      }
+      cs[k] = c;
+      sn[k] = s;
+      for (int j = k; j < m; ++j) {
+        const cplx t0 = H[(size_t)k * m + j], t1 = H[(size_t)(k + 1) * m + j];
+        H[(size_t)k * m + j] = c * t0 + s * t1;
+        H[(size_t)(k + 1) * m + j] = -std::conj(s) * t0 + c * t1;
+      }
+      H[(size_t)(k + 1) * m + k] = 0.0;
+    }
+    for (int k = l; k < en; ++k) {  // R Q: the same rotations from the right (and into Z)
+      const double c = cs[k];
+      const cplx s = sn[k];
+      for (int i = 0; i <= k + 1; ++i) {
+        const cplx t0 = H[(size_t)i * m + k], t1 = H[(size_t)i * m + k + 1];
+        H[(size_t)i * m + k] = c * t0 + std::conj(s) * t1;
+        H[(size_t)i * m + k + 1] = -s * t0 + c * t1;
+      }
+      for (int i = 0; i < m; ++i) {
+        const cplx t0 = Z[(size_t)i * m + k], t1 = Z[(size_t)i * m + k + 1];
+        Z[(size_t)i * m + k] = c * t0 + std::conj(s) * t1;
+        Z[(size_t)i * m + k + 1] = -s * t0 + c * t1;
+      }
+    }
+    for (int i = l; i <= en; ++i) H[(size_t)i * m + i] += mu;
+  }
+  // ---- 3. order by real part, eigenvectors of T by back substitution
+  std::vector<int> order(m);
+  for (int i = 0; i < m; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int p, int q) {
+    return H[(size_t)p * m + p].real() > H[(size_t)q * m + q].real();
+  });
+  for (int q = 0; q < m; ++q) {
+    wr[q] = H[(size_t)order[q] * m + order[q]].real();
+    wi[q] = H[(size_t)order[q] * m + order[q]].imag();
+  }
+  std::vector<cplx> x(m), y(m);
+  const double small = eps * std::max(norm, 1e-300);
+  for (int q = 0; q < std::min(nvec, m); ++q) {
+    const int k = order[q];
+    const cplx lam = H[(size_t)k * m + k];
+    x[k] = 1.0;
+    for (int i = k - 1; i >= 0; --i) {
+      cplx s = 0.0;
+      for (int j = i + 1; j <= k; ++j) s += H[(size_t)i * m + j] * x[j];
+      cplx den = H[(size_t)i * m + i] - lam;
+      if (abs1(den) < small) den = small;
+      x[i] = -s / den;
+      if (abs1(x[i]) > 1e150) {  // rescale: the vector is normalised below anyway
+        for (int j = i; j <= k; ++j) x[j] *= 1e-150;
+      }
+    }
+    double n2 = 0.0;
+    for (int i = 0; i < m; ++i) {
+      cplx s = 0.0;
+      for (int j = 0; j <= k; ++j) s += Z[(size_t)i * m + j] * x[j];
+      y[i] = s;
+      n2 += std::norm(s);
+    }
+    const double inv = n2 > 0.0 ? 1.0 / std::sqrt(n2) : 0.0;
+    for (int i = 0; i < m; ++i) {
+      yre[(size_t)i * ldy + q] = y[i].real() * inv;
+      yim[(size_t)i * ldy + q] = y[i].imag() * inv;
+    }
+  }
+  return true;
+}
+
+extern "C" int sc_host_general_eig(const double* a, int m, int nvec, double* values_re,
+                                   double* values_im, double* vectors_re, double* vectors_im) {
+  if (!a || m <= 0 || nvec < 0 || nvec > m || !values_re || !values_im ||
+      (nvec > 0 && (!vectors_re || !vectors_im)))
+    return SC_ERR_INVALID;
+  return host_general_eig(a, m, m, nvec, values_re, values_im, vectors_re, vectors_im, nvec)
+             ? SC_OK
+             : SC_ERR_NOT_CONVERGED;
+}

@@ -27,4 +27,10 @@ struct HostTridiag {
 bool host_partial_values(const double* T, int ld, int m, HostTridiag* w);
 bool host_partial_vectors(const HostTridiag& w, int need, double* Y, int ldy);
 
+// General (non-symmetric) real a (m x m, row-major lda): eigenvalues sorted by real part,
+// descending, into wr / wi; the first nvec eigenvectors (unit 2-norm) into Y[:, q] = yre + i yim
+// (row-major, ldy).  Hessenberg + shifted complex QR + back substitution.  false: no convergence.
+bool host_general_eig(const double* a, int lda, int m, int nvec, double* wr, double* wi,
+                      double* yre, double* yim, int ldy);
+
 #endif  // SPECTRALCLUSTER_AMD_HOST_EIG_H_

@@ -41,9 +41,10 @@ def compute_sorted_eigenvectors(
 
   A symmetric input runs on the symmetric solver (dense Jacobi for n <= 128 -- every
   eigenpair, as the reference returns -- else block Lanczos for the `count` (default
-  and max 64) extreme ones).  Anything else runs on the general solver (Hessenberg +
-  complex QR for n <= 64, else block Arnoldi for `count` <= 32 extreme ones, default
-  32); eigenvectors of complex pairs carry LAPACK's normalisation before `.real`.
+  extreme ones; more than 64 come from the dense tridiagonal path).  Anything else runs on
+  the general solver (Hessenberg + complex QR for n <= 64, else block Arnoldi for `count` <= 64
+  extreme ones, default 32); eigenvectors of complex pairs carry LAPACK's normalisation
+  before `.real`.
   """
   m = np.ascontiguousarray(input_matrix, dtype=np.float64)
   if m.ndim != 2 or m.shape[0] != m.shape[1]:

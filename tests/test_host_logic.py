@@ -533,6 +533,35 @@ def test_host_partial_symmetric_eig_vs_numpy():
     assert np.abs(v.T @ v - np.eye(need)).max() < 1e-12 * m
 
 
+def test_host_general_eig_vs_numpy():
+  """The Rayleigh-Ritz solve of the WIDE block Arnoldi (general eigen path, projected
+  problems of order up to 128): eigenvalues sorted by real part, unit-norm eigenvectors."""
+  lib = _lib.load()
+  rng = np.random.default_rng(11)
+  for m, nvec in ((1, 1), (2, 2), (7, 7), (24, 10), (64, 64), (100, 50), (128, 128)):
+    for kind in ("random", "nearly symmetric", "block Hessenberg"):
+      a = rng.standard_normal((m, m))
+      if kind == "nearly symmetric":
+        a = a + a.T + 0.01 * rng.standard_normal((m, m))
+      if kind == "block Hessenberg":  # what Q^T Op Q of a block Arnoldi looks like
+        a = np.triu(a, -8)
+      a = np.ascontiguousarray(a)
+      wr, wi = np.empty(m), np.empty(m)
+      vr, vi = np.empty((m, nvec)), np.empty((m, nvec))
+      assert lib.sc_host_general_eig(_lib.as_double_p(a), m, nvec, _lib.as_double_p(wr),
+                                     _lib.as_double_p(wi), _lib.as_double_p(vr),
+                                     _lib.as_double_p(vi)) == 0
+      assert np.all(np.diff(wr) <= 0.0)  # sorted by real part, descending
+      w = wr + 1j * wi
+      ref = np.linalg.eigvals(a)
+      scale = np.abs(ref).max()
+      dist = np.abs(w[:, None] - ref[None, :])
+      assert max(dist.min(axis=1).max(), dist.min(axis=0).max()) < 1e-10 * scale * m, (m, kind)
+      v = vr + 1j * vi
+      assert np.abs(a @ v - v * w[None, :nvec]).max() < 1e-12 * scale * m, (m, kind)
+      assert np.abs(np.linalg.norm(v, axis=0) - 1.0).max() < 1e-13 * m
+
+
 def test_host_tridiag_eigvectors_vs_scipy():
   """The host step of the dense landing pad (inverse iteration on the tridiagonal form,
   LAPACK dstein's method) against scipy's eigh_tridiagonal, including clustered spectra."""

@@ -748,7 +748,14 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
   // the n-vectors and the eigensolver workspace -- no affinity copy, no k-means workspace.
   // The group is as wide as free memory allows (16 members of n = 16384 are 69 GB); whatever
   // does not fit is evaluated one value at a time on this handle, like before the grouping.
-  const size_t member_bytes = 2 * (size_t)n * ld * sizeof(double) + (size_t)n * 8192;
+  // Matrix-free Diffuse (free_api.hip): a member then holds the thresholded matrix, its digits
+  // and the fp32 tiles of their product instead of S, and the lockstep solver applies A twice.
+  // The cut vector bounds max|a| when the affinity is non-negative by construction.
+  const bool free_route = free_diffuse_wanted(h, cfg, n, rq);
+  const bool amax_from_cut = free_route && h->affinity_from_embeddings && !h->constraint_applied &&
+                             cfg->soft_multiplier >= 0.0 && cfg->soft_multiplier <= 1.0;
+  const size_t member_bytes = 2 * (size_t)n * ld * sizeof(double) + (size_t)n * 8192 +
+                              (free_route ? free_q_bytes(n) + free_t32_bytes(n) : 0);
   int width = 0;
   {
     size_t free_b = 0, total_b = 0;
@@ -782,6 +789,7 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       int rc = ensure_matrices(hz, n, 0, false);
       if (rc == SC_OK) rc = ensure_eig(hz, n);
       if (rc == SC_OK) rc = ensure_tilemap(hz, n);
+      if (rc == SC_OK && free_route) rc = ensure_free(hz, n);
       if (rc == SC_ERR_OOM) {  // the estimate above was optimistic: the rest one by one
         out_of_memory = true;
         break;
@@ -820,10 +828,11 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       dif[z].rowsum = ptr<double>(hz->rowsum);
       em[z] = GroupEigMember();
       em[z].h = hz;
-      em[z].S = ptr<double>(hz->B1);
+      em[z].S = free_route ? ptr<double>(hz->B2) : ptr<double>(hz->B1);
       em[z].ld = ld;
       em[z].n = n;
       em[z].rq = rq;
+      em[z].free_op = free_route;
     }
     if (out_of_memory) {
       (void)hipGetLastError();
@@ -839,12 +848,40 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
     launch_threshold_symmetrize_group(s, fi, cnt, cfg->p_percentile, cfg->soft_multiplier,
                                       cfg->binarize, cfg->symmetrize_type,
                                       cfg->preserve_diagonal);
-    launch_gemm_nt_group(s, dif, cnt, kEpiNone, 1);
+    if (free_route) {
+      // rowmax / rowsum of every member's S = A A^T without forming it: digits per member,
+      // ONE launch for the digit products of all members, candidates + exact recheck per member
+      const signed char* qs[kGroupMax];
+      float* ts[kGroupMax];
+      unsigned* ms[kGroupMax];
+      for (int z = 0; z < cnt; ++z) {
+        sc_handle hz = em[z].h;
+        if (amax_from_cut)
+          launch_free_amax_from_cut(s, ptr<double>(hz->cut), n, p_values[base + z], 0.0,
+                                    ptr<double>(hz->fscal));
+        SC_TRY(free_stats_begin(hz, s, em[z].S, ld, n, amax_from_cut));
+        qs[z] = ptr<signed char>(hz->fq);
+        ts[z] = ptr<float>(hz->ft32);
+        ms[z] = ptr<unsigned>(hz->fwords);
+      }
+      launch_gemm_i8_sym_group(s, qs, ts, ms, cnt, n, em[0].h->tilemap_cur);
+      for (int z = 0; z < cnt; ++z) SC_TRY(free_stats_end(em[z].h, s, em[z].S, ld, n, false));
+    } else {
+      launch_gemm_nt_group(s, dif, cnt, kEpiNone, 1);
+    }
     launch_scaling_vectors_group(s, fi, cnt, cfg->laplacian_type, 1);
     SC_TRY(check_last(h, "sweep launch"));
     // (with the Ritz vectors: the level's winner is then adopted, not evaluated again --
     //  one upload and one launch for the whole group against a Diffuse + a solve)
     SC_TRY(sym_topk_group(h, em, cnt, true));
+    if (free_route) {
+      // a value with rows the candidate search could not prune (their exact evaluation needs
+      // the host in the loop) goes through the single-call route, like any value that left
+      // the lockstep solver: the overflow words arrived with the solver's synchronisations
+      SC_HIP(h, hipStreamSynchronize(s));
+      for (int z = 0; z < cnt; ++z)
+        if (em[z].status == 0 && em[z].h->h_free[0] != 0) em[z].status = 1;
+    }
     for (int& slot : h->sweep_slot)
       if (slot >= 0 && slot < cnt) slot = -1;  // an earlier round's member: arena reused
     for (int z = 0; z < cnt; ++z) {
@@ -868,6 +905,8 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       dg->eig_block = kEigBlock;
       dg->eig_basis = em[z].basis;
       dg->eig_max_residual = em[z].dc.max_resid;
+      dg->diffuse_path = free_route ? SC_DIFFUSE_PATH_FREE : SC_DIFFUSE_PATH_EXPLICIT;
+      if (free_route) dg->free_candidates = em[z].h->h_free[65];
     }
   }
   SC_HIP(h, hipStreamSynchronize(s));

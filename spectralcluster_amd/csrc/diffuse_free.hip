@@ -222,7 +222,7 @@ struct I8Frag {
 // PROBE (tests/probes/i8_gemm_probe.hip only; the library instantiates 0): 1 = no DMA inside
 // the loop, 2 = no MFMA, 3 = no fragment reads inside the loop -- what each part costs.
 template <int PROBE>
-__global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
+__device__ __forceinline__ void gemm_i8_sym_body(
     const signed char* __restrict__ Q, size_t pitch, int nstages, const int2* __restrict__ tilemap,
     int xcd_chunk, float* __restrict__ T32, int nt, int n, unsigned* __restrict__ M,
     unsigned long long* __restrict__ probe_clk) {
@@ -400,6 +400,28 @@ __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
     const float v = fmaxf(fmaxf(pcol[c], pcol[128 + c]), fmaxf(pcol[256 + c], pcol[384 + c]));
     if (row < n && v > -INFINITY) atomicMax(&M[row], ordered_bits(v));
   }
+}
+
+template <int PROBE>
+__global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
+    const signed char* __restrict__ Q, size_t pitch, int nstages, const int2* __restrict__ tilemap,
+    int xcd_chunk, float* __restrict__ T32, int nt, int n, unsigned* __restrict__ M,
+    unsigned long long* __restrict__ probe_clk) {
+  gemm_i8_sym_body<PROBE>(Q, pitch, nstages, tilemap, xcd_chunk, T32, nt, n, M, probe_clk);
+}
+// Grouped form (AutoTune sweep, batch_group.hip): blockIdx.y picks one of up to kGroupMax
+// problems of the same size; the tiles of all of them fill the chip where one problem's 528
+// (n = 4096) leave the third round of workgroups nearly empty.
+struct I8GroupItem {
+  const signed char* Q;
+  float* T32;
+  unsigned* M;
+};
+__global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym_g(
+    const GroupOf<I8GroupItem> g, size_t pitch, int nstages, const int2* __restrict__ tilemap,
+    int nt, int n) {
+  const I8GroupItem& a = g.s[blockIdx.y];
+  gemm_i8_sym_body<0>(a.Q, pitch, nstages, tilemap, 0, a.T32, nt, n, a.M, nullptr);
 }
 
 // ---------------------------------------------------------------- candidates
@@ -593,6 +615,20 @@ void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* 
   hipLaunchKernelGGL(k_gemm_i8_sym<0>, dim3(tiles), dim3(kI8Threads), lds, s, Q, (size_t)2 * Kp,
                      Kp / 64, tilemap, xcd_chunk, T32, nt, n, M,
                      static_cast<unsigned long long*>(nullptr));
+}
+
+void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
+                              unsigned* const* M, int count, int n, const int2* tilemap) {
+  const int nt = (n + kI8Tile - 1) / kI8Tile;
+  const int tiles = nt * (nt + 1) / 2;
+  const int Kp = free_k_padded(n);
+  const int lds = kI8Buffers * kI8StageBytes;
+  SC_OPT_IN_LDS(k_gemm_i8_sym_g, lds);
+  GroupOf<I8GroupItem> g;
+  memset(&g, 0, sizeof(g));
+  for (int z = 0; z < count; ++z) g.s[z] = I8GroupItem{Q[z], T32[z], M[z]};
+  hipLaunchKernelGGL(k_gemm_i8_sym_g, dim3(tiles, count), dim3(kI8Threads), lds, s, g,
+                     (size_t)2 * Kp, Kp / 64, tilemap, nt, n);
 }
 
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,

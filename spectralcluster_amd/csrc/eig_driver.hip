@@ -874,6 +874,8 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
   for (int z = 0; z < count; ++z) matrix_bytes += (size_t)mem[z].n * mem[z].ld * sizeof(double);
   const size_t sym_min_bytes = (size_t)128 << 20;
   const bool sym_matvec = matrix_bytes >= sym_min_bytes;
+  bool any_free = false;
+  for (int z = 0; z < count; ++z) any_free = any_free || mem[z].free_op;
   const uint64_t seed = 0x5eed5eedull;
   launch_lz_link_group(s, lz, count, 0, 0, 4, -1, 0, true, seed, false);
   launch_lz_link_group(s, lz, count, 0, 4, 3, -1, 0, false, 0, true);
@@ -906,6 +908,21 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
       mv[z].W = ptr<double>(h->W);
       mv[z].slabs = ptr<double>(h->mvsym);
       ++mem[z].passes;
+    }
+    if (any_free) {
+      // matrix-free members: fY = A Vs first (c = 1, p = 0), then W = p .* V + c .* (A fY)
+      MatvecItem inner[kGroupMax];
+      memset(inner, 0, sizeof(inner));
+      for (int z = 0; z < count; ++z) {
+        if (!lz[z].active || !mem[z].free_op) continue;
+        inner[z] = mv[z];
+        inner[z].cvec = inner[z].pvec = nullptr;
+        inner[z].V = mv[z].Vs;
+        inner[z].ldv = kEigBlock;
+        inner[z].W = ptr<double>(mem[z].h->fY);
+        mv[z].Vs = ptr<double>(mem[z].h->fY);
+      }
+      launch_block_matvec_group(s, inner, count, sym_matvec);
     }
     launch_block_matvec_group(s, mv, count, sym_matvec);
     const int m = m_before + kEigBlock;

@@ -60,34 +60,45 @@ int ensure_free(sc_handle h, int n) {
   return SC_OK;
 }
 
-int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax) {
-  hipStream_t s = h->stream;
+// the pipeline in three pieces, all on stream `s` (the handle's own for a single call; the
+// sweep's for a member arena, whose product is one grouped launch for all members)
+int free_stats_begin(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool have_amax) {
   SC_TRY(ensure_free(h, n));
-  SC_TRY(ensure_tilemap(h, n));
-  unsigned* M = ptr<unsigned>(h->fwords);
-  int* count = ptr<int>(h->fwords) + n;
-  int* ovf = ptr<int>(h->fwords) + 2 * (size_t)n;
   // ([0] max|a| stays when the caller has it; [2] max R starts from zero)
   SC_HIP(h, hipMemsetAsync(ptr<double>(h->fscal) + (have_amax ? 1 : 0), 0,
                            (have_amax ? 3 : 4) * sizeof(double), s));
   SC_HIP(h, hipMemsetAsync(h->fwords.p, 0, ((size_t)2 * n + kOvfWords) * sizeof(int), s));
-  ev_rec(h, &h->free_ev[0]);
   if (!have_amax) launch_free_absmax(s, A, n, ld, ptr<double>(h->fscal));
   launch_free_quantize(s, A, n, ld, ptr<signed char>(h->fq), ptr<double>(h->fscal),
                        ptr<double>(h->fy1), ptr<double>(h->fR));
-  ev_rec(h, &h->free_ev[1]);
-  launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32), M);
-  ev_rec(h, &h->free_ev[2]);
+  return SC_OK;
+}
+int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool timed) {
+  unsigned* M = ptr<unsigned>(h->fwords);
+  int* count = ptr<int>(h->fwords) + n;
+  int* ovf = ptr<int>(h->fwords) + 2 * (size_t)n;
   launch_t32_candidates(s, ptr<float>(h->ft32), n, M, ptr<double>(h->fR), ptr<double>(h->fscal),
                         count, ptr<int>(h->fcand));
-  ev_rec(h, &h->free_ev[3]);
+  if (timed) ev_rec(h, &h->free_ev[3]);
   launch_free_row_stats(s, A, n, ld, ptr<double>(h->fy1), count, ptr<int>(h->fcand),
                         ptr<double>(h->rowmax), ptr<double>(h->rowsum), ovf);
-  ev_rec(h, &h->free_ev[4]);
+  if (timed) ev_rec(h, &h->free_ev[4]);
   SC_TRY(check_last(h, "matrix-free diffuse launch"));
   SC_HIP(h, hipMemcpyAsync(h->h_free, ovf, kOvfWords * sizeof(int), hipMemcpyDeviceToHost, s));
   h->free_checked = false;
   return SC_OK;
+}
+
+int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax) {
+  hipStream_t s = h->stream;
+  SC_TRY(ensure_tilemap(h, n));
+  ev_rec(h, &h->free_ev[0]);
+  SC_TRY(free_stats_begin(h, s, A, ld, n, have_amax));
+  ev_rec(h, &h->free_ev[1]);
+  launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32),
+                     ptr<unsigned>(h->fwords));
+  ev_rec(h, &h->free_ev[2]);
+  return free_stats_end(h, s, A, ld, n, true);
 }
 
 // plain product W = A Vs by the solver's own block matvec (c = 1, p = 0)

@@ -304,6 +304,9 @@ struct GroupEigMember {
   EigDecision dc;
   std::vector<double> w;      // consumed eigenvalues (reference order)
   int basis = 0, passes = 0;
+  // matrix-free Diffuse: S is the symmetric A before Diffuse, the operator is
+  // diag(p) + diag(c) A A diag(c) (two block products per step, through h->fY)
+  bool free_op = false;
 };
 // Block Lanczos of up to kGroupMax members in lockstep: one launch per chain link / matvec
 // for the whole group, one host synchronisation per Rayleigh-Ritz check for the whole group.
@@ -329,6 +332,11 @@ bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequ
 // `have_amax`: h->fscal[0] already holds max|a| (or an upper bound of it) for this A
 int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax = false);
 int ensure_free(sc_handle h, int n);
+// the same pipeline in pieces on a given stream (the AutoTune sweep runs the digit product of
+// all its members as one grouped launch between them): max|a| + digits | ... | candidates +
+// exact statistics + the overflow words on their way to h->h_free
+int free_stats_begin(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool have_amax);
+int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool timed);
 // after the stream has drained: rows with more candidates than the cap are evaluated in full.
 // *changed: rowmax was rewritten (the scaling vectors must be rebuilt); *too_many: more such
 // rows than the exact route takes (the caller forms S explicitly).

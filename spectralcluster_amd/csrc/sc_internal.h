@@ -383,6 +383,9 @@ void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed 
                           double* scal, double* y1, double* R);
 void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
                         float* T32, unsigned* M);
+// the same product for `count` (<= kGroupMax) problems of one size in ONE launch
+void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
+                              unsigned* const* M, int count, int n, const int2* tilemap);
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,
                            const double* R, const double* scal, int* count, int* cand);
 void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const double* y1,

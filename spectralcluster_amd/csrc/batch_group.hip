@@ -716,27 +716,36 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
     c.p_percentile = p_values[i];
     return sc_eig_ncluster(h, &c, diags + i);
   };
-  const bool grouped = count > 1 && grouped_front_covers(cfg) && h->affinity_symmetric &&
+  // Two sequences are swept as groups: the ICASSP2018 one, and [RowWiseThreshold, Symmetrize]
+  // alone -- the Turn-to-Diarize refinement (reference configs.py:49-59: Percentile cut,
+  // binarisation, preserved diagonal, Average), whose values are the thresholded affinity
+  // itself: no blur to share, no Diffuse, the lockstep solver works on the symmetrised matrix.
+  const bool icassp = grouped_front_covers(cfg);
+  const bool thr_sym_only = cfg->n_ops == 2 && cfg->ops[0] == SC_OP_ROW_WISE_THRESHOLD &&
+                            cfg->ops[1] == SC_OP_SYMMETRIZE;
+  const bool grouped = count > 1 && (icassp || thr_sym_only) && h->affinity_symmetric &&
                        !constraint_active(h, cfg, false) &&
-                       blur_group_supported(n, cfg->blur_radius) &&
+                       (!icassp || blur_group_supported(n, cfg->blur_radius)) &&
                        sym_group_eligible(n, rq, true) && !sw::sweep_one_by_one();
   if (!grouped) {
     for (int i = 0; i < count; ++i) SC_TRY(one_by_one(i));
     return SC_OK;
   }
   hipStream_t s = h->stream;
-  // ---- shared by every value: CropDiagonal's value and the blurred matrix (+ row maxima)
-  const double* crop = ptr<double>(h->cropval);
-  if (!h->have_cropval) {
-    launch_crop_value(s, ptr<double>(h->A0), n, ld, ptr<double>(h->dvec));
-    crop = ptr<double>(h->dvec);
+  if (icassp) {
+    // ---- shared by every value: CropDiagonal's value and the blurred matrix (+ row maxima)
+    const double* crop = ptr<double>(h->cropval);
+    if (!h->have_cropval) {
+      launch_crop_value(s, ptr<double>(h->A0), n, ld, ptr<double>(h->dvec));
+      crop = ptr<double>(h->dvec);
+    }
+    SC_TRY(upload_blur_weights(h, cfg));
+    if (!launch_gaussian_blur_fused(s, ptr<double>(h->A0), ptr<double>(h->B1), n, ld,
+                                    cfg->blur_radius, ptr<double>(h->blurw), crop,
+                                    ptr<double>(h->rmpart)))
+      return fail(h, SC_ERR_HIP, "fused blur not taken");
+    SC_TRY(check_last(h, "sweep blur launch"));
   }
-  SC_TRY(upload_blur_weights(h, cfg));
-  if (!launch_gaussian_blur_fused(s, ptr<double>(h->A0), ptr<double>(h->B1), n, ld,
-                                  cfg->blur_radius, ptr<double>(h->blurw), crop,
-                                  ptr<double>(h->rmpart)))
-    return fail(h, SC_ERR_HIP, "fused blur not taken");
-  SC_TRY(check_last(h, "sweep blur launch"));
   memset(h->gconv_hist, 0, sizeof(h->gconv_hist));
   h->gconv_seen = 0;
   std::vector<int> later;  // values whose solve left the common path
@@ -751,7 +760,7 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
   // Matrix-free Diffuse (free_api.hip): a member then holds the thresholded matrix, its digits
   // and the fp32 tiles of their product instead of S, and the lockstep solver applies A twice.
   // The cut vector bounds max|a| when the affinity is non-negative by construction.
-  const bool free_route = free_diffuse_wanted(h, cfg, n, rq);
+  const bool free_route = icassp && free_diffuse_wanted(h, cfg, n, rq);
   const bool amax_from_cut = free_route && h->affinity_from_embeddings && !h->constraint_applied &&
                              cfg->soft_multiplier >= 0.0 && cfg->soft_multiplier <= 1.0;
   const size_t member_bytes = 2 * (size_t)n * ld * sizeof(double) + (size_t)n * 8192 +
@@ -801,7 +810,8 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       FrontItem& f = fi[z];
       f.n = n;
       f.ldn = ld;
-      f.B1 = ptr<double>(h->B1);  // the shared blurred matrix: read only
+      // the matrix every value thresholds: the shared blurred one, or the affinity itself
+      f.B1 = icassp ? ptr<double>(h->B1) : ptr<double>(h->A0);  // read only
       f.B2 = ptr<double>(hz->B2);
       f.rmpart = ptr<double>(h->rmpart);
       f.blur_cols = blur_tile_columns(n, cfg->blur_radius);
@@ -828,7 +838,7 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       dif[z].rowsum = ptr<double>(hz->rowsum);
       em[z] = GroupEigMember();
       em[z].h = hz;
-      em[z].S = free_route ? ptr<double>(hz->B2) : ptr<double>(hz->B1);
+      em[z].S = (free_route || !icassp) ? ptr<double>(hz->B2) : ptr<double>(hz->B1);
       em[z].ld = ld;
       em[z].n = n;
       em[z].rq = rq;
@@ -845,10 +855,26 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       for (int z = 0; z < cnt; ++z) init[z].symflag = nullptr;
       launch_front_begin_group(s, init, cnt, false);
     }
+    const bool own_cuts = !icassp;  // (RowMax cuts of the ICASSP front come from the blur's partials)
+    if (own_cuts) {
+      for (int z = 0; z < cnt; ++z) {
+        if (cfg->threshold_type == SC_THRESHOLD_PERCENTILE)
+          launch_cut_percentile(s, fi[z].B1, n, ld, p_values[base + z], fi[z].cut,
+                                cfg->preserve_diagonal);
+        else
+          launch_cut_from_rows(s, fi[z].B1, n, ld, p_values[base + z], fi[z].cut,
+                               cfg->preserve_diagonal);
+      }
+    }
     launch_threshold_symmetrize_group(s, fi, cnt, cfg->p_percentile, cfg->soft_multiplier,
                                       cfg->binarize, cfg->symmetrize_type,
-                                      cfg->preserve_diagonal);
-    if (free_route) {
+                                      cfg->preserve_diagonal, own_cuts);
+    if (!icassp) {
+      // no Diffuse: the row sums of the symmetrised matrix are the degrees
+      for (int z = 0; z < cnt; ++z)
+        launch_row_stats(s, fi[z].B2, n, ld, ptr<double>(em[z].h->rowmax),
+                         ptr<double>(em[z].h->rowsum));
+    } else if (free_route) {
       // rowmax / rowsum of every member's S = A A^T without forming it: digits per member,
       // ONE launch for the digit products of all members, candidates + exact recheck per member
       const signed char* qs[kGroupMax];
@@ -869,7 +895,7 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
     } else {
       launch_gemm_nt_group(s, dif, cnt, kEpiNone, 1);
     }
-    launch_scaling_vectors_group(s, fi, cnt, cfg->laplacian_type, 1);
+    launch_scaling_vectors_group(s, fi, cnt, cfg->laplacian_type, icassp ? 1 : 0);
     SC_TRY(check_last(h, "sweep launch"));
     // (with the Ritz vectors: the level's winner is then adopted, not evaluated again --
     //  one upload and one launch for the whole group against a Diffuse + a solve)
@@ -899,13 +925,14 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       dg->eig_descending = rq.descend;
       dg->n_eigenvalues = std::min((int)em[z].w.size(), SC_MAX_EIG);
       for (int i = 0; i < dg->n_eigenvalues; ++i) dg->eigenvalues[i] = em[z].w[i];
-      dg->symmetry_state = 2;
+      dg->symmetry_state = icassp ? 2 : 1;
       dg->eig_path = SC_EIG_PATH_BLOCK_LANCZOS;
       dg->eig_matvec_passes = em[z].passes;
       dg->eig_block = kEigBlock;
       dg->eig_basis = em[z].basis;
       dg->eig_max_residual = em[z].dc.max_resid;
-      dg->diffuse_path = free_route ? SC_DIFFUSE_PATH_FREE : SC_DIFFUSE_PATH_EXPLICIT;
+      dg->diffuse_path = !icassp ? SC_DIFFUSE_PATH_NONE
+                                 : (free_route ? SC_DIFFUSE_PATH_FREE : SC_DIFFUSE_PATH_EXPLICIT);
       if (free_route) dg->free_candidates = em[z].h->h_free[65];
     }
   }

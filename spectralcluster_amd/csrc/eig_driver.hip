@@ -830,8 +830,8 @@ bool sym_group_eligible(int n, const EigRequest& rq, bool any_size) {
 // pinned host + device staging of the group checks: per member m*m (T) + 64 (G) doubles +
 // 16 flag words going out, kHostRR^2 (Y) doubles coming back
 static int ensure_group_staging(sc_handle lead) {
-  const size_t out_doubles = (size_t)kGroupMax * (kHostRR * kHostRR + 64 + 8);
-  const size_t y_doubles = (size_t)kGroupMax * kHostRR * kHostRR;
+  const size_t out_doubles = (size_t)kGroupMax * (kEigBasisCap * kEigBasisCap + 64 + 8);
+  const size_t y_doubles = (size_t)kGroupMax * kEigBasisCap * kEigBasisCap;
   SC_TRY(grow(lead, lead->gpack, out_doubles * sizeof(double)));
   SC_TRY(grow(lead, lead->gypack, y_doubles * sizeof(double)));
   if (!lead->h_gpack) {
@@ -864,7 +864,7 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
     lz[z].vs_scale = h->vs_scale ? h->vs_scale : ptr<double>(h->cvec);
     lz[z].active = true;
     const int cap = std::min(kEigBasisCap, ((mem[z].n - kEigBlock) / kEigBlock) * kEigBlock);
-    limit[z] = std::min(cap, kHostRR);
+    limit[z] = cap;
     mem[z].status = 0;
     mem[z].passes = 0;
     mem[z].basis = 0;
@@ -936,7 +936,18 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
   };
   // T (m x m), the residual Gram and the flags of every active member: one gather kernel, one
   // copy to the host, an event to wait on
-  const int out_stride = kHostRR * kHostRR + 64 + 8;
+  const int out_stride = kEigBasisCap * kEigBasisCap + 64 + 8;
+  const int y_stride = kEigBasisCap * kEigBasisCap;
+  // Round 4: the group no longer ends at kHostRR basis vectors.  Members that have not
+  // converged keep growing their bases in lockstep up to the cap (the leading-vector
+  // Rayleigh-Ritz of sym_topk above 64 vectors), and at the cap the whole group makes a thick
+  // restart -- same kept size for every member, so that they stay in lockstep -- instead of
+  // each member being solved again from scratch on the single-call path (binarised
+  // affinities, unstructured embeddings: 28-64 passes per solve).
+  int group_cap = kEigBasisCap;
+  for (int z = 0; z < count; ++z) group_cap = std::min(group_cap, limit[z]);
+  int cycles = 0, max_cycles = 1 << 30;
+  for (int z = 0; z < count; ++z) max_cycles = std::min(max_cycles, mem[z].rq.max_cycles);
   auto request_check = [&](int m) -> int {
     GatherItem gi[kGroupMax];
     memset(gi, 0, sizeof(gi));
@@ -973,7 +984,8 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
     // (never speculating costs 3 % on config 5; speculating while most members are already
     //  done wastes a matvec pass over their matrices: stop once half of the members seen so
     //  far in this batch had converged by this basis size)
-    const bool speculate = seen < 2 * kGroupMax || done_by * 2 < seen;
+    // (never at the basis cap: the next block has no room, a restart follows)
+    const bool speculate = (seen < 2 * kGroupMax || done_by * 2 < seen) && m + kEigBlock <= group_cap;
     if (speculate) SC_TRY(block_step(m));
     const double t_sync0 = trace ? now_us() : 0.0;
     SC_HIP(lead, hipEventSynchronize(lead->gcheck_ev));
@@ -984,6 +996,7 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
     // host workers + this thread (one after the other they were 1.0-1.9 ms per group, during
     // which this stream has nothing queued but the speculative block).
     bool rr_wanted[kGroupMax], rr_ok[kGroupMax];
+    int keep_want[kGroupMax] = {0};
     for (int z = 0; z < count; ++z) {
       rr_wanted[z] = rr_ok[z] = false;
       if (!lz[z].active) continue;
@@ -996,8 +1009,26 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
       if (!rr_wanted[z]) return;
       sc_handle h = mem[z].h;
       const double* pack = lead->h_gpack + (size_t)z * out_stride;
-      double* hy = lead->h_gypack + (size_t)z * kHostRR * kHostRR;
-      bool ok = host_rayleigh_ritz(pack, m, pack + m * m, m, h->h_theta, h->h_theta + kLdq, hy, m);
+      double* hy = lead->h_gypack + (size_t)z * y_stride;
+      bool ok;
+      if (m <= kHostRR) {
+        ok = host_rayleigh_ritz(pack, m, pack + m * m, m, h->h_theta, h->h_theta + kLdq, hy, m);
+      } else {
+        // the pairs the analysis reads and a thick restart keeps, + a block (as sym_topk)
+        const EigRequest& rqz = mem[z].rq;
+        const int nz = mem[z].n;
+        auto leading = [&](const double* theta) {
+          // at the cap a restart follows whose kept size is the GROUP's: every vector it
+          // could keep
+          if (m + kEigBlock > group_cap) return m - kEigBlock;
+          std::vector<double> zero(m, 0.0);
+          const EigDecision d0 = analyze(rqz, theta, zero.data(), m, nz, false);
+          const int want = d0.enough ? std::max(d0.kw, d0.kvec) : group_cap / 4;
+          return round_up(want + kEigBlock, kEigBlock) + kEigBlock;
+        };
+        ok = host_rayleigh_ritz_leading(pack, m, pack + m * m, m, h->h_theta, h->h_theta + kLdq, hy,
+                                        m, leading);
+      }
       for (int i = 0; ok && i < m; ++i) ok = std::isfinite(h->h_theta[i]);
       rr_ok[z] = ok;
     });
@@ -1042,7 +1073,7 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
         lz[z].active = false;
         --active;
         any_solved = true;
-        if (m / kEigBlock < 16) ++lead->gconv_hist[m / kEigBlock];
+        if (cycles == 0 && m / kEigBlock < 16) ++lead->gconv_hist[m / kEigBlock];
         ++lead->gconv_seen;
         continue;
       }
@@ -1052,13 +1083,62 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
         hand_back();
         continue;
       }
-      if (m + kEigBlock > limit[z]) hand_back();  // restart territory: the single-call path
+      keep_want[z] = dc.enough ? std::max(dc.kw, dc.kvec) : group_cap / 4;
     }
     if (trace) us_host += now_us() - t_sync1;
     if (speculate) wasted += active_before - active;
     if (active == 0) break;
-    if (!speculate) SC_TRY(block_step(m));
-    m += kEigBlock;
+    bool speculated = speculate;
+    if (m + kEigBlock > group_cap) {
+      // ---- thick restart of every member still active: [leading Ritz vectors | current block]
+      if (++cycles > max_cycles) {  // restart budget spent: the single-call path lands them
+        for (int z = 0; z < count; ++z)
+          if (lz[z].active) {
+            mem[z].status = 1;
+            lz[z].active = false;
+            --active;
+          }
+        break;
+      }
+      int keep = kEigBlock;
+      for (int z = 0; z < count; ++z)
+        if (lz[z].active) keep = std::max(keep, round_up(keep_want[z] + kEigBlock, kEigBlock));
+      keep = std::max(kEigBlock, std::min(keep, group_cap - 2 * kEigBlock));
+      for (int z = 0; z < count; ++z) {
+        if (!lz[z].active) continue;
+        sc_handle h = mem[z].h;
+        const double* hy = lead->h_gypack + (size_t)z * y_stride;
+        // Ritz coefficients and values of this member -> its arena (where k_jacobi leaves them)
+        SC_HIP(lead, hipMemcpy2DAsync(h->Y.p, (size_t)kLdq * sizeof(double), hy,
+                                      (size_t)m * sizeof(double), (size_t)m * sizeof(double), m,
+                                      hipMemcpyHostToDevice, s));
+        SC_HIP(lead, hipMemcpyAsync(h->theta.p, h->h_theta, m * sizeof(double),
+                                    hipMemcpyHostToDevice, s));
+        // (the speculative block step, if one ran, wrote Q[:, m + 8 ..] and W: the block that
+        //  continues the recurrence is Q[:, m : m + 8], which the restart keeps)
+        launch_basis_times_Y(s, ptr<double>(h->Q), kLdq, m, ptr<double>(h->Y), kLdq, keep,
+                             ptr<double>(h->Q2), kLdq, mem[z].n, 0);
+        launch_copy_block(s, ptr<double>(h->Q) + m, kLdq, ptr<double>(h->Q2) + keep, kLdq,
+                          mem[z].n, kEigBlock);
+        std::swap(h->Q, h->Q2);
+        launch_set_diag_T(s, ptr<double>(h->T), kLdq, kLdq, ptr<double>(h->theta), keep);
+        lz[z].ws = eig_workspace(h);
+      }
+      SC_TRY(check_last(lead, "group restart launch"));
+      SC_HIP(lead, hipStreamSynchronize(s));  // (h_theta / h_gypack are rewritten by the next check)
+      if (trace)
+        fprintf(stderr, "[sc] group restart %d: %d members keep %d vectors\n", cycles, active, keep);
+      m = keep;  // the recurrence continues from the kept block: Vs = c .* Q[:, m : m + 8] still holds
+      speculated = false;
+    }
+    // next check: every block early in the first cycle (where convergence is expected), then
+    // every other block, and only with a full basis once restarts have begun (sym_topk's rule)
+    do {
+      if (!speculated) SC_TRY(block_step(m));
+      speculated = false;
+      m += kEigBlock;
+    } while (!(cycles == 0 ? (m <= 4 * kEigBlock || m % (2 * kEigBlock) == 0 || m + kEigBlock > group_cap)
+                           : (m + kEigBlock > group_cap)));
     SC_TRY(request_check(m));
   }
   if (trace)
@@ -1079,7 +1159,7 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
     rz[z].Q = ptr<double>(h->Q);
     rz[z].ldq = kLdq;
     rz[z].m = mem[z].basis;
-    rz[z].Y = ptr<double>(lead->gypack) + (size_t)z * kHostRR * kHostRR;
+    rz[z].Y = ptr<double>(lead->gypack) + (size_t)z * y_stride;
     rz[z].ldy = mem[z].basis;
     rz[z].cols = cols;
     rz[z].E = ptr<double>(h->E);
@@ -1091,7 +1171,7 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
     last = z;
   }
   SC_HIP(lead, hipMemcpyAsync(lead->gypack.p, lead->h_gypack,
-                              (size_t)(last + 1) * kHostRR * kHostRR * sizeof(double),
+                              (size_t)(last + 1) * y_stride * sizeof(double),
                               hipMemcpyHostToDevice, s));
   launch_ritz_vectors_group(s, rz, count);
   return check_last(lead, "group ritz vector launch");

@@ -679,11 +679,14 @@ void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count,
 }
 void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,
                                        double p, double mult, int binarize, int symtype,
-                                       int preserve_diag) {
+                                       int preserve_diag, bool cut_ready) {
   int nmax;
   const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
   if (nmax == 0) return;
-  hipLaunchKernelGGL(k_cut_from_partials_g, dim3((nmax + 3) / 4, count), dim3(256), 0, s, g, p);
+  // (cut_ready: every member's cut vector is already there -- Percentile cuts come from their
+  //  own per-member kernel; RowMax cuts are taken from the blur's per-strip row maxima here)
+  if (!cut_ready)
+    hipLaunchKernelGGL(k_cut_from_partials_g, dim3((nmax + 3) / 4, count), dim3(256), 0, s, g, p);
   const int t = (nmax + 31) / 32;
   hipLaunchKernelGGL(k_threshold_symmetrize_g, dim3(t * (t + 1) / 2, count), dim3(256), 0, s, g,
                      mult, binarize, symtype, preserve_diag);

@@ -274,7 +274,7 @@ void launch_gaussian_blur_group(hipStream_t s, const FrontItem* items, int count
                                 const double* weights_dev);
 void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,
                                        double p, double mult, int binarize, int symtype,
-                                       int preserve_diag);
+                                       int preserve_diag, bool cut_ready = false);
 void launch_scaling_vectors_group(hipStream_t s, const FrontItem* items, int count,
                                   int laplacian_type, int row_normalized);
 struct GatherItem {  // T == nullptr: idle

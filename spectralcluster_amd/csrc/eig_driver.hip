@@ -586,39 +586,49 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
     // at the tolerance level -- depend on the call history.  A solve is now a function of
     // its input alone: tests/test_gpu_predict.py::test_results_do_not_depend_on_call_history.)
     const int first_check = std::min(3 * kEigBlock, cap);
-    while (!done) {
-      // block V_j lives in Q[:, m : m + 16]; Vs = c .* V_j
+    // Rayleigh-Ritz is the expensive serial step: every block early on (where convergence is
+    // expected), then sparser, then once per restart cycle.
+    auto check_due = [&](int mm) {
+      return cycles == 0 ? (mm >= first_check && (mm <= 4 * kEigBlock ||
+                                                  mm % (2 * kEigBlock) == 0 || mm + kEigBlock > cap))
+                         : (mm + kEigBlock > cap);
+    };
+    // one block step from a basis of m_before vectors: the operator on the block
+    // V_j = Q[:, m_before : m_before + 8] (Vs = c .* V_j), then the orthonormalisation chain
+    auto enqueue_step = [&](int m_before) -> int {
       const bool time_mv = h->profile_level >= 2 && h->n_mv_ev < 16;
       if (time_mv) ev_rec(h, &h->mv_ev[h->n_mv_ev][0]);
       if (h->free_on)
-        free_apply_operator(h, S, ld, n, sym_mv, ptr<double>(h->Q) + m, kLdq);
+        free_apply_operator(h, S, ld, n, sym_mv, ptr<double>(h->Q) + m_before, kLdq);
       else if (sym_mv)
-        launch_block_matvec_sym(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
+        launch_block_matvec_sym(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m_before, kLdq,
                                 ptr<double>(h->Vs), ptr<double>(h->W), ptr<double>(h->mvsym));
       else
-        launch_block_matvec(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m, kLdq,
+        launch_block_matvec(s, S, ld, n, cvec, pvec, ptr<double>(h->Q) + m_before, kLdq,
                             ptr<double>(h->Vs), ptr<double>(h->W));
       if (time_mv) ev_rec(h, &h->mv_ev[h->n_mv_ev++][1]);
       ++passes;
-      m += kEigBlock;
+      const int mm = m_before + kEigBlock;
       if (fused) {
         // CGS-1 | CGS-2 + CholQR | re-projection + CholQR on the normalised block | store
         const EigWorkspace ws = eig_workspace(h);
-        launch_lz_link(s, ws, &chain, n, m, 0, 1, -1, vscale, m - kEigBlock, false, 0, false);
-        launch_lz_link(s, ws, &chain, n, m, 1, 2, -1, vscale, m - kEigBlock, false, 0, false);
-        launch_lz_link(s, ws, &chain, n, m, 2, 3, -1, vscale, m - kEigBlock, false, 0, false);
-        if (three_pass) launch_lz_link(s, ws, &chain, n, m, 3, 3, -1, vscale, 0, false, 0, false);
-        launch_lz_link(s, ws, &chain, n, m, 3, 0, m, vscale, 0, false, 0, false);
-        SC_TRY(check_last(h, "block step launch"));
-      } else {
-        SC_TRY(orthonormalize(h, n, m, true, m - kEigBlock, m, true));
+        launch_lz_link(s, ws, &chain, n, mm, 0, 1, -1, vscale, mm - kEigBlock, false, 0, false);
+        launch_lz_link(s, ws, &chain, n, mm, 1, 2, -1, vscale, mm - kEigBlock, false, 0, false);
+        launch_lz_link(s, ws, &chain, n, mm, 2, 3, -1, vscale, mm - kEigBlock, false, 0, false);
+        if (three_pass) launch_lz_link(s, ws, &chain, n, mm, 3, 3, -1, vscale, 0, false, 0, false);
+        launch_lz_link(s, ws, &chain, n, mm, 3, 0, mm, vscale, 0, false, 0, false);
+        return check_last(h, "block step launch");
       }
-      // Rayleigh-Ritz is the expensive serial step: every block early on (where
-      // convergence is expected), then sparser, then once per restart cycle.
-      const bool check = cycles == 0 ? (m >= first_check && (m <= 4 * kEigBlock ||
-                                                               m % (2 * kEigBlock) == 0 ||
-                                                               m + kEigBlock > cap))
-                                     : (m + kEigBlock > cap);
+      return orthonormalize(h, n, mm, true, mm - kEigBlock, mm, true);
+    };
+    int ahead = 0;  // block steps already enqueued beyond m (run-ahead during a host solve)
+    while (!done) {
+      if (ahead > 0)
+        --ahead;
+      else
+        SC_TRY(enqueue_step(m));
+      m += kEigBlock;
+      const bool check = check_due(m);
       const bool host_rr = check && m <= kHostRRSingle && !sw::eig_device_rr();
       if (host_rr) {
         // small projected problem: T and G come back with the flags; solved on the host
@@ -646,8 +656,26 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
         }
         SC_TRY(rcb);
       } else if (check) {
-        int mask = 0;
-        SC_TRY(read_flags(h, &mask));  // the one synchronisation of the fused chain
+        // the one synchronisation of the fused chain.  From the third check of the first
+        // cycle on (a spectrum that did not converge in 32 vectors will not in 48 either,
+        // more often than not) the device runs ahead to the next check point while the host
+        // waits for and solves this one: the projected problems of 48-128 vectors take
+        // 0.13-0.93 ms on the host, a block step 0.1-0.25 ms on the device.  What the check
+        // reads -- T[0:m, 0:m], G, the flags -- is copied out before the run-ahead in stream
+        // order; what a converged check uses -- Q[:, 0:m] -- is not touched by it.
+        SC_HIP(h, hipMemcpyAsync(h->h_flags, h->flags.p, 16 * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (!h->sync_ev) SC_HIP(h, hipEventCreateWithFlags(&h->sync_ev, hipEventDisableTiming));
+        SC_HIP(h, hipEventRecord(h->sync_ev, s));
+        if (host_rr && cycles == 0 && m >= 6 * kEigBlock && m + kEigBlock <= cap) {
+          int mm = m;
+          do {
+            SC_TRY(enqueue_step(mm));
+            mm += kEigBlock;
+            ++ahead;
+          } while (!check_due(mm));
+        }
+        SC_HIP(h, hipEventSynchronize(h->sync_ev));
+        if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
         if (h->h_flags[13] != 0) {
           // a dependent column or a hopeless first Cholesky somewhere in the chain: redo the
           // solve with the host-driven chain, which repairs blocks one by one
@@ -683,6 +711,8 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
         double* hy = h->h_rr + kHostRRSingle * kHostRRSingle + 64;
         const double* hG = h->h_rr + kHostRRSingle * kHostRRSingle;
         bool rr_ok;
+        timespec ts0;
+        if (sw::eig_trace()) clock_gettime(CLOCK_MONOTONIC, &ts0);
         if (m <= kHostRR) {
           rr_ok = host_rayleigh_ritz(h->h_rr, m, hG, m, h->h_theta, h->h_theta + kLdq, hy, m);
         } else {
@@ -695,6 +725,12 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
           };
           rr_ok = host_rayleigh_ritz_leading(h->h_rr, m, hG, m, h->h_theta, h->h_theta + kLdq,
                                              hy, m, leading);
+        }
+        if (sw::eig_trace()) {
+          timespec ts1;
+          clock_gettime(CLOCK_MONOTONIC, &ts1);
+          fprintf(stderr, "[sc]   host Rayleigh-Ritz m=%d: %.0f us\n", m,
+                  (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-3);
         }
         if (!rr_ok) {
           SC_TRY(dense_fallback(2));

@@ -102,6 +102,7 @@ struct Member {
   FrontResult front;
   int state = 0;         // 0 in the group, 1 single-call path, 2 done
   int k = 0;
+  bool free_op = false;  // matrix-free Diffuse: front.matrix is A, the solver applies it twice
 };
 
 // Stages before the eigensolver of one group, member after member, each on its member's
@@ -241,6 +242,21 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
     m.front.ld = h->ldn;
     m.front.symmetric = true;
     m.front.folded_rownorm = true;
+    // Large members take the matrix-free Diffuse (free_api.hip): their n^3 product is most of
+    // a batch's GEMM time (78 % of config 5's Diffuse flops sit in utterances of n >= 2048)
+    m.free_op = free_diffuse_wanted(lead, cfg, n, make_eig_request(cfg)) &&
+                cfg->soft_multiplier >= 0.0 && cfg->soft_multiplier <= 1.0 &&
+                cfg->p_percentile > 0.0;
+    if (m.free_op) {
+      rc = ensure_free(h, n);
+      if (rc != SC_OK) {
+        lead->err = h->err;
+        return rc;
+      }
+      dif[z].n = 0;          // idle in the grouped fp64 product
+      m.front.matrix = f.B2;  // the thresholded + symmetrised A stays the operand
+      m.front.scratch = f.B1;
+    }
   }
   launch_front_begin_group(s, fi, count, true);
   launch_gemm_nt_group(s, aff, count, kEpiAffinity, 2);
@@ -248,6 +264,20 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
   launch_threshold_symmetrize_group(s, fi, count, cfg->p_percentile, cfg->soft_multiplier,
                                     cfg->binarize, cfg->symmetrize_type, cfg->preserve_diagonal);
   launch_gemm_nt_group(s, dif, count, kEpiNone, 1);
+  for (int z = 0; z < count; ++z) {
+    if (!mb[z].free_op) continue;
+    // rowmax / rowsum of S = A A^T without forming it (the cut vector bounds max|a|: the
+    // grouped front is the ICASSP2018 sequence on a cosine affinity)
+    sc_handle h = mb[z].h;
+    const int n = h->n;
+    launch_free_amax_from_cut(s, ptr<double>(h->cut), n, cfg->p_percentile,
+                              (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0,
+                              ptr<double>(h->fscal));
+    SC_TRY(free_stats_begin(h, s, fi[z].B2, h->ldn, n, true));
+    launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32),
+                       ptr<unsigned>(h->fwords));
+    SC_TRY(free_stats_end(h, s, fi[z].B2, h->ldn, n, false));
+  }
   launch_scaling_vectors_group(s, fi, count, cfg->laplacian_type, 1);
   SC_TRY(check_last(lead, "grouped front launch"));
   SC_HIP(lead, hipEventRecord(lead->gbank_ev[bank], s));
@@ -276,9 +306,15 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
     em[ne].ld = mb[z].front.ld;
     em[ne].n = ns[mb[z].index];
     em[ne].rq = rq;
+    em[ne].free_op = mb[z].free_op;
     emz[ne++] = z;
   }
   if (ne > 0) SC_TRY(sym_topk_group(lead, em, ne));
+  for (int e = 0; e < ne; ++e) {
+    // a matrix-free member with rows the candidate search could not prune: the single-call
+    // path evaluates those rows exactly (its overflow words came back with the solver's syncs)
+    if (em[e].free_op && em[e].status == 0 && em[e].h->h_free[0] != 0) em[e].status = 1;
+  }
   const double t2 = trace ? now_us() : 0.0;
   // ---- k-means: lockstep over the solved members
   KmGroupItem km[kGroupMax];
@@ -337,6 +373,12 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
       dg->eig_basis = em[e].basis;
       dg->eig_max_residual = em[e].dc.max_resid;
       dg->n_clusters = k;
+      if (m.free_op) {
+        dg->diffuse_path = SC_DIFFUSE_PATH_FREE;
+        dg->free_candidates = h->h_free[65];
+      } else if (m.front.folded_rownorm) {  // (the grouped front: the explicit product)
+        dg->diffuse_path = SC_DIFFUSE_PATH_EXPLICIT;
+      }
     }
     SC_TRY(ensure_kmeans(h, n));
     const int lde = round_up(n, 16);

@@ -206,6 +206,25 @@ def tri_tiles(n):
   return nt * (nt + 1) // 2
 
 
+FREE_MIN_N = 2048  # default route switch of the matrix-free Diffuse (free_api.hip)
+
+
+def icassp_floor_seconds(n, d, passes):
+  """Floor of one ICASSP2018 predict() AS IT RUNS: the explicit route below FREE_MIN_N
+  (`icassp_work`), the matrix-free route from there on -- n^2 d fp64 flops + 4 n^3 int8 ops
+  (upper triangle, 2 ops per MAC) at their MFMA peaks; A1 write, Crop+Blur R/W, Thr+Sym R/W,
+  one read of A + n^2 * 2 B of digits, T written and read once as fp32 upper-triangle tiles,
+  one more read of A for the exact statistics, 2 x passes half-matrix products; 8 TB/s."""
+  nn = float(n) * n
+  if n < FREE_MIN_N:
+    flops, hbm = icassp_work(n, d, passes)
+    return flops / (PEAK_F64_MFMA_TFLOPS * 1e12) + hbm / (PEAK_HBM_TBS * 1e12)
+  mat = nn * 8.0
+  hbm = 5.0 * mat + mat + nn * 2.0 + 2 * nn * 2.0 + mat + 2.0 * passes * 0.5 * mat + n * d * 8.0
+  return (nn * d / (PEAK_F64_MFMA_TFLOPS * 1e12) + 4.0 * nn * n / (PEAK_I8_MFMA_TOPS * 1e12) +
+          hbm / (PEAK_HBM_TBS * 1e12))
+
+
 def icassp_work(n, d, passes):
   """Algorithmic work of one ICASSP2018 predict() (fused lower bound): the
   two products with their symmetry exploited, n^2 (n + d) flops (no tile rounding: padding a
@@ -281,6 +300,13 @@ def batch512_leg(sca, multigpu, comm, fence, group=16, streams=8, project=True):
       hbm += b
     out["roofline"] = workload_roofline(flops, hbm, elapsed)
     out["roofline"]["matvec_passes_mean"] = float(np.mean(list(passes.values())))
+    out["roofline"]["floor_note"] = ("floor_ms / frac price the EXPLICIT route (n^3 fp64 flops per "
+                                     "utterance): the yardstick of rounds 1-3")
+    as_run = sum(icassp_floor_seconds(sizes[i], N_FEATURES, passes[i]) for i in owned)
+    out["roofline"]["as_run"] = {
+        "floor_ms": 1e3 * as_run, "frac": as_run / elapsed,
+        "note": "utterances of n >= %d take the matrix-free Diffuse: their floor is the int8 "
+                "digit product + the extra passes over A instead of the fp64 product" % FREE_MIN_N}
   gpath = os.path.join(ROOT, "tests", "golden", "batch512.npz")
   if comm.rank == 0 and os.path.exists(gpath):
     g = np.load(gpath)
@@ -381,6 +407,19 @@ def autotune16_leg(sca, multigpu, comm, fence, variant="icassp", project=True):
     out["roofline"] = workload_roofline(flops, hbm, elapsed)
     out["roofline"]["matvec_passes_per_value"] = per_value_passes
     out["eig_paths"] = [int(d.eig_path) for d in sweep]
+    if diffuse and n >= FREE_MIN_N:
+      # as it runs: every value on the matrix-free Diffuse (floor_ms / frac above keep pricing
+      # the explicit route, the yardstick of rounds 1-3)
+      nn = float(n) * n
+      hbm_free = (mat + n * N_FEATURES * 8.0 + 2 * mat +
+                  evals * (2 * mat + mat + nn * 2.0 + 2 * nn * 2.0 + mat) +
+                  sum(per_value_passes) * 2 * 0.5 * mat)
+      floor = (prod * N_FEATURES / (PEAK_F64_MFMA_TFLOPS * 1e12) +
+               evals * 4.0 * nn * n / (PEAK_I8_MFMA_TOPS * 1e12) + hbm_free / (PEAK_HBM_TBS * 1e12))
+      out["roofline"]["as_run"] = {"floor_ms": 1e3 * floor, "frac": floor / elapsed,
+                                   "note": "matrix-free Diffuse per value: int8 digit product at "
+                                           "5 POP/s + its passes over A; 2 half-matrix products "
+                                           "per executed block pass"}
   gname = "autotune_ttd_n4096.npz" if variant == "ttd" else "autotune_n4096.npz"
   gpath = os.path.join(ROOT, "tests", "golden", gname)
   if os.path.exists(gpath):
@@ -505,10 +544,10 @@ def kernel_roofline(stage_ms, passes):
                  "note": "int8 multiply-adds counted as 2 ops; 4 digit products (hh, hl, lh, ll) "
                          "of the upper-triangle tiles"})
     t32 = nt * (nt + 1) // 2 * GEMM_TILE * GEMM_TILE * 4.0
-    hbm("k_free_absmax + k_free_quantize", "free_quantize", 2 * mat + n * n * 2.0,
-        "2 reads of A (max|a|, then the digits) + n^2 * 2 B of digits written")
-    hbm("k_t32_rowmax + k_t32_candidates", "free_scan", 2 * t32,
-        "2 reads of the fp32 upper-triangle tiles of T")
+    hbm("k_free_amax_from_cut + k_free_quantize", "free_quantize", mat + n * n * 2.0,
+        "1 read of A + n^2 * 2 B of digits written (max|a| comes from the cut vector)")
+    hbm("k_t32_candidates", "free_scan", t32,
+        "1 read of the fp32 upper-triangle tiles of T (row maxima come from the product's epilogue)")
     hbm("k_free_row_stats (exact rowmax / rowsum of S)", "free_stats", 2.2 * mat,
         "row i and its ~1.2 candidate rows: ~2.2 n^2 * 8 B")
   else:
@@ -784,6 +823,18 @@ def main():
       target["traffic_measured_on"] = {
           "commit": t.get("commit"), "gemm_f64_sha16": t.get("gemm_f64_sha16"),
           "kernel_source_unchanged_since": t.get("gemm_f64_sha16") == now}
+    ipath = os.path.join(ROOT, "profiles", "pmc_traffic_i8.json")
+    if free and os.path.exists(ipath):  # HBM bytes per digit-product launch (separate --pmc run)
+      t = json.load(open(ipath))
+      import hashlib
+      src = os.path.join(ROOT, "spectralcluster_amd", "csrc", "diffuse_free.hip")
+      now = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+      out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+      out["roofline"]["traffic_source"] = t["source"]
+      out["roofline"]["algorithmic_bytes_per_launch"] = t["algorithmic_bytes_per_launch"]
+      out["roofline"]["traffic_measured_on"] = {
+          "commit": t.get("commit"), "diffuse_free_sha16": t.get("diffuse_free_sha16"),
+          "kernel_source_unchanged_since": t.get("diffuse_free_sha16") == now}
     out.update(extras)
     if args.workload != "predict8192":
       leg = extras[args.workload]

@@ -497,6 +497,44 @@ __global__ __launch_bounds__(256) void k_t32_candidates(
 // ovf[0] = rows with more candidates than `cap`, ovf[1 + e] their indices (first 64),
 // ovf[65] = candidates evaluated in total, ovf[66] = largest candidate count of a row.
 constexpr int kFreeCapMax = 8;
+// CNT candidates of this row (a compile-time count: the loads of a k-step -- the row, y1 and
+// the candidate rows, two steps per trip -- are all in flight together instead of sitting
+// behind one branch each)
+template <int CNT>
+__device__ __forceinline__ void free_row_dots(const double* __restrict__ x,
+                                              const double* const* __restrict__ xj,
+                                              const double* __restrict__ y1, int n, double* rs_out,
+                                              double* acc_out) {
+  double rs = 0.0;
+  double acc[CNT > 0 ? CNT : 1];
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) acc[c] = 0.0;
+#pragma unroll 2
+  for (int k = 2 * threadIdx.x; k < n; k += 512) {
+    double2 a = *reinterpret_cast<const double2*>(x + k);
+    double2 yy = *reinterpret_cast<const double2*>(y1 + k);
+    double2 b[CNT > 0 ? CNT : 1];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) b[c] = *reinterpret_cast<const double2*>(xj[c] + k);
+    if (k + 1 >= n) {
+      a.y = 0.0;
+      yy.y = 0.0;
+#pragma unroll
+      for (int c = 0; c < CNT; ++c) b[c].y = 0.0;
+    }
+    rs = __builtin_fma(a.x, yy.x, rs);
+    rs = __builtin_fma(a.y, yy.y, rs);
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      acc[c] = __builtin_fma(a.x, b[c].x, acc[c]);
+      acc[c] = __builtin_fma(a.y, b[c].y, acc[c]);
+    }
+  }
+  *rs_out = rs;
+#pragma unroll
+  for (int c = 0; c < CNT; ++c) acc_out[c] = acc[c];
+}
+
 __global__ __launch_bounds__(256) void k_free_row_stats(
     const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
     const int* __restrict__ count, const int* __restrict__ cand, int cap,
@@ -514,21 +552,13 @@ __global__ __launch_bounds__(256) void k_free_row_stats(
 #pragma unroll
   for (int c = 0; c < kFreeCapMax; ++c) acc[c] = 0.0;
   double rs = 0.0;
-  for (int k = 2 * threadIdx.x; k < n; k += 512) {
-    double2 a = *reinterpret_cast<const double2*>(x + k);
-    double2 yy = *reinterpret_cast<const double2*>(y1 + k);
-    if (k + 1 >= n) { a.y = 0.0; yy.y = 0.0; }
-    rs = __builtin_fma(a.x, yy.x, rs);
-    rs = __builtin_fma(a.y, yy.y, rs);
-#pragma unroll
-    for (int c = 0; c < kFreeCapMax; ++c) {
-      if (c < cnt) {
-        double2 b = *reinterpret_cast<const double2*>(xj[c] + k);
-        if (k + 1 >= n) b.y = 0.0;
-        acc[c] = __builtin_fma(a.x, b.x, acc[c]);
-        acc[c] = __builtin_fma(a.y, b.y, acc[c]);
-      }
-    }
+  switch (cnt) {  // (uniform over the workgroup; 1 and 2 are nearly every row)
+    case 0: free_row_dots<0>(x, xj, y1, n, &rs, acc); break;
+    case 1: free_row_dots<1>(x, xj, y1, n, &rs, acc); break;
+    case 2: free_row_dots<2>(x, xj, y1, n, &rs, acc); break;
+    case 3: free_row_dots<3>(x, xj, y1, n, &rs, acc); break;
+    case 4: free_row_dots<4>(x, xj, y1, n, &rs, acc); break;
+    default: free_row_dots<kFreeCapMax>(x, xj, y1, n, &rs, acc); break;  // (spare slots: the row itself)
   }
   rs = fr_block_sum(rs, sm);
   double best = -INFINITY;

@@ -57,6 +57,9 @@ inline bool kmeans_single() {
   static const bool v = getenv("SC_KMEANS_SINGLE") != nullptr;
   return v;
 }
+// SC_DIFFUSE=explicit|free|auto and SC_DIFFUSE_FREE_MIN_N=<n> (default 2048): route of a Diffuse
+// that only feeds RowWiseNormalize / the Laplacian -- the fp64 product, or the matrix-free
+// search of free_api.hip (read there; sc_config.diffuse_mode / sc_set_diffuse_mode override)
 // SC_SWEEP_ONE_BY_ONE=1: an AutoTune level as separate sc_eig_ncluster calls (what a level
 // falls back to when member arenas do not fit or a value leaves the grouped path)
 inline bool sweep_one_by_one() {

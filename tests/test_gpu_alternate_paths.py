@@ -16,6 +16,12 @@ they are the repair / large-problem routes of the default ones:
                         tridiagonalisation + bisection, eigenvectors by inverse iteration +
                         Householder back-transform (sc_diag.eig_path == 6)
 
+  SC_DIFFUSE=free       (with SC_DIFFUSE_FREE_MIN_N unset: the size rule is bypassed) the
+                        matrix-free Diffuse on every golden, n = 1000 included, where the
+                        default takes the explicit product
+  SC_DIFFUSE=explicit   the fp64 Diffuse product on every golden, n = 2048 included, where the
+                        default is matrix-free
+
 Each runs in a fresh interpreter (the switches are read once per process) over reference
 goldens of both Laplacian branches."""
 
@@ -60,6 +66,10 @@ for name in ("e2e_n1000_lap0_max7", "e2e_n1000_lap4_max20", "e2e_n1000_lap3_max2
     assert dg.eig_host_chain == 1
   if os.environ.get("SC_EIG_FORCE_DENSE"):
     assert dg.eig_path == 6 and dg.eig_fallback == 4
+  if os.environ.get("SC_DIFFUSE") == "free" and not os.environ.get("SC_EIG_FORCE_DENSE"):
+    assert dg.diffuse_path == 2, name
+  if os.environ.get("SC_DIFFUSE") == "explicit":
+    assert dg.diffuse_path == 1, name
 # one AutoTune search (16 values) against the reference golden: per-value proxies and labels
 g = np.load(os.path.join(ROOT, "tests", "golden", "autotune_n512.npz"))
 x = so.blobs(512, 64, 6, 512)
@@ -102,12 +112,17 @@ print("ALTERNATE_PATH_OK")
 
 @pytest.mark.parametrize("switch", ["SC_EIG_HOST_CHAIN", "SC_EIG_DEVICE_RR", "SC_KMEANS_SINGLE",
                                     "SC_MATVEC_SYM_MIN_N", "SC_SWEEP_ONE_BY_ONE",
-                                    "SC_EIG_FORCE_DENSE"])
+                                    "SC_EIG_FORCE_DENSE", "SC_DIFFUSE=free", "SC_DIFFUSE=explicit",
+                                    "SC_DIFFUSE=free+SC_EIG_HOST_CHAIN",
+                                    "SC_DIFFUSE=free+SC_EIG_FORCE_DENSE",
+                                    "SC_DIFFUSE=free+SC_MATVEC_SYM_MIN_N"])
 def test_alternate_path(tmp_path, switch):
   script = tmp_path / "alt.py"
   script.write_text(_SCRIPT)
   env = dict(os.environ)
-  env[switch] = "129" if switch == "SC_MATVEC_SYM_MIN_N" else "1"
+  for item in switch.split("+"):
+    name, _, value = item.partition("=")
+    env[name] = value or ("129" if name == "SC_MATVEC_SYM_MIN_N" else "1")
   r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True,
                      timeout=600, env=env)
   assert r.returncode == 0 and "ALTERNATE_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

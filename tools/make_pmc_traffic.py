@@ -32,22 +32,35 @@ def per_dispatch(d, counter):
 fetch = per_dispatch(sys.argv[1], "FETCH_SIZE")
 write = per_dispatch(sys.argv[2], "WRITE_SIZE")
 label = sys.argv[3] if len(sys.argv) > 3 else ""
-main, red = "sc::k_gemm_nt<0, true>", "sc::k_gemm_reduce<0, true>"
+# which kernel: "diffuse" (the fp64 product, default) or "i8" (the digit product of the
+# matrix-free Diffuse: reads n^2 * 2 B of digits, writes the fp32 upper-triangle tiles)
+which = sys.argv[4] if len(sys.argv) > 4 else "diffuse"
+n = 8192
+if which == "i8":
+  main, red = "sc::k_gemm_i8_sym<0>", "-"
+  algorithmic = n * n * 2 + (n // 128) * (n // 128 + 1) // 2 * 128 * 128 * 4
+  what = "k_gemm_i8_sym"
+else:
+  main, red = "sc::k_gemm_nt<0, true>", "sc::k_gemm_reduce<0, true>"
+  algorithmic = 2 * n * n * 8
+  what = "k_gemm_nt<EpiNone,SYM> (+ split-K reduce)"
 f = fetch[main][0] + (fetch[red][0] if red in fetch else 0.0)
 w = write[main][0] + (write[red][0] if red in write else 0.0)
-n = 8192
 print(json.dumps({
+    "kernel": what,
     "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024),
     "source": "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3 "
-              "--no-extras`, per-dispatch average over %d launches of k_gemm_nt<EpiNone,SYM> at n=8192 "
-              "(+ split-K reduce): FETCH_SIZE %.4g KiB x 2 (gfx950 16 B/lane correction) + WRITE_SIZE "
-              "%.4g KiB" % (label, fetch[main][1], f, w),
-    "algorithmic_bytes_per_launch": 2 * n * n * 8,
+              "--no-extras`, per-dispatch average over %d launches of %s at n=8192: FETCH_SIZE "
+              "%.4g KiB x 2 (gfx950 16 B/lane correction) + WRITE_SIZE %.4g KiB"
+              % (label, fetch[main][1], what, f, w),
+    "algorithmic_bytes_per_launch": algorithmic,
     # what it was measured on (bench.py compares the hash with the current source)
     "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
                              capture_output=True, text=True).stdout.strip() or None,
     "gemm_f64_sha16": hashlib.sha256(open(os.path.join(
         ROOT, "spectralcluster_amd", "csrc", "gemm_f64.hip"), "rb").read()).hexdigest()[:16],
+    "diffuse_free_sha16": hashlib.sha256(open(os.path.join(
+        ROOT, "spectralcluster_amd", "csrc", "diffuse_free.hip"), "rb").read()).hexdigest()[:16],
     "per_kernel_bytes": {k: int(fetch[k][0] * 2048 + (write[k][0] if k in write else 0.0) * 1024)
                          for k in sorted(fetch)},
 }, indent=1))

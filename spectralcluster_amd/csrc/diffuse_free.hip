@@ -220,7 +220,8 @@ struct I8Frag {
 };
 
 // PROBE (tests/probes/i8_gemm_probe.hip only; the library instantiates 0): 1 = no DMA inside
-// the loop, 2 = no MFMA, 3 = no fragment reads inside the loop -- what each part costs.
+// the loop, 2 = no MFMA, 3 = no fragment reads inside the loop, 4 = no s_barrier in the loop
+// (wrong results) -- what each part costs.
 template <int PROBE>
 __device__ __forceinline__ void gemm_i8_sym_body(
     const signed char* __restrict__ Q, size_t pitch, int nstages, const int2* __restrict__ tilemap,
@@ -335,7 +336,7 @@ __device__ __forceinline__ void gemm_i8_sym_body(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ... and this wave's reads of stage st have returned (its buffer is refilled next round)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (PROBE != 4) __builtin_amdgcn_s_barrier();
     // (the last round re-reads its own stage: straight-line code lets the compiler count the
     //  fragment reads still in flight instead of waiting for all of them before the MFMAs)
     mfma_first(f1);
@@ -640,8 +641,8 @@ void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* 
   const int tiles = nt * (nt + 1) / 2;
   const int Kp = free_k_padded(n);
   const int lds = kI8Buffers * kI8StageBytes;
-  SC_OPT_IN_LDS(k_gemm_i8_sym<0>, lds);
   const int xcd_chunk = (tiles % 8 == 0 && tiles >= 512) ? tiles / 8 : 0;
+  SC_OPT_IN_LDS(k_gemm_i8_sym<0>, lds);
   hipLaunchKernelGGL(k_gemm_i8_sym<0>, dim3(tiles), dim3(kI8Threads), lds, s, Q, (size_t)2 * Kp,
                      Kp / 64, tilemap, xcd_chunk, T32, nt, n, M,
                      static_cast<unsigned long long*>(nullptr));

@@ -274,8 +274,7 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
                               (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0,
                               ptr<double>(h->fscal));
     SC_TRY(free_stats_begin(h, s, fi[z].B2, h->ldn, n, true));
-    launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32),
-                       ptr<unsigned>(h->fwords));
+    SC_TRY(free_product(h, s, n));
     SC_TRY(free_stats_end(h, s, fi[z].B2, h->ldn, n, false));
   }
   launch_scaling_vectors_group(s, fi, count, cfg->laplacian_type, 1);

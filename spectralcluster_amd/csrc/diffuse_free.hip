@@ -218,6 +218,12 @@ __device__ __forceinline__ void glds16(const signed char* g, unsigned char* l) {
 struct I8Frag {
   v4i ah, al, bh[2], bl[2];
 };
+// split-K tail: tiles >= full_tiles of the list are computed by `parts` workgroups each, which
+// leave their accumulators in ws (parts x 96 x 512 ints per tail tile) for k_i8_tail_finish
+struct I8Split {
+  int full_tiles, parts;
+  int* ws;
+};
 
 // PROBE (tests/probes/i8_gemm_probe.hip only; the library instantiates 0): 1 = no DMA inside
 // the loop, 2 = no MFMA, 3 = no fragment reads inside the loop, 4 = no s_barrier in the loop
@@ -226,15 +232,27 @@ template <int PROBE>
 __device__ __forceinline__ void gemm_i8_sym_body(
     const signed char* __restrict__ Q, size_t pitch, int nstages, const int2* __restrict__ tilemap,
     int xcd_chunk, float* __restrict__ T32, int nt, int n, unsigned* __restrict__ M,
-    unsigned long long* __restrict__ probe_clk) {
+    unsigned long long* __restrict__ probe_clk, I8Split sp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // (probe only: shader cycles and 100 MHz wall ticks of this workgroup's K loop)
   const unsigned long long c_begin = probe_clk ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long t_begin = probe_clk ? wall_clock64() : 0ull;
   int tile = blockIdx.x;
-  // XCD-aware order (workgroup ids go round-robin over the 8 XCDs, each with its own L2): XCD x
-  // walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the patch-ordered tile list
-  if (xcd_chunk > 0) tile = (tile & 7) * xcd_chunk + (tile >> 3);
+  // the tail of the tile list (what would be a last, nearly empty round of workgroups) is cut
+  // along K: `parts` workgroups per tile, each with nstages / parts stages
+  int part = 0, kb = 0;
+  const bool split = sp.parts > 1 && tile >= sp.full_tiles;
+  if (split) {
+    const int tb = tile - sp.full_tiles;
+    tile = sp.full_tiles + tb / sp.parts;
+    part = tb % sp.parts;
+    nstages /= sp.parts;
+    kb = part * nstages;
+  } else if (xcd_chunk > 0) {
+    // XCD-aware order (workgroup ids go round-robin over the 8 XCDs, each with its own L2): XCD
+    // x walks the contiguous run [x * xcd_chunk, (x + 1) * xcd_chunk) of the patch-ordered list
+    tile = (tile & 7) * xcd_chunk + (tile >> 3);
+  }
   const int2 tij = tilemap[tile];
   const int I = tij.x, J = tij.y;
   const int lane = threadIdx.x & 63;
@@ -243,9 +261,9 @@ __device__ __forceinline__ void gemm_i8_sym_body(
   // stage image [A tile | B tile]; unit e = row * 8 + stored chunk
   const int sr = 8 * w + (lane >> 3);
   const int cx = (lane & 7) ^ ((4 * w + (lane >> 4)) & 7);
-  const signed char* gA0 = Q + (size_t)(I * kI8Tile + sr) * pitch + 16 * cx;
+  const signed char* gA0 = Q + (size_t)(I * kI8Tile + sr) * pitch + 16 * cx + (size_t)kb * 128;
   const signed char* gA1 = gA0 + (size_t)64 * pitch;
-  const signed char* gB0 = Q + (size_t)(J * kI8Tile + sr) * pitch + 16 * cx;
+  const signed char* gB0 = Q + (size_t)(J * kI8Tile + sr) * pitch + 16 * cx + (size_t)kb * 128;
   const signed char* gB1 = gB0 + (size_t)64 * pitch;
   auto issue = [&](int stage) {
     if (PROBE == 1 && stage > 2) return;
@@ -349,6 +367,28 @@ __device__ __forceinline__ void gemm_i8_sym_body(
     probe_clk[2 * blockIdx.x] = __builtin_readcyclecounter() - c_begin;
     probe_clk[2 * blockIdx.x + 1] = wall_clock64() - t_begin;
   }
+  if (split) {
+    // partial accumulators -> workspace (24 x 16 B per thread, each a coalesced 8 KB store of
+    // the workgroup).  (A first form let the last workgroup to arrive at a ticket add the
+    // others' parts in this launch: bit-equal, and 15-27 us SLOWER than no split at all -- the
+    // two agent-scope fences per workgroup are an L2 write-back + invalidate of the whole XCD,
+    // and 16-32 workgroups per XCD queue up behind each other for them.)
+    const int tt = tile - sp.full_tiles;
+    int4* ws = reinterpret_cast<int4*>(sp.ws) + (size_t)tt * sp.parts * 24 * kI8Threads + threadIdx.x;
+    int4* mine = ws + (size_t)part * 24 * kI8Threads;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        mine[(size_t)(cb * 4 + q) * kI8Threads] =
+            make_int4(hh[cb][4 * q], hh[cb][4 * q + 1], hh[cb][4 * q + 2], hh[cb][4 * q + 3]);
+        mine[(size_t)(8 + cb * 4 + q) * kI8Threads] =
+            make_int4(mid[cb][4 * q], mid[cb][4 * q + 1], mid[cb][4 * q + 2], mid[cb][4 * q + 3]);
+        mine[(size_t)(16 + cb * 4 + q) * kI8Threads] =
+            make_int4(ll[cb][4 * q], ll[cb][4 * q + 1], ll[cb][4 * q + 2], ll[cb][4 * q + 3]);
+      }
+    return;  // k_i8_tail_finish adds the parts and writes the tile
+  }
   // ---- epilogue: T = 65536 hh + 256 mid + ll, exact in fp64 (|T| < 2^53), stored as fp32 into
   // the tile's slot (tile-major, row-major inside).  D layout of the 32 x 32 block: lane l,
   // register r: row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
@@ -407,8 +447,8 @@ template <int PROBE>
 __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
     const signed char* __restrict__ Q, size_t pitch, int nstages, const int2* __restrict__ tilemap,
     int xcd_chunk, float* __restrict__ T32, int nt, int n, unsigned* __restrict__ M,
-    unsigned long long* __restrict__ probe_clk) {
-  gemm_i8_sym_body<PROBE>(Q, pitch, nstages, tilemap, xcd_chunk, T32, nt, n, M, probe_clk);
+    unsigned long long* __restrict__ probe_clk, I8Split sp) {
+  gemm_i8_sym_body<PROBE>(Q, pitch, nstages, tilemap, xcd_chunk, T32, nt, n, M, probe_clk, sp);
 }
 // Grouped form (AutoTune sweep, batch_group.hip): blockIdx.y picks one of up to kGroupMax
 // problems of the same size; the tiles of all of them fill the chip where one problem's 528
@@ -422,7 +462,54 @@ __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym_g(
     const GroupOf<I8GroupItem> g, size_t pitch, int nstages, const int2* __restrict__ tilemap,
     int nt, int n) {
   const I8GroupItem& a = g.s[blockIdx.y];
-  gemm_i8_sym_body<0>(a.Q, pitch, nstages, tilemap, 0, a.T32, nt, n, a.M, nullptr);
+  gemm_i8_sym_body<0>(a.Q, pitch, nstages, tilemap, 0, a.T32, nt, n, a.M, nullptr,
+                      I8Split{0, 1, nullptr});
+}
+
+// The tail tiles' epilogue: thread t of workgroup (tt, cq) owns what thread t of the product's
+// workgroup owned in accumulator registers [4 q, 4 q + 4) of column block cb (cq = 4 cb + q):
+// adds the parts (integers: the order does not matter), stores the four values of T and folds
+// them into the row / column maxima.
+__global__ __launch_bounds__(kI8Threads) void k_i8_tail_finish(
+    const int* __restrict__ wsp, int parts, int full_tiles, const int2* __restrict__ tilemap,
+    float* __restrict__ T32, int nt, int n, unsigned* __restrict__ M) {
+  const int tt = blockIdx.x, cq = blockIdx.y, cb = cq >> 2, q = cq & 3;
+  const int2 tij = tilemap[full_tiles + tt];
+  const int I = tij.x, J = tij.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rr = lane & 31, g = lane >> 5, wr = w >> 1, wc = w & 1;
+  const int4* ws = reinterpret_cast<const int4*>(wsp) + (size_t)tt * parts * 24 * kI8Threads + threadIdx.x;
+  int4 a = make_int4(0, 0, 0, 0), b = a, c = a;
+  for (int p = 0; p < parts; ++p) {
+    const int4* src = ws + (size_t)p * 24 * kI8Threads;
+    const int4 x = src[(size_t)cq * kI8Threads];
+    const int4 y = src[(size_t)(8 + cq) * kI8Threads];
+    const int4 z = src[(size_t)(16 + cq) * kI8Threads];
+    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+    c.x += z.x; c.y += z.y; c.z += z.z; c.w += z.w;
+  }
+  const int hh[4] = {a.x, a.y, a.z, a.w}, mid[4] = {b.x, b.y, b.z, b.w}, ll[4] = {c.x, c.y, c.z, c.w};
+  float* out = T32 + (size_t)tile_to_slot(I, J, nt) * (kI8Tile * kI8Tile);
+  const int col = 64 * wc + 32 * cb + rr;
+  const bool col_ok = J * kI8Tile + col < n;
+  float colm = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = 32 * wr + e + 8 * q + 4 * g;  // register r = 4 q + e of the product's layout
+    const double t = (double)hh[e] * 65536.0 + (double)mid[e] * 256.0 + (double)ll[e];
+    const float tf = (float)t;
+    out[row * kI8Tile + col] = tf;
+    if (I * kI8Tile + row < n) colm = fmaxf(colm, tf);
+    float v = col_ok ? tf : -INFINITY;  // the row's maximum over the half-wave's 32 columns
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if (rr == 0 && I * kI8Tile + row < n && v > -INFINITY)
+      atomicMax(&M[I * kI8Tile + row], ordered_bits(v));
+  }
+  colm = fmaxf(colm, __shfl_xor(colm, 32));
+  if (g == 0 && I != J && J * kI8Tile + col < n && colm > -INFINITY)
+    atomicMax(&M[J * kI8Tile + col], ordered_bits(colm));
 }
 
 // ---------------------------------------------------------------- candidates
@@ -635,17 +722,61 @@ void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed 
                      reinterpret_cast<unsigned long long*>(scal) + 2);
 }
 
+// The tail of the product: `tiles` tiles on `cus` compute units leave tiles % cus tiles for a
+// last round in which most of the chip idles (n = 8192: 2080 = 8 x 256 + 32).  Those tiles are
+// cut along K into the largest number of parts (<= 8, dividing the stage count, >= 4 stages
+// each) that still fits one round.  parts = 1: no tail worth cutting.
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+void free_i8_split_plan(int n, int* tail_tiles, int* parts) {
+  const int nt = (n + kI8Tile - 1) / kI8Tile;
+  const int tiles = nt * (nt + 1) / 2;
+  const int stages = free_k_padded(n) / 64;
+  const int cus = device_cus();
+  *tail_tiles = 0;
+  *parts = 1;
+  const int r = tiles % cus;
+  if (tiles <= cus || r == 0 || 2 * r > cus) return;
+  for (int f = std::min(8, cus / r); f >= 2; --f)
+    if (stages % f == 0 && stages / f >= 4) {
+      *tail_tiles = r;
+      *parts = f;
+      return;
+    }
+}
+size_t free_i8_split_bytes(int n) {
+  int r, f;
+  free_i8_split_plan(n, &r, &f);
+  return f > 1 ? (size_t)r * f * 96 * kI8Threads * sizeof(int) : 0;
+}
+
 void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
-                        float* T32, unsigned* M) {
+                        float* T32, unsigned* M, int* split_ws) {
   const int nt = (n + kI8Tile - 1) / kI8Tile;
   const int tiles = nt * (nt + 1) / 2;
   const int Kp = free_k_padded(n);
   const int lds = kI8Buffers * kI8StageBytes;
-  const int xcd_chunk = (tiles % 8 == 0 && tiles >= 512) ? tiles / 8 : 0;
+  int r = 0, f = 1;
+  if (split_ws != nullptr) free_i8_split_plan(n, &r, &f);
+  const int full = tiles - r;
+  const int xcd_chunk = (full % 8 == 0 && full >= 512) ? full / 8 : 0;
   SC_OPT_IN_LDS(k_gemm_i8_sym<0>, lds);
-  hipLaunchKernelGGL(k_gemm_i8_sym<0>, dim3(tiles), dim3(kI8Threads), lds, s, Q, (size_t)2 * Kp,
-                     Kp / 64, tilemap, xcd_chunk, T32, nt, n, M,
-                     static_cast<unsigned long long*>(nullptr));
+  hipLaunchKernelGGL(k_gemm_i8_sym<0>, dim3(full + r * f), dim3(kI8Threads), lds, s, Q,
+                     (size_t)2 * Kp, Kp / 64, tilemap, xcd_chunk, T32, nt, n, M,
+                     static_cast<unsigned long long*>(nullptr), I8Split{full, f, split_ws});
+  if (f > 1)
+    hipLaunchKernelGGL(k_i8_tail_finish, dim3(r, 8), dim3(kI8Threads), 0, s, split_ws, f, full,
+                       tilemap, T32, nt, n, M);
 }
 
 void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,

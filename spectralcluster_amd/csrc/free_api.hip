@@ -60,6 +60,16 @@ int ensure_free(sc_handle h, int n) {
   return SC_OK;
 }
 
+// the integer product of the handle's digits (split-K tail on the handle's workspace)
+int free_product(sc_handle h, hipStream_t s, int n) {
+  // (the workspace of the split-K tail belongs to handles that launch a product of their own:
+  //  the members of a sweep share one grouped launch and never need it)
+  if (free_i8_split_bytes(n) > 0) SC_TRY(grow(h, h->fsplit, free_i8_split_bytes(n)));
+  launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32),
+                     ptr<unsigned>(h->fwords), ptr<int>(h->fsplit));
+  return SC_OK;
+}
+
 // the pipeline in three pieces, all on stream `s` (the handle's own for a single call; the
 // sweep's for a member arena, whose product is one grouped launch for all members)
 int free_stats_begin(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool have_amax) {
@@ -95,8 +105,7 @@ int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_am
   ev_rec(h, &h->free_ev[0]);
   SC_TRY(free_stats_begin(h, s, A, ld, n, have_amax));
   ev_rec(h, &h->free_ev[1]);
-  launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32),
-                     ptr<unsigned>(h->fwords));
+  SC_TRY(free_product(h, s, n));
   ev_rec(h, &h->free_ev[2]);
   return free_stats_end(h, s, A, ld, n, true);
 }

@@ -136,7 +136,7 @@ struct sc_handle_s {
   // ---- matrix-free Diffuse (free_api.hip)
   int diffuse_mode = -1;   // sc_set_diffuse_mode: 0 auto, 1 explicit fp64 product, 2 matrix-free
                            // wherever the sequence allows it; -1: the environment's default
-  DevBuf fq, ft32, fy1, fR, fscal, fwords, fcand, fY;  // digits, T (fp32 tiles), A 1, sum|q|,
+  DevBuf fq, ft32, fy1, fR, fscal, fwords, fcand, fY, fsplit;  // digits, T (fp32 tiles), A 1, sum|q|,
                            // scalars, M | count | ovf words, candidate lists, A Vs
   int* h_free = nullptr;   // pinned copy of the ovf words (80)
   bool free_on = false;    // the operator of the current solve is c .* A (A (c .* v)) + p .* v
@@ -335,6 +335,7 @@ int ensure_free(sc_handle h, int n);
 // the same pipeline in pieces on a given stream (the AutoTune sweep runs the digit product of
 // all its members as one grouped launch between them): max|a| + digits | ... | candidates +
 // exact statistics + the overflow words on their way to h->h_free
+int free_product(sc_handle h, hipStream_t s, int n);
 int free_stats_begin(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool have_amax);
 int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool timed);
 // after the stream has drained: rows with more candidates than the cap are evaluated in full.

@@ -381,8 +381,12 @@ void launch_free_amax_from_cut(hipStream_t s, const double* cut, int n, double p
                                double floor_value, double* scal);
 void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed char* Q,
                           double* scal, double* y1, double* R);
+// (split_ws: workspace of free_i8_split_bytes(n) for the split-K tail; nullptr = every tile
+//  by one workgroup)
 void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
-                        float* T32, unsigned* M);
+                        float* T32, unsigned* M, int* split_ws);
+void free_i8_split_plan(int n, int* tail_tiles, int* parts);
+size_t free_i8_split_bytes(int n);
 // the same product for `count` (<= kGroupMax) problems of one size in ONE launch
 void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
                               unsigned* const* M, int count, int n, const int2* tilemap);

@@ -81,6 +81,9 @@ class SpectralClusterer:
     # not in the reference: restart cycles block Lanczos may spend before the dense
     # eigensolver takes over (0 = the library default, 40); predict() returns either way
     self.eig_max_cycles = 0
+    # not in the reference: bound on |eigenvalue error| / |eigenvalue| for the values the
+    # eigengap rule reads (0 = the library default, 1e-6; the parity bar is 1e-5)
+    self.eig_value_tol = 0.0
     # not in the reference: route of a Diffuse that only feeds RowWiseNormalize / the Laplacian
     # (sc_config.diffuse_mode): 0 default (matrix-free from n = 2048 on), 1 explicit fp64
     # product, 2 matrix-free wherever the sequence allows it.  Same results to summation order.
@@ -112,6 +115,8 @@ class SpectralClusterer:
     cfg.row_wise_renorm = int(bool(self.row_wise_renorm))
     cfg.max_iter = int(self.max_iter)
     cfg.eig_max_cycles = int(getattr(self, "eig_max_cycles", 0) or 0)
+    if getattr(self, "eig_value_tol", 0.0):
+      cfg.eig_value_tol = float(self.eig_value_tol)
     cfg.diffuse_mode = int(getattr(self, "diffuse_mode", 0) or 0)
     if self.post_eigen_cluster_function is custom_distance_kmeans.run_kmeans:
       cfg.kmeans_metric = _lib.kmeans_metric_code(self.custom_dist)

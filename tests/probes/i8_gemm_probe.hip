@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace sc {
@@ -231,7 +232,8 @@ static float run(const signed char* Q, int n, const int2* tilemap, float* T32, u
   for (int r = 0; r < reps + 1; ++r) {
     hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_gemm_i8_sym<PROBE>, dim3(tiles), dim3(kI8Threads), lds, 0, Q,
-                       (size_t)2 * Kp, Kp / 64, tilemap, xcd_chunk, T32, nt, n, M, g_clk);
+                       (size_t)2 * Kp, Kp / 64, tilemap, xcd_chunk, T32, nt, n, M, g_clk,
+                       I8Split{tiles, 1, nullptr});
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -312,6 +314,52 @@ int main(int argc, char** argv) {
     clk("4-wave x2 no barrier");
     printf("  4-wave x 2-per-CU form: %.3f ms (tile 777 differs from the 8-wave form in %d entries); "
            "no DMA %.3f, no MFMA %.3f, no barrier %.3f\n", u0, bad, u1, u2, u4);
+  }
+  {  // the library's launcher with and without the split-K tail: same bits, less time?
+    int r = 0, f = 1;
+    free_i8_split_plan(n, &r, &f);
+    int* ws = nullptr;
+    unsigned* cnt = nullptr;
+    hipMalloc(&ws, std::max<size_t>(free_i8_split_bytes(n), 16));
+    hipMalloc(&cnt, 256 * sizeof(unsigned));
+    hipMemset(cnt, 0, 256 * sizeof(unsigned));
+    const size_t words = free_t32_bytes(n) / 4;
+    std::vector<float> a(words), b(words);
+    std::vector<unsigned> ma(n), mb(n);
+    auto timed = [&](int* w, unsigned* c) {
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      float best = 1e9f;
+      for (int it = 0; it < reps + 1; ++it) {
+        hipMemset(M, 0, n * sizeof(unsigned));
+        hipEventRecord(e0, 0);
+        launch_gemm_i8_sym(0, Q, n, tm, T32, M, w);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (it > 0 && ms < best) best = ms;
+      }
+      return best;
+    };
+    hipMemset(T32, 0, free_t32_bytes(n));
+    const float plain = timed(nullptr, nullptr);
+    hipMemcpy(a.data(), T32, words * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(ma.data(), M, n * 4, hipMemcpyDeviceToHost);
+    hipMemset(T32, 0, free_t32_bytes(n));
+    const float cut = timed(ws, cnt);
+    hipMemcpy(b.data(), T32, words * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(mb.data(), M, n * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0, badm = 0;
+    for (size_t i = 0; i < words; ++i) bad += memcmp(&a[i], &b[i], 4) != 0;
+    for (int i = 0; i < n; ++i) badm += ma[i] != mb[i];
+    std::vector<unsigned> hc(256);
+    hipMemcpy(hc.data(), cnt, 256 * 4, hipMemcpyDeviceToHost);
+    unsigned left = 0;
+    for (unsigned v : hc) left += v;
+    printf("  split-K tail: %d tiles x %d parts: %.3f ms against %.3f without; T32 differs in %zu "
+           "words, M in %zu rows, counters left %u\n", r, f, cut, plain, bad, badm, left);
   }
   // the same on mostly-small digits (what a thresholded affinity looks like: 7/8 of the high
   // digits are 0 or 1)

@@ -66,6 +66,16 @@ __device__ __forceinline__ double fr_block_sum(double v, double* sm) {
   return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
+// atomicMax on ONE word from every workgroup of a launch: 8192 same-address atomics cost the
+// quantiser 19 us of 142 at n = 8192 and 30 of 60 at n = 4096 (tests/probes/quantize_probe.hip).
+// A workgroup first looks at the word (agent-scope load: the value in memory, not a stale line
+// of its XCD's L2) and only joins the queue if it would raise it: after the first wave of
+// workgroups almost none does.
+__device__ __forceinline__ void atomic_max_if_larger(unsigned long long* word, unsigned long long v) {
+  const unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v > cur) atomicMax(word, v);
+}
+
 // order-preserving map float -> unsigned (for atomicMax on values of either sign)
 __device__ __forceinline__ unsigned ordered_bits(float f) {
   const unsigned u = __float_as_uint(f);
@@ -106,7 +116,8 @@ __global__ __launch_bounds__(256) void k_free_absmax(const double* __restrict__ 
     if (j + 1 < n) m = fmax(m, fabs(v.y));
   }
   m = fr_block_max(m, sm);
-  if (threadIdx.x == 0 && m > 0.0) atomicMax(amax_bits, (unsigned long long)__double_as_longlong(m));
+  if (threadIdx.x == 0 && m > 0.0)
+    atomic_max_if_larger(amax_bits, (unsigned long long)__double_as_longlong(m));
 }
 
 // The same bound without a pass over the matrix, for A = Symmetrize(RowWiseThreshold(B)) with
@@ -130,6 +141,8 @@ __global__ __launch_bounds__(256) void k_free_amax_from_cut(const double* __rest
 // 64 k's of block b live in one 128-byte line: bytes [0, 64) the high digits, [64, 128) the low
 // digits -- a K stage of the GEMM reads whole lines.  Rows >= n and columns >= n are zero.
 // Also y1 = rowsum(A) (fp64, fixed order), R = sum |q| and its maximum.
+// (PROBE, tests/probes/quantize_probe.hip only: 1 = no atomicMax, 2 = no digits, 3 = no copy-out)
+template <int PROBE>
 __global__ __launch_bounds__(256) void k_free_quantize(
     const double* __restrict__ A, int n, int ld, signed char* __restrict__ Q, size_t pitch, int Kp,
     const double* __restrict__ scal, double* __restrict__ y1, double* __restrict__ R,
@@ -147,40 +160,55 @@ __global__ __launch_bounds__(256) void k_free_quantize(
   const double sigma = (amax > 0.0 && isfinite(amax)) ? 32639.0 / amax : 0.0;
   const double* x = A + (size_t)row * ld;
   double sum = 0.0, rsum = 0.0;
-  // coalesced: lane t reads the pair k = 2 t + 512 m (16 B), digits go to the LDS image
-  for (int k = 2 * threadIdx.x; k < Kp; k += 512) {
-    // rows are padded to ld (a multiple of 16 doubles): a pair that starts inside the row's
-    // storage stays inside it
-    double2 v = k < ld ? *reinterpret_cast<const double2*>(x + k) : make_double2(0.0, 0.0);
-    if (k >= n) v.x = 0.0;
-    if (k + 1 >= n) v.y = 0.0;
-    sum += v.x;
-    sum += v.y;
-    const double e[2] = {v.x, v.y};
-    signed char hb[2], lb[2];
+  // coalesced: lane t reads the pair k = 2 t + 512 m (16 B), digits go to the LDS image.
+  // FOUR pairs are requested before the first is used: with one load in flight per wave the
+  // kernel ran at exactly the 4.1 TB/s that 32 KB in flight per CU and 2 us of latency give.
+  for (int k0 = 2 * threadIdx.x; k0 < Kp; k0 += 2048) {
+    double2 v4[4];
 #pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      double qd = rint(e[w] * sigma);
-      qd = fmin(fmax(qd, -32639.0), 32639.0);  // (NaN -> -32639: such a row is flagged later)
-      const int q = (int)qd;
-      const int h = (q + 128) >> 8;             // floor((q + 128) / 256): l in [-128, 127]
-      const int l = q - (h << 8);
-      rsum += (double)(q < 0 ? -q : q);
-      hb[w] = (signed char)h;
-      lb[w] = (signed char)l;
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 512 * u;
+      // rows are padded to ld (a multiple of 16 doubles): a pair that starts inside the row's
+      // storage stays inside it
+      v4[u] = (k < Kp && k < ld) ? *reinterpret_cast<const double2*>(x + k) : make_double2(0.0, 0.0);
     }
-    signed char* dst = qimg + (k >> 6) * 128 + (k & 63);
-    *reinterpret_cast<short*>(dst) = (short)((unsigned char)hb[0] | ((unsigned short)(unsigned char)hb[1] << 8));
-    *reinterpret_cast<short*>(dst + 64) = (short)((unsigned char)lb[0] | ((unsigned short)(unsigned char)lb[1] << 8));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 512 * u;
+      if (k >= Kp) break;
+      double2 v = v4[u];
+      if (k >= n) v.x = 0.0;
+      if (k + 1 >= n) v.y = 0.0;
+      sum += v.x;
+      sum += v.y;
+      const double e[2] = {v.x, v.y};
+      signed char hb[2], lb[2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        double qd = rint(e[w] * sigma);
+        qd = fmin(fmax(qd, -32639.0), 32639.0);  // (NaN -> -32639: such a row is flagged later)
+        const int q = (int)qd;
+        const int h = (q + 128) >> 8;             // floor((q + 128) / 256): l in [-128, 127]
+        const int l = q - (h << 8);
+        rsum += (double)(q < 0 ? -q : q);
+        hb[w] = (signed char)h;
+        lb[w] = (signed char)l;
+      }
+      if (PROBE == 2) continue;
+      signed char* dst = qimg + (k >> 6) * 128 + (k & 63);
+      *reinterpret_cast<short*>(dst) = (short)((unsigned char)hb[0] | ((unsigned short)(unsigned char)hb[1] << 8));
+      *reinterpret_cast<short*>(dst + 64) = (short)((unsigned char)lb[0] | ((unsigned short)(unsigned char)lb[1] << 8));
+    }
   }
   sum = fr_block_sum(sum, sm);   // (its barriers also publish the image)
   rsum = fr_block_sum(rsum, sm);
-  for (int u = threadIdx.x; u < (int)(pitch / 16); u += 256)
-    reinterpret_cast<int4*>(qrow)[u] = reinterpret_cast<const int4*>(qimg)[u];
+  if (PROBE != 3)
+    for (int u = threadIdx.x; u < (int)(pitch / 16); u += 256)
+      reinterpret_cast<int4*>(qrow)[u] = reinterpret_cast<const int4*>(qimg)[u];
   if (threadIdx.x == 0) {
     y1[row] = sum;
     R[row] = rsum;
-    atomicMax(rmax_bits, (unsigned long long)__double_as_longlong(rsum));
+    if (PROBE != 1) atomic_max_if_larger(rmax_bits, (unsigned long long)__double_as_longlong(rsum));
   }
 }
 
@@ -716,8 +744,8 @@ void launch_free_amax_from_cut(hipStream_t s, const double* cut, int n, double p
 void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed char* Q,
                           double* scal, double* y1, double* R) {
   const int Kp = free_k_padded(n);
-  SC_OPT_IN_LDS(k_free_quantize, 2 * 65536);  // (n <= 65536: the row image is 2 Kp bytes)
-  hipLaunchKernelGGL(k_free_quantize, dim3(free_rows_padded(n)), dim3(256), (size_t)2 * Kp, s, A,
+  SC_OPT_IN_LDS(k_free_quantize<0>, 2 * 65536);  // (n <= 65536: the row image is 2 Kp bytes)
+  hipLaunchKernelGGL(k_free_quantize<0>, dim3(free_rows_padded(n)), dim3(256), (size_t)2 * Kp, s, A,
                      n, ld, Q, (size_t)2 * Kp, Kp, scal, y1, R,
                      reinterpret_cast<unsigned long long*>(scal) + 2);
 }

@@ -294,12 +294,18 @@ __global__ __launch_bounds__(kRowThreads) void k_row_threshold_cut(
 // handles tiles (I, J) and (J, I), I <= J: both are read once, the symmetric result is
 // computed once and written to both places (the mirror through LDS, so both stores are
 // coalesced): 1 read + 1 write of n^2 for the two ops together.
+constexpr int kTsTile = 64;  // tile edge of the threshold + symmetrise pass
 __device__ __forceinline__ void threshold_symmetrize_body(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles,
     int preserve_diag) {
-  __shared__ double tA[32][33];  // thr(tile (I, J))
-  __shared__ double tB[32][33];  // thr(tile (J, I))
+  // One workgroup = the tile pair (I, J), (J, I) of 64 x 64 entries.  O = sym(thr(A), thr(B)^T)
+  // is tile (I, J) of the result and O^T is tile (J, I) (max and average are symmetric in their
+  // arguments), so B and then O take one trip each through the one LDS tile.  Every thread
+  // owns 8 x 2 entries of a tile and requests all 16 of its 16-byte loads before it touches the
+  // first (round 3's 32 x 32 form had two 8-byte loads in flight per thread and 256-byte row
+  // segments: 4.7 TB/s).
+  __shared__ double tT[kTsTile][kTsTile + 1];
   // tile pair of this workgroup: row ti of the upper triangle starts at
   // off(ti) = ti * ntiles - ti (ti - 1) / 2.  Closed form + one correction step (a counting
   // loop here was 5.6e7 scalar instructions per launch at n = 8192: up to 256 trips per wave)
@@ -311,48 +317,84 @@ __device__ __forceinline__ void threshold_symmetrize_body(
   while (ti > 0 && off(ti) > id) --ti;
   while (ti + 1 < ntiles && off(ti + 1) <= id) ++ti;
   const int tj = ti + (id - off(ti));
-  const int bi = ti * 32, bj = tj * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int bi = ti * kTsTile, bj = tj * kTsTile;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 column pairs x 8 rows
+  const int c0 = 2 * tx;
+  const bool diag_tile = ti == tj;
+  // (rows are padded to ld, a multiple of 16 doubles: a pair that starts inside a row's
+  //  storage stays inside it)
+  double2 a[8], b[8];
+  double ca[8], cb[8];  // the rows' cuts (requested with the tiles, not one wait each later)
 #pragma unroll
-  for (int r = ty; r < 32; r += 8) {
-    {
-      const int gi = bi + r, gj = bj + tx;
-      double v = 0.0;
-      if (gi < n && gj < n) {
-        v = in[(size_t)gi * ld + gj];
-        v = v < cut[gi] ? v * mult : (binarize ? 1.0 : v);
-        if (preserve_diag && gi == gj) v = 1.0;  // diagonal restored to 1 (:208-209)
-      }
-      tA[r][tx] = v;
+  for (int q = 0; q < 8; ++q) {
+    const int r = ty + 8 * q;
+    const int gi = bi + r, gj = bj + c0;
+    a[q] = (gi < n && gj < n) ? *reinterpret_cast<const double2*>(in + (size_t)gi * ld + gj)
+                              : make_double2(0.0, 0.0);
+    ca[q] = gi < n ? cut[gi] : 0.0;
+  }
+  if (!diag_tile) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = ty + 8 * q;
+      const int gi = bj + r, gj = bi + c0;
+      b[q] = (gi < n && gj < n) ? *reinterpret_cast<const double2*>(in + (size_t)gi * ld + gj)
+                                : make_double2(0.0, 0.0);
+      cb[q] = gi < n ? cut[gi] : 0.0;
     }
-    {
-      const int gi = bj + r, gj = bi + tx;
-      double v = 0.0;
-      if (gi < n && gj < n) {
-        v = in[(size_t)gi * ld + gj];
-        v = v < cut[gi] ? v * mult : (binarize ? 1.0 : v);
-        if (preserve_diag && gi == gj) v = 1.0;
-      }
-      tB[r][tx] = v;
+  }
+  auto thr = [&](double v, double c, int gi, int gj) {
+    if (!(gi < n && gj < n)) return 0.0;
+    v = v < c ? v * mult : (binarize ? 1.0 : v);
+    if (preserve_diag && gi == gj) v = 1.0;  // diagonal restored to 1 (:208-209)
+    return v;
+  };
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int r = ty + 8 * q;
+    a[q].x = thr(a[q].x, ca[q], bi + r, bj + c0);
+    a[q].y = thr(a[q].y, ca[q], bi + r, bj + c0 + 1);
+    if (diag_tile) {
+      b[q] = a[q];
+    } else {
+      b[q].x = thr(b[q].x, cb[q], bj + r, bi + c0);
+      b[q].y = thr(b[q].y, cb[q], bj + r, bi + c0 + 1);
     }
+    tT[r][c0] = b[q].x;
+    tT[r][c0 + 1] = b[q].y;
+  }
+  __syncthreads();
+  // O (r, c) = sym(thr A (r, c), thr B (c, r)), kept in a[]
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int r = ty + 8 * q;
+    const double b0 = tT[c0][r], b1 = tT[c0 + 1][r];
+    a[q].x = symtype == SC_SYMMETRIZE_MAX ? fmax(a[q].x, b0) : 0.5 * (a[q].x + b0);
+    a[q].y = symtype == SC_SYMMETRIZE_MAX ? fmax(a[q].y, b1) : 0.5 * (a[q].y + b1);
+    const int gi = bi + r, gj = bj + c0;
+    if (gi < n && gj + 1 < n)
+      *reinterpret_cast<double2*>(out + (size_t)gi * ld + gj) = a[q];
+    else if (gi < n && gj < n)
+      out[(size_t)gi * ld + gj] = a[q].x;
+  }
+  if (diag_tile) return;
+  __syncthreads();  // everybody has read B^T
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int r = ty + 8 * q;
+    tT[r][c0] = a[q].x;
+    tT[r][c0 + 1] = a[q].y;
   }
   __syncthreads();
 #pragma unroll
-  for (int r = ty; r < 32; r += 8) {
-    {  // tile (I, J): element (r, tx) pairs with tB[tx][r]
-      const int gi = bi + r, gj = bj + tx;
-      if (gi < n && gj < n) {
-        const double a = tA[r][tx], b = tB[tx][r];
-        out[(size_t)gi * ld + gj] = symtype == SC_SYMMETRIZE_MAX ? fmax(a, b) : 0.5 * (a + b);
-      }
-    }
-    if (ti != tj) {  // tile (J, I): element (r, tx) pairs with tA[tx][r]
-      const int gi = bj + r, gj = bi + tx;
-      if (gi < n && gj < n) {
-        const double a = tB[r][tx], b = tA[tx][r];
-        out[(size_t)gi * ld + gj] = symtype == SC_SYMMETRIZE_MAX ? fmax(a, b) : 0.5 * (a + b);
-      }
-    }
+  for (int q = 0; q < 8; ++q) {  // tile (J, I) = O^T
+    const int r = ty + 8 * q;
+    const int gi = bj + r, gj = bi + c0;
+    const double2 o = make_double2(tT[c0][r], tT[c0 + 1][r]);
+    if (gi < n && gj + 1 < n)
+      *reinterpret_cast<double2*>(out + (size_t)gi * ld + gj) = o;
+    else if (gi < n && gj < n)
+      out[(size_t)gi * ld + gj] = o.x;
   }
 }
 __global__ __launch_bounds__(256) void k_threshold_symmetrize(
@@ -365,7 +407,7 @@ __global__ __launch_bounds__(256) void k_threshold_symmetrize_g(const GroupOf<Fr
                                                                 double mult, int binarize,
                                                                 int symtype, int preserve_diag) {
   const FrontItem& a = g.s[blockIdx.y];
-  const int t = (a.n + 31) / 32;
+  const int t = (a.n + kTsTile - 1) / kTsTile;
   if ((int)blockIdx.x >= t * (t + 1) / 2) return;
   threshold_symmetrize_body(a.B1, a.B2, a.n, a.ldn, a.cut, mult, binarize, symtype, t,
                             preserve_diag);
@@ -636,7 +678,7 @@ void launch_row_threshold_cut(hipStream_t s, const double* in, double* out, int 
 void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
                                  const double* cut, double mult, int binarize, int symtype,
                                  int preserve_diag) {
-  const int t = (n + 31) / 32;
+  const int t = (n + kTsTile - 1) / kTsTile;
   hipLaunchKernelGGL(k_threshold_symmetrize, dim3(t * (t + 1) / 2), dim3(256), 0, s, in, out,
                      n, ld, cut, mult, binarize, symtype, t, preserve_diag);
 }
@@ -687,7 +729,7 @@ void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, in
   //  own per-member kernel; RowMax cuts are taken from the blur's per-strip row maxima here)
   if (!cut_ready)
     hipLaunchKernelGGL(k_cut_from_partials_g, dim3((nmax + 3) / 4, count), dim3(256), 0, s, g, p);
-  const int t = (nmax + 31) / 32;
+  const int t = (nmax + kTsTile - 1) / kTsTile;
   hipLaunchKernelGGL(k_threshold_symmetrize_g, dim3(t * (t + 1) / 2, count), dim3(256), 0, s, g,
                      mult, binarize, symtype, preserve_diag);
 }

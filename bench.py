@@ -213,14 +213,15 @@ def icassp_floor_seconds(n, d, passes):
   """Floor of one ICASSP2018 predict() AS IT RUNS: the explicit route below FREE_MIN_N
   (`icassp_work`), the matrix-free route from there on -- n^2 d fp64 flops + 4 n^3 int8 ops
   (upper triangle, 2 ops per MAC) at their MFMA peaks; A1 write, Crop+Blur R/W, Thr+Sym R/W,
-  one read of A + n^2 * 2 B of digits, T written and read once as fp32 upper-triangle tiles,
-  one more read of A for the exact statistics, 2 x passes half-matrix products; 8 TB/s."""
+  n^2 * 2 B of digits (written by the Thr+Sym pass: no read of their own), T written and read
+  once as fp32 upper-triangle tiles, one read of A for the exact statistics, 2 x passes
+  half-matrix products; 8 TB/s."""
   nn = float(n) * n
   if n < FREE_MIN_N:
     flops, hbm = icassp_work(n, d, passes)
     return flops / (PEAK_F64_MFMA_TFLOPS * 1e12) + hbm / (PEAK_HBM_TBS * 1e12)
   mat = nn * 8.0
-  hbm = 5.0 * mat + mat + nn * 2.0 + 2 * nn * 2.0 + mat + 2.0 * passes * 0.5 * mat + n * d * 8.0
+  hbm = 5.0 * mat + nn * 2.0 + 2 * nn * 2.0 + mat + 2.0 * passes * 0.5 * mat + n * d * 8.0
   return (nn * d / (PEAK_F64_MFMA_TFLOPS * 1e12) + 4.0 * nn * n / (PEAK_I8_MFMA_TOPS * 1e12) +
           hbm / (PEAK_HBM_TBS * 1e12))
 
@@ -544,8 +545,11 @@ def kernel_roofline(stage_ms, passes):
                  "note": "int8 multiply-adds counted as 2 ops; 4 digit products (hh, hl, lh, ll) "
                          "of the upper-triangle tiles"})
     t32 = nt * (nt + 1) // 2 * GEMM_TILE * GEMM_TILE * 4.0
-    hbm("k_free_amax_from_cut + k_free_quantize", "free_quantize", mat + n * n * 2.0,
-        "1 read of A + n^2 * 2 B of digits written (max|a| comes from the cut vector)")
+    nblk = (n + 63) // 64
+    hbm("k_free_partials_reduce (row partials of the quantiser fused into threshold+symmetrise)",
+        "free_quantize", n * nblk * 12.0 + n * 16.0,
+        "the digits are written by k_threshold_symmetrize_digits; what is left is the sum of "
+        "its per-block partials: n * n/64 * 12 B read")
     hbm("k_t32_candidates", "free_scan", t32,
         "1 read of the fp32 upper-triangle tiles of T (row maxima come from the product's epilogue)")
     hbm("k_free_row_stats (exact rowmax / rowsum of S)", "free_stats", 2.2 * mat,
@@ -556,8 +560,14 @@ def kernel_roofline(stage_ms, passes):
        "K=%d: write floor %.0f us" % (d, mat / (PEAK_HBM_TBS * 1e12) * 1e6))
   hbm("k_gaussian_blur_stream<4> (CropDiagonal+GaussianBlur)", "blur", 2 * mat,
       "1 read + 1 write of n^2")
-  hbm("k_threshold_symmetrize (RowWiseThreshold+Symmetrize)", "threshold_sym", 2 * mat,
-      "1 read + 1 write of n^2")
+  if stage_ms.get("free_product", 0.0) > 0:
+    hbm("k_threshold_symmetrize_digits (RowWiseThreshold+Symmetrize + the digits of the "
+        "matrix-free Diffuse)", "threshold_sym",
+        2 * mat + n * n * 2.0 + n * ((n + 63) // 64) * 12.0,
+        "1 read + 1 write of n^2 * 8 B + n^2 * 2 B of digits + the row partials")
+  else:
+    hbm("k_threshold_symmetrize (RowWiseThreshold+Symmetrize)", "threshold_sym", 2 * mat,
+        "1 read + 1 write of n^2")
   # (matrix-free Diffuse: an operator application is two products with A)
   products = passes * (2 if stage_ms.get("free_product", 0.0) > 0 else 1)
   hbm("block matvec of the eigen stage", "matvec", products * mat,
@@ -742,8 +752,8 @@ def main():
     # whole call against its floors (SURVEY 8d arithmetic, symmetry exploited, 8 TB/s):
     #   explicit route: (n^3 + n^2 d) fp64 flops on MFMA + (7 + passes) n^2 * 8 B
     #   matrix-free:    n^2 d fp64 flops + the digit product on the int8 cores + A1 write,
-    #                   Crop+Blur R/W, Thr+Sym R/W, one read of A + n^2 * 2 B of digits, T written
-    #                   and read once (fp32 upper triangle), one read of A for the exact
+    #                   Crop+Blur R/W, Thr+Sym R/W + n^2 * 2 B of digits from the same pass, T
+    #                   written and read once (fp32 upper triangle), one read of A for the exact
     #                   statistics, and 2 x passes half-matrix products
     nn = float(N_SAMPLES) * N_SAMPLES
     mat = nn * 8.0
@@ -751,7 +761,7 @@ def main():
                ((7.0 + passes_per_call) * mat + N_SAMPLES * N_FEATURES * 8.0) / (PEAK_HBM_TBS * 1e12))
     f_floor = (nn * N_FEATURES / (PEAK_F64_MFMA_TFLOPS * 1e12) +
                4.0 * nn * N_SAMPLES / (PEAK_I8_MFMA_TOPS * 1e12) +
-               (5.0 * mat + mat + nn * 2.0 + 2 * nn * 2.0 + mat + 2.0 * passes_per_call * 0.5 * mat +
+               (5.0 * mat + nn * 2.0 + 2 * nn * 2.0 + mat + 2.0 * passes_per_call * 0.5 * mat +
                 N_SAMPLES * N_FEATURES * 8.0) / (PEAK_HBM_TBS * 1e12))
     whole = {"measured_ms": 1e3 * elapsed / k,
              "floor_ms": 1e3 * (f_floor if free else x_floor),

@@ -246,7 +246,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->td_tau, &h->td_panel, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
                     &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd, &h->gpack, &h->gypack, &h->ginfo, &h->glabels,
-                    &h->kbig, &h->kbigw, &h->fq, &h->ft32, &h->fy1, &h->fR, &h->fscal, &h->fwords, &h->fcand, &h->fY, &h->fsplit};
+                    &h->kbig, &h->kbigw, &h->fq, &h->ft32, &h->fy1, &h->fR, &h->fscal, &h->fwords, &h->fcand, &h->fY, &h->fsplit, &h->fypart, &h->frpart};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);
@@ -714,6 +714,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   h->free_on = false;
   bool free_path = false;
   const double* amax_of = nullptr;  // matrix whose max|a| h->fscal[0] bounds (matrix-free Diffuse)
+  const double* digits_of = nullptr;  // ... whose digits the threshold pass has already written
   float diffuse_ms_events[SC_MAX_OPS][2];
   int n_diffuse = 0;
   ev_rec(h, &e_begin);
@@ -780,22 +781,42 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
       else
         launch_cut_from_rows(s, cur, n, ld, cfg->p_percentile, ptr<double>(h->cut),
                              cfg->preserve_diagonal);
-      if (fine) ev_rec(h, &et0);
-      launch_threshold_symmetrize(s, cur, out, n, ld, ptr<double>(h->cut),
-                                  cfg->soft_multiplier, cfg->binarize, cfg->symmetrize_type,
-                                  cfg->preserve_diagonal);
-      if (fine) ev_rec(h, &et1);
-      SC_TRY(check_last(h, "threshold+symmetrize launch"));
-      // the matrix-free Diffuse quantises this matrix: when it is non-negative by
+      // the matrix-free Diffuse quantises this pass's result: when it is non-negative by
       // construction (cosine affinity, no constraint applied to it) and thresholded by RowMax
-      // with a multiplier in [0, 1], its maximum is known from the cut vector
-      if (cfg->threshold_type == SC_THRESHOLD_ROW_MAX && h->affinity_from_embeddings &&
+      // with a multiplier in [0, 1], its maximum is known from the cut vector ...
+      const bool amax_known =
+          cfg->threshold_type == SC_THRESHOLD_ROW_MAX && h->affinity_from_embeddings &&
           !h->constraint_applied && cfg->p_percentile > 0.0 && cfg->soft_multiplier >= 0.0 &&
           cfg->soft_multiplier <= 1.0 && i + 2 < cfg->n_ops && cfg->ops[i + 2] == SC_OP_DIFFUSE &&
-          free_diffuse_wanted(h, cfg, n, make_eig_request(cfg))) {
+          free_diffuse_wanted(h, cfg, n, make_eig_request(cfg));
+      // ... and when that Diffuse will take the matrix-free route (the conditions of its branch
+      // below), this pass writes the digits and row partials too: no quantiser pass
+      const bool fuse_digits =
+          amax_known && !constrain_after && !front_only &&
+          (i + 2 == cfg->n_ops - 1 ||
+           (i + 2 == cfg->n_ops - 2 && cfg->ops[i + 3] == SC_OP_ROW_WISE_NORMALIZE));
+      const double amax_floor = (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0;
+      if (fuse_digits)
+        SC_TRY(free_fused_prepare(h, s, n, ptr<double>(h->cut), cfg->p_percentile, amax_floor));
+      if (fine) ev_rec(h, &et0);
+      if (fuse_digits)
+        launch_threshold_symmetrize_digits(s, cur, out, n, ld, ptr<double>(h->cut),
+                                           cfg->soft_multiplier, cfg->binarize,
+                                           cfg->symmetrize_type, cfg->preserve_diagonal,
+                                           ptr<signed char>(h->fq), ptr<double>(h->fscal),
+                                           ptr<double>(h->fypart), ptr<int>(h->frpart));
+      else
+        launch_threshold_symmetrize(s, cur, out, n, ld, ptr<double>(h->cut),
+                                    cfg->soft_multiplier, cfg->binarize, cfg->symmetrize_type,
+                                    cfg->preserve_diagonal);
+      if (fine) ev_rec(h, &et1);
+      SC_TRY(check_last(h, "threshold+symmetrize launch"));
+      if (fuse_digits) {
+        amax_of = out;
+        digits_of = out;
+      } else if (amax_known) {
         SC_TRY(ensure_free(h, n));
-        launch_free_amax_from_cut(s, ptr<double>(h->cut), n, cfg->p_percentile,
-                                  (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0,
+        launch_free_amax_from_cut(s, ptr<double>(h->cut), n, cfg->p_percentile, amax_floor,
                                   ptr<double>(h->fscal));
         amax_of = out;
       }
@@ -812,7 +833,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
       // S = A A^T -- only rowmax(S) (the RowWiseNormalize fold), rowsum(S) (the Laplacian) and
       // S V (the eigensolver).  `cur` stays the symmetric A; `out` stays free.
       SC_TRY(ensure_eig(h, n));
-      SC_TRY(free_diffuse_stats(h, cur, ld, n, amax_of == cur));
+      SC_TRY(free_diffuse_stats(h, cur, ld, n, amax_of == cur, digits_of == cur));
       h->free_on = true;
       h->free_lap = cfg->laplacian_type;
       h->free_rownorm = next == SC_OP_ROW_WISE_NORMALIZE ? 1 : 0;

@@ -99,11 +99,31 @@ int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, b
   return SC_OK;
 }
 
-int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax) {
+// The threshold + symmetrise pass can write the digits itself (rowops.hip, TsDigits): what it
+// needs before it runs -- the buffers, zeroed words, max|a| from the cut vector in fscal[0] ...
+int free_fused_prepare(sc_handle h, hipStream_t s, int n, const double* cut, double p,
+                       double floor_value) {
+  SC_TRY(ensure_free(h, n));
+  const size_t rows64 = (size_t)round_up(n, 64), nblk = rows64 / 64;
+  SC_TRY(grow(h, h->fypart, rows64 * nblk * sizeof(double)));
+  SC_TRY(grow(h, h->frpart, rows64 * nblk * sizeof(int)));
+  SC_HIP(h, hipMemsetAsync(h->fscal.p, 0, 4 * sizeof(double), s));
+  SC_HIP(h, hipMemsetAsync(h->fwords.p, 0, ((size_t)2 * n + kOvfWords) * sizeof(int), s));
+  launch_free_amax_from_cut(s, cut, n, p, floor_value, ptr<double>(h->fscal));
+  return SC_OK;
+}
+
+// (digits_ready: ... and what is left of the quantiser's work afterwards, the row partials)
+int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax,
+                       bool digits_ready) {
   hipStream_t s = h->stream;
   SC_TRY(ensure_tilemap(h, n));
   ev_rec(h, &h->free_ev[0]);
-  SC_TRY(free_stats_begin(h, s, A, ld, n, have_amax));
+  if (digits_ready)
+    launch_free_partials_reduce(s, ptr<double>(h->fypart), ptr<int>(h->frpart), n,
+                                ptr<double>(h->fy1), ptr<double>(h->fR), ptr<double>(h->fscal));
+  else
+    SC_TRY(free_stats_begin(h, s, A, ld, n, have_amax));
   ev_rec(h, &h->free_ev[1]);
   SC_TRY(free_product(h, s, n));
   ev_rec(h, &h->free_ev[2]);

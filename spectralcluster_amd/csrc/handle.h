@@ -136,7 +136,7 @@ struct sc_handle_s {
   // ---- matrix-free Diffuse (free_api.hip)
   int diffuse_mode = -1;   // sc_set_diffuse_mode: 0 auto, 1 explicit fp64 product, 2 matrix-free
                            // wherever the sequence allows it; -1: the environment's default
-  DevBuf fq, ft32, fy1, fR, fscal, fwords, fcand, fY, fsplit;  // digits, T (fp32 tiles), A 1, sum|q|,
+  DevBuf fq, ft32, fy1, fR, fscal, fwords, fcand, fY, fsplit, fypart, frpart;  // digits, T (fp32 tiles), A 1, sum|q|,
                            // scalars, M | count | ovf words, candidate lists, A Vs
   int* h_free = nullptr;   // pinned copy of the ovf words (80)
   bool free_on = false;    // the operator of the current solve is c .* A (A (c .* v)) + p .* v
@@ -330,7 +330,10 @@ bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequ
 // enqueue the statistics of S = A A^T (h->rowmax, h->rowsum) on h->stream; no synchronisation.
 // The overflow words travel to h->h_free behind them.
 // `have_amax`: h->fscal[0] already holds max|a| (or an upper bound of it) for this A
-int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax = false);
+int free_fused_prepare(sc_handle h, hipStream_t s, int n, const double* cut, double p,
+                       double floor_value);
+int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax = false,
+                       bool digits_ready = false);
 int ensure_free(sc_handle h, int n);
 // the same pipeline in pieces on a given stream (the AutoTune sweep runs the digit product of
 // all its members as one grouped launch between them): max|a| + digits | ... | candidates +

@@ -295,10 +295,55 @@ __global__ __launch_bounds__(kRowThreads) void k_row_threshold_cut(
 // computed once and written to both places (the mirror through LDS, so both stores are
 // coalesced): 1 read + 1 write of n^2 for the two ops together.
 constexpr int kTsTile = 64;  // tile edge of the threshold + symmetrise pass
+// DIGITS: the pass also leaves what the quantiser of the matrix-free Diffuse (diffuse_free.hip,
+// k_free_quantize) would compute from its result in a pass of its own -- the two 8-bit digits of
+// q = rint(sigma a) in the product's layout (a 64 x 64 tile is exactly one 128-byte line per row:
+// 64 high digits, 64 low digits) and, per row and 64-column block, the partial sums of a and of
+// |q| (k_free_partials_reduce adds them in block order).  Saves one read of the matrix.
+struct TsDigits {
+  signed char* Q;      // digits, row pitch `pitch` bytes
+  size_t pitch;
+  int nblk;            // 64-column blocks per row
+  const double* scal;  // [0] = max |a| (known from the cut vector before this pass)
+  double* ypart;       // [block * 64 nblk + row] sum of a  (a tile's 64 partials are contiguous:
+  int* rpart;          // [block * 64 nblk + row] sum of |q|   whole lines leave the L2)
+};
+__device__ __forceinline__ void ts_digits(const TsDigits& dg, double sigma, int row, int blk,
+                                          int c0, double v0, double v1, bool lane0) {
+  int qv[2];
+  const double e[2] = {v0, v1};
+  signed char hb[2], lb[2];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {  // (the quantiser's arithmetic, word for word)
+    double qd = rint(e[w] * sigma);
+    qd = fmin(fmax(qd, -32639.0), 32639.0);
+    const int q = (int)qd;
+    const int h = (q + 128) >> 8;
+    const int l = q - (h << 8);
+    qv[w] = q < 0 ? -q : q;
+    hb[w] = (signed char)h;
+    lb[w] = (signed char)l;
+  }
+  signed char* dst = dg.Q + (size_t)row * dg.pitch + (size_t)blk * 128 + c0;
+  *reinterpret_cast<short*>(dst) = (short)((unsigned char)hb[0] | ((unsigned short)(unsigned char)hb[1] << 8));
+  *reinterpret_cast<short*>(dst + 64) = (short)((unsigned char)lb[0] | ((unsigned short)(unsigned char)lb[1] << 8));
+  double ys = v0 + v1;
+  int rs = qv[0] + qv[1];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {  // the 32 lanes of a half-wave hold the row's 64 columns
+    ys += __shfl_xor(ys, o);
+    rs += __shfl_xor(rs, o);
+  }
+  if (lane0) {
+    dg.ypart[(size_t)blk * (kTsTile * dg.nblk) + row] = ys;
+    dg.rpart[(size_t)blk * (kTsTile * dg.nblk) + row] = rs;
+  }
+}
+template <bool DIGITS>
 __device__ __forceinline__ void threshold_symmetrize_body(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles,
-    int preserve_diag) {
+    int preserve_diag, const TsDigits dg) {
   // One workgroup = the tile pair (I, J), (J, I) of 64 x 64 entries.  O = sym(thr(A), thr(B)^T)
   // is tile (I, J) of the result and O^T is tile (J, I) (max and average are symmetric in their
   // arguments), so B and then O take one trip each through the one LDS tile.  Every thread
@@ -364,6 +409,11 @@ __device__ __forceinline__ void threshold_symmetrize_body(
     tT[r][c0 + 1] = b[q].y;
   }
   __syncthreads();
+  double sigma = 0.0;
+  if (DIGITS) {
+    const double amax = dg.scal[0];
+    sigma = (amax > 0.0 && isfinite(amax)) ? 32639.0 / amax : 0.0;
+  }
   // O (r, c) = sym(thr A (r, c), thr B (c, r)), kept in a[]
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -376,6 +426,8 @@ __device__ __forceinline__ void threshold_symmetrize_body(
       *reinterpret_cast<double2*>(out + (size_t)gi * ld + gj) = a[q];
     else if (gi < n && gj < n)
       out[(size_t)gi * ld + gj] = a[q].x;
+    // (entries outside the matrix are zero here: thr() returned 0 for them and sym(0, 0) = 0)
+    if (DIGITS) ts_digits(dg, sigma, gi, tj, c0, a[q].x, a[q].y, tx == 0);
   }
   if (diag_tile) return;
   __syncthreads();  // everybody has read B^T
@@ -395,13 +447,64 @@ __device__ __forceinline__ void threshold_symmetrize_body(
       *reinterpret_cast<double2*>(out + (size_t)gi * ld + gj) = o;
     else if (gi < n && gj < n)
       out[(size_t)gi * ld + gj] = o.x;
+    if (DIGITS) ts_digits(dg, sigma, gi, ti, c0, o.x, o.y, tx == 0);
   }
 }
 __global__ __launch_bounds__(256) void k_threshold_symmetrize(
     const double* __restrict__ in, double* __restrict__ out, int n, int ld,
     const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles,
     int preserve_diag) {
-  threshold_symmetrize_body(in, out, n, ld, cut, mult, binarize, symtype, ntiles, preserve_diag);
+  threshold_symmetrize_body<false>(in, out, n, ld, cut, mult, binarize, symtype, ntiles,
+                                   preserve_diag, TsDigits{});
+}
+__global__ __launch_bounds__(256) void k_threshold_symmetrize_digits(
+    const double* __restrict__ in, double* __restrict__ out, int n, int ld,
+    const double* __restrict__ cut, double mult, int binarize, int symtype, int ntiles,
+    int preserve_diag, const TsDigits dg) {
+  threshold_symmetrize_body<true>(in, out, n, ld, cut, mult, binarize, symtype, ntiles,
+                                  preserve_diag, dg);
+}
+// y1 = rowsum(A), R = sum |q| and its maximum from the per-block partials ([block][row]).  A
+// workgroup takes 64 rows; thread (row, quarter) adds a quarter of the row's blocks in order,
+// the quarters are folded in order, and the workgroup sends ONE candidate for the maximum (a
+// wave per row and a look at the word each cost 40 us of same-address traffic for 8 us of work).
+__global__ __launch_bounds__(256) void k_free_partials_reduce(
+    const double* __restrict__ ypart, const int* __restrict__ rpart, int n, int nblk,
+    double* __restrict__ y1, double* __restrict__ R, unsigned long long* __restrict__ rmax_bits) {
+  __shared__ double sy[4][64];
+  __shared__ long long sr[4][64];
+  const int r = threadIdx.x & 63, qd = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + r;
+  const size_t rows = (size_t)kTsTile * nblk;
+  const int b0 = (int)((long long)nblk * qd / 4), b1 = (int)((long long)nblk * (qd + 1) / 4);
+  double ys = 0.0;
+  long long rs = 0;
+#pragma unroll 8
+  for (int b = b0; b < b1; ++b) {
+    ys += ypart[(size_t)b * rows + row];
+    rs += rpart[(size_t)b * rows + row];
+  }
+  sy[qd][r] = ys;
+  sr[qd][r] = rs;
+  __syncthreads();
+  if (qd == 0) {
+    ys = ((sy[0][r] + sy[1][r]) + sy[2][r]) + sy[3][r];
+    rs = sr[0][r] + sr[1][r] + sr[2][r] + sr[3][r];
+    const double rd = (double)rs;
+    if (row < n) {
+      y1[row] = ys;
+      R[row] = rd;
+    }
+    double m = row < n ? rd : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if (r == 0) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+      const unsigned long long cur =
+          __hip_atomic_load(rmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (bits > cur) atomicMax(rmax_bits, bits);
+    }
+  }
 }
 __global__ __launch_bounds__(256) void k_threshold_symmetrize_g(const GroupOf<FrontItem> g,
                                                                 double mult, int binarize,
@@ -409,8 +512,8 @@ __global__ __launch_bounds__(256) void k_threshold_symmetrize_g(const GroupOf<Fr
   const FrontItem& a = g.s[blockIdx.y];
   const int t = (a.n + kTsTile - 1) / kTsTile;
   if ((int)blockIdx.x >= t * (t + 1) / 2) return;
-  threshold_symmetrize_body(a.B1, a.B2, a.n, a.ldn, a.cut, mult, binarize, symtype, t,
-                            preserve_diag);
+  threshold_symmetrize_body<false>(a.B1, a.B2, a.n, a.ldn, a.cut, mult, binarize, symtype, t,
+                                   preserve_diag, TsDigits{});
 }
 
 // ---- R3: RowWiseThreshold, RowMax (refinement.py:182-210) --------------------
@@ -681,6 +784,28 @@ void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, i
   const int t = (n + kTsTile - 1) / kTsTile;
   hipLaunchKernelGGL(k_threshold_symmetrize, dim3(t * (t + 1) / 2), dim3(256), 0, s, in, out,
                      n, ld, cut, mult, binarize, symtype, t, preserve_diag);
+}
+// the same pass + digits and row partials for the matrix-free Diffuse (TsDigits above); Q has
+// round_up(n, 128) rows of `pitch` = 2 round_up(n, 64) bytes, the partials round_up(n, 64) rows
+void launch_threshold_symmetrize_digits(hipStream_t s, const double* in, double* out, int n, int ld,
+                                        const double* cut, double mult, int binarize, int symtype,
+                                        int preserve_diag, signed char* Q, const double* scal,
+                                        double* ypart, int* rpart) {
+  const int t = (n + kTsTile - 1) / kTsTile;
+  const size_t pitch = (size_t)2 * t * kTsTile;
+  // rows [64 t, round_up(n, 128)) belong to no tile: zero digits
+  const int rows_padded = (n + 127) / 128 * 128;
+  if (rows_padded > t * kTsTile)
+    hipMemsetAsync(Q + (size_t)t * kTsTile * pitch, 0, (size_t)(rows_padded - t * kTsTile) * pitch, s);
+  const TsDigits dg{Q, pitch, t, scal, ypart, rpart};
+  hipLaunchKernelGGL(k_threshold_symmetrize_digits, dim3(t * (t + 1) / 2), dim3(256), 0, s, in,
+                     out, n, ld, cut, mult, binarize, symtype, t, preserve_diag, dg);
+}
+void launch_free_partials_reduce(hipStream_t s, const double* ypart, const int* rpart, int n,
+                                 double* y1, double* R, double* scal) {
+  const int nblk = (n + kTsTile - 1) / kTsTile;
+  hipLaunchKernelGGL(k_free_partials_reduce, dim3(nblk), dim3(256), 0, s, ypart, rpart, n,
+                     nblk, y1, R, reinterpret_cast<unsigned long long*>(scal) + 2);
 }
 void launch_row_normalize(hipStream_t s, const double* in, double* out, int n,
                           int ld) {

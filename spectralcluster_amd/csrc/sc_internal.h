@@ -121,6 +121,13 @@ void launch_row_threshold_cut(hipStream_t s, const double* in, double* out, int 
 void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, int n, int ld,
                                  const double* cut, double mult, int binarize, int symtype,
                                  int preserve_diag);
+// ... + the digits and row partials of the matrix-free Diffuse's quantiser (rowops.hip)
+void launch_threshold_symmetrize_digits(hipStream_t s, const double* in, double* out, int n, int ld,
+                                        const double* cut, double mult, int binarize, int symtype,
+                                        int preserve_diag, signed char* Q, const double* scal,
+                                        double* ypart, int* rpart);
+void launch_free_partials_reduce(hipStream_t s, const double* ypart, const int* rpart, int n,
+                                 double* y1, double* R, double* scal);
 void launch_row_threshold(hipStream_t s, const double* in, double* out, int n,
                           int ld, double p, double mult, int binarize,
                           int preserve_diag);

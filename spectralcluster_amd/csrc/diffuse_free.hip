@@ -572,6 +572,14 @@ __global__ __launch_bounds__(256) void k_t32_candidates(
   slot_to_tile(blockIdx.x, nt, &I, &J);
   const float* tile = T32 + (size_t)blockIdx.x * (kI8Tile * kI8Tile);
   const int r0 = I * kI8Tile, c0 = J * kI8Tile;
+  // the thread's 16 pieces of the tile are requested before anything else (they depend on
+  // nothing): with one load in flight per thread behind the thresholds' own round trip the
+  // scan ran at 3.2 TB/s
+  const int c4 = 4 * (threadIdx.x & 31);
+  float4 tv[16];
+#pragma unroll
+  for (int rg = 0; rg < 16; ++rg)
+    tv[rg] = *reinterpret_cast<const float4*>(tile + (8 * rg + (threadIdx.x >> 5)) * kI8Tile + c4);
   const double Rmax = __longlong_as_double((long long)*rmax_bits);
   if (threadIdx.x < 128) {
     const int row = r0 + threadIdx.x;
@@ -582,13 +590,12 @@ __global__ __launch_bounds__(256) void k_t32_candidates(
         (row < n && I != J) ? free_threshold(ordered_value(M[row]), R[row], Rmax, n) : INFINITY;
   }
   __syncthreads();
-  const int c4 = 4 * (threadIdx.x & 31);
   const float tj0 = thrJ[c4], tj1 = thrJ[c4 + 1], tj2 = thrJ[c4 + 2], tj3 = thrJ[c4 + 3];
   const float tjmin = fminf(fminf(tj0, tj1), fminf(tj2, tj3));
-#pragma unroll 4
+#pragma unroll
   for (int rg = 0; rg < 16; ++rg) {
     const int r = 8 * rg + (threadIdx.x >> 5);
-    const float4 v = *reinterpret_cast<const float4*>(tile + r * kI8Tile + c4);
+    const float4 v = tv[rg];
     const float ti = thrI[r];
     const float vmax = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
     if (vmax >= ti) {  // (rare) as entries of row r0 + r; padding columns are not entries

@@ -31,16 +31,20 @@ import numpy as np
 def cost_model(n: int) -> float:
   """Cost of one utterance of n samples inside a grouped batch (predict_batch(group=16), the
   execution the partition schedules), in microseconds on one MI355X.  Calibrated on measured
-  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r03b_cost_fit.txt: 109 us
-  at n=650 ... 757 us at n=3000; non-negative least squares on the relative error, 2 %):
-  a fixed per-utterance share of the group's launch chains, the O(n^2) passes, the O(n^3)
-  Diffuse product.  Below n=512 the stages before the eigensolver run member by member
-  (143-156 us measured, flat).  Round 2's n^3 + 64 n^2 put a factor 900 between n=300 and
-  n=3000 where the measured factor is 5."""
+  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r05i_cost_fit.txt: 58 us
+  at n=300, 80 at 650, 182 at 1600, 297 at 2048, 452 at 3000; non-negative least squares on
+  the relative error, 3 % per branch): a fixed per-utterance share of the group's launch
+  chains, the O(n^2) passes, the O(n^3) product -- the fp64 Diffuse product below n=2048, the
+  int8 digit product of the matrix-free route from there on (round 4), hence two branches.
+  (Round 3's single cubic, calibrated on the explicit route, was 2x too high everywhere and
+  had no kink at 2048: the 8 shares of config 5 came out 10 % apart.  Round 2's n^3 + 64 n^2
+  put a factor 900 between n=300 and n=3000 where the measured factor is 8.)"""
   n = float(n)
   if n < 512.0:
-    return 150.0
-  return 89.4 + 3.26e-5 * n * n + 1.45e-8 * n * n * n
+    return 50.0 + 6.5e-5 * n * n
+  if n < 2048.0:
+    return 69.7 + 1.154e-5 * n * n + 2.146e-8 * n * n * n
+  return 218.5 + 8.19e-9 * n * n * n
 
 
 def lpt_assignment(sizes: typing.Sequence[int], world: int) -> typing.List[typing.List[int]]:

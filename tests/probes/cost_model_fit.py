@@ -15,7 +15,7 @@ import spectralcluster_amd as sca  # noqa: E402
 from bench import blobs  # noqa: E402
 
 c = sca.configs.icassp2018_clusterer
-sizes = [300, 450, 650, 900, 1200, 1600, 2000, 2500, 3000]
+sizes = [300, 450, 650, 900, 1200, 1600, 2000, 2047, 2048, 2200, 2500, 2750, 3000]
 per = []
 for n in sizes:
   xs = [blobs(n, 256, 2 + i % 6, seed=1000 + i)[0] for i in range(64)]
@@ -27,11 +27,21 @@ for n in sizes:
     best = min(best, time.perf_counter() - t0)
   per.append(best / 64)
   print("n=%d: %.1f us per utterance (64 utterances, 4 groups)" % (n, 1e6 * per[-1]), flush=True)
-n = np.array(sizes, dtype=np.float64)
-t = np.array(per) * 1e6
-A = np.stack([np.ones_like(n), n ** 2, n ** 3], axis=1) / t[:, None]  # relative error
-coef, *_ = np.linalg.lstsq(A, np.ones_like(t), rcond=None)
-fit = coef[0] + coef[1] * n ** 2 + coef[2] * n ** 3
-print("fit us = %.4g + %.4g n^2 + %.4g n^3" % tuple(coef))
-print("max rel err %.3f" % np.max(np.abs(fit - t) / t))
-print("COEF", repr(list(coef)))
+
+
+def fit(ns, ts, what):
+  n = np.array(ns, dtype=np.float64)
+  t = np.array(ts) * 1e6
+  A = np.stack([np.ones_like(n), n ** 2, n ** 3], axis=1) / t[:, None]  # relative error
+  import scipy.optimize
+  coef, _ = scipy.optimize.nnls(A, np.ones_like(t))
+  f = coef[0] + coef[1] * n ** 2 + coef[2] * n ** 3
+  print("%s: fit us = %.4g + %.4g n^2 + %.4g n^3, max rel err %.3f" % ((what,) + tuple(coef) + (np.max(np.abs(f - t) / t),)))
+  print("COEF", what, repr(list(coef)))
+
+
+# (members of n >= 2048 take the matrix-free Diffuse inside the grouped front: two branches)
+lo = [(n, t) for n, t in zip(sizes, per) if 512 <= n < 2048]
+hi = [(n, t) for n, t in zip(sizes, per) if n >= 2048]
+fit([n for n, _ in lo], [t for _, t in lo], "512 <= n < 2048")
+fit([n for n, _ in hi], [t for _, t in hi], "n >= 2048")

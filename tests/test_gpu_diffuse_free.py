@@ -178,6 +178,34 @@ def test_predict_vs_reference_golden_both_routes(name, mode):
     assert dg.free_candidates >= n and dg.free_candidates <= 3 * n
 
 
+@pytest.mark.parametrize("n", [1050, 2100, 2239, 3007])
+@pytest.mark.parametrize("lap", [0, 4])
+def test_routes_agree_at_ragged_sizes(n, lap):
+  """Sizes whose 64-row tile count is odd or that end inside a tile: the digits written by the
+  threshold + symmetrise pass (edge tiles, the 64 rows between the last tile and the product's
+  128-row padding) against the explicit product on the same input."""
+  x = so.blobs(n, 48, 5, seed=n + lap)
+  out = {}
+  for mode in (FREE, EXPLICIT):
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=12, refinement_options=icassp_options(),
+                              laplacian_type=LAP[lap])
+    c.diffuse_mode = mode
+    labels = c.predict(x)
+    dg = c.last_diag
+    assert dg.diffuse_path == (_lib.DIFFUSE_PATH_FREE if mode == FREE else _lib.DIFFUSE_PATH_EXPLICIT)
+    out[mode] = (labels, dg.n_clusters_raw, dg.max_delta, c.consumed_eigenvalues())
+  assert out[FREE][1] == out[EXPLICIT][1]
+  np.testing.assert_allclose(out[FREE][2], out[EXPLICIT][2], rtol=1e-6)
+  wf, wx = out[FREE][3], out[EXPLICIT][3]
+  if lap == 0:  # the descending loop stops reading after the first value < 1e-2
+    below = np.nonzero(wx < 1e-2)[0]
+    stop = int(below[0]) + 1 if below.size else wx.size
+    wf, wx = wf[:stop], wx[:stop]
+  scale = np.abs(wx).max()
+  assert np.max(np.abs(wf - wx)) < 2e-6 * scale
+  assert so.adjusted_rand_index(out[FREE][0], out[EXPLICIT][0]) == 1.0
+
+
 def test_default_routing_by_size():
   opts = icassp_options()
   for n, want in ((1000, _lib.DIFFUSE_PATH_EXPLICIT), (2048, _lib.DIFFUSE_PATH_FREE)):

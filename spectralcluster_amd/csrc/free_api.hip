@@ -8,24 +8,6 @@ constexpr int kOvfWords = 80;   // [0] rows over the cap, [1..64] their ids, [65
 constexpr int kOvfRowsMax = 64;
 }  // namespace
 
-// SC_DIFFUSE=explicit|free|auto (default auto) and SC_DIFFUSE_FREE_MIN_N=<n> (default 2048):
-// path switches in the sense of switches.h -- both routes are held to the same goldens
-// (tests/test_gpu_diffuse_free.py, tests/test_gpu_alternate_paths.py).
-static int env_diffuse_mode() {
-  static const int v = [] {
-    const char* e = getenv("SC_DIFFUSE");
-    if (!e) return 0;
-    if (!strcmp(e, "explicit")) return 1;
-    if (!strcmp(e, "free")) return 2;
-    return 0;
-  }();
-  return v;
-}
-static int env_free_min_n() {
-  static const int v = getenv("SC_DIFFUSE_FREE_MIN_N") ? atoi(getenv("SC_DIFFUSE_FREE_MIN_N")) : 2048;
-  return v;
-}
-
 extern "C" int sc_set_diffuse_mode(sc_handle h, int mode) {
   if (!h || mode < -1 || mode > 2) return SC_ERR_INVALID;
   h->diffuse_mode = mode;
@@ -36,13 +18,13 @@ bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequ
   // the call's own choice, else the handle's, else the process default
   const int mode = cfg->diffuse_mode == 1 || cfg->diffuse_mode == 2
                        ? cfg->diffuse_mode
-                       : (h->diffuse_mode >= 0 ? h->diffuse_mode : env_diffuse_mode());
+                       : (h->diffuse_mode >= 0 ? h->diffuse_mode : sw::diffuse_mode());
   if (mode == 1) return false;
   // the dense routes read entries of the operator; n <= 128 is one Jacobi launch on it; the
   // i32 accumulators of the digit products hold K <= 65536
   if (n <= kDenseMax || n > 65536 || wants_full_spectrum(rq)) return false;
   if (mode == 2) return true;
-  return n >= env_free_min_n();
+  return n >= sw::diffuse_free_min_n();
 }
 
 int ensure_free(sc_handle h, int n) {

@@ -10,6 +10,7 @@
 #define SPECTRALCLUSTER_AMD_SWITCHES_H_
 
 #include <cstdlib>
+#include <cstring>
 
 namespace sc {
 namespace sw {
@@ -59,7 +60,23 @@ inline bool kmeans_single() {
 }
 // SC_DIFFUSE=explicit|free|auto and SC_DIFFUSE_FREE_MIN_N=<n> (default 2048): route of a Diffuse
 // that only feeds RowWiseNormalize / the Laplacian -- the fp64 product, or the matrix-free
-// search of free_api.hip (read there; sc_config.diffuse_mode / sc_set_diffuse_mode override)
+// search of free_api.hip (sc_config.diffuse_mode / sc_set_diffuse_mode override).  Both routes
+// are held to the same goldens (tests/test_gpu_diffuse_free.py, test_gpu_alternate_paths.py).
+inline int diffuse_mode() {  // 0 auto, 1 explicit, 2 free
+  static const int v = [] {
+    const char* e = getenv("SC_DIFFUSE");
+    if (!e) return 0;
+    if (!strcmp(e, "explicit")) return 1;
+    if (!strcmp(e, "free")) return 2;
+    return 0;
+  }();
+  return v;
+}
+inline int diffuse_free_min_n() {
+  static const int v =
+      getenv("SC_DIFFUSE_FREE_MIN_N") ? atoi(getenv("SC_DIFFUSE_FREE_MIN_N")) : 2048;
+  return v;
+}
 // SC_SWEEP_ONE_BY_ONE=1: an AutoTune level as separate sc_eig_ncluster calls (what a level
 // falls back to when member arenas do not fit or a value leaves the grouped path)
 inline bool sweep_one_by_one() {

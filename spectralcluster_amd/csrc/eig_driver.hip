@@ -900,7 +900,10 @@ static int ensure_group_staging(sc_handle lead) {
   }
   if (!lead->gpool) {
     const unsigned hw = std::thread::hardware_concurrency();
-    lead->gpool = new HostPool(hw >= 8 ? 6 : (hw >= 4 ? 2 : 0));
+    // one worker per member of a full group where the host has the cores for it (a sweep of
+    // slowly converging values spends half its time in these solves: 16 members on 7 threads
+    // are three rounds of up to 0.9 ms per check); three lanes of a batch have a pool each
+    lead->gpool = new HostPool(hw >= 64 ? kGroupMax - 1 : (hw >= 8 ? 6 : (hw >= 4 ? 2 : 0)));
   }
   return SC_OK;
 }

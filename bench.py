@@ -609,7 +609,17 @@ def main():
   # (one rank per GPU; on a box with fewer GPUs than ranks -- a 1-GPU test box -- ranks share)
   handle = _lib.default_handle(local_rank % max(1, _lib.device_count()))
   lib = handle.lib
-  comm = multigpu.RcclComm.from_env(handle)  # RCCL (C ABI) for N > 1, identity for N = 1
+  # (librccl prints a version banner on stdout when its first communicator comes up: stdout is
+  #  this program's ONE JSON line, so fd 1 points at stderr while the ranks meet)
+  sys.stdout.flush()
+  saved_stdout = os.dup(1)
+  os.dup2(2, 1)
+  try:
+    comm = multigpu.RcclComm.from_env(handle)  # RCCL (C ABI) for N > 1, identity for N = 1
+  finally:
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
   clusterer = sca.SpectralClusterer(
       min_clusters=2, max_clusters=MAX_CLUSTERS,
       refinement_options=sca.configs.icassp2018_refinement_options,

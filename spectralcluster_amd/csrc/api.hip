@@ -951,7 +951,11 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   EigDecision dc;
   std::vector<double> w;
   if (symmetric) {
-    SC_TRY(sym_topk(h, cur, ld, n, rq, diag, &dc, &w, bufs[which]));
+    // (free_on describes THIS solve's operator: it must not outlive it -- sc_stage_sym_eig and
+    //  every other caller of sym_topk on this handle would apply A twice to their matrix)
+    const int rc_eig = sym_topk(h, cur, ld, n, rq, diag, &dc, &w, bufs[which]);
+    h->free_on = false;
+    SC_TRY(rc_eig);
   } else {
     rq.decision_aware = 1;
     SC_TRY(gen_topk(h, cur, ld, n, cfg->laplacian_type, rq, diag, &dc, &w));
@@ -1431,6 +1435,7 @@ extern "C" int sc_stage_sym_eig(sc_handle h, const double* m, int n, int count, 
   h->nev = 0;
   SC_TRY(ensure_eig(h, n));
   SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 12, 0, sizeof(int), h->stream));
+  h->free_on = false;  // (a stage call solves the matrix it is given)
   SC_TRY(sym_topk(h, S, ld, n, rq, dg, &dc, &w,
                   S == ptr<double>(h->B1) ? ptr<double>(h->B2) : ptr<double>(h->B1)));
   SC_HIP(h, hipStreamSynchronize(h->stream));

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "dpp.h"
 #include "sc_internal.h"
 
 namespace sc {
@@ -242,12 +243,16 @@ __device__ __forceinline__ void gaussian_blur_stream_body(
       double ext[(2 * NB + 1) * 4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) ext[NB * 4 + e] = t[e];
+      // (neighbour lanes by whole-wave DPP shifts, not ds_bpermute: dpp.h)
 #pragma unroll
-      for (int d = 1; d <= NB; ++d) {
+      for (int e = 0; e < 4; ++e) {
+        double below = t[e], above = t[e];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ext[(NB - d) * 4 + e] = __shfl_up(t[e], d);
-          ext[(NB + d) * 4 + e] = __shfl_down(t[e], d);
+        for (int d = 1; d <= NB; ++d) {
+          below = lane_from_below(below);
+          above = lane_from_above(above);
+          ext[(NB - d) * 4 + e] = below;
+          ext[(NB + d) * 4 + e] = above;
         }
       }
       double res[4];
@@ -262,7 +267,9 @@ __device__ __forceinline__ void gaussian_blur_stream_body(
         if (lane_ok && gjo0 + e < n) m = fmax(m, acc);
       }
       double* orow = out + (size_t)gi * ld + gjo0;
-      if (full_store) {
+      if (out == nullptr) {
+        // (row maxima only: tests/probes/blur_probe.hip measures what the write costs)
+      } else if (full_store) {
         *reinterpret_cast<double2*>(orow) = make_double2(res[0], res[1]);
         *reinterpret_cast<double2*>(orow + 2) = make_double2(res[2], res[3]);
       } else if (lane_ok) {
@@ -271,9 +278,8 @@ __device__ __forceinline__ void gaussian_blur_stream_body(
           if (gjo0 + e < n) orow[e] = res[e];
       }
       if (rowmax != nullptr) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-        if (lane == 0) rowmax[(size_t)gi * ncols + bx] = m;
+        m = wave_max_to_last(m);
+        if (lane == 63) rowmax[(size_t)gi * ncols + bx] = m;
       }
     }
   }

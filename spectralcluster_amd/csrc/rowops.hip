@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "dpp.h"
 #include "sc_internal.h"
 
 namespace sc {
@@ -309,7 +310,7 @@ struct TsDigits {
   int* rpart;          // [block * 64 nblk + row] sum of |q|   whole lines leave the L2)
 };
 __device__ __forceinline__ void ts_digits(const TsDigits& dg, double sigma, int row, int blk,
-                                          int c0, double v0, double v1, bool lane0) {
+                                          int c0, double v0, double v1, bool lane0 /* the half-wave's LAST lane */) {
   int qv[2];
   const double e[2] = {v0, v1};
   signed char hb[2], lb[2];
@@ -327,13 +328,9 @@ __device__ __forceinline__ void ts_digits(const TsDigits& dg, double sigma, int 
   signed char* dst = dg.Q + (size_t)row * dg.pitch + (size_t)blk * 128 + c0;
   *reinterpret_cast<short*>(dst) = (short)((unsigned char)hb[0] | ((unsigned short)(unsigned char)hb[1] << 8));
   *reinterpret_cast<short*>(dst + 64) = (short)((unsigned char)lb[0] | ((unsigned short)(unsigned char)lb[1] << 8));
-  double ys = v0 + v1;
-  int rs = qv[0] + qv[1];
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) {  // the 32 lanes of a half-wave hold the row's 64 columns
-    ys += __shfl_xor(ys, o);
-    rs += __shfl_xor(rs, o);
-  }
+  // the 32 lanes of a half-wave hold the row's 64 columns: their sums land in its last lane
+  const double ys = half_sum_to_last(v0 + v1);
+  const int rs = half_sum_to_last(qv[0] + qv[1]);
   if (lane0) {
     dg.ypart[(size_t)blk * (kTsTile * dg.nblk) + row] = ys;
     dg.rpart[(size_t)blk * (kTsTile * dg.nblk) + row] = rs;
@@ -427,7 +424,7 @@ __device__ __forceinline__ void threshold_symmetrize_body(
     else if (gi < n && gj < n)
       out[(size_t)gi * ld + gj] = a[q].x;
     // (entries outside the matrix are zero here: thr() returned 0 for them and sym(0, 0) = 0)
-    if (DIGITS) ts_digits(dg, sigma, gi, tj, c0, a[q].x, a[q].y, tx == 0);
+    if (DIGITS) ts_digits(dg, sigma, gi, tj, c0, a[q].x, a[q].y, tx == 31);
   }
   if (diag_tile) return;
   __syncthreads();  // everybody has read B^T
@@ -447,7 +444,7 @@ __device__ __forceinline__ void threshold_symmetrize_body(
       *reinterpret_cast<double2*>(out + (size_t)gi * ld + gj) = o;
     else if (gi < n && gj < n)
       out[(size_t)gi * ld + gj] = o.x;
-    if (DIGITS) ts_digits(dg, sigma, gi, ti, c0, o.x, o.y, tx == 0);
+    if (DIGITS) ts_digits(dg, sigma, gi, ti, c0, o.x, o.y, tx == 31);
   }
 }
 __global__ __launch_bounds__(256) void k_threshold_symmetrize(

@@ -206,6 +206,29 @@ def test_routes_agree_at_ragged_sizes(n, lap):
   assert so.adjusted_rand_index(out[FREE][0], out[EXPLICIT][0]) == 1.0
 
 
+def test_stage_eig_after_a_matrix_free_predict():
+  """The matrix-free operator is a property of ONE solve: a stage call on the same handle right
+  after such a predict() solves the matrix it is given (the flag used to outlive the call)."""
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=7, refinement_options=icassp_options(),
+                            laplacian_type=LAP[4])
+  c.diffuse_mode = FREE
+  c.predict(so.blobs(2048, 64, 4, seed=5))
+  assert c.last_diag.diffuse_path == _lib.DIFFUSE_PATH_FREE
+  rng = np.random.default_rng(9)
+  n, count = 600, 6
+  q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+  lam = np.concatenate([np.linspace(3.0, 2.0, count), rng.uniform(-0.5, 0.5, n - count)])
+  m = (q * lam) @ q.T
+  m = 0.5 * (m + m.T)
+  h = _lib.default_handle()
+  values = np.empty(count)
+  vectors = np.empty((n, count))
+  h.check(h.lib.sc_stage_sym_eig(h.raw, _lib.as_double_p(np.ascontiguousarray(m)), n, count, 1,
+                                 _lib.as_double_p(values), _lib.as_double_p(vectors), _lib.ScDiag()))
+  want = np.sort(np.linalg.eigvalsh(m))[::-1][:count]
+  np.testing.assert_allclose(values, want, rtol=1e-9)
+
+
 def test_default_routing_by_size():
   opts = icassp_options()
   for n, want in ((1000, _lib.DIFFUSE_PATH_EXPLICIT), (2048, _lib.DIFFUSE_PATH_FREE)):

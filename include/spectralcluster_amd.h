@@ -456,6 +456,14 @@ int sc_host_tridiag_eigvectors(const double* d, const double* e, int n, const do
  * substitution.  Host-only; exported so it can be pinned against numpy without a GPU. */
 int sc_host_general_eig(const double* a, int m, int nvec, double* values_re, double* values_im,
                         double* vectors_re, double* vectors_im);
+/* The eigensolver's stopping rule for one Ritz value (eig_driver.hip): a bound on the distance
+ * from theta[i] (Ritz values of a SYMMETRIC operator, descending) to the eigenvalue it
+ * approximates, from the residual norms resid[] -- resid[i] itself, or the Kato-Temple bound
+ * resid[i]^2 / delta where the neighbouring Ritz values fence theta[i] off.  Host-only;
+ * exported so the bound can be checked against true Rayleigh-Ritz errors without a GPU.
+ * Returns the bound through *bound. */
+int sc_host_value_error_bound(const double* theta, const double* resid, int m, int i,
+                              double* bound);
 /* utils.compute_number_of_clusters (utils.py:74-130) -- host scalar loop */
 int sc_eigengap(const double* eigenvalues, int count, int max_clusters,
                 double stop_eigenvalue, int eigengap_type, int descend,

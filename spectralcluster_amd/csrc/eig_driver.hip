@@ -33,6 +33,13 @@ static double value_error_bound(const double* theta, const double* resid, int m,
   return std::min(r, r * r / delta);
 }
 
+extern "C" int sc_host_value_error_bound(const double* theta, const double* resid, int m, int i,
+                                         double* bound) {
+  if (!theta || !resid || !bound || m < 1 || i < 0 || i >= m) return SC_ERR_INVALID;
+  *bound = value_error_bound(theta, resid, m, i, true);
+  return SC_OK;
+}
+
 // Inspect Ritz values theta[0..m) (descending) + residual estimates.
 static EigDecision analyze(const EigRequest& rq, const double* theta, const double* resid,
                            int m, int n, bool exact, bool symmetric_op = true) {

@@ -562,6 +562,47 @@ def test_host_general_eig_vs_numpy():
       assert np.abs(np.linalg.norm(v, axis=0) - 1.0).max() < 1e-13 * m
 
 
+def test_value_error_bound_holds_for_rayleigh_ritz():
+  """The stopping rule's bound (residual, or Kato-Temple where the neighbours fence a Ritz value
+  off) against the TRUE error of Rayleigh-Ritz values: random subspaces of matrices with
+  well-separated, clustered and repeated leading eigenvalues.  The bound must hold, never
+  exceed the residual, and be much smaller than it where the spectrum is separated."""
+  lib = _lib.load()
+  rng = np.random.default_rng(21)
+  n, m = 300, 40
+  shrunk = 0
+  for kind in ("separated", "clustered", "repeated"):
+    for trial in range(6):
+      lead = {"separated": np.linspace(3.0, 2.0, 12),
+              "clustered": 2.0 + 1e-4 * np.arange(12),
+              "repeated": np.repeat([3.0, 2.5, 2.0], 4)}[kind]
+      lam = np.concatenate([lead, rng.uniform(-1.0, 1.0, n - lead.size)])
+      q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+      a = (q * lam) @ q.T
+      a = 0.5 * (a + a.T)
+      # a subspace that holds the leading eigenvectors up to a perturbation of size eps
+      eps = 10.0 ** rng.uniform(-7, -2)
+      basis = np.concatenate([q[:, :lead.size] + eps * rng.standard_normal((n, lead.size)),
+                              rng.standard_normal((n, m - lead.size))], axis=1)
+      v, _ = np.linalg.qr(basis)
+      t = v.T @ a @ v
+      theta, y = np.linalg.eigh(0.5 * (t + t.T))
+      theta, y = theta[::-1].copy(), y[:, ::-1]
+      x = v @ y
+      resid = np.linalg.norm(a @ x - x * theta, axis=0)
+      true = np.sort(lam)[::-1]
+      for i in range(lead.size):
+        b = ctypes.c_double()
+        assert lib.sc_host_value_error_bound(_lib.as_double_p(theta), _lib.as_double_p(resid), m,
+                                             i, ctypes.byref(b)) == 0
+        err = abs(true[i] - theta[i])  # (Cauchy interlacing: the i-th Ritz value belongs to the i-th eigenvalue)
+        assert b.value <= resid[i] * (1 + 1e-15)
+        assert err <= b.value * (1 + 1e-9) + 1e-13, (kind, trial, i, err, b.value, resid[i])
+        if kind == "separated" and b.value < 1e-2 * resid[i]:
+          shrunk += 1
+  assert shrunk >= 12  # the quadratic bound is what makes separated spectra cheap
+
+
 def test_host_tridiag_eigvectors_vs_scipy():
   """The host step of the dense landing pad (inverse iteration on the tridiagonal form,
   LAPACK dstein's method) against scipy's eigh_tridiagonal, including clustered spectra."""

@@ -264,18 +264,34 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
   launch_threshold_symmetrize_group(s, fi, count, cfg->p_percentile, cfg->soft_multiplier,
                                     cfg->binarize, cfg->symmetrize_type, cfg->preserve_diagonal);
   launch_gemm_nt_group(s, dif, count, kEpiNone, 1);
-  for (int z = 0; z < count; ++z) {
-    if (!mb[z].free_op) continue;
-    // rowmax / rowsum of S = A A^T without forming it (the cut vector bounds max|a|: the
-    // grouped front is the ICASSP2018 sequence on a cosine affinity)
-    sc_handle h = mb[z].h;
-    const int n = h->n;
-    launch_free_amax_from_cut(s, ptr<double>(h->cut), n, cfg->p_percentile,
-                              (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0,
-                              ptr<double>(h->fscal));
-    SC_TRY(free_stats_begin(h, s, fi[z].B2, h->ldn, n, true));
-    SC_TRY(free_product(h, s, n));
-    SC_TRY(free_stats_end(h, s, fi[z].B2, h->ldn, n, false));
+  {
+    // rowmax / rowsum of S = A A^T without forming it, for the members that take that route
+    // (the cut vector bounds max|a|: the grouped front is the ICASSP2018 sequence on a cosine
+    // affinity): begin, quantiser, scan and statistics are one launch each for all of them,
+    // the digit products one per member (their sizes differ)
+    sc_handle fh[kGroupMax];
+    const double* mats[kGroupMax];
+    const double* cuts[kGroupMax];
+    double ps[kGroupMax];
+    int nn[kGroupMax], ll[kGroupMax], nf = 0;
+    FreeItem fitems[kGroupMax];
+    for (int z = 0; z < count; ++z) {
+      if (!mb[z].free_op) continue;
+      sc_handle h = mb[z].h;
+      fh[nf] = h;
+      mats[nf] = fi[z].B2;
+      cuts[nf] = ptr<double>(h->cut);
+      ps[nf] = cfg->p_percentile;
+      nn[nf] = h->n;
+      ll[nf] = h->ldn;
+      ++nf;
+    }
+    if (nf > 0) {
+      SC_TRY(free_group_begin(fh, mats, cuts, ps, nf, ll, nn, s,
+                              (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0, fitems));
+      for (int q = 0; q < nf; ++q) SC_TRY(free_product(fh[q], s, nn[q]));
+      SC_TRY(free_group_end(fh, fitems, nf, s));
+    }
   }
   launch_scaling_vectors_group(s, fi, count, cfg->laplacian_type, 1);
   SC_TRY(check_last(lead, "grouped front launch"));
@@ -921,18 +937,35 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       const signed char* qs[kGroupMax];
       float* ts[kGroupMax];
       unsigned* ms[kGroupMax];
+      FreeItem fitems[kGroupMax];
+      sc_handle fh[kGroupMax];
+      for (int z = 0; z < cnt; ++z) fh[z] = em[z].h;
+      if (amax_from_cut) {
+        // begin, quantiser, scan and statistics of all members: one launch each
+        const double* mats[kGroupMax];
+        const double* cuts[kGroupMax];
+        for (int z = 0; z < cnt; ++z) {
+          mats[z] = em[z].S;
+          cuts[z] = ptr<double>(em[z].h->cut);
+        }
+        int nn[kGroupMax], ll[kGroupMax];
+        for (int z = 0; z < cnt; ++z) { nn[z] = n; ll[z] = ld; }
+        SC_TRY(free_group_begin(fh, mats, cuts, p_values + base, cnt, ll, nn, s, 0.0, fitems));
+      } else {
+        for (int z = 0; z < cnt; ++z) SC_TRY(free_stats_begin(em[z].h, s, em[z].S, ld, n, false));
+      }
       for (int z = 0; z < cnt; ++z) {
         sc_handle hz = em[z].h;
-        if (amax_from_cut)
-          launch_free_amax_from_cut(s, ptr<double>(hz->cut), n, p_values[base + z], 0.0,
-                                    ptr<double>(hz->fscal));
-        SC_TRY(free_stats_begin(hz, s, em[z].S, ld, n, amax_from_cut));
         qs[z] = ptr<signed char>(hz->fq);
         ts[z] = ptr<float>(hz->ft32);
         ms[z] = ptr<unsigned>(hz->fwords);
       }
       launch_gemm_i8_sym_group(s, qs, ts, ms, cnt, n, em[0].h->tilemap_cur);
-      for (int z = 0; z < cnt; ++z) SC_TRY(free_stats_end(em[z].h, s, em[z].S, ld, n, false));
+      if (amax_from_cut) {
+        SC_TRY(free_group_end(fh, fitems, cnt, s));
+      } else {
+        for (int z = 0; z < cnt; ++z) SC_TRY(free_stats_end(em[z].h, s, em[z].S, ld, n, false));
+      }
     } else {
       launch_gemm_nt_group(s, dif, cnt, kEpiNone, 1);
     }

@@ -76,6 +76,8 @@ __device__ __forceinline__ void atomic_max_if_larger(unsigned long long* word, u
   if (v > cur) atomicMax(word, v);
 }
 
+constexpr int kFreeOvfWords = 80;  // (free_api.hip's kOvfWords: the overflow record behind M and count)
+
 // order-preserving map float -> unsigned (for atomicMax on values of either sign)
 __device__ __forceinline__ unsigned ordered_bits(float f) {
   const unsigned u = __float_as_uint(f);
@@ -125,15 +127,40 @@ __global__ __launch_bounds__(256) void k_free_absmax(const double* __restrict__ 
 // cut_i = rowmax(B)_i * p is what the threshold stage already holds.  `floor_value`: 1 when the
 // stage writes ones (binarisation, preserved diagonal).  Any upper bound of max|a| will do for
 // the quantiser (it only has to keep sigma |a| <= 32639); this one is attained.
-__global__ __launch_bounds__(256) void k_free_amax_from_cut(const double* __restrict__ cut, int n,
-                                                            double p, double floor_value,
-                                                            double* __restrict__ scal) {
+__device__ __forceinline__ void free_amax_from_cut_body(const double* __restrict__ cut, int n,
+                                                        double p, double floor_value,
+                                                        double* __restrict__ scal) {
   __shared__ double sm[4];
   double m = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, cut[i]);
   m = fr_block_max(m, sm);
   // (cut_i / p can round below the row maximum it came from: one part in 1e12 on top)
   if (threadIdx.x == 0) scal[0] = fmax(m / p * (1.0 + 1e-12), floor_value);
+}
+__global__ __launch_bounds__(256) void k_free_amax_from_cut(const double* __restrict__ cut, int n,
+                                                            double p, double floor_value,
+                                                            double* __restrict__ scal) {
+  free_amax_from_cut_body(cut, n, p, floor_value, scal);
+}
+// The start of the pipeline for a GROUP of matrices (AutoTune sweep, large members of a batch
+// group; blockIdx.y = member): workgroup 0 of a member turns its cut vector into max|a| and
+// clears the other scalars, the others clear its words (row maxima, candidate counts, overflow
+// record) -- one launch where every member had two fills and a reduction of its own.
+__global__ __launch_bounds__(256) void k_free_begin_g(const GroupOf<FreeItem> g, double floor_value) {
+  const FreeItem& a = g.s[blockIdx.y];
+  if (a.n <= 0) return;
+  if (blockIdx.x == 0) {
+    free_amax_from_cut_body(a.cut, a.n, a.p, floor_value, a.scal);
+    if (threadIdx.x < 3) a.scal[1 + threadIdx.x] = 0.0;
+    return;
+  }
+  const int nwords = 2 * a.n + kFreeOvfWords;
+  const int e = ((int)blockIdx.x - 1) * 1024 + 4 * threadIdx.x;
+  if (e + 3 < nwords) {
+    *reinterpret_cast<int4*>(a.words + e) = make_int4(0, 0, 0, 0);
+  } else {
+    for (int u = e; u < nwords && u < e + 4; ++u) a.words[u] = 0;
+  }
 }
 
 // ---------------------------------------------------------------- quantiser
@@ -143,7 +170,7 @@ __global__ __launch_bounds__(256) void k_free_amax_from_cut(const double* __rest
 // Also y1 = rowsum(A) (fp64, fixed order), R = sum |q| and its maximum.
 // (PROBE, tests/probes/quantize_probe.hip only: 1 = no atomicMax, 2 = no digits, 3 = no copy-out)
 template <int PROBE>
-__global__ __launch_bounds__(256) void k_free_quantize(
+__device__ __forceinline__ void free_quantize_body(
     const double* __restrict__ A, int n, int ld, signed char* __restrict__ Q, size_t pitch, int Kp,
     const double* __restrict__ scal, double* __restrict__ y1, double* __restrict__ R,
     unsigned long long* __restrict__ rmax_bits) {
@@ -210,6 +237,20 @@ __global__ __launch_bounds__(256) void k_free_quantize(
     R[row] = rsum;
     if (PROBE != 1) atomic_max_if_larger(rmax_bits, (unsigned long long)__double_as_longlong(rsum));
   }
+}
+template <int PROBE>
+__global__ __launch_bounds__(256) void k_free_quantize(
+    const double* __restrict__ A, int n, int ld, signed char* __restrict__ Q, size_t pitch, int Kp,
+    const double* __restrict__ scal, double* __restrict__ y1, double* __restrict__ R,
+    unsigned long long* __restrict__ rmax_bits) {
+  free_quantize_body<PROBE>(A, n, ld, Q, pitch, Kp, scal, y1, R, rmax_bits);
+}
+__global__ __launch_bounds__(256) void k_free_quantize_g(const GroupOf<FreeItem> g) {
+  const FreeItem& a = g.s[blockIdx.y];
+  if (a.n <= 0 || (int)blockIdx.x >= (a.n + 127) / 128 * 128) return;  // rows padded to a product tile
+  const int Kp = (a.n + 63) / 64 * 64;
+  free_quantize_body<0>(a.A, a.n, a.ld, a.Q, (size_t)2 * Kp, Kp, a.scal, a.y1, a.R,
+                        reinterpret_cast<unsigned long long*>(a.scal) + 2);
 }
 
 // ---------------------------------------------------------------- T = Q Q^T, integer MFMA
@@ -563,7 +604,7 @@ __device__ __forceinline__ void free_append(int row, int col, int cap, int* __re
 // One workgroup per stored tile (I, J): every entry is looked at once, as T[row][col] against
 // its row's threshold and -- off the diagonal tiles -- as T[col][row] (T is symmetric) against
 // its column's.  A wave reads whole 512-byte tile rows.
-__global__ __launch_bounds__(256) void k_t32_candidates(
+__device__ __forceinline__ void t32_candidates_body(
     const float* __restrict__ T32, int nt, int n, const unsigned* __restrict__ M,
     const double* __restrict__ R, const unsigned long long* __restrict__ rmax_bits, int cap,
     int* __restrict__ count, int* __restrict__ cand) {
@@ -613,6 +654,21 @@ __global__ __launch_bounds__(256) void k_t32_candidates(
     }
   }
 }
+__global__ __launch_bounds__(256) void k_t32_candidates(
+    const float* __restrict__ T32, int nt, int n, const unsigned* __restrict__ M,
+    const double* __restrict__ R, const unsigned long long* __restrict__ rmax_bits, int cap,
+    int* __restrict__ count, int* __restrict__ cand) {
+  t32_candidates_body(T32, nt, n, M, R, rmax_bits, cap, count, cand);
+}
+__global__ __launch_bounds__(256) void k_t32_candidates_g(const GroupOf<FreeItem> g, int cap) {
+  const FreeItem& a = g.s[blockIdx.y];
+  const int nt = (a.n + kI8Tile - 1) / kI8Tile;
+  if (a.n <= 0 || (int)blockIdx.x >= nt * (nt + 1) / 2) return;
+  t32_candidates_body(a.T32, nt, a.n, reinterpret_cast<const unsigned*>(a.words), a.R,
+                      reinterpret_cast<const unsigned long long*>(a.scal) + 2, cap, a.words + a.n,
+                      a.cand);
+}
+
 
 // ---------------------------------------------------------------- exact statistics of S
 // rowmax(S)_i = max over the candidates j of <A_i, A_j>, rowsum(S)_i = <A_i, y1>, y1 = A 1:
@@ -658,7 +714,7 @@ __device__ __forceinline__ void free_row_dots(const double* __restrict__ x,
   for (int c = 0; c < CNT; ++c) acc_out[c] = acc[c];
 }
 
-__global__ __launch_bounds__(256) void k_free_row_stats(
+__device__ __forceinline__ void free_row_stats_body(
     const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
     const int* __restrict__ count, const int* __restrict__ cand, int cap,
     double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
@@ -702,6 +758,18 @@ __global__ __launch_bounds__(256) void k_free_row_stats(
       if (e < 64) ovf[1 + e] = row;
     }
   }
+}
+__global__ __launch_bounds__(256) void k_free_row_stats(
+    const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
+    const int* __restrict__ count, const int* __restrict__ cand, int cap,
+    double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
+  free_row_stats_body(A, n, ld, y1, count, cand, cap, rowmax, rowsum, ovf);
+}
+__global__ __launch_bounds__(256) void k_free_row_stats_g(const GroupOf<FreeItem> g, int cap) {
+  const FreeItem& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.n) return;
+  free_row_stats_body(a.A, a.n, a.ld, a.y1, a.words + a.n, a.cand, cap, a.rowmax, a.rowsum,
+                      a.words + 2 * (size_t)a.n);
 }
 
 // ---------------------------------------------------------------- rows evaluated in full
@@ -841,6 +909,43 @@ void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const 
                            int* ovf) {
   hipLaunchKernelGGL(k_free_row_stats, dim3(n), dim3(256), 0, s, A, n, ld, y1, count, cand,
                      kFreeCapMax, rowmax, rowsum, ovf);
+}
+
+// ---- the same steps for a group of matrices (FreeItem per member, n = 0: idle)
+static GroupOf<FreeItem> free_pack(const FreeItem* items, int count, int* nmax) {
+  GroupOf<FreeItem> g;
+  memset(&g, 0, sizeof(g));
+  *nmax = 0;
+  for (int z = 0; z < count; ++z) {
+    g.s[z] = items[z];
+    *nmax = std::max(*nmax, items[z].n);
+  }
+  return g;
+}
+void launch_free_begin_group(hipStream_t s, const FreeItem* items, int count, double floor_value) {
+  int nmax;
+  const GroupOf<FreeItem> g = free_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  const int nwords = 2 * nmax + kFreeOvfWords;
+  hipLaunchKernelGGL(k_free_begin_g, dim3(1 + (nwords + 1023) / 1024, count), dim3(256), 0, s, g,
+                     floor_value);
+}
+void launch_free_quantize_group(hipStream_t s, const FreeItem* items, int count) {
+  int nmax;
+  const GroupOf<FreeItem> g = free_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  SC_OPT_IN_LDS(k_free_quantize_g, 2 * 65536);
+  hipLaunchKernelGGL(k_free_quantize_g, dim3(free_rows_padded(nmax), count), dim3(256),
+                     (size_t)2 * free_k_padded(nmax), s, g);
+}
+void launch_free_scan_stats_group(hipStream_t s, const FreeItem* items, int count) {
+  int nmax;
+  const GroupOf<FreeItem> g = free_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  const int nt = (nmax + kI8Tile - 1) / kI8Tile;
+  hipLaunchKernelGGL(k_t32_candidates_g, dim3(nt * (nt + 1) / 2, count), dim3(256), 0, s, g,
+                     kFreeCapMax);
+  hipLaunchKernelGGL(k_free_row_stats_g, dim3(nmax, count), dim3(256), 0, s, g, kFreeCapMax);
 }
 
 void launch_free_gather_rows(hipStream_t s, const double* A, int n, int ld, const int* rows,

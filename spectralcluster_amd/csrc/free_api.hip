@@ -81,6 +81,39 @@ int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, b
   return SC_OK;
 }
 
+// The same two pieces for a GROUP of matrices of ICASSP fronts (AutoTune sweep: 16 members of
+// one size): the begin step, quantiser, candidate scan and exact statistics of all members are
+// one launch each -- a member's own kernels of 20-100 us left most of the chip idle between
+// their tails, and 16 x 7 launches were 16 x 7 launch latencies.  The caller puts the digit
+// product (one grouped launch, or one per member) between the two.
+int free_group_begin(sc_handle* hs, const double* const* A, const double* const* cuts,
+                     const double* ps, int count, const int* lds, const int* ns, hipStream_t s,
+                     double floor_value, FreeItem* items) {
+  for (int z = 0; z < count; ++z) {
+    sc_handle h = hs[z];
+    const int n = ns[z], ld = lds[z];
+    SC_TRY(ensure_free(h, n));
+    items[z] = FreeItem{A[z], n, ld, ptr<signed char>(h->fq), ptr<float>(h->ft32),
+                        ptr<int>(h->fwords), ptr<double>(h->fscal), ptr<double>(h->fy1),
+                        ptr<double>(h->fR), ptr<int>(h->fcand), ptr<double>(h->rowmax),
+                        ptr<double>(h->rowsum), cuts[z], ps[z]};
+  }
+  launch_free_begin_group(s, items, count, floor_value);
+  launch_free_quantize_group(s, items, count);
+  return SC_OK;
+}
+int free_group_end(sc_handle* hs, const FreeItem* items, int count, hipStream_t s) {
+  launch_free_scan_stats_group(s, items, count);
+  SC_TRY(check_last(hs[0], "matrix-free diffuse launch"));
+  for (int z = 0; z < count; ++z) {
+    sc_handle h = hs[z];
+    SC_HIP(h, hipMemcpyAsync(h->h_free, items[z].words + 2 * (size_t)items[z].n,
+                             kOvfWords * sizeof(int), hipMemcpyDeviceToHost, s));
+    h->free_checked = false;
+  }
+  return SC_OK;
+}
+
 // The threshold + symmetrise pass can write the digits itself (rowops.hip, TsDigits): what it
 // needs before it runs -- the buffers, zeroed words, max|a| from the cut vector in fscal[0] ...
 int free_fused_prepare(sc_handle h, hipStream_t s, int n, const double* cut, double p,

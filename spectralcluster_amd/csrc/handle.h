@@ -330,6 +330,10 @@ bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequ
 // enqueue the statistics of S = A A^T (h->rowmax, h->rowsum) on h->stream; no synchronisation.
 // The overflow words travel to h->h_free behind them.
 // `have_amax`: h->fscal[0] already holds max|a| (or an upper bound of it) for this A
+int free_group_begin(sc_handle* hs, const double* const* A, const double* const* cuts,
+                     const double* ps, int count, const int* lds, const int* ns, hipStream_t s,
+                     double floor_value, struct FreeItem* items);
+int free_group_end(sc_handle* hs, const struct FreeItem* items, int count, hipStream_t s);
 int free_fused_prepare(sc_handle h, hipStream_t s, int n, const double* cut, double p,
                        double floor_value);
 int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax = false,

@@ -392,6 +392,25 @@ void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed 
 //  by one workgroup)
 void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
                         float* T32, unsigned* M, int* split_ws);
+// one member of a grouped run of the pipeline (AutoTune sweep, large members of a batch group)
+struct FreeItem {
+  const double* A;   // the symmetric matrix, row pitch ld
+  int n, ld;         // n = 0: idle member
+  signed char* Q;
+  float* T32;
+  int* words;        // M (n) | candidate counts (n) | overflow record (80)
+  double* scal;      // [0] max|a|, [2] max R
+  double* y1;
+  double* R;
+  int* cand;
+  double* rowmax;
+  double* rowsum;
+  const double* cut; // RowMax cut vector (max|a| = max cut / p) and its p
+  double p;
+};
+void launch_free_begin_group(hipStream_t s, const FreeItem* items, int count, double floor_value);
+void launch_free_quantize_group(hipStream_t s, const FreeItem* items, int count);
+void launch_free_scan_stats_group(hipStream_t s, const FreeItem* items, int count);
 void free_i8_split_plan(int n, int* tail_tiles, int* parts);
 size_t free_i8_split_bytes(int n);
 // the same product for `count` (<= kGroupMax) problems of one size in ONE launch

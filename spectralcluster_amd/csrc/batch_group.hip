@@ -914,11 +914,10 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
     }
     const bool own_cuts = !icassp;  // (RowMax cuts of the ICASSP front come from the blur's partials)
     if (own_cuts) {
-      for (int z = 0; z < cnt; ++z) {
-        if (cfg->threshold_type == SC_THRESHOLD_PERCENTILE)
-          launch_cut_percentile(s, fi[z].B1, n, ld, p_values[base + z], fi[z].cut,
-                                cfg->preserve_diagonal);
-        else
+      if (cfg->threshold_type == SC_THRESHOLD_PERCENTILE) {
+        launch_cut_percentile_group(s, fi, cnt, cfg->preserve_diagonal);  // (p_own per member)
+      } else {
+        for (int z = 0; z < cnt; ++z)
           launch_cut_from_rows(s, fi[z].B1, n, ld, p_values[base + z], fi[z].cut,
                                cfg->preserve_diagonal);
       }
@@ -928,9 +927,7 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
                                       cfg->preserve_diagonal, own_cuts);
     if (!icassp) {
       // no Diffuse: the row sums of the symmetrised matrix are the degrees
-      for (int z = 0; z < cnt; ++z)
-        launch_row_stats(s, fi[z].B2, n, ld, ptr<double>(em[z].h->rowmax),
-                         ptr<double>(em[z].h->rowsum));
+      launch_row_stats_group(s, fi, cnt);
     } else if (free_route) {
       // rowmax / rowsum of every member's S = A A^T without forming it: digits per member,
       // ONE launch for the digit products of all members, candidates + exact recheck per member

@@ -190,7 +190,7 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
   return __longlong_as_double((long long)b);
 }
 
-__global__ __launch_bounds__(256) void k_row_percentile_cut(
+__device__ __forceinline__ void row_percentile_cut_body(
     const double* __restrict__ in, int n, int ld, int zero_diag, int prev, int next,
     double gamma, double* __restrict__ cut, int keys_in_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long pkeys[];
@@ -269,6 +269,35 @@ __global__ __launch_bounds__(256) void k_row_percentile_cut(
     const double diff = b - a;
     cut[row] = gamma >= 0.5 ? b - diff * (1.0 - gamma) : a + diff * gamma;
   }
+}
+// numpy's "linear" quantile position for q = p (np.percentile(row, 100 p)): virtual index
+// (n - 1) q, its floor, the next rank and the interpolation weight (host and device: the same
+// IEEE double operations, no contraction)
+__host__ __device__ inline void percentile_position(int n, double p, int* prev, int* next,
+                                                    double* gamma) {
+  const double q = (p * 100.0) / 100.0;
+  const double vi = (double)(n - 1) * q;
+  *prev = (int)floor(vi);
+  *next = *prev + 1;
+  *gamma = vi - (double)*prev;
+  if (vi >= (double)(n - 1)) { *prev = n - 1; *next = n - 1; *gamma = 0.0; }
+  if (vi < 0.0) { *prev = 0; *next = 0; *gamma = 0.0; }
+}
+__global__ __launch_bounds__(256) void k_row_percentile_cut(
+    const double* __restrict__ in, int n, int ld, int zero_diag, int prev, int next,
+    double gamma, double* __restrict__ cut, int keys_in_lds) {
+  row_percentile_cut_body(in, n, ld, zero_diag, prev, next, gamma, cut, keys_in_lds);
+}
+// the members of a group (AutoTune sweep under the Turn-to-Diarize sequence: one size, one
+// p_percentile each) in one launch: B1 -> cut
+__global__ __launch_bounds__(256) void k_row_percentile_cut_g(const GroupOf<FrontItem> g,
+                                                              int zero_diag, int keys_in_lds) {
+  const FrontItem& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.n) return;
+  int prev, next;
+  double gamma;
+  percentile_position(a.n, a.p_own, &prev, &next, &gamma);
+  row_percentile_cut_body(a.B1, a.n, a.ldn, zero_diag, prev, next, gamma, a.cut, keys_in_lds);
 }
 
 // generic thresholding against a precomputed per-row cut (RowMax with preserved
@@ -574,7 +603,7 @@ __global__ __launch_bounds__(kRowThreads) void k_row_normalize(
 }
 
 // ---- row max + row sum of the (symmetric) refined matrix ----------------------
-__global__ __launch_bounds__(kRowThreads) void k_row_stats(
+__device__ __forceinline__ void row_stats_body(
     const double* __restrict__ in, int n, int ld, double* __restrict__ rowmax,
     double* __restrict__ rowsum) {
   __shared__ double sm[4];
@@ -596,6 +625,17 @@ __global__ __launch_bounds__(kRowThreads) void k_row_stats(
     rowmax[row] = m;
     rowsum[row] = s;
   }
+}
+__global__ __launch_bounds__(kRowThreads) void k_row_stats(
+    const double* __restrict__ in, int n, int ld, double* __restrict__ rowmax,
+    double* __restrict__ rowsum) {
+  row_stats_body(in, n, ld, rowmax, rowsum);
+}
+// ... of every member of a group: B2 -> rowmax, rowsum (the fields scaling_vectors_g reads)
+__global__ __launch_bounds__(kRowThreads) void k_row_stats_g(const GroupOf<FrontItem> g) {
+  const FrontItem& a = g.s[blockIdx.y];
+  if ((int)blockIdx.x >= a.n) return;
+  row_stats_body(a.B2, a.n, a.ldn, const_cast<double*>(a.rowmax), const_cast<double*>(a.rowsum));
 }
 
 // ---- scaling vectors of Op = diag(p) + diag(c) S diag(c)  ---------------------
@@ -755,14 +795,9 @@ void launch_cut_from_rows(hipStream_t s, const double* in, int n, int ld, double
 // cut[i] = np.percentile(row_i (diagonal zeroed if asked), 100 * p)
 void launch_cut_percentile(hipStream_t s, const double* in, int n, int ld, double p,
                            double* cut, int zero_diag) {
-  // numpy: q = (p * 100) / 100; virtual index (n - 1) q; floor / +1 / gamma
-  const double q = (p * 100.0) / 100.0;
-  const double vi = (double)(n - 1) * q;
-  int prev = (int)floor(vi);
-  int next = prev + 1;
-  double gamma = vi - (double)prev;
-  if (vi >= (double)(n - 1)) { prev = n - 1; next = n - 1; gamma = 0.0; }
-  if (vi < 0.0) { prev = 0; next = 0; gamma = 0.0; }
+  int prev, next;
+  double gamma;
+  percentile_position(n, p, &prev, &next, &gamma);
   const size_t bytes = (size_t)n * sizeof(unsigned long long);
   const int in_lds = bytes <= 128 * 1024;
   SC_OPT_IN_LDS(k_row_percentile_cut, 128 * 1024);
@@ -840,6 +875,24 @@ void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count,
   if (normalize_rows)
     hipLaunchKernelGGL(k_normalize_rows_g, dim3((nmax + 3) / 4, count), dim3(kRowThreads), 0, s,
                        g);
+}
+// Percentile cuts (p_own per member) and, after the threshold pass, row maxima / sums of B2 for
+// every member of a group in one launch each
+void launch_cut_percentile_group(hipStream_t s, const FrontItem* items, int count, int zero_diag) {
+  int nmax;
+  const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  const size_t bytes = (size_t)nmax * sizeof(unsigned long long);
+  const int in_lds = bytes <= 128 * 1024;
+  SC_OPT_IN_LDS(k_row_percentile_cut_g, 128 * 1024);
+  hipLaunchKernelGGL(k_row_percentile_cut_g, dim3(nmax, count), dim3(256), in_lds ? bytes : 0, s,
+                     g, zero_diag, in_lds);
+}
+void launch_row_stats_group(hipStream_t s, const FrontItem* items, int count) {
+  int nmax;
+  const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_row_stats_g, dim3(nmax, count), dim3(kRowThreads), 0, s, g);
 }
 void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,
                                        double p, double mult, int binarize, int symtype,

@@ -273,6 +273,8 @@ struct FrontItem {
 };
 void launch_front_begin_group(hipStream_t s, const FrontItem* items, int count,
                               bool normalize_rows);
+void launch_cut_percentile_group(hipStream_t s, const FrontItem* items, int count, int zero_diag);
+void launch_row_stats_group(hipStream_t s, const FrontItem* items, int count);
 bool blur_group_supported(int n_min, int radius);
 // grouped front of a batch (16 members per launch): from n = 256 on; its strips per row
 bool blur_group_front_supported(int n_min, int radius);

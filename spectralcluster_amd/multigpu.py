@@ -31,9 +31,9 @@ import numpy as np
 def cost_model(n: int) -> float:
   """Cost of one utterance of n samples inside a grouped batch (predict_batch(group=16), the
   execution the partition schedules), in microseconds on one MI355X.  Calibrated on measured
-  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r05i_cost_fit.txt: 58 us
-  at n=300, 80 at 650, 182 at 1600, 297 at 2048, 452 at 3000; non-negative least squares on
-  the relative error, 3 % per branch): a fixed per-utterance share of the group's launch
+  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r06c_cost_fit.txt: 57 us
+  at n=300, 80 at 650, 189 at 1600, 287 at 2047, 237 at 2048, 401 at 3000; non-negative least
+  squares on the relative error, 3 % per branch): a fixed per-utterance share of the group's launch
   chains, the O(n^2) passes, the O(n^3) product -- the fp64 Diffuse product below n=2048, the
   int8 digit product of the matrix-free route from there on (round 4), hence two branches.
   (Round 3's single cubic, calibrated on the explicit route, was 2x too high everywhere and
@@ -43,8 +43,8 @@ def cost_model(n: int) -> float:
   if n < 512.0:
     return 50.0 + 6.5e-5 * n * n
   if n < 2048.0:
-    return 69.7 + 1.154e-5 * n * n + 2.146e-8 * n * n * n
-  return 218.5 + 8.19e-9 * n * n * n
+    return 65.1 + 2.481e-5 * n * n + 1.361e-8 * n * n * n
+  return 94.6 + 3.441e-5 * n * n
 
 
 def lpt_assignment(sizes: typing.Sequence[int], world: int) -> typing.List[typing.List[int]]:

@@ -243,8 +243,9 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
     m.front.symmetric = true;
     m.front.folded_rownorm = true;
     // Large members take the matrix-free Diffuse (free_api.hip): their n^3 product is most of
-    // a batch's GEMM time (78 % of config 5's Diffuse flops sit in utterances of n >= 2048)
-    m.free_op = free_diffuse_wanted(lead, cfg, n, make_eig_request(cfg)) &&
+    // a batch's GEMM time (78 % of config 5's Diffuse flops sit in utterances of n >= 2048;
+    // members switch from n = 1536 on: free_diffuse_wanted)
+    m.free_op = free_diffuse_wanted(lead, cfg, n, make_eig_request(cfg), true) &&
                 cfg->soft_multiplier >= 0.0 && cfg->soft_multiplier <= 1.0 &&
                 cfg->p_percentile > 0.0;
     if (m.free_op) {

@@ -14,7 +14,8 @@ extern "C" int sc_set_diffuse_mode(sc_handle h, int mode) {
   return SC_OK;
 }
 
-bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequest& rq) {
+bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequest& rq,
+                         bool in_group) {
   // the call's own choice, else the handle's, else the process default
   const int mode = cfg->diffuse_mode == 1 || cfg->diffuse_mode == 2
                        ? cfg->diffuse_mode
@@ -24,7 +25,11 @@ bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequ
   // i32 accumulators of the digit products hold K <= 65536
   if (n <= kDenseMax || n > 65536 || wants_full_spectrum(rq)) return false;
   if (mode == 2) return true;
-  return n >= sw::diffuse_free_min_n();
+  // (a single call is a chain of launch latencies up to n ~ 2000, where the route's extra
+  //  launches cost what its smaller product saves: 0.80 / 0.81 ms at n = 1792, 0.90 / 0.87 at
+  //  2048; in a group the latencies are shared and the work decides: 6044-6315 utterances/s
+  //  on config 5 with the members from 1536 on, 5782-5913 from 2048 on -- profiles/r06e)
+  return n >= (in_group ? sw::diffuse_free_min_n_group() : sw::diffuse_free_min_n());
 }
 
 int ensure_free(sc_handle h, int n) {

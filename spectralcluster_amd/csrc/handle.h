@@ -326,7 +326,8 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
 // matrix-free Diffuse (free_api.hip)
 // does this call take the matrix-free route for a Diffuse whose output only feeds
 // RowWiseNormalize / the Laplacian?  (mode of the handle, problem size, request)
-bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequest& rq);
+bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequest& rq,
+                         bool in_group = false);
 // enqueue the statistics of S = A A^T (h->rowmax, h->rowsum) on h->stream; no synchronisation.
 // The overflow words travel to h->h_free behind them.
 // `have_amax`: h->fscal[0] already holds max|a| (or an upper bound of it) for this A

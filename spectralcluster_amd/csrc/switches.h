@@ -77,6 +77,12 @@ inline int diffuse_free_min_n() {
       getenv("SC_DIFFUSE_FREE_MIN_N") ? atoi(getenv("SC_DIFFUSE_FREE_MIN_N")) : 2048;
   return v;
 }
+// (members of a grouped batch: the same switch, default 1536)
+inline int diffuse_free_min_n_group() {
+  static const int v =
+      getenv("SC_DIFFUSE_FREE_MIN_N") ? atoi(getenv("SC_DIFFUSE_FREE_MIN_N")) : 1536;
+  return v;
+}
 // SC_SWEEP_ONE_BY_ONE=1: an AutoTune level as separate sc_eig_ncluster calls (what a level
 // falls back to when member arenas do not fit or a value leaves the grouped path)
 inline bool sweep_one_by_one() {

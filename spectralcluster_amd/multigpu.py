@@ -31,20 +31,21 @@ import numpy as np
 def cost_model(n: int) -> float:
   """Cost of one utterance of n samples inside a grouped batch (predict_batch(group=16), the
   execution the partition schedules), in microseconds on one MI355X.  Calibrated on measured
-  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r06c_cost_fit.txt: 57 us
-  at n=300, 80 at 650, 189 at 1600, 287 at 2047, 237 at 2048, 401 at 3000; non-negative least
-  squares on the relative error, 3 % per branch): a fixed per-utterance share of the group's launch
-  chains, the O(n^2) passes, the O(n^3) product -- the fp64 Diffuse product below n=2048, the
-  int8 digit product of the matrix-free route from there on (round 4), hence two branches.
+  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r06g_cost_fit.txt: 55 us
+  at n=300, 77 at 650, 121 at 1200, 163 at 1535, 177 at 1536, 238 at 2000, 407 at 3000;
+  non-negative least squares on the relative error, 1 % per branch): a fixed per-utterance
+  share of the group's launch chains and the O(n^2) passes -- the cubic term of the fp64
+  Diffuse product no longer shows below n=1536, and from there on members take the
+  matrix-free route (round 4), hence two branches.
   (Round 3's single cubic, calibrated on the explicit route, was 2x too high everywhere and
-  had no kink at 2048: the 8 shares of config 5 came out 10 % apart.  Round 2's n^3 + 64 n^2
-  put a factor 900 between n=300 and n=3000 where the measured factor is 8.)"""
+  had no kink: the 8 shares of config 5 came out 10-14 % apart.  Round 2's n^3 + 64 n^2 put a
+  factor 900 between n=300 and n=3000 where the measured factor is 7.)"""
   n = float(n)
   if n < 512.0:
     return 50.0 + 6.5e-5 * n * n
-  if n < 2048.0:
-    return 65.1 + 2.481e-5 * n * n + 1.361e-8 * n * n * n
-  return 94.6 + 3.441e-5 * n * n
+  if n < 1536.0:
+    return 58.3 + 4.429e-5 * n * n
+  return 97.3 + 3.437e-5 * n * n
 
 
 def lpt_assignment(sizes: typing.Sequence[int], world: int) -> typing.List[typing.List[int]]:

@@ -15,7 +15,7 @@ import spectralcluster_amd as sca  # noqa: E402
 from bench import blobs  # noqa: E402
 
 c = sca.configs.icassp2018_clusterer
-sizes = [300, 450, 650, 900, 1200, 1600, 2000, 2047, 2048, 2200, 2500, 2750, 3000]
+sizes = [300, 450, 650, 900, 1200, 1400, 1535, 1536, 1700, 2000, 2250, 2500, 2750, 3000]
 per = []
 for n in sizes:
   xs = [blobs(n, 256, 2 + i % 6, seed=1000 + i)[0] for i in range(64)]
@@ -40,8 +40,8 @@ def fit(ns, ts, what):
   print("COEF", what, repr(list(coef)))
 
 
-# (members of n >= 2048 take the matrix-free Diffuse inside the grouped front: two branches)
-lo = [(n, t) for n, t in zip(sizes, per) if 512 <= n < 2048]
-hi = [(n, t) for n, t in zip(sizes, per) if n >= 2048]
-fit([n for n, _ in lo], [t for _, t in lo], "512 <= n < 2048")
-fit([n for n, _ in hi], [t for _, t in hi], "n >= 2048")
+# (members of n >= 1536 take the matrix-free Diffuse inside the grouped front: two branches)
+lo = [(n, t) for n, t in zip(sizes, per) if 512 <= n < 1536]
+hi = [(n, t) for n, t in zip(sizes, per) if n >= 1536]
+fit([n for n, _ in lo], [t for _, t in lo], "512 <= n < 1536")
+fit([n for n, _ in hi], [t for _, t in hi], "n >= 1536")

@@ -290,7 +290,19 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
     if (nf > 0) {
       SC_TRY(free_group_begin(fh, mats, cuts, ps, nf, ll, nn, s,
                               (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0, fitems));
-      for (int q = 0; q < nf; ++q) SC_TRY(free_product(fh[q], s, nn[q]));
+      {  // the digit products of all of them: one launch (blockIdx.y = member)
+        const signed char* qs[kGroupMax];
+        float* ts[kGroupMax];
+        unsigned* ms[kGroupMax];
+        const int2* tms[kGroupMax];
+        for (int q = 0; q < nf; ++q) {
+          qs[q] = ptr<signed char>(fh[q]->fq);
+          ts[q] = ptr<float>(fh[q]->ft32);
+          ms[q] = ptr<unsigned>(fh[q]->fwords);
+          tms[q] = fh[q]->tilemap_cur;
+        }
+        launch_gemm_i8_sym_group(s, qs, ts, ms, nf, nn, tms);
+      }
       SC_TRY(free_group_end(fh, fitems, nf, s));
     }
   }
@@ -958,7 +970,12 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
         ts[z] = ptr<float>(hz->ft32);
         ms[z] = ptr<unsigned>(hz->fwords);
       }
-      launch_gemm_i8_sym_group(s, qs, ts, ms, cnt, n, em[0].h->tilemap_cur);
+      {
+        int nn[kGroupMax];
+        const int2* tms[kGroupMax];
+        for (int z = 0; z < cnt; ++z) { nn[z] = n; tms[z] = em[0].h->tilemap_cur; }
+        launch_gemm_i8_sym_group(s, qs, ts, ms, cnt, nn, tms);
+      }
       if (amax_from_cut) {
         SC_TRY(free_group_end(fh, fitems, cnt, s));
       } else {

@@ -522,16 +522,21 @@ __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym(
 // Grouped form (AutoTune sweep, batch_group.hip): blockIdx.y picks one of up to kGroupMax
 // problems of the same size; the tiles of all of them fill the chip where one problem's 528
 // (n = 4096) leave the third round of workgroups nearly empty.
+// (members may differ in size -- the large members of a batch group: a product of n = 1536 is
+//  78 tiles, a third of the chip, on its own)
 struct I8GroupItem {
   const signed char* Q;
   float* T32;
   unsigned* M;
+  const int2* tilemap;
+  int n;
 };
-__global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym_g(
-    const GroupOf<I8GroupItem> g, size_t pitch, int nstages, const int2* __restrict__ tilemap,
-    int nt, int n) {
+__global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym_g(const GroupOf<I8GroupItem> g) {
   const I8GroupItem& a = g.s[blockIdx.y];
-  gemm_i8_sym_body<0>(a.Q, pitch, nstages, tilemap, 0, a.T32, nt, n, a.M, nullptr,
+  const int nt = (a.n + kI8Tile - 1) / kI8Tile;
+  if (a.n <= 0 || (int)blockIdx.x >= nt * (nt + 1) / 2) return;
+  const int Kp = (a.n + 63) / 64 * 64;
+  gemm_i8_sym_body<0>(a.Q, (size_t)2 * Kp, Kp / 64, a.tilemap, 0, a.T32, nt, a.n, a.M, nullptr,
                       I8Split{0, 1, nullptr});
 }
 
@@ -883,17 +888,20 @@ void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* 
 }
 
 void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
-                              unsigned* const* M, int count, int n, const int2* tilemap) {
-  const int nt = (n + kI8Tile - 1) / kI8Tile;
-  const int tiles = nt * (nt + 1) / 2;
-  const int Kp = free_k_padded(n);
+                              unsigned* const* M, int count, const int* ns,
+                              const int2* const* tilemaps) {
   const int lds = kI8Buffers * kI8StageBytes;
   SC_OPT_IN_LDS(k_gemm_i8_sym_g, lds);
   GroupOf<I8GroupItem> g;
   memset(&g, 0, sizeof(g));
-  for (int z = 0; z < count; ++z) g.s[z] = I8GroupItem{Q[z], T32[z], M[z]};
-  hipLaunchKernelGGL(k_gemm_i8_sym_g, dim3(tiles, count), dim3(kI8Threads), lds, s, g,
-                     (size_t)2 * Kp, Kp / 64, tilemap, nt, n);
+  int tiles = 0;
+  for (int z = 0; z < count; ++z) {
+    g.s[z] = I8GroupItem{Q[z], T32[z], M[z], tilemaps[z], ns[z]};
+    const int nt = (ns[z] + kI8Tile - 1) / kI8Tile;
+    tiles = std::max(tiles, nt * (nt + 1) / 2);
+  }
+  if (tiles == 0) return;
+  hipLaunchKernelGGL(k_gemm_i8_sym_g, dim3(tiles, count), dim3(kI8Threads), lds, s, g);
 }
 
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,

@@ -417,7 +417,8 @@ void free_i8_split_plan(int n, int* tail_tiles, int* parts);
 size_t free_i8_split_bytes(int n);
 // the same product for `count` (<= kGroupMax) problems of one size in ONE launch
 void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
-                              unsigned* const* M, int count, int n, const int2* tilemap);
+                              unsigned* const* M, int count, const int* ns,
+                              const int2* const* tilemaps);
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,
                            const double* R, const double* scal, int* count, int* cand);
 void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const double* y1,

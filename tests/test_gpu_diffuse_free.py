@@ -206,6 +206,35 @@ def test_routes_agree_at_ragged_sizes(n, lap):
   assert so.adjusted_rand_index(out[FREE][0], out[EXPLICIT][0]) == 1.0
 
 
+@pytest.mark.parametrize("binarize,preserve,sym", [(True, False, "Max"), (False, True, "Average"),
+                                                   (True, True, "Average")])
+def test_routes_agree_with_binarisation_and_preserved_diagonal(binarize, preserve, sym):
+  """The digit-writing threshold pass with the options that put exact ones into the matrix
+  (max|a| is then floored at 1) and with the Average symmetrisation: both routes, same input."""
+  n = 1390
+  x = so.blobs(n, 64, 4, seed=31)
+  opts = sca.RefinementOptions(
+      gaussian_blur_sigma=1, p_percentile=0.9, thresholding_soft_multiplier=0.01,
+      thresholding_type=sca.ThresholdType.RowMax, thresholding_with_binarization=binarize,
+      thresholding_preserve_diagonal=preserve, symmetrize_type=getattr(sca.SymmetrizeType, sym),
+      refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
+  out = {}
+  for mode in (FREE, EXPLICIT):
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=10, refinement_options=opts,
+                              laplacian_type=LAP[4])
+    c.diffuse_mode = mode
+    labels = c.predict(x)
+    dg = c.last_diag
+    assert dg.diffuse_path in ((_lib.DIFFUSE_PATH_FREE, _lib.DIFFUSE_PATH_FREE_THEN_EXPLICIT)
+                               if mode == FREE else (_lib.DIFFUSE_PATH_EXPLICIT,))
+    out[mode] = (labels, dg.n_clusters_raw, dg.max_delta, c.consumed_eigenvalues())
+  assert out[FREE][1] == out[EXPLICIT][1]
+  np.testing.assert_allclose(out[FREE][2], out[EXPLICIT][2], rtol=1e-6)
+  wf, wx = out[FREE][3], out[EXPLICIT][3]
+  assert np.max(np.abs(wf - wx)) < 2e-6 * np.abs(wx).max()
+  assert so.adjusted_rand_index(out[FREE][0], out[EXPLICIT][0]) == 1.0
+
+
 def test_stage_eig_after_a_matrix_free_predict():
   """The matrix-free operator is a property of ONE solve: a stage call on the same handle right
   after such a predict() solves the matrix it is given (the flag used to outlive the call)."""

@@ -8,11 +8,14 @@
 //     rowmax(S)_i    = max_j <A_i, A_j>   the one quantity that is not a matrix-vector product.
 // rowmax(S) is found without the fp64 n^3 product:
 //   1. k_free_quantize   A -> 15-bit fixed point q = rint(sigma a), sigma = 32639 / max|a|, split
-//                        into two signed 8-bit digits q = 256 h + l;
+//                        into two signed 8-bit digits q = 256 h + l  (a single ICASSP call never
+//                        runs it: its threshold + symmetrise pass writes the digits itself,
+//                        rowops.hip k_threshold_symmetrize_digits + k_free_partials_reduce);
 //   2. k_gemm_i8_sym     T = Q Q^T EXACTLY (integer MFMA, v_mfma_i32_32x32x32_i8: hh, hl + lh and
 //                        ll products in three i32 accumulators), upper-triangle tiles, stored as
-//                        fp32;
-//   3. k_t32_rowmax / k_t32_candidates   row maxima M_i of T and every j with
+//                        fp32, row maxima M_i of T from its epilogue; the last tiles mod #CUs
+//                        are cut along K and finished by k_i8_tail_finish;
+//   3. k_t32_candidates  every j with
 //                        T_ij >= M_i - slack_i, where slack_i is a PROVEN bound: with
 //                        sigma a_ik = q_ik + d_ik, |d_ik| <= 1/2 (+ one fp64 rounding),
 //                        sigma^2 S_ij - T_ij = sum_k (q_ik d_jk + d_ik q_jk + d_ik d_jk), so
@@ -27,6 +30,8 @@
 //
 // Integer arithmetic makes the bound a statement about the QUANTISER alone: no assumption
 // about the accumulation order or internal precision of the matrix core enters it.
+// Every step also exists for a GROUP of matrices (k_*_g, blockIdx.y = member: AutoTune sweep,
+// the large members of a batch group).
 #include <algorithm>
 #include <cstring>
 #include <mutex>

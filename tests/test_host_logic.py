@@ -562,6 +562,19 @@ def test_host_general_eig_vs_numpy():
       assert np.abs(np.linalg.norm(v, axis=0) - 1.0).max() < 1e-13 * m
 
 
+def test_cost_model_matches_its_calibration_record():
+  """multigpu.cost_model against the measured per-utterance times it was fitted on
+  (profiles/r06g_cost_fit.txt, written by tests/probes/cost_model_fit.py on the GPU box):
+  the code and the record the docs cite must not drift apart."""
+  import re
+  path = os.path.join(ROOT, "profiles", "r06g_cost_fit.txt")
+  rows = [(int(m.group(1)), float(m.group(2)))
+          for m in (re.match(r"n=(\d+): ([0-9.]+) us", line) for line in open(path)) if m]
+  assert len(rows) >= 12
+  for n, measured in rows:
+    assert abs(multigpu.cost_model(n) / measured - 1.0) < 0.03, (n, measured)
+
+
 def test_value_error_bound_holds_for_rayleigh_ritz():
   """The stopping rule's bound (residual, or Kato-Temple where the neighbours fence a Ritz value
   off) against the TRUE error of Rayleigh-Ritz values: random subspaces of matrices with

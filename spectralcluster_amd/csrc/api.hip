@@ -731,6 +731,16 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
     symmetric = resume->symmetric;
     folded_rownorm = resume->folded_rownorm;
     which = resume->scratch == bufs[0] ? 0 : 1;
+    if (resume->free_op) {
+      // the front left A, not S = A A^T (a matrix-free member of a batch group or sweep handed
+      // back by the lockstep solve): sym_topk has to apply it twice, and its first host sync
+      // looks at the rows the candidate search could not prune (h_free came back behind the
+      // group's statistics; free_group_end left free_checked false)
+      h->free_on = true;
+      h->free_lap = cfg->laplacian_type;
+      h->free_rownorm = resume->folded_rownorm ? 1 : 0;
+      h->free_checked = false;  // (the stage timers of the statistics belong to the front)
+    }
   }
   for (int i = 0; i < (resume ? 0 : cfg->n_ops); ++i) {
     const int op = cfg->ops[i];

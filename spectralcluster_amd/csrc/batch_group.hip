@@ -257,6 +257,7 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
       dif[z].n = 0;          // idle in the grouped fp64 product
       m.front.matrix = f.B2;  // the thresholded + symmetrised A stays the operand
       m.front.scratch = f.B1;
+      m.front.free_op = true;  // (a hand-back resumes on the two-pass operator: api.hip)
     }
   }
   launch_front_begin_group(s, fi, count, true);
@@ -340,7 +341,8 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
   if (ne > 0) SC_TRY(sym_topk_group(lead, em, ne));
   for (int e = 0; e < ne; ++e) {
     // a matrix-free member with rows the candidate search could not prune: the single-call
-    // path evaluates those rows exactly (its overflow words came back with the solver's syncs)
+    // path evaluates those rows exactly (its overflow words came back with the solver's syncs;
+    // eig_ncluster_impl's resume branch turns the two-pass operator back on: front.free_op)
     if (em[e].free_op && em[e].status == 0 && em[e].h->h_free[0] != 0) em[e].status = 1;
   }
   const double t2 = trace ? now_us() : 0.0;
@@ -960,7 +962,10 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
         }
         int nn[kGroupMax], ll[kGroupMax];
         for (int z = 0; z < cnt; ++z) { nn[z] = n; ll[z] = ld; }
-        SC_TRY(free_group_begin(fh, mats, cuts, p_values + base, cnt, ll, nn, s, 0.0, fitems));
+        // (floor 1 when the pass writes ones: the same expression as the single call and the
+        //  grouped batch front; grouped_front_covers() has excluded a preserved diagonal)
+        SC_TRY(free_group_begin(fh, mats, cuts, p_values + base, cnt, ll, nn, s,
+                                (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0, fitems));
       } else {
         for (int z = 0; z < cnt; ++z) SC_TRY(free_stats_begin(em[z].h, s, em[z].S, ld, n, false));
       }

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_free_begin_g(const GroupOf<FreeItem> g,
 template <int PROBE>
 __device__ __forceinline__ void free_quantize_body(
     const double* __restrict__ A, int n, int ld, signed char* __restrict__ Q, size_t pitch, int Kp,
-    const double* __restrict__ scal, double* __restrict__ y1, double* __restrict__ R,
+    double* scal, double* __restrict__ y1, double* __restrict__ R,
     unsigned long long* __restrict__ rmax_bits) {
   extern __shared__ __attribute__((aligned(16))) signed char qimg[];  // the row's digit image
   __shared__ double sm[4];
@@ -218,6 +218,9 @@ __device__ __forceinline__ void free_quantize_body(
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
         double qd = rint(e[w] * sigma);
+        // max|a| in scal[0] is an upper bound by construction; should a value exceed it after all,
+        // the |d| <= 1/2 premise of the slack is gone: scal[3] sends the call to the explicit product
+        if (fabs(qd) > 32639.0) scal[3] = 1.0;
         qd = fmin(fmax(qd, -32639.0), 32639.0);  // (NaN -> -32639: such a row is flagged later)
         const int q = (int)qd;
         const int h = (q + 128) >> 8;             // floor((q + 128) / 256): l in [-128, 127]
@@ -246,7 +249,7 @@ __device__ __forceinline__ void free_quantize_body(
 template <int PROBE>
 __global__ __launch_bounds__(256) void k_free_quantize(
     const double* __restrict__ A, int n, int ld, signed char* __restrict__ Q, size_t pitch, int Kp,
-    const double* __restrict__ scal, double* __restrict__ y1, double* __restrict__ R,
+    double* scal, double* __restrict__ y1, double* __restrict__ R,
     unsigned long long* __restrict__ rmax_bits) {
   free_quantize_body<PROBE>(A, n, ld, Q, pitch, Kp, scal, y1, R, rmax_bits);
 }
@@ -632,6 +635,10 @@ __device__ __forceinline__ void t32_candidates_body(
   for (int rg = 0; rg < 16; ++rg)
     tv[rg] = *reinterpret_cast<const float4*>(tile + (8 * rg + (threadIdx.x >> 5)) * kI8Tile + c4);
   const double Rmax = __longlong_as_double((long long)*rmax_bits);
+  // (rmax_bits[1] = scal[3]: a quantiser had to clamp a finite value -- the proven slack does not
+  //  hold for this matrix; the overflow count goes past anything the exact-row route accepts, so
+  //  the host forms S = A A^T explicitly.  ovf = count + n.)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && rmax_bits[1] != 0ull) atomicMax(count + n, 1 << 20);
   if (threadIdx.x < 128) {
     const int row = r0 + threadIdx.x;
     thrI[threadIdx.x] = row < n ? free_threshold(ordered_value(M[row]), R[row], Rmax, n) : INFINITY;

@@ -282,6 +282,9 @@ struct FrontResult {
   double* scratch = nullptr;
   int ld = 0;
   bool symmetric = false, folded_rownorm = false;
+  // matrix-free Diffuse: `matrix` is the symmetric A BEFORE Diffuse (the operator applies it
+  // twice), the row statistics of S = A A^T are in the handle, its overflow record in h_free
+  bool free_op = false;
 };
 EigRequest make_eig_request(const sc_config* cfg);
 int upload_blur_weights(sc_handle h, const sc_config* cfg);  // into h->blurw, on h->stream

@@ -334,7 +334,8 @@ struct TsDigits {
   signed char* Q;      // digits, row pitch `pitch` bytes
   size_t pitch;
   int nblk;            // 64-column blocks per row
-  const double* scal;  // [0] = max |a| (known from the cut vector before this pass)
+  double* scal;        // [0] = max |a| (known from the cut vector before this pass); [3] set when
+                       // a finite value had to be clamped after all (diffuse_free.hip)
   double* ypart;       // [block * 64 nblk + row] sum of a  (a tile's 64 partials are contiguous:
   int* rpart;          // [block * 64 nblk + row] sum of |q|   whole lines leave the L2)
 };
@@ -346,6 +347,7 @@ __device__ __forceinline__ void ts_digits(const TsDigits& dg, double sigma, int 
 #pragma unroll
   for (int w = 0; w < 2; ++w) {  // (the quantiser's arithmetic, word for word)
     double qd = rint(e[w] * sigma);
+    if (fabs(qd) > 32639.0) dg.scal[3] = 1.0;
     qd = fmin(fmax(qd, -32639.0), 32639.0);
     const int q = (int)qd;
     const int h = (q + 128) >> 8;
@@ -821,7 +823,7 @@ void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, i
 // round_up(n, 128) rows of `pitch` = 2 round_up(n, 64) bytes, the partials round_up(n, 64) rows
 void launch_threshold_symmetrize_digits(hipStream_t s, const double* in, double* out, int n, int ld,
                                         const double* cut, double mult, int binarize, int symtype,
-                                        int preserve_diag, signed char* Q, const double* scal,
+                                        int preserve_diag, signed char* Q, double* scal,
                                         double* ypart, int* rpart) {
   const int t = (n + kTsTile - 1) / kTsTile;
   const size_t pitch = (size_t)2 * t * kTsTile;

@@ -124,7 +124,7 @@ void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, i
 // ... + the digits and row partials of the matrix-free Diffuse's quantiser (rowops.hip)
 void launch_threshold_symmetrize_digits(hipStream_t s, const double* in, double* out, int n, int ld,
                                         const double* cut, double mult, int binarize, int symtype,
-                                        int preserve_diag, signed char* Q, const double* scal,
+                                        int preserve_diag, signed char* Q, double* scal,
                                         double* ypart, int* rpart);
 void launch_free_partials_reduce(hipStream_t s, const double* ypart, const int* rpart, int n,
                                  double* y1, double* R, double* scal);

@@ -106,6 +106,23 @@ got = c.predict(x)
 w = c.consumed_eigenvalues()
 assert np.max(np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-12)) < 1e-5
 assert so.adjusted_rand_index(got, want) == 1.0
+if os.environ.get("SC_KMEANS_SINGLE"):
+  # every member of a grouped batch is handed back after its front (the lockstep k-means chain
+  # is switched off): the large ones took the matrix-free Diffuse and must be resumed on the
+  # two-pass operator (FrontResult.free_op)
+  from spectralcluster_amd import _lib
+  utts = [so.blobs(m, 48, 4, seed=m) for m in (1650, 700, 2100)]
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=12, refinement_options=opts,
+                            laplacian_type=sca.LaplacianType.GraphCut)
+  got = c.predict_batch(utts, group=8)
+  bd = c.last_batch_diags
+  for i, u in enumerate(utts):
+    want = c.predict(u)
+    assert bd[i].n_clusters_raw == c.last_diag.n_clusters_raw, i
+    assert abs(bd[i].max_delta - c.last_diag.max_delta) <= 1e-6 * abs(c.last_diag.max_delta), i
+    assert np.array_equal(got[i], want), i
+    if u.shape[0] >= 1536:
+      assert bd[i].diffuse_path in (_lib.DIFFUSE_PATH_FREE, _lib.DIFFUSE_PATH_FREE_THEN_EXPLICIT)
 print("ALTERNATE_PATH_OK")
 """
 

@@ -106,3 +106,41 @@ def test_adopted_eigenvectors_equal_a_fresh_evaluation(n, lap):
   assert handle.lib.sc_sweep_adopt(handle.raw, c.build_config(0.61), 0, dg) == _lib.SC_ERR_UNSUPPORTED
   c._upload(handle, x)  # a new affinity: nothing of the old sweep may be adopted
   assert handle.lib.sc_sweep_adopt(handle.raw, c.build_config(ps[1]), 1, dg) == _lib.SC_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("n", [2100])
+def test_sweep_with_binarisation_on_both_diffuse_routes(n):
+  """thresholding_with_binarization puts exact ones into the thresholded matrix: max|a| of the
+  matrix-free route's quantiser is floored at 1 (the sweep once passed a floor of 0, so that
+  sigma * 1 overflowed the 15-bit digits and was clamped silently -- ADVICE r4).  Every value of
+  the level must report on the matrix-free route what the explicit fp64 product reports, and what
+  a single evaluation reports."""
+  from spectralcluster_amd import _lib
+  x = so.blobs(n, 64, 5, seed=n)
+  opts = sca.RefinementOptions(
+      gaussian_blur_sigma=1, p_percentile=0.95, thresholding_soft_multiplier=0.01,
+      thresholding_with_binarization=True,
+      refinement_sequence=sca.ICASSP2018_REFINEMENT_SEQUENCE)
+  ps = [float(p) for p in np.linspace(0.6, 0.95, 6)]
+  out = {}
+  for mode in (1, 2):
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=12, refinement_options=opts,
+                              laplacian_type=sca.LaplacianType.GraphCut)
+    c.diffuse_mode = mode
+    handle = c._handle()
+    c._upload(handle, x)
+    diags = c._eig_sweep(handle, ps)
+    for p, d in zip(ps, diags):
+      one = c._eig_resident(handle, p)
+      assert d.n_clusters_raw == one.n_clusters_raw, (mode, p)
+      assert abs(d.max_delta - one.max_delta) <= 1e-6 * abs(one.max_delta), (mode, p)
+      want = (_lib.DIFFUSE_PATH_EXPLICIT,) if mode == 1 else (
+          _lib.DIFFUSE_PATH_FREE, _lib.DIFFUSE_PATH_FREE_THEN_EXPLICIT)
+      assert d.diffuse_path in want, (mode, p, d.diffuse_path)
+    out[mode] = diags
+  for p, de, df in zip(ps, out[1], out[2]):
+    assert de.n_clusters_raw == df.n_clusters_raw, p
+    np.testing.assert_allclose(df.max_delta, de.max_delta, rtol=1e-6)
+    we, wf = de.eigenvalue_array(), df.eigenvalue_array()
+    idx = so.consumed_eigen_indices(n, 12, False, we, 1e-2)
+    np.testing.assert_allclose(wf[idx], we[idx], rtol=2e-6, atol=2e-6 * np.abs(we).max())

@@ -205,3 +205,30 @@ def test_config5_batch512_grouped_vs_reference():
       bad.append(i)
   assert not bad, bad
   assert worst < 1e-5, worst
+
+
+def test_matrix_free_member_handed_back_resumes_on_its_two_pass_operator():
+  """A large member of a batch group (n >= 1536) takes the matrix-free Diffuse: its front leaves
+  A, not S = A A^T.  When such a member leaves the lockstep path AFTER its front (here: 40
+  clusters wanted, beyond the 32 the k-means chain holds) the single-call solver resumes from
+  that front and must apply A twice -- it once solved diag(p) + diag(c) A diag(c) with the
+  scaling vectors of S, silently.  Labels, eigenvalues and eigengap must be those
+  of the member's own predict() call."""
+  from spectralcluster_amd import _lib
+  utts = [so.blobs(n, 48, 5, seed=n) for n in (1700, 600, 2250, 1990)]
+  c = icassp(min_clusters=40, max_clusters=12, laplacian_type=sca.LaplacianType.GraphCut)
+  got = c.predict_batch(utts, group=8)
+  diags = c.last_batch_diags
+  for i, u in enumerate(utts):
+    want = c.predict(u)
+    one = c.last_diag
+    assert diags[i].n_clusters == 40 and one.n_clusters == 40
+    assert diags[i].n_clusters_raw == one.n_clusters_raw, i
+    if u.shape[0] >= 1536:
+      assert diags[i].diffuse_path in (_lib.DIFFUSE_PATH_FREE,
+                                       _lib.DIFFUSE_PATH_FREE_THEN_EXPLICIT), i
+    w, w1 = diags[i].eigenvalue_array(), one.eigenvalue_array()
+    idx = so.consumed_eigen_indices(u.shape[0], 12, False, w1, 1e-2)
+    np.testing.assert_allclose(w[idx], w1[idx], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(diags[i].max_delta, one.max_delta, rtol=1e-6)
+    assert so.adjusted_rand_index(got[i], want) == 1.0, i

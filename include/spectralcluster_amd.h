@@ -100,7 +100,13 @@ enum {
   /* block Lanczos gave up (sc_diag.eig_fallback says why): values as above and the vectors by
    * inverse iteration on the tridiagonal form + the Householder back-transform.  Always
    * returns, like np.linalg.eig (utils.py:59) */
-  SC_EIG_PATH_DENSE_FULL = 6
+  SC_EIG_PATH_DENSE_FULL = 6,
+  /* non-symmetric, n > 64, when more eigenvalues are read than a block Arnoldi basis holds
+   * (max_clusters=None with a Laplacian, max_clusters > 63, min_clusters > 64) or block Arnoldi
+   * gives up: Householder reduction to Hessenberg form on the device, every eigenvalue by the
+   * double-shift QR iteration and the eigenvectors k-means reads by inverse iteration on the
+   * host.  Always returns, like np.linalg.eig (utils.py:59) */
+  SC_EIG_PATH_DENSE_HESSENBERG = 7
 };
 
 /* Stage slots of sc_diag.stage_ms */
@@ -203,7 +209,9 @@ typedef struct sc_diag {
   int32_t eig_fallback;          /* 0, or why block Lanczos handed over to the dense path:
                                     1 restart budget spent, 2 projected eigenproblem failed,
                                     3 no full-rank Krylov block, 4 forced (SC_EIG_FORCE_DENSE),
-                                    5 more than 64 eigenvectors wanted (> 64 selected clusters) */
+                                    5 more than 64 eigenvectors wanted (> 64 selected clusters);
+                                    on the general path (eig_path 7) also 6: every eigenvalue
+                                    is read (max_clusters=None with a Laplacian) */
   float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */
   int32_t diffuse_path;          /* SC_DIFFUSE_PATH_* */
   int32_t free_candidates;       /* matrix-free Diffuse: exact dot products evaluated (n + few) */
@@ -456,6 +464,19 @@ int sc_host_tridiag_eigvectors(const double* d, const double* e, int n, const do
  * substitution.  Host-only; exported so it can be pinned against numpy without a GPU. */
 int sc_host_general_eig(const double* a, int m, int nvec, double* values_re, double* values_im,
                         double* vectors_re, double* vectors_im);
+/* The host half of the dense general eigensolver for n > 64 (SC_EIG_PATH_DENSE_HESSENBERG;
+ * replaces np.linalg.eig, utils.py:59, where more eigenvalues of a non-symmetric matrix are read
+ * than a Krylov basis holds).  `packed` (n, n) row-major: an upper Hessenberg matrix on and
+ * above the subdiagonal and, below it, the Householder reflectors that produced it (LAPACK
+ * dgehd2's storage, what the device reduction leaves), tau (n - 2).  values: all n eigenvalues
+ * (implicit double-shift QR, unordered); vectors_re / vectors_im ((n, count) row-major): the
+ * eigenvectors of the ORIGINAL matrix for the eigenvalues values[pick[q]] -- inverse iteration on
+ * the Hessenberg form + back-transform through the reflectors, not normalised; *max_resid: the
+ * largest relative residual on the Hessenberg form.  Host-only; exported so it can be pinned
+ * against numpy without a GPU. */
+int sc_host_hessenberg_eig(const double* packed, const double* tau, int n, int count,
+                           const int32_t* pick, double* values_re, double* values_im,
+                           double* vectors_re, double* vectors_im, double* max_resid);
 /* The eigensolver's stopping rule for one Ritz value (eig_driver.hip): a bound on the distance
  * from theta[i] (Ritz values of a SYMMETRIC operator, descending) to the eigenvalue it
  * approximates, from the residual norms resid[] -- resid[i] itself, or the Kato-Temple bound

@@ -604,6 +604,46 @@ def general_wide_golden():
       c["k"], c["delta"], len(np.unique(labels))), flush=True)
 
 
+def general_dense_goldens():
+  """17. The general (non-symmetrisable) path where np.linalg.eig's WHOLE spectrum is read, or
+  more of it than a Krylov basis holds (round 5: the device's dense Hessenberg route):
+    a/b  [RowWiseThreshold] + GraphCut with max_clusters=None -- the ascending eigengap loop reads
+         every eigenvalue (utils.py:100-115) -- at n = 300 and n = 1000;
+    c    [RowWiseThreshold (Percentile)] + GraphCut, n = 500 samples of 70 speakers,
+         max_clusters = 80: 81 values read, 70ish eigenvectors used;
+    d    [RowWiseThreshold] without a Laplacian, max_clusters=None: the descending loop reads on
+         until an eigenvalue falls below stop_eigenvalue = 1e-2 (utils.py:116-128).
+  Every case stores the full real-part spectrum in the reference's order."""
+  cases = [
+      ("general_dense_n300_lap4", 300, 32, 5, 1701, 4, None, 2, 0.95, "rowmax"),
+      ("general_dense_n1000_lap4", 1000, 48, 6, 1702, 4, None, 2, 0.95, "rowmax"),
+      ("general_dense_n500_max80", 500, 32, 70, 1703, 4, 80, 66, 0.9, "pct"),
+      ("general_dense_n300_lap0", 300, 32, 5, 1704, 0, None, 2, 0.95, "rowmax"),
+  ]
+  for name, n, d, k, seed, lap, maxc, minc, p, ttype in cases:
+    x = so.blobs(n, d, k, seed)
+    opts = ref_refinement.RefinementOptions(
+        p_percentile=p, thresholding_soft_multiplier=0.01,
+        thresholding_type=(ref_refinement.ThresholdType.Percentile if ttype == "pct"
+                           else ref_refinement.ThresholdType.RowMax),
+        refinement_sequence=[ref_refinement.RefinementName.RowWiseThreshold])
+    clusterer = ref_sc.SpectralClusterer(
+        min_clusters=minc, max_clusters=maxc, refinement_options=opts, laplacian_type=LAP[lap])
+    t0 = time.perf_counter()
+    with _Spy() as spy:
+      labels = clusterer.predict(x)
+    secs = time.perf_counter() - t0
+    c = spy.calls[-1]
+    w = np.real(c["w"])
+    save(name + ".npz", params=np.array([n, d, k, seed, lap, -1 if maxc is None else maxc]),
+         min_clusters=np.int64(minc), p_percentile=np.float64(p),
+         percentile=np.int64(ttype == "pct"), eigenvalues=w,
+         n_clusters_raw=np.int64(c["k"]), max_delta=np.float64(c["delta"]), labels=labels,
+         ref_seconds=np.float64(secs))
+    print("  %s: k=%d delta=%.6g distinct labels %d, %.1f s" % (
+        name, c["k"], c["delta"], len(np.unique(labels)), secs), flush=True)
+
+
 def main():
   os.makedirs(GOLDEN, exist_ok=True)
   large = "--large" in sys.argv
@@ -612,6 +652,9 @@ def main():
     return
   if "--general-wide" in sys.argv:  # only section 16
     general_wide_golden()
+    return
+  if "--general-dense" in sys.argv:  # only section 17
+    general_dense_goldens()
     return
   if "--hard" in sys.argv:  # only section 14 (optionally: --hard kind [kind ...])
     kinds = [a for a in sys.argv[sys.argv.index("--hard") + 1:] if a in so.HARD_KINDS]

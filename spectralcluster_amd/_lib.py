@@ -225,6 +225,9 @@ PROTOTYPES = {
                                                   _c_double_p, ctypes.c_int, _c_double_p]),
     "sc_host_general_eig": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p,
                                            _c_double_p, _c_double_p, _c_double_p]),
+    "sc_host_hessenberg_eig": (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_int32), _c_double_p,
+                                              _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "sc_host_value_error_bound": (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_int,
                                                  ctypes.c_int, _c_double_p]),
     "sc_eigengap": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int,

@@ -968,7 +968,7 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
     SC_TRY(rc_eig);
   } else {
     rq.decision_aware = 1;
-    SC_TRY(gen_topk(h, cur, ld, n, cfg->laplacian_type, rq, diag, &dc, &w));
+    SC_TRY(gen_topk(h, cur, ld, n, cfg->laplacian_type, rq, diag, &dc, &w, bufs[which]));
   }
   int e_after_eig;
   ev_rec(h, &e_after_eig);
@@ -1463,8 +1463,6 @@ extern "C" int sc_stage_eig(sc_handle h, const double* m, int n, int count, int 
   if (!h) return SC_ERR_INVALID;
   if (!m || n <= 0 || count <= 0 || count > n || !values)
     return fail(h, SC_ERR_INVALID, "bad eigen request");
-  if (n > kGenMax && count > 64)
-    return fail(h, SC_ERR_UNSUPPORTED, "at most 64 eigenpairs for n > 64 on the general path");
   SC_HIP(h, hipSetDevice(h->device));
   SC_TRY(ensure_matrices(h, n, 0));
   SC_TRY(ensure_gen(h, n));
@@ -1503,7 +1501,8 @@ extern "C" int sc_stage_eig(sc_handle h, const double* m, int n, int count, int 
   h->nev = 0;
   SC_TRY(ensure_eig(h, n));
   SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 12, 0, sizeof(int), h->stream));
-  SC_TRY(gen_topk(h, S, ld, n, SC_LAPLACIAN_NONE, rq, dg, &dc, &w));
+  SC_TRY(gen_topk(h, S, ld, n, SC_LAPLACIAN_NONE, rq, dg, &dc, &w,
+                  S == ptr<double>(h->B1) ? ptr<double>(h->B2) : ptr<double>(h->B1)));
   SC_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < count; ++i) values[i] = w[i];
   if (vectors) {

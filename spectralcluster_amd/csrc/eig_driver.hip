@@ -1258,9 +1258,111 @@ int sym_topk_group(sc_handle lead, GroupEigMember* mem, int count, bool want_vec
 // re-orthogonalisation, explicit Rayleigh-Ritz H = Q^T Op Q (basis <= 64), explicit
 // residuals ||Op v - theta v||, explicit restart from the wanted Ritz vectors (real and
 // imaginary parts of complex pairs).
+
+// Dense route for n > 64 (eig_path 7): every eigenvalue of the reference's own matrix -- M, or
+// the Laplacian of M -- and the eigenvectors k-means reads.  Taken when the request reads more
+// eigenvalues than a block Arnoldi basis holds (max_clusters=None with a Laplacian: all n of
+// them, utils.py:100-115; max_clusters > 63; min_clusters > 64) and as the landing pad of a
+// block Arnoldi that gives up: np.linalg.eig (utils.py:59) always returns.
+//   device  the matrix is formed in `scratch` and reduced to Hessenberg form (hessenberg.hip)
+//   host    QR iteration for the n eigenvalues, inverse iteration + back-transform for the
+//           leading max(n_clusters, min_clusters) eigenvectors (host_eig.cpp)
+//   device  dgeev's norm / phase convention and the real parts (k_gen_phase)
+constexpr int kGenDenseLimit = 16384;  // (the host QR iteration is ~10 n^3 flops: minutes beyond)
+static int gen_dense_large(sc_handle h, const double* M, int ld, int n, int laplacian_type,
+                           const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
+                           std::vector<double>* out_w, double* scratch, int reason) {
+  hipStream_t s = h->stream;
+  if (scratch == nullptr || scratch == M)
+    return fail(h, SC_ERR_UNSUPPORTED, "no scratch matrix for the dense general eigen path");
+  if (n > kGenDenseLimit)
+    return fail(h, SC_ERR_UNSUPPORTED,
+                "the dense general eigen path (every eigenvalue of a matrix that is not "
+                "diagonally similar to a symmetric one) is limited to n <= 16384");
+  const bool is_lap = laplacian_type >= SC_LAPLACIAN_UNNORMALIZED;
+  if (sw::eig_trace())
+    fprintf(stderr, "[sc] general eigen path: dense Hessenberg route, n=%d (reason %d)\n", n, reason);
+  SC_TRY(grow(h, h->td_tau, (size_t)n * sizeof(double)));
+  SC_TRY(grow(h, h->td_work, (size_t)(5 * (size_t)n + 2048) * sizeof(double)));
+  if (is_lap) {
+    launch_laplacian(s, M, scratch, n, ld, laplacian_type, ptr<double>(h->deg));
+  } else {
+    SC_HIP(h, hipMemcpyAsync(scratch, M, (size_t)n * ld * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  SC_HIP(h, hipMemsetAsync(h->td_tau.p, 0, (size_t)n * sizeof(double), s));
+  launch_hessenberg(s, scratch, ld, n, ptr<double>(h->td_tau), ptr<double>(h->td_work));
+  SC_TRY(check_last(h, "Hessenberg reduction launch"));
+  std::vector<double> packed((size_t)n * ld), tau(n);
+  SC_HIP(h, hipMemcpyAsync(packed.data(), scratch, packed.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipMemcpyAsync(tau.data(), h->td_tau.p, (size_t)n * sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipMemcpyAsync(h->h_flags + 12, ptr<int>(h->flags) + 12, sizeof(int),
+                           hipMemcpyDeviceToHost, s));
+  SC_HIP(h, hipStreamSynchronize(s));
+  if (h->h_flags[12] != 0) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+  HostHessenberg hw;
+  if (!host_hessenberg_unpack(packed.data(), (size_t)ld, n, tau.data(), &hw))
+    return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
+  packed.clear();
+  packed.shrink_to_fit();
+  std::vector<double> wr(n), wi(n);
+  if (!host_hessenberg_eigenvalues(hw, wr.data(), wi.data()))
+    return fail(h, SC_ERR_NOT_CONVERGED, "QR iteration on the Hessenberg form failed");
+  // np.linalg.eig + .real + argsort (utils.py:59-67): by real part, descending for the
+  // affinity itself, ascending for a Laplacian (= descending in -L, the convention of `theta`)
+  const double sign = is_lap ? -1.0 : 1.0;
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int a, int b) { return sign * wr[a] > sign * wr[b]; });
+  std::vector<double> theta(n), zeros(n, 0.0);
+  for (int i = 0; i < n; ++i) theta[i] = sign * wr[order[i]];
+  EigDecision dc = analyze(rq, theta.data(), zeros.data(), n, n, true, false);
+  if (!dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
+  const int cols = std::max(1, std::min(n, dc.kvec));
+  SC_TRY(ensure_vectors(h, n, cols));
+  const int ldv = round_up(n, 16);
+  SC_TRY(grow(h, h->Vre, (size_t)ldv * std::max(cols, kGenMax) * sizeof(double)));
+  SC_TRY(grow(h, h->Vim, (size_t)ldv * std::max(cols, kGenMax) * sizeof(double)));
+  std::vector<double> pr(cols), pi(cols), vre((size_t)ldv * cols, 0.0), vim((size_t)ldv * cols, 0.0);
+  for (int q = 0; q < cols; ++q) {
+    pr[q] = wr[order[q]];
+    pi[q] = wi[order[q]];
+  }
+  double max_resid = 0.0;
+  if (!host_hessenberg_vectors(hw, pr.data(), pi.data(), cols, vre.data(), vim.data(), (size_t)ldv,
+                               &max_resid))
+    return fail(h, SC_ERR_NOT_CONVERGED, "inverse iteration on the Hessenberg form failed");
+  SC_HIP(h, hipMemcpyAsync(h->Vre.p, vre.data(), vre.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  SC_HIP(h, hipMemcpyAsync(h->Vim.p, vim.data(), vim.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  launch_gen_phase(s, ptr<double>(h->Vre), ptr<double>(h->Vim), ldv, n, cols, ptr<double>(h->E), ldv);
+  SC_TRY(check_last(h, "eigenvector normalisation launch"));
+  SC_HIP(h, hipStreamSynchronize(s));  // vre / vim are locals
+  h->n_vec = cols;
+  dc.kw = n;
+  dc.converged = true;
+  dc.max_resid = max_resid * std::max(hw.norm, 1e-300);
+  if (out_w) {  // the whole spectrum, in the reference's order
+    out_w->resize(n);
+    for (int i = 0; i < n; ++i) (*out_w)[i] = rq.descend ? theta[i] : -theta[i];
+  }
+  if (diag) {
+    diag->eig_path = SC_EIG_PATH_DENSE_HESSENBERG;
+    diag->eig_matvec_passes = 0;
+    diag->eig_block = kEigBlock;
+    diag->eig_basis = n;
+    diag->eig_cycles = 0;
+    diag->eig_max_residual = dc.max_resid;
+    diag->eig_fallback = reason;
+  }
+  *out_dc = dc;
+  return SC_OK;
+}
+
 int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
                     const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
-                    std::vector<double>* out_w) {
+                    std::vector<double>* out_w, double* scratch) {
   hipStream_t s = h->stream;
   SC_TRY(ensure_eig(h, n));
   SC_TRY(ensure_gen(h, n));
@@ -1316,10 +1418,12 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
     dc.kw = n;
     if (diag) diag->eig_path = SC_EIG_PATH_DENSE_GENERAL;
   } else {
+    // test switch (tests/test_gpu_alternate_paths.py): straight to the landing pad
+    if (sw::eig_force_dense())
+      return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 4);
+    // max_clusters=None with a Laplacian reads every eigenvalue (utils.py:100-115): dense route
     if (rq.fixed_count == 0 && rq.max_clusters == 0 && !rq.descend)
-      return fail(h, SC_ERR_UNSUPPORTED,
-                  "max_clusters=None with a Laplacian needs every eigenvalue; only "
-                  "supported for n <= 64 on the general eigen path");
+      return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 6);
     // Narrow form: basis <= 64, projected problems solved by the one-wavefront device kernel,
     // up to 32 Ritz pairs.  WIDE form (a request for more -- max_clusters up to 63,
     // min_clusters up to 64 -- or a descending request whose stop_eigenvalue turns out to lie
@@ -1329,10 +1433,8 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
                           ? rq.fixed_count
                           : std::max(rq.max_clusters > 0 ? rq.max_clusters + 1 : 0, rq.min_clusters);
     bool wide = asked > 32;
-    if (asked > 64)
-      return fail(h, SC_ERR_UNSUPPORTED,
-                  "the general eigen path reports at most 64 eigenpairs for n > 64; set "
-                  "max_clusters <= 63");
+    if (asked > 64)  // more pairs than the wide Arnoldi basis yields: dense route
+      return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 5);
   general_restart:
     if (wide) {  // Ritz vectors: 104 kept + 1 far end + 8 residual columns
       SC_TRY(grow(h, h->Vre, (size_t)ldv * 2 * kGenMax * sizeof(double)));
@@ -1458,16 +1560,15 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
           passes = 0;
           goto general_restart;
         }
+        // (a descending request whose stop_eigenvalue lies deeper than 64 values: dense route)
         if (dc.unsupported || (dc.enough && std::max(dc.kw, dc.kvec) > kMaxCheck))
-          return fail(h, SC_ERR_UNSUPPORTED,
-                      "the general eigen path reports at most 64 eigenpairs for n > 64; set "
-                      "max_clusters <= 63");
+          return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 5);
         if (dc.enough && dc.converged) break;
       }
       if (m + kEigBlock > cap) {
         // ---- explicit restart from the wanted Ritz vectors
-        if (++cycles > rq.max_cycles)
-          return fail(h, SC_ERR_NOT_CONVERGED, "block Arnoldi did not converge");
+        if (++cycles > rq.max_cycles)  // restart budget spent: the landing pad
+          return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 1);
         // (thick restart: the new basis is [wanted Ritz vectors | residual block], after
         // which the Arnoldi recurrence continues from the residual block)
         const int kStash = wide ? 112 : 48;  // Vre columns [kStash, kStash + 8): the residual block

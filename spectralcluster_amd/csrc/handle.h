@@ -322,9 +322,11 @@ bool sym_group_eligible(int n, const EigRequest& rq, bool any_size = false);
 // `scratch`: a free n x ld matrix (the dense full-spectrum path materialises Op there)
 int sym_topk(sc_handle h, const double* S, int ld, int n, const EigRequest& rq, sc_diag* diag,
              EigDecision* out_dc, std::vector<double>* out_w, double* scratch);
+// `scratch`: a free n x ld matrix (the dense Hessenberg route reduces a copy of M there; may be
+// null for n <= 64)
 int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
              const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
-             std::vector<double>* out_w);
+             std::vector<double>* out_w, double* scratch);
 
 // matrix-free Diffuse (free_api.hip)
 // does this call take the matrix-free route for a Diffuse whose output only feeds

@@ -635,3 +635,438 @@ extern "C" int sc_host_general_eig(const double* a, int m, int nvec, double* val
              ? SC_OK
              : SC_ERR_NOT_CONVERGED;
 }
+
+// ------------------------------------------------------------------------------
+// dense general eigenproblem of order n > 64: the host half
+// ------------------------------------------------------------------------------
+// np.linalg.eig (reference utils.py:59) on a matrix that is not diagonally similar to a symmetric
+// one returns all n eigenpairs.  The device reduces the matrix to upper Hessenberg form
+// (eig_general.hip: Householder reflectors, LAPACK dgehd2's storage -- reflector k below the
+// subdiagonal of column k, v(k+1) = 1 implied, tau[k]); from there on the work is a serial
+// recurrence per eigenvalue, which is why it runs here:
+//   eigenvalues   Francis' implicit double-shift QR on the Hessenberg matrix, active block only
+//                 (no Schur form is accumulated): the textbook algorithm of EISPACK hqr / LAPACK
+//                 dlahqr, incl. the two-consecutive-small-subdiagonals start, the conservative
+//                 deflation test and exceptional shifts -- ~10 n^3 flops;
+//   eigenvectors  of the few eigenvalues k-means reads: inverse iteration on H - lambda I (LU
+//                 with row interchanges of a Hessenberg matrix: one elimination per column,
+//                 O(n^2) per solve; LAPACK dhsein / dlaein's method), complex arithmetic for a
+//                 complex eigenvalue; close eigenvalues are separated like dhsein does, and the
+//                 iterates of a cluster of real eigenvalues are kept independent;
+//   x = Q y       through the reflectors (O(n^2) per vector).
+// The phase / norm convention of dgeev is applied on the device (k_gen_phase).
+
+bool host_hessenberg_unpack(const double* packed, size_t ld, int n, const double* tau,
+                            HostHessenberg* w) {
+  w->n = n;
+  w->H.assign((size_t)n * n, 0.0);
+  w->V.assign((size_t)n * n, 0.0);
+  w->tau.assign(tau, tau + std::max(0, n - 2));
+  w->norm = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double* row = packed + (size_t)i * ld;
+    for (int j = std::max(0, i - 1); j < n; ++j) {
+      const double v = row[j];
+      if (!std::isfinite(v)) return false;
+      w->H[(size_t)i * n + j] = v;
+      w->norm = std::max(w->norm, std::fabs(v));
+    }
+    // reflector k (column k, rows k + 2 ..) -> row k of V, contiguous
+    for (int k = 0; k + 2 <= i && k + 2 < n; ++k) {
+      if (!std::isfinite(row[k])) return false;
+      w->V[(size_t)k * n + i] = row[k];
+    }
+  }
+  for (int k = 0; k + 2 < n; ++k) w->V[(size_t)k * n + k + 1] = 1.0;
+  return true;
+}
+
+namespace {
+// LAPACK dlarfg for a vector of 2 or 3 elements (x[0] = alpha): H = I - tau v v^T, v[0] = 1
+inline void small_reflector(int nr, double* x, double* tau) {
+  double xnorm = nr == 3 ? std::hypot(x[1], x[2]) : std::fabs(x[1]);
+  if (xnorm == 0.0) {
+    *tau = 0.0;
+    return;
+  }
+  const double alpha = x[0];
+  const double beta = -std::copysign(std::hypot(alpha, xnorm), alpha);
+  *tau = (beta - alpha) / beta;
+  const double scale = 1.0 / (alpha - beta);
+  for (int i = 1; i < nr; ++i) x[i] *= scale;
+  x[0] = beta;
+}
+}  // namespace
+
+// Eigenvalues of the upper Hessenberg matrix in w (copied; w is left intact), unordered.
+bool host_hessenberg_eigenvalues(const HostHessenberg& w, double* wr, double* wi) {
+  const int n = w.n;
+  if (n <= 0) return true;
+  std::vector<double> hbuf(w.H);
+  double* h = hbuf.data();
+  auto H = [&](int i, int j) -> double& { return h[(size_t)i * n + j]; };
+  const double ulp = 2.220446049250313e-16;
+  const double safmin = 2.2250738585072014e-308;
+  const double smlnum = safmin * ((double)n / ulp);
+  const int itmax = 30 * std::max(10, n);
+  int i = n - 1;
+  while (i >= 0) {
+    int l = 0;
+    bool found = false;
+    for (int its = 0; its <= itmax; ++its) {
+      // ---- a negligible subdiagonal entry splits the active block
+      int k;
+      for (k = i; k > l; --k) {
+        const double sub = std::fabs(H(k, k - 1));
+        if (sub <= smlnum) break;
+        double tst = std::fabs(H(k - 1, k - 1)) + std::fabs(H(k, k));
+        if (tst == 0.0) {
+          if (k - 2 >= 0) tst += std::fabs(H(k - 1, k - 2));
+          if (k + 1 <= n - 1) tst += std::fabs(H(k + 1, k));
+        }
+        if (sub <= ulp * tst) {  // (Ahues & Tisseur's conservative criterion)
+          const double up = std::fabs(H(k - 1, k));
+          const double ab = std::max(sub, up), ba = std::min(sub, up);
+          const double dd = std::fabs(H(k - 1, k - 1) - H(k, k)), hk = std::fabs(H(k, k));
+          const double aa = std::max(hk, dd), bb = std::min(hk, dd);
+          const double s = aa + ab;
+          if (ba * (ab / s) <= std::max(smlnum, ulp * (bb * (aa / s)))) break;
+        }
+      }
+      l = k;
+      if (l > 0) H(l, l - 1) = 0.0;
+      if (l >= i - 1) {
+        found = true;
+        break;
+      }
+      // ---- shifts: eigenvalues of the trailing 2 x 2 (exceptional ones now and then)
+      double h11, h21, h12, h22;
+      if (its > 0 && its % 20 == 0) {
+        const double s = std::fabs(H(i, i - 1)) + std::fabs(H(i - 1, i - 2));
+        h11 = 0.75 * s + H(i, i);
+        h12 = -0.4375 * s;
+        h21 = s;
+        h22 = h11;
+      } else if (its > 0 && its % 10 == 0) {
+        const double s = std::fabs(H(l + 1, l)) + std::fabs(H(l + 2, l + 1));
+        h11 = 0.75 * s + H(l, l);
+        h12 = -0.4375 * s;
+        h21 = s;
+        h22 = h11;
+      } else {
+        h11 = H(i - 1, i - 1);
+        h21 = H(i, i - 1);
+        h12 = H(i - 1, i);
+        h22 = H(i, i);
+      }
+      double rt1r, rt1i, rt2r, rt2i;
+      {
+        const double s = std::fabs(h11) + std::fabs(h12) + std::fabs(h21) + std::fabs(h22);
+        if (s == 0.0) {
+          rt1r = rt1i = rt2r = rt2i = 0.0;
+        } else {
+          h11 /= s;
+          h21 /= s;
+          h12 /= s;
+          h22 /= s;
+          const double tr = 0.5 * (h11 + h22);
+          const double det = (h11 - tr) * (h22 - tr) - h12 * h21;
+          const double rtdisc = std::sqrt(std::fabs(det));
+          if (det >= 0.0) {  // complex conjugate shifts
+            rt1r = rt2r = tr * s;
+            rt1i = rtdisc * s;
+            rt2i = -rt1i;
+          } else {  // real shifts: the one closer to h22, twice
+            rt1r = tr + rtdisc;
+            rt2r = tr - rtdisc;
+            if (std::fabs(rt1r - h22) <= std::fabs(rt2r - h22)) {
+              rt1r *= s;
+              rt2r = rt1r;
+            } else {
+              rt2r *= s;
+              rt1r = rt2r;
+            }
+            rt1i = rt2i = 0.0;
+          }
+        }
+      }
+      // ---- start of the bulge: two consecutive small subdiagonal entries
+      int m;
+      double v[3];
+      for (m = i - 2; m >= l; --m) {
+        double h21s = std::fabs(H(m + 1, m));
+        double s = std::fabs(H(m, m) - rt2r) + std::fabs(rt2i) + h21s;
+        h21s = H(m + 1, m) / s;
+        v[0] = h21s * H(m, m + 1) + (H(m, m) - rt1r) * ((H(m, m) - rt2r) / s) - rt1i * (rt2i / s);
+        v[1] = h21s * (H(m, m) + H(m + 1, m + 1) - rt1r - rt2r);
+        v[2] = h21s * H(m + 2, m + 1);
+        s = std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]);
+        if (s != 0.0) {
+          v[0] /= s;
+          v[1] /= s;
+          v[2] /= s;
+        }
+        if (m == l) break;
+        const double h00 = std::fabs(H(m - 1, m - 1)), hmm = std::fabs(H(m, m)),
+                     h11a = std::fabs(H(m + 1, m + 1));
+        if (std::fabs(H(m, m - 1)) * (std::fabs(v[1]) + std::fabs(v[2])) <=
+            ulp * std::fabs(v[0]) * (h00 + hmm + h11a))
+          break;
+      }
+      // ---- the double-shift sweep on rows / columns l .. i only (no Schur form is kept)
+      for (k = m; k <= i - 1; ++k) {
+        const int nr = std::min(3, i - k + 1);
+        if (k > m) {
+          v[0] = H(k, k - 1);
+          v[1] = H(k + 1, k - 1);
+          v[2] = nr == 3 ? H(k + 2, k - 1) : 0.0;
+        }
+        double t1;
+        small_reflector(nr, v, &t1);
+        if (k > m) {
+          H(k, k - 1) = v[0];
+          H(k + 1, k - 1) = 0.0;
+          if (k < i - 1) H(k + 2, k - 1) = 0.0;
+        } else if (m > l) {
+          H(k, k - 1) *= (1.0 - t1);
+        }
+        const double v2 = v[1], t2 = t1 * v2;
+        if (nr == 3) {
+          const double v3 = v[2], t3 = t1 * v3;
+          double* r0 = h + (size_t)k * n;
+          double* r1 = r0 + n;
+          double* r2 = r1 + n;
+          for (int j = k; j <= i; ++j) {
+            const double sum = r0[j] + v2 * r1[j] + v3 * r2[j];
+            r0[j] -= sum * t1;
+            r1[j] -= sum * t2;
+            r2[j] -= sum * t3;
+          }
+          const int jend = std::min(k + 3, i);
+          for (int j = l; j <= jend; ++j) {
+            double* r = h + (size_t)j * n + k;
+            const double sum = r[0] + v2 * r[1] + v3 * r[2];
+            r[0] -= sum * t1;
+            r[1] -= sum * t2;
+            r[2] -= sum * t3;
+          }
+        } else {
+          double* r0 = h + (size_t)k * n;
+          double* r1 = r0 + n;
+          for (int j = k; j <= i; ++j) {
+            const double sum = r0[j] + v2 * r1[j];
+            r0[j] -= sum * t1;
+            r1[j] -= sum * t2;
+          }
+          for (int j = l; j <= i; ++j) {
+            double* r = h + (size_t)j * n + k;
+            const double sum = r[0] + v2 * r[1];
+            r[0] -= sum * t1;
+            r[1] -= sum * t2;
+          }
+        }
+      }
+    }
+    if (!found) return false;
+    if (l == i) {
+      wr[i] = H(i, i);
+      wi[i] = 0.0;
+    } else {  // a 2 x 2 block: both eigenvalues
+      const double a = H(i - 1, i - 1), b = H(i - 1, i), c = H(i, i - 1), d = H(i, i);
+      const double p = 0.5 * (a - d), bc = b * c, disc = p * p + bc;
+      if (disc >= 0.0) {
+        const double z = p + std::copysign(std::sqrt(disc), p);
+        wr[i - 1] = d + z;
+        wr[i] = z != 0.0 ? d - bc / z : d;
+        wi[i - 1] = wi[i] = 0.0;
+      } else {
+        wr[i - 1] = wr[i] = d + p;
+        wi[i - 1] = std::sqrt(-disc);
+        wi[i] = -wi[i - 1];
+      }
+    }
+    i = l - 1;
+  }
+  for (int q = 0; q < n; ++q)
+    if (!std::isfinite(wr[q]) || !std::isfinite(wi[q])) return false;
+  return true;
+}
+
+// Eigenvectors of the ORIGINAL matrix (x = Q y, y an eigenvector of H) for `count` of its
+// eigenvalues (wr, wi), column-major into vre / vim (column q at + q * ldv); *max_resid: the
+// largest ||H y - lambda y||_2 / (||H||_max ||y||_2) seen.  A conjugate partner that follows its
+// pair directly is the conjugate vector.  false: an iterate failed to grow.
+bool host_hessenberg_vectors(const HostHessenberg& w, const double* wr, const double* wi, int count,
+                             double* vre, double* vim, size_t ldv, double* max_resid) {
+  const int n = w.n;
+  *max_resid = 0.0;
+  if (count <= 0) return true;
+  const double ulp = 2.220446049250313e-16;
+  const double hnorm = std::max(w.norm, 1e-300);
+  const double eps3 = hnorm * ulp;
+  std::vector<cplx> U((size_t)n * n), y(n), t(n);
+  std::vector<cplx> mult(n);
+  std::vector<char> swapped(n);
+  std::vector<cplx> lam(count);
+  for (int q = 0; q < count; ++q) lam[q] = cplx(wr[q], wi[q]);
+  // dhsein: an eigenvalue closer than eps3 to one already used is moved by eps3
+  for (int q = 0; q < count; ++q) {
+    bool again = true;
+    while (again) {
+      again = false;
+      for (int p = 0; p < q; ++p)
+        if (abs1(lam[p] - lam[q]) < eps3) {
+          lam[q] += eps3;
+          again = true;
+          break;
+        }
+    }
+  }
+  const double cluster_tol = 1e-10 * hnorm;  // real eigenvalues this close: one invariant subspace
+  std::vector<std::vector<cplx>> done;       // eigenvectors of H so far (for the cluster step)
+  done.reserve(count);
+  for (int q = 0; q < count; ++q) {
+    // the conjugate of the pair just computed
+    if (q > 0 && wi[q] != 0.0 && wi[q] == -wi[q - 1] && wr[q] == wr[q - 1]) {
+      for (int r = 0; r < n; ++r) {
+        vre[(size_t)q * ldv + r] = vre[(size_t)(q - 1) * ldv + r];
+        vim[(size_t)q * ldv + r] = -vim[(size_t)(q - 1) * ldv + r];
+      }
+      std::vector<cplx> c(done.back());
+      for (cplx& z : c) z = std::conj(z);
+      done.push_back(std::move(c));
+      continue;
+    }
+    // ---- LU of H - lambda I with row interchanges: column k eliminates H(k + 1, k)
+    for (int i = 0; i < n; ++i) {
+      const double* hr = w.H.data() + (size_t)i * n;
+      cplx* ur = U.data() + (size_t)i * n;
+      for (int j = 0; j < n; ++j) ur[j] = hr[j];
+      ur[i] -= lam[q];
+    }
+    for (int k = 0; k + 1 < n; ++k) {
+      cplx* rk = U.data() + (size_t)k * n;
+      cplx* rn = rk + n;
+      if (abs1(rk[k]) < abs1(rn[k])) {
+        for (int j = k; j < n; ++j) std::swap(rk[j], rn[j]);
+        swapped[k] = 1;
+      } else {
+        swapped[k] = 0;
+      }
+      if (abs1(rk[k]) == 0.0) rk[k] = eps3;
+      const cplx f = rn[k] / rk[k];
+      mult[k] = f;
+      if (f != cplx(0.0)) {
+        for (int j = k + 1; j < n; ++j) rn[j] -= f * rk[j];
+      }
+      rn[k] = 0.0;
+    }
+    if (abs1(U[(size_t)(n - 1) * n + n - 1]) == 0.0) U[(size_t)(n - 1) * n + n - 1] = eps3;
+    for (int i = 0; i < n; ++i)
+      if (abs1(U[(size_t)i * n + i]) < eps3) U[(size_t)i * n + i] = eps3;  // (dlaein)
+    // ---- inverse iteration
+    const double rootn = std::sqrt((double)n);
+    for (int i = 0; i < n; ++i) y[i] = 1.0 / rootn;
+    for (int iter = 0; iter < 6; ++iter) {
+      if (iter > 0) {  // forward: P and L (the first solve takes its start vector as L^-1 P b)
+        for (int k = 0; k + 1 < n; ++k) {
+          if (swapped[k]) std::swap(y[k], y[k + 1]);
+          y[k + 1] -= mult[k] * y[k];
+        }
+      }
+      for (int i = n - 1; i >= 0; --i) {  // U x = y
+        const cplx* ur = U.data() + (size_t)i * n;
+        cplx s = y[i];
+        for (int j = i + 1; j < n; ++j) s -= ur[j] * y[j];
+        y[i] = s / ur[i];
+      }
+      // a cluster of (numerically) equal real eigenvalues: stay independent of its earlier
+      // vectors (any basis of the invariant subspace will do; np.linalg.eig returns one)
+      if (wi[q] == 0.0) {
+        for (int p = 0; p < q; ++p) {
+          if (wi[p] != 0.0 || std::fabs(wr[p] - wr[q]) > cluster_tol) continue;
+          cplx dot = 0.0;
+          double nn = 0.0;
+          for (int r = 0; r < n; ++r) {
+            dot += std::conj(done[p][r]) * y[r];
+            nn += std::norm(done[p][r]);
+          }
+          if (nn > 0.0)
+            for (int r = 0; r < n; ++r) y[r] -= (dot / nn) * done[p][r];
+        }
+      }
+      double big = 0.0, n2 = 0.0;
+      for (int r = 0; r < n; ++r) big = std::max(big, abs1(y[r]));
+      if (!(big > 0.0) || !std::isfinite(big)) return false;
+      for (int r = 0; r < n; ++r) {
+        y[r] /= big;
+        n2 += std::norm(y[r]);
+      }
+      const double inv = 1.0 / std::sqrt(n2);
+      for (int r = 0; r < n; ++r) y[r] *= inv;
+      // converged when the residual is at rounding level (one solve with the shift at an
+      // eigenvalue already multiplies a generic start vector by ~1 / eps3; two are the rule)
+      double res2 = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double* hr = w.H.data() + (size_t)i * n;
+        cplx s = -lam[q] * y[i];
+        for (int j = std::max(0, i - 1); j < n; ++j) s += hr[j] * y[j];
+        res2 += std::norm(s);
+      }
+      const double res = std::sqrt(res2) / hnorm;
+      if (iter >= 1 && res <= 1e-12 * rootn) {
+        *max_resid = std::max(*max_resid, res);
+        break;
+      }
+      if (iter == 5) *max_resid = std::max(*max_resid, res);
+    }
+    done.emplace_back(y);
+    // ---- x = Q y = H_0 H_1 ... H_{n-3} y
+    t = y;
+    for (int k = n - 3; k >= 0; --k) {
+      const double tk = w.tau[k];
+      if (tk == 0.0) continue;
+      const double* v = w.V.data() + (size_t)k * n;
+      cplx dot = 0.0;
+      for (int r = k + 1; r < n; ++r) dot += v[r] * t[r];
+      dot *= tk;
+      for (int r = k + 1; r < n; ++r) t[r] -= dot * v[r];
+    }
+    for (int r = 0; r < n; ++r) {
+      vre[(size_t)q * ldv + r] = t[r].real();
+      vim[(size_t)q * ldv + r] = t[r].imag();
+    }
+  }
+  return true;
+}
+
+// host-only exports (CPU tests): `packed` (n, n) row-major in the device reduction's storage
+// (Hessenberg matrix on and above the subdiagonal, reflectors below it), tau (n - 2).
+extern "C" int sc_host_hessenberg_eig(const double* packed, const double* tau, int n, int count,
+                                      const int32_t* pick, double* values_re, double* values_im,
+                                      double* vectors_re, double* vectors_im, double* max_resid) {
+  if (!packed || n < 1 || count < 0 || count > n || !values_re || !values_im ||
+      (n > 2 && !tau) || (count > 0 && (!pick || !vectors_re || !vectors_im)))
+    return SC_ERR_INVALID;
+  HostHessenberg w;
+  if (!host_hessenberg_unpack(packed, (size_t)n, n, tau, &w)) return SC_ERR_NON_FINITE;
+  if (!host_hessenberg_eigenvalues(w, values_re, values_im)) return SC_ERR_NOT_CONVERGED;
+  if (count == 0) return SC_OK;
+  std::vector<double> pr(count), pi(count), cre((size_t)n * count), cim((size_t)n * count);
+  for (int q = 0; q < count; ++q) {
+    if (pick[q] < 0 || pick[q] >= n) return SC_ERR_INVALID;
+    pr[q] = values_re[pick[q]];
+    pi[q] = values_im[pick[q]];
+  }
+  double res = 0.0;
+  if (!host_hessenberg_vectors(w, pr.data(), pi.data(), count, cre.data(), cim.data(), (size_t)n,
+                               &res))
+    return SC_ERR_NOT_CONVERGED;
+  if (max_resid) *max_resid = res;
+  for (int q = 0; q < count; ++q)
+    for (int r = 0; r < n; ++r) {  // (n, count) row-major out
+      vectors_re[(size_t)r * count + q] = cre[(size_t)q * n + r];
+      vectors_im[(size_t)r * count + q] = cim[(size_t)q * n + r];
+    }
+  return SC_OK;
+}

@@ -33,4 +33,20 @@ bool host_partial_vectors(const HostTridiag& w, int need, double* Y, int ldy);
 bool host_general_eig(const double* a, int lda, int m, int nvec, double* wr, double* wi,
                       double* yre, double* yim, int ldy);
 
+// ---- dense general eigenproblem of order n > 64: what follows the device's Hessenberg reduction
+struct HostHessenberg {
+  int n = 0;
+  double norm = 0.0;            // max |h_ij|
+  std::vector<double> H, V, tau;  // H: n x n upper Hessenberg; V: reflector k in row k (v[k+1] = 1)
+};
+// packed (n x n, row-major ld): Hessenberg matrix on and above the subdiagonal, reflector k in
+// column k below it (LAPACK dgehd2's storage); false: a non-finite entry
+bool host_hessenberg_unpack(const double* packed, size_t ld, int n, const double* tau,
+                            HostHessenberg* w);
+// all n eigenvalues (unordered); false: the QR iteration did not converge
+bool host_hessenberg_eigenvalues(const HostHessenberg& w, double* wr, double* wi);
+// eigenvectors of the original matrix for `count` eigenvalues, column-major (column q at q * ldv)
+bool host_hessenberg_vectors(const HostHessenberg& w, const double* wr, const double* wi, int count,
+                             double* vre, double* vim, size_t ldv, double* max_resid);
+
 #endif  // SPECTRALCLUSTER_AMD_HOST_EIG_H_

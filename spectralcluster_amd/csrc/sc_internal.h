@@ -368,6 +368,9 @@ void launch_gen_ritz(hipStream_t s, const double* Q, int ldq, int m, int n, cons
 // receives the real parts, column-major lde
 void launch_gen_phase(hipStream_t s, double* Vre, double* Vim, int ldv, int n, int cols,
                       double* E, int lde);
+// hessenberg.hip: B (n x n, ld) -> upper Hessenberg form in place, reflector k below the
+// subdiagonal of column k (LAPACK dgehd2's storage), tau (n), vwork (2 n doubles)
+void launch_hessenberg(hipStream_t s, double* B, int ld, int n, double* tau, double* vwork);
 void launch_gen_gather(hipStream_t s, const double* Vre, const double* Vim, int ldv, int n,
                        const int* src, uint64_t seed, double* W);
 void launch_scaling_general(hipStream_t s, const double* deg, int n, int laplacian_type,

@@ -43,8 +43,9 @@ def compute_sorted_eigenvectors(
   eigenpair, as the reference returns -- else block Lanczos for the `count` (default
   extreme ones; more than 64 come from the dense tridiagonal path).  Anything else runs on
   the general solver (Hessenberg + complex QR for n <= 64, else block Arnoldi for `count` <= 64
-  extreme ones, default 32); eigenvectors of complex pairs carry LAPACK's normalisation
-  before `.real`.
+  extreme ones, default 32; more than 64 -- up to all n -- take the dense Hessenberg route:
+  reduction on the device, QR iteration + inverse iteration on the host); eigenvectors of
+  complex pairs carry LAPACK's normalisation before `.real`.
   """
   m = np.ascontiguousarray(input_matrix, dtype=np.float64)
   if m.ndim != 2 or m.shape[0] != m.shape[1]:

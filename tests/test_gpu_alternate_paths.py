@@ -106,6 +106,23 @@ got = c.predict(x)
 w = c.consumed_eigenvalues()
 assert np.max(np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-12)) < 1e-5
 assert so.adjusted_rand_index(got, want) == 1.0
+if os.environ.get("SC_EIG_FORCE_DENSE") and not os.environ.get("SC_DIFFUSE"):
+  # the general (non-symmetric) path has a landing pad too: Hessenberg reduction on the device,
+  # QR + inverse iteration on the host (eig_path 7), here forced on a request block Arnoldi solves
+  g = np.load(os.path.join(ROOT, "tests", "golden", "general_wide_n400.npz"))
+  n, d, k, seed, lap, maxc = (int(v) for v in g["params"])
+  c = sca.SpectralClusterer(
+      min_clusters=int(g["min_clusters"]), max_clusters=maxc,
+      refinement_options=sca.RefinementOptions(
+          thresholding_type=sca.ThresholdType.Percentile, p_percentile=float(g["p_percentile"]),
+          refinement_sequence=[sca.RefinementName.RowWiseThreshold]),
+      laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  labels = c.predict(so.blobs(n, d, k, seed))
+  dg = c.last_diag
+  assert dg.eig_path == 7 and dg.eig_fallback == 4
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"])
+  assert abs(dg.max_delta - float(g["max_delta"])) <= 1e-6 * float(g["max_delta"])
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
 if os.environ.get("SC_KMEANS_SINGLE"):
   # every member of a grouped batch is handed back after its front (the lockstep k-means chain
   # is switched off): the large ones took the matrix-free Diffuse and must be resumed on the

@@ -366,3 +366,122 @@ def test_general_path_limit_is_reported():
   m, _ = thresholded(300, 16, 3, seed=5)
   with pytest.raises(sca.UnsupportedOnDeviceError):
     sca.utils.compute_sorted_eigenvectors(m, descend=True, count=65)
+
+
+# --- the dense Hessenberg route: the WHOLE spectrum of a non-symmetric matrix, n > 64 --------
+def _dense_case(name):
+  g = golden(name)
+  n, d, k, seed, lap, maxc = [int(v) for v in g["params"]]
+  x = so.blobs(n, d, k, seed)
+  ttype = sca.ThresholdType.Percentile if int(g["percentile"]) else sca.ThresholdType.RowMax
+  opts = sca.RefinementOptions(
+      p_percentile=float(g["p_percentile"]), thresholding_soft_multiplier=0.01,
+      thresholding_type=ttype, refinement_sequence=[sca.RefinementName.RowWiseThreshold])
+  c = sca.SpectralClusterer(
+      min_clusters=int(g["min_clusters"]), max_clusters=None if maxc < 0 else maxc,
+      refinement_options=opts,
+      laplacian_type={0: None, 4: sca.LaplacianType.GraphCut}[lap])
+  return g, x, c, n, lap, maxc
+
+
+@pytest.mark.parametrize("name", ["general_dense_n300_lap4.npz", "general_dense_n1000_lap4.npz"])
+def test_max_clusters_none_with_laplacian_on_a_general_matrix_vs_reference_golden(name):
+  """[RowWiseThreshold] + GraphCut with max_clusters=None: the ascending eigengap loop reads EVERY
+  eigenvalue of a matrix that is not diagonally similar to a symmetric one (utils.py:59,
+  100-115).  Rounds 1-4 raised here for n > 64; now: Hessenberg reduction on the device, QR
+  iteration + inverse iteration on the host (eig_path 7).  Golden: the real reference
+  (oracle/make_golden.py --general-dense)."""
+  g, x, c, n, lap, maxc = _dense_case(name)
+  labels = c.predict(x)
+  dg = c.last_diag
+  assert dg.symmetry_state == 3 and dg.eig_path == 7
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"])
+  np.testing.assert_allclose(dg.max_delta, float(g["max_delta"]), rtol=1e-6)
+  w = c.consumed_eigenvalues()
+  ref = g["eigenvalues"]
+  assert w.size == n
+  idx = np.arange(1, n)  # ascending branch: w[1 .. n - 1] are read
+  err = np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-9 * np.abs(ref).max())
+  assert err.max() < 1e-5, err.max()
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+
+
+def test_more_than_64_eigenpairs_of_a_general_matrix_vs_reference_golden():
+  """max_clusters = 80 and min_clusters = 66 on a non-symmetric refined matrix: 81 eigenvalues
+  read, 66 eigenvectors (complex pairs among them) embedded.  Rounds 1-4 raised beyond 64."""
+  g, x, c, n, lap, maxc = _dense_case("general_dense_n500_max80.npz")
+  labels = c.predict(x)
+  dg = c.last_diag
+  assert dg.symmetry_state == 3 and dg.eig_path == 7
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"])
+  assert dg.n_clusters == int(g["min_clusters"]) == 66
+  np.testing.assert_allclose(dg.max_delta, float(g["max_delta"]), rtol=1e-6)
+  w = c.consumed_eigenvalues()
+  ref = g["eigenvalues"]
+  idx = np.arange(1, maxc)
+  err = np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-9 * np.abs(ref).max())
+  assert err.max() < 1e-5, err.max()
+  assert np.unique(labels).size == np.unique(g["labels"]).size
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+
+
+def test_descending_request_that_reads_past_64_values_of_a_general_matrix():
+  """[RowWiseThreshold] without a Laplacian and max_clusters=None: the descending loop reads on
+  until an eigenvalue falls below stop_eigenvalue (181 values here, utils.py:116-128): the wide
+  block Arnoldi finds out and hands over to the dense route."""
+  g, x, c, n, lap, maxc = _dense_case("general_dense_n300_lap0.npz")
+  labels = c.predict(x)
+  dg = c.last_diag
+  assert dg.symmetry_state == 3 and dg.eig_path == 7
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"])
+  np.testing.assert_allclose(dg.max_delta, float(g["max_delta"]), rtol=1e-6)
+  w = c.consumed_eigenvalues()
+  ref = g["eigenvalues"]
+  idx = so.consumed_eigen_indices(n, None, True, ref, 1e-2)
+  assert idx.size > 64
+  err = np.abs(w[idx] - ref[idx]) / np.maximum(np.abs(ref[idx]), 1e-9 * np.abs(ref).max())
+  assert err.max() < 1e-5, err.max()
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+
+
+@pytest.mark.parametrize("n,count,descend", [(150, 150, True), (700, 100, False), (2100, 70, True)])
+def test_dense_general_route_vs_numpy(n, count, descend):
+  """sc_stage_eig with more than 64 pairs of a non-symmetric matrix: eigenvalues against
+  np.linalg.eig (all of them when count = n), residuals of the real eigenvectors."""
+  m, _ = thresholded(n, 24, 12, seed=n + 7)
+  assert not np.allclose(m, m.T)
+  w, v = sca.utils.compute_sorted_eigenvectors(m, descend=descend, count=count)
+  ev = np.linalg.eigvals(m)
+  order = np.argsort(-ev.real if descend else ev.real, kind="stable")
+  ev = ev[order]
+  scale = np.abs(ev).max()
+  np.testing.assert_allclose(w, ev.real[:count], rtol=1e-8, atol=1e-9 * scale)
+  checked = 0
+  for j in range(count):
+    if abs(ev[j].imag) == 0.0:
+      r = m @ v[:, j] - w[j] * v[:, j]
+      assert np.abs(r).max() < 1e-8 * scale, j
+      assert abs(np.linalg.norm(v[:, j]) - 1.0) < 1e-10
+      checked += 1
+  assert checked > 0
+
+
+def test_block_arnoldi_that_spends_its_restart_budget_lands_on_the_dense_route():
+  """np.linalg.eig always returns (utils.py:59): with a zero restart budget the block Arnoldi of a
+  slowly converging request gives up at its first full basis and the dense route takes over --
+  same eigengap decision and labels as with the default budget."""
+  g = golden("general_wide_n400.npz")
+  n, d, k, seed, lap, maxc = [int(v) for v in g["params"]]
+  x = so.blobs(n, d, k, seed)
+  c = sca.SpectralClusterer(
+      min_clusters=int(g["min_clusters"]), max_clusters=maxc,
+      refinement_options=threshold_only_options(p_percentile=float(g["p_percentile"])),
+      laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  c.eig_max_cycles = -1
+  labels = c.predict(x)
+  dg = c.last_diag
+  # (a request the first full basis already satisfies never reaches the budget: path 4 then)
+  assert dg.eig_path in (4, 7) and (dg.eig_path == 4 or dg.eig_fallback == 1)
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"])
+  np.testing.assert_allclose(dg.max_delta, float(g["max_delta"]), rtol=1e-6)
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0

@@ -562,6 +562,114 @@ def test_host_general_eig_vs_numpy():
       assert np.abs(np.linalg.norm(v, axis=0) - 1.0).max() < 1e-13 * m
 
 
+def _gehd2(a):
+  """LAPACK dgehd2 in NumPy, in the storage the device reduction (hessenberg.hip) leaves: the
+  Hessenberg matrix on and above the subdiagonal, reflector k (v[k + 1] = 1 implied) below the
+  subdiagonal of column k, tau."""
+  a = a.copy()
+  n = a.shape[0]
+  tau = np.zeros(max(n - 2, 1))
+  for k in range(n - 2):
+    x = a[k + 1:, k].copy()
+    alpha, xnorm = x[0], np.linalg.norm(x[1:])
+    if xnorm == 0.0:
+      continue
+    beta = -np.copysign(np.hypot(alpha, xnorm), alpha)
+    tau[k] = (beta - alpha) / beta
+    v = x / (alpha - beta)
+    v[0] = 1.0
+    a[:, k + 1:] -= tau[k] * np.outer(a[:, k + 1:] @ v, v)
+    a[k + 1:, k + 1:] -= tau[k] * np.outer(v, v @ a[k + 1:, k + 1:])
+    a[k + 1, k] = beta
+    a[k + 2:, k] = v[1:]
+  return np.ascontiguousarray(a), tau
+
+
+def _host_hessenberg_eig(a, pick):
+  lib = _lib.load()
+  n = a.shape[0]
+  packed, tau = _gehd2(a)
+  count = len(pick)
+  wr, wi = np.empty(n), np.empty(n)
+  vr, vi = np.empty((n, max(count, 1))), np.empty((n, max(count, 1)))
+  res = np.zeros(1)
+  pk = np.asarray(pick, dtype=np.int32)
+  rc = lib.sc_host_hessenberg_eig(
+      _lib.as_double_p(packed), _lib.as_double_p(tau), n, count,
+      pk.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _lib.as_double_p(wr), _lib.as_double_p(wi),
+      _lib.as_double_p(vr), _lib.as_double_p(vi), _lib.as_double_p(res))
+  return rc, wr + 1j * wi, (vr + 1j * vi)[:, :count], float(res[0])
+
+
+def test_host_hessenberg_eigenvalues_vs_numpy():
+  """The QR iteration behind eig_path 7 (every eigenvalue of a general matrix of order > 64):
+  random, graph-Laplacian, defective-looking and block-diagonal inputs against np.linalg.eig."""
+  rng = np.random.default_rng(70)
+  cases = []
+  for n in (3, 4, 17, 65, 200, 421):
+    cases.append(("randn", rng.standard_normal((n, n))))
+  x = so.blobs(300, 24, 5, seed=9)
+  a = so.row_wise_threshold(so.affinity(x), p_percentile=0.9)
+  cases.append(("thresholded affinity", a))
+  cases.append(("graph-cut laplacian", so.laplacian(a, so.LAPLACIAN_GRAPH_CUT)))
+  cases.append(("random-walk laplacian", so.laplacian(a, so.LAPLACIAN_RANDOM_WALK)))
+  blk = np.zeros((120, 120))
+  for b in range(4):  # four disconnected components: eigenvalue 0 four times
+    blk[30 * b:30 * b + 30, 30 * b:30 * b + 30] = rng.uniform(0.5, 1.0, (30, 30))
+  cases.append(("disconnected", np.diag(blk.sum(1)) - blk))
+  jordan = np.diag(np.full(40, 2.0)) + np.diag(np.full(39, 1e-3), 1)
+  q, _ = np.linalg.qr(rng.standard_normal((40, 40)))
+  cases.append(("nearly defective", q @ jordan @ q.T))
+  cases.append(("already hessenberg", np.triu(rng.standard_normal((50, 50)), -1)))
+  cases.append(("zero", np.zeros((10, 10))))
+  for name, m in cases:
+    rc, w, _, _ = _host_hessenberg_eig(m, [])
+    assert rc == 0, name
+    ref = np.linalg.eigvals(m)
+    scale = max(np.abs(ref).max(), 1e-300)
+    dist = np.abs(w[:, None] - ref[None, :])
+    # (a 40 x 40 Jordan-like block with coupling 1e-3: rounding moves its eigenvalues by
+    #  ~1e-3 * eps^(1/40) ~ 4e-4 in ANY backward-stable solver, numpy's included)
+    tol = (1e-4 if name == "nearly defective" else 1e-11) * scale * max(m.shape[0], 10)
+    assert max(dist.min(axis=1).max(), dist.min(axis=0).max()) <= tol, name
+    # conjugate pairs sit next to each other, positive imaginary part first
+    for i in np.nonzero(w.imag > 0)[0]:
+      assert w[i + 1] == np.conj(w[i]), name
+
+
+def test_host_hessenberg_eigenvectors_are_eigenvectors_of_the_original_matrix():
+  """Inverse iteration on the Hessenberg form + back-transform through the reflectors: residual
+  of A x = lambda x on the ORIGINAL matrix, independence inside clusters of equal eigenvalues,
+  conjugate pairs."""
+  rng = np.random.default_rng(71)
+  x = so.blobs(260, 24, 6, seed=4)
+  a = so.row_wise_threshold(so.affinity(x), p_percentile=0.9)
+  lap = so.laplacian(a, so.LAPLACIAN_GRAPH_CUT)
+  blk = np.zeros((120, 120))
+  for b in range(4):
+    blk[30 * b:30 * b + 30, 30 * b:30 * b + 30] = rng.uniform(0.5, 1.0, (30, 30))
+  q = rng.standard_normal((60, 60))
+  rep = q @ np.diag([2.0] * 5 + [1.0] * 5 + list(rng.uniform(-1, 0.5, 50))) @ np.linalg.inv(q)
+  for name, m, count in (("randn", rng.standard_normal((150, 150)), 40),
+                         ("laplacian", -lap, 80), ("affinity", a, 80),
+                         ("disconnected", blk - np.diag(blk.sum(1)), 8), ("repeated", rep, 12)):
+    rc, w, _, _ = _host_hessenberg_eig(m, [])
+    assert rc == 0
+    pick = np.argsort(-w.real, kind="stable")[:count]
+    rc, w2, v, res = _host_hessenberg_eig(m, pick)
+    assert rc == 0 and np.array_equal(w, w2)
+    lam = w[pick]
+    scale = np.abs(m).max()
+    r = np.linalg.norm(m @ v - v * lam[None, :], axis=0) / np.linalg.norm(v, axis=0)
+    assert r.max() < 1e-10 * scale * m.shape[0], (name, r.max())
+    assert res < 1e-10
+    unit = v / np.linalg.norm(v, axis=0)
+    assert np.linalg.svd(unit, compute_uv=False).min() > 1e-4, name  # an independent set
+    for i in range(count - 1):
+      if lam[i].imag > 0 and lam[i + 1] == np.conj(lam[i]):
+        assert np.array_equal(v[:, i + 1], np.conj(v[:, i])), name
+
+
 def test_cost_model_matches_its_calibration_record():
   """multigpu.cost_model against the measured per-utterance times it was fitted on
   (profiles/r06g_cost_fit.txt, written by tests/probes/cost_model_fit.py on the GPU box):

@@ -82,7 +82,10 @@ enum {
   SC_KMEANS_EUCLIDEAN = 1,
   SC_KMEANS_SQEUCLIDEAN = 2,
   SC_KMEANS_CITYBLOCK = 3,
-  SC_KMEANS_CHEBYSHEV = 4
+  SC_KMEANS_CHEBYSHEV = 4,
+  SC_KMEANS_CORRELATION = 5, /* cosine distance of the row-centred operands */
+  SC_KMEANS_BRAYCURTIS = 6,
+  SC_KMEANS_CANBERRA = 7
 };
 /* utils.py:10-17 EigenGapType */
 enum { SC_EIGENGAP_RATIO = 1, SC_EIGENGAP_NORMALIZED_DIFF = 2 };

@@ -355,7 +355,8 @@ def kmeans_metric_goldens():
     cent = r2.standard_normal((k, k))
     e = cent[r2.integers(0, k, n)] * 0.6 + 0.35 * r2.standard_normal((n, k))
     km["e_" + tag] = e
-    for metric in ("euclidean", "sqeuclidean", "cityblock", "chebyshev"):
+    for metric in ("euclidean", "sqeuclidean", "cityblock", "chebyshev",
+                   "correlation", "braycurtis", "canberra", "minkowski"):  # (last four: round 5)
       km["labels_%s_%s" % (tag, metric)] = ref_kmeans.run_kmeans(e, k, metric, 300)
   save("kmeans_metrics.npz", **km)
 

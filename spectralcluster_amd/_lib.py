@@ -259,7 +259,18 @@ PROTOTYPES = {
 
 # custom_dist values that run on the device (scipy cdist names)
 KMEANS_METRICS = {"cosine": 0, "euclidean": 1, "sqeuclidean": 2, "cityblock": 3,
-                  "chebyshev": 4}
+                  "chebyshev": 4, "correlation": 5, "braycurtis": 6, "canberra": 7,
+                  # scipy's cdist without a `p` argument (the reference passes none,
+                  # custom_distance_kmeans.py:123-124) takes p = 2: the Euclidean distance
+                  "minkowski": 1}
+# ... and the aliases scipy.spatial.distance accepts for them (scipy 1.15 _METRIC_INFOS;
+# cdist lower-cases the name first)
+_KMEANS_METRIC_ALIASES = {
+    "cos": "cosine", "e": "euclidean", "eu": "euclidean", "euclid": "euclidean",
+    "sqe": "sqeuclidean", "sqeuclid": "sqeuclidean", "c": "cityblock", "cb": "cityblock",
+    "cblock": "cityblock", "ch": "chebyshev", "cheb": "chebyshev", "cheby": "chebyshev",
+    "chebychev": "chebyshev", "co": "correlation", "m": "minkowski", "mi": "minkowski",
+    "pnorm": "minkowski"}
 
 
 class NotFittedError(ValueError, AttributeError):
@@ -276,11 +287,14 @@ def kmeans_metric_code(custom_dist) -> int:
     raise NotFittedError(
         "This KMeans instance is not fitted yet. Call 'fit' with appropriate arguments "
         "before using this estimator.")
-  if isinstance(custom_dist, str) and custom_dist in KMEANS_METRICS:
-    return KMEANS_METRICS[custom_dist]
+  if isinstance(custom_dist, str):
+    name = custom_dist.lower()
+    name = _KMEANS_METRIC_ALIASES.get(name, name)
+    if name in KMEANS_METRICS:
+      return KMEANS_METRICS[name]
   raise UnsupportedOnDeviceError(
-      "custom_dist=%r: the device path implements %s; other scipy metrics and callables "
-      "are not on it" % (custom_dist, ", ".join(sorted(KMEANS_METRICS))))
+      "custom_dist=%r: the device path implements %s (and scipy's aliases of those); other "
+      "scipy metrics and callables are not on it" % (custom_dist, ", ".join(sorted(KMEANS_METRICS))))
 
 
 _lib = None

@@ -1071,11 +1071,10 @@ KmeansWorkspace kmeans_workspace(sc_handle h) {
 static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k, int max_iter,
                             int64_t* labels, double* centroids_out, int* iterations,
                             int metric = kKmeansCosine) {
-  if (metric != kKmeansCosine && metric != kKmeansEuclidean && metric != kKmeansSqeuclidean &&
-      metric != kKmeansCityblock && metric != kKmeansChebyshev)
+  if (metric < kKmeansCosine || metric > kKmeansCanberra)
     return fail(h, SC_ERR_UNSUPPORTED,
-                "custom_dist on the device: cosine, euclidean, sqeuclidean, cityblock, "
-                "chebyshev");
+                "custom_dist on the device: cosine, euclidean (minkowski), sqeuclidean, "
+                "cityblock, chebyshev, correlation, braycurtis, canberra");
   if (max_iter <= 0)
     return fail(h, SC_ERR_INVALID, "Number of iterations should be a positive number");
   if (n < k) return fail(h, SC_ERR_INVALID, "n_samples should be >= n_clusters");

@@ -358,10 +358,39 @@ __global__ __launch_bounds__(KT) void k_kmeans(
   if (tid == 0) info[3] = (int)(wall_clock64() - t_start);
   double prev = 0.0;
   int it = 0;
+  // scipy's `correlation` is its cosine distance on row-centred operands (scipy 1.15
+  // spatial/distance.py _correlation_cdist_wrap: X - X.mean(axis=1, keepdims=True)): the row mean
+  // in numpy's summation order for short rows, then the cosine code on the differences
+  auto row_mean = [&](auto at) -> double {
+    double s;
+    if (k < 8) {
+      s = 0.0;
+      for (int j = 0; j < k; ++j) s += at(j);
+    } else {
+      double a8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a8[q] = at(q);
+      int j = 8;
+      for (; j < k - (k % 8); j += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a8[q] += at(j + q);
+      }
+      s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+      for (; j < k; ++j) s += at(j);
+    }
+    return s / (double)k;
+  };
   for (;; ++it) {
     for (int t = tid; t < k; t += KT) {
       double s = 0.0;
-      for (int j = 0; j < k; ++j) s += cent[t * k + j] * cent[t * k + j];
+      if (metric == kKmeansCorrelation) {
+        const double mc = row_mean([&](int j) { return cent[t * k + j]; });
+        for (int j = 0; j < k; ++j) s += (cent[t * k + j] - mc) * (cent[t * k + j] - mc);
+        // (the centred centroid's mean rides in the wave-partial scratch: free at this point)
+        wpart[t] = mc;
+      } else {
+        for (int j = 0; j < k; ++j) s += cent[t * k + j] * cent[t * k + j];
+      }
       cnorm[t] = sqrt(s);
     }
     __syncthreads();
@@ -370,11 +399,20 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     for (int r = tid; r < n; r += KT) {
       int best = 0;
       double bd = INFINITY;
-      const double nu = enorm[r];
+      double nu = enorm[r], mx = 0.0;
+      if (metric == kKmeansCorrelation) {
+        mx = row_mean([&](int j) { return ET[(size_t)j * lde + r]; });
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) {
+          const double e = ET[(size_t)j * lde + r] - mx;
+          s += e * e;
+        }
+        nu = sqrt(s);
+      }
       for (int c0 = 0; c0 < k; c0 += 8) {
-        double dot[8];
+        double dot[8], aux[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) dot[q] = 0.0;
+        for (int q = 0; q < 8; ++q) dot[q] = aux[q] = 0.0;
         for (int j = 0; j < k; ++j) {
           const double x = ET[(size_t)j * lde + r];
 #pragma unroll
@@ -383,10 +421,18 @@ __global__ __launch_bounds__(KT) void k_kmeans(
               const double cv = cent[(c0 + q) * k + j];
               if (metric == kKmeansCosine) {
                 dot[q] += x * cv;
+              } else if (metric == kKmeansCorrelation) {
+                dot[q] += (x - mx) * (cv - wpart[c0 + q]);
               } else if (metric == kKmeansCityblock) {
                 dot[q] += fabs(x - cv);
               } else if (metric == kKmeansChebyshev) {
                 dot[q] = fmax(dot[q], fabs(x - cv));
+              } else if (metric == kKmeansBraycurtis) {  // sum |u - v| / sum |u + v|
+                dot[q] += fabs(x - cv);
+                aux[q] += fabs(x + cv);
+              } else if (metric == kKmeansCanberra) {  // sum |u - v| / (|u| + |v|), 0 / 0 = 0
+                const double den = fabs(x) + fabs(cv);
+                if (den > 0.0) dot[q] += fabs(x - cv) / den;
               } else {  // (squared) Euclidean
                 dot[q] += (x - cv) * (x - cv);
               }
@@ -397,10 +443,12 @@ __global__ __launch_bounds__(KT) void k_kmeans(
         for (int q = 0; q < 8; ++q) {
           if (c0 + q < k) {
             double d;
-            if (metric == kKmeansCosine) {
+            if (metric == kKmeansCosine || metric == kKmeansCorrelation) {
               double cosine = dot[q] / (nu * cnorm[c0 + q]);
               if (fabs(cosine) > 1.0) cosine = copysign(1.0, cosine);
               d = 1.0 - cosine;
+            } else if (metric == kKmeansBraycurtis) {
+              d = dot[q] / aux[q];
             } else {
               d = metric == kKmeansEuclidean ? sqrt(dot[q]) : dot[q];
             }

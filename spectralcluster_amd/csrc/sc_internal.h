@@ -493,7 +493,10 @@ enum {
   kKmeansEuclidean = 1,
   kKmeansSqeuclidean = 2,
   kKmeansCityblock = 3,
-  kKmeansChebyshev = 4
+  kKmeansChebyshev = 4,
+  kKmeansCorrelation = 5,
+  kKmeansBraycurtis = 6,
+  kKmeansCanberra = 7
 };
 void launch_kmeans(hipStream_t s, const double* ET, int lde, int n, int k,
                    int max_iter, int first_center, int trials,

@@ -321,7 +321,8 @@ def test_size_reduction_vs_reference():
 def test_kmeans_other_metrics_vs_reference():
   g = golden("kmeans_metrics.npz")
   for tag, k in (("a", 4), ("b", 7), ("c", 2)):
-    for metric in ("euclidean", "sqeuclidean", "cityblock", "chebyshev"):
+    for metric in ("euclidean", "sqeuclidean", "cityblock", "chebyshev", "correlation",
+                   "braycurtis", "canberra", "minkowski"):
       got = so.run_kmeans_metric(g["e_" + tag], k, 300, metric)
       assert np.array_equal(got, g["labels_%s_%s" % (tag, metric)])
   # cosine through the generic function equals the bit-exact restatement

@@ -212,7 +212,9 @@ typedef struct sc_diag {
   int32_t eig_fallback;          /* 0, or why block Lanczos handed over to the dense path:
                                     1 restart budget spent, 2 projected eigenproblem failed,
                                     3 no full-rank Krylov block, 4 forced (SC_EIG_FORCE_DENSE),
-                                    5 more than 64 eigenvectors wanted (> 64 selected clusters);
+                                    5 more than 64 eigenvectors wanted (> 64 selected clusters),
+                                    7 eight equal Ritz values ahead of the decisive gap (an
+                                    eigenvalue of multiplicity > 8: the dense path counts it);
                                     on the general path (eig_path 7) also 6: every eigenvalue
                                     is read (max_clusters=None with a Laplacian) */
   float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */

@@ -106,3 +106,120 @@ def test_restart_budget_exhausted_lands_on_dense_path(name):
   dg = c.last_diag
   assert dg.eig_path == 6 and dg.eig_fallback == 1  # SC_EIG_PATH_DENSE_FULL, budget spent
   _check(g, labels, dg.n_clusters_raw, dg.max_delta, dg.eigenvalue_array(), name)
+
+
+# --- attacks on the stopping rule's assumptions --------------------------------
+# Kato-Temple and the residual bound both say "an eigenvalue lies this close to theta"; neither
+# can COUNT eigenvalues.  A block Krylov space of 8 start vectors shows at most 8 copies of an
+# eigenvalue: multiplicity beyond the block size is the deterministic form of "a start block
+# numerically orthogonal to an eigenvector" (the missing copies are exactly the ones the start
+# block has no independent component for).  The spectra below are built so that everything the
+# request reads converges within the first three block steps -- the solver stops long before
+# rounding noise could grow the missing copies.
+def _matrix_with_spectrum(lam, seed):
+  rng = np.random.default_rng(seed)
+  q, _ = np.linalg.qr(rng.standard_normal((len(lam), len(lam))))
+  m = (q * np.asarray(lam)) @ q.T
+  return 0.5 * (m + m.T)
+
+
+def _spectrum(n, head, bulk_hi, seed):
+  rng = np.random.default_rng(seed)
+  bulk = np.sort(rng.uniform(0.0, bulk_hi, n - len(head)))[::-1]
+  return np.concatenate([np.asarray(head, dtype=float), bulk])
+
+
+@pytest.mark.parametrize("mult,isolated", [(9, False), (12, False), (20, False), (9, True),
+                                           (12, True)])
+def test_eigenvalue_of_multiplicity_beyond_the_block_size_is_counted(mult, isolated):
+  """`mult` copies of the largest eigenvalue, four more large ones, a bulk below
+  stop_eigenvalue: the reference reads mult + 5 values and finds the gap behind mult + 4.  A block
+  of 8 sees 8 copies; the guard (eight equal Ritz values ahead of the decisive gap) must send the
+  solve to the dense path, which counts by Sturm sequences.  `isolated`: the first value below
+  stop_eigenvalue stands alone above a bulk 10 x smaller, so that EVERYTHING the request reads
+  has converged by the first check -- the solver gets no extra passes in which rounding noise
+  could grow the missing copies."""
+  n = 700
+  head = [3.0] * mult + [2.0, 1.5, 1.0, 0.5] + ([1e-3] if isolated else [])
+  lam = _spectrum(n, head, 1e-4 if isolated else 5e-3, seed=mult)
+  a = _matrix_with_spectrum(lam, seed=100 + mult)
+  ref_k, ref_delta = so.eigengap(np.sort(np.linalg.eigvalsh(a))[::-1], None, 1e-2,
+                                 so.EIGENGAP_RATIO, True)
+  assert ref_k == mult + 4
+  c = sca.SpectralClusterer(min_clusters=2, refinement_options=sca.RefinementOptions(
+      refinement_sequence=[]), affinity_function=lambda x: a)
+  c.predict(np.zeros((n, 2)))
+  dg = c.last_diag
+  assert dg.n_clusters_raw == ref_k, (dg.n_clusters_raw, dg.eig_path, dg.eig_fallback)
+  np.testing.assert_allclose(dg.max_delta, ref_delta, rtol=1e-5)
+  w = c.consumed_eigenvalues()
+  np.testing.assert_allclose(w[:mult + 5], lam[:mult + 5], rtol=1e-5, atol=1e-9)
+
+
+def test_fixed_count_request_across_a_multiplicity_beyond_the_block_size():
+  """sc_stage_sym_eig: 16 leading eigenpairs of a matrix whose largest eigenvalue has
+  multiplicity 12."""
+  n = 600
+  lam = _spectrum(n, [3.0] * 12 + [2.0, 1.5, 1.0, 0.5], 5e-3, seed=5)
+  a = _matrix_with_spectrum(lam, seed=6)
+  w, v = sca.utils.compute_sorted_eigenvectors(a, descend=True, count=16)
+  np.testing.assert_allclose(w, lam[:16], rtol=1e-8, atol=1e-9)
+  r = a @ v - v * w[None, :]
+  assert np.abs(r).max() < 1e-8
+  # an orthonormal basis of the 12-dimensional eigenspace, not 8 vectors and 4 strangers
+  g = v[:, :12].T @ v[:, :12]
+  assert np.abs(g - np.eye(12)).max() < 1e-8
+
+
+def test_cluster_tighter_than_the_tolerance_in_front_of_the_gap():
+  """k + 1 = 9 eigenvalues inside one interval narrower than the stopping tolerance (spread
+  1e-8 relative): indistinguishable from a multiple eigenvalue for the solver, and all nine are
+  in front of the decisive gap."""
+  n = 650
+  head = list(3.0 * (1.0 + 1e-8 * np.arange(9)[::-1] / 9.0)) + [1.2, 0.7]
+  lam = _spectrum(n, head, 5e-3, seed=7)
+  a = _matrix_with_spectrum(lam, seed=8)
+  ref_k, ref_delta = so.eigengap(np.sort(np.linalg.eigvalsh(a))[::-1], None, 1e-2,
+                                 so.EIGENGAP_RATIO, True)
+  assert ref_k == 11
+  c = sca.SpectralClusterer(min_clusters=2, refinement_options=sca.RefinementOptions(
+      refinement_sequence=[]), affinity_function=lambda x: a)
+  c.predict(np.zeros((n, 2)))
+  dg = c.last_diag
+  assert dg.n_clusters_raw == ref_k
+  np.testing.assert_allclose(dg.max_delta, ref_delta, rtol=1e-5)
+
+
+def test_repeated_eigenvalue_at_the_eigengap_position_with_a_laplacian():
+  """Ten exactly disconnected, identical components: the unnormalised Laplacian has the
+  eigenvalue 0 ten times (more than a block shows) and the ascending eigengap sits right behind
+  them.  Reference: n_clusters = 10."""
+  rng = np.random.default_rng(11)
+  blk = rng.uniform(0.6, 1.0, (40, 40))
+  blk = 0.5 * (blk + blk.T)
+  a = np.kron(np.eye(10), blk)
+  n = a.shape[0]
+  lap = np.diag(a.sum(1)) - a
+  wl = np.sort(np.linalg.eigvalsh(lap))
+  ref_k, ref_delta = so.eigengap(wl, 20, None, so.EIGENGAP_RATIO, False)
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=20,
+                            laplacian_type=sca.LaplacianType.Unnormalized,
+                            refinement_options=sca.RefinementOptions(refinement_sequence=[]),
+                            affinity_function=lambda x: a)
+  c.predict(np.zeros((n, 2)))
+  dg = c.last_diag
+  assert ref_k == 10 and dg.n_clusters_raw == ref_k
+  # (max_delta = w[10] / (w[9] + 1e-10) with w[9] a rounding-level zero, +-1e-15: 1e-5 relative
+  #  is the noise floor of this quotient in ANY solver)
+  np.testing.assert_allclose(dg.max_delta, ref_delta, rtol=1e-3)
+
+
+def test_bulk_behind_the_gap_is_not_a_multiplicity_suspect():
+  """The guard looks in FRONT of the decisive gap only: a dense bulk of near-equal values behind
+  it (what a GraphCut Laplacian's spectrum looks like: 13 of the 21 values read at n = 8192 lie
+  within 2e-6 of 1) must stay on the Krylov path."""
+  g = golden("e2e_n2048_lap4_max20.npz")
+  n, d, k, seed, lap, maxc = (int(v) for v in g["params"])
+  c = _clusterer(4, maxc)
+  c.predict(so.blobs(n, d, k, seed))
+  assert c.last_diag.eig_path == 2 and c.last_diag.eig_fallback == 0

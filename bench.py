@@ -678,7 +678,13 @@ def main():
   eigenvalues = diag.eigenvalue_array()
 
   step()
-  elapsed_resident = timed(step, k)
+  res_sum = np.zeros(len(names))
+
+  def collect_res():
+    res_sum[:] += [diag.stage_ms[i] for i in range(len(names))]
+
+  elapsed_resident = timed(step, k, collect_res)
+  resident_stage_ms = {name: float(res_sum[i] / k) for i, name in enumerate(names)}
   resident_labels = labels.copy()
 
   # per-kernel timers (a few extra steps with event pairs around the hot kernels)
@@ -805,7 +811,10 @@ def main():
             "value": world * k / elapsed_resident, "unit": "calls/s",
             "ms_per_step": 1e3 * elapsed_resident / k,
             "step": "sc_run_resident: the same pipeline with the embeddings already in HBM "
-                    "(no H2D of X; labels D2H inside)"},
+                    "(no H2D of X; labels D2H inside)",
+            "stage_ms": {kk: v for kk, v in resident_stage_ms.items()
+                         if kk in ("affinity", "refine", "diffuse", "scaling", "eig", "kmeans",
+                                   "total")}},
         "roofline": roof,
         "whole_call": whole,
         "stage_ms": {kk: v for kk, v in stage_ms.items()

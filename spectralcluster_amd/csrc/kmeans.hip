@@ -132,7 +132,9 @@ __device__ __forceinline__ void cluster_means(const double* __restrict__ data, i
 // 13-52 takes any k) -- the per-cluster arrays live in a global workspace `gws` / `gwi` instead
 // of LDS (one workgroup: its own stores are visible to it behind __syncthreads), everything else
 // is the same code.  gws: k (2 + 8 + 2 KW) + k^2 doubles, gwi: 3 k ints.
-size_t kmeans_big_workspace_doubles(int k) { return (size_t)k * (2 + 8 + 2 * KW) + (size_t)k * k; }
+// (16 k-means++ trial slots in the BIG form: sklearn draws 2 + int(log k) candidates per centre,
+//  more than 8 from k = 1097 on; 16 cover every k a 32-bit sample count allows)
+size_t kmeans_big_workspace_doubles(int k) { return (size_t)k * (2 + 16 + 2 * KW) + (size_t)k * k; }
 template <bool BIG>
 __global__ __launch_bounds__(KT) void k_kmeans(
     const double* __restrict__ ET, int lde, int n, int k, int max_iter,
@@ -147,12 +149,13 @@ __global__ __launch_bounds__(KT) void k_kmeans(
   __shared__ double s_mean[KL];
   __shared__ double s_cent[KL * KL];   // k x k, stride k
   __shared__ double s_cnorm[KL];
+  constexpr int TS = BIG ? 16 : 8;              // k-means++ trial slots (2 + int(log k) used)
   __shared__ double s_candrow[8 * KL];          // candidate rows, stride k
-  __shared__ double candsq[8];
+  __shared__ double candsq[TS];
   __shared__ double scan[KT];
-  __shared__ double pots[8];
-  __shared__ double rvals[8];
-  __shared__ int cand[8];
+  __shared__ double pots[TS];
+  __shared__ double rvals[TS];
+  __shared__ int cand[TS];
   __shared__ int s_seeds[KL];
   __shared__ int s_counts[KL];
   __shared__ int s_nzcounts[KL];
@@ -161,8 +164,8 @@ __global__ __launch_bounds__(KT) void k_kmeans(
   double* mean = BIG ? gws : s_mean;
   double* cnorm = BIG ? gws + k : s_cnorm;
   double* candrow = BIG ? gws + 2 * (size_t)k : s_candrow;
-  double* wpart = BIG ? gws + 10 * (size_t)k : s_wpart;
-  double* cent = BIG ? gws + (size_t)k * (10 + 2 * KW) : s_cent;
+  double* wpart = BIG ? gws + (2 + TS) * (size_t)k : s_wpart;
+  double* cent = BIG ? gws + (size_t)k * (2 + TS + 2 * KW) : s_cent;
   int* seeds = BIG ? gwi : s_seeds;
   int* counts = BIG ? gwi + k : s_counts;
   int* nzcounts = BIG ? gwi + 2 * (size_t)k : s_nzcounts;
@@ -265,23 +268,23 @@ __global__ __launch_bounds__(KT) void k_kmeans(
     }
     if (tid < trials) candsq[tid] = xsq[cand[tid]];
     __syncthreads();
-    double part[8];
+    double part[TS];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) part[t] = 0.0;
+    for (int t = 0; t < TS; ++t) part[t] = 0.0;
 #pragma unroll 4
     for (int r = tid; r < n; r += KT) {
-      double dot[8];
+      double dot[TS];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) dot[t] = 0.0;
+      for (int t = 0; t < TS; ++t) dot[t] = 0.0;
       for (int j = 0; j < k; ++j) {
         const double x = XcT[(size_t)j * n + r];
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < TS; ++t)
           if (t < trials) dot[t] += candrow[t * k + j] * x;
       }
       const double xs = xsq[r], cl = closest[r];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < TS; ++t) {
         if (t < trials) {
           double d = -2.0 * dot[t];
           d += candsq[t];
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(KT) void k_kmeans(
       }
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < TS; ++t) {
       if (t < trials) {  // uniform
         const double tot = bsum(part[t], sm);
         if (tid == 0) pots[t] = tot;

@@ -85,12 +85,20 @@ def test_run_kmeans_more_than_64_centres(k):
   assert np.array_equal(got, want)
 
 
-def test_kmeans_trial_limit_is_reported():
-  # sklearn's k-means++ draws 2 + int(log k) candidates per centre; the kernels hold 8,
-  # i.e. k <= 1096 -- beyond that the device path says so instead of guessing
-  e = np.random.default_rng(0).standard_normal((1200, 1100))
-  with pytest.raises(_lib.UnsupportedOnDeviceError):
-    sca.custom_distance_kmeans.run_kmeans(e, 1100, "cosine", 10)
+def test_kmeans_with_more_than_1096_centres():
+  """sklearn's k-means++ draws 2 + int(log k) candidates per centre: 9 from k = 1097 on, one more
+  than the 8 trial slots rounds 1-4 held (they refused such a k); the large-k form now holds 16.
+  Against the oracle's restatement, like the smaller k above."""
+  k = 1100
+  rng = np.random.default_rng(k)
+  n = 3 * k
+  centers = rng.standard_normal((k, 24))
+  e = np.zeros((n, k))
+  e[:, :24] = centers[rng.permutation(n) % k] + 0.02 * rng.standard_normal((n, 24))
+  e[:, 24:] = 1e-3 * rng.standard_normal((n, k - 24))
+  want = so.run_kmeans(e, k, 300)
+  got = sca.custom_distance_kmeans.run_kmeans(e, k, "cosine", 300)
+  assert np.array_equal(got, want)
 
 
 def test_stage_sym_eig_more_than_64_vectors():

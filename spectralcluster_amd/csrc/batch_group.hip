@@ -497,8 +497,10 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
 
 // ---- streams on hardware queues of their own
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by
-// default, 8 once this library is loaded: api.hip), and streams that share a queue run one
-// after the other.  A chain's 10 us launches queued behind a front's multi-millisecond GEMM cost
+// default; the library does not touch the process environment -- a caller may export 8 before
+// its first HIP call, api.hip / INTEGRATION.md section 4; round 5's probe measured 5950-6280
+// utterances/s on config 5 with the default 4 and 5750-6120 with 8: no longer a difference),
+// and streams that share a queue run one after the other.  A chain's 10 us launches queued behind a front's multi-millisecond GEMM cost
 // a two-lane batch 10 % (3700 instead of 4100 utterances/s on config 5) whenever the creation
 // order of the process's streams (every member arena owns one, an application has its own) put
 // them together.  Which queue a new stream lands on is the runtime's business (ROCm 7.2: up

@@ -783,33 +783,26 @@ __global__ __launch_bounds__(256) void k_free_row_stats_wg(
   free_row_stats_body(A, n, ld, y1, count, cand, cap, rowmax, rowsum, ovf);
 }
 
-// Round 5: one WAVEFRONT per row, four consecutive rows per workgroup.  The one-workgroup-per-
-// row form above moved its 546 MB per launch (n = 8192) at 2.5 TB/s: 8192 workgroups of ~7 us
-// whose last third is two or three block reductions (barriers) and the atomics.  Here a row is
-// 64 lanes x 16 bytes per step, FOUR steps of the row, of y1 and of every candidate row requested
-// before the first is used, the reductions are wave shuffles (no barrier anywhere), and a
-// candidate that is the row itself (the diagonal entry <A_i, A_i>: half of all candidates) costs
-// no second stream.  Neighbouring rows -- the usual other candidate -- sit in the same workgroup.
-// Fixed order: lane l owns k = 2 l, 2 l + 1 (mod 128) in ascending order, then the xor tree.
-// (U steps in flight: 4 for the common one or two candidates, fewer for the rare long lists --
-//  the kernel's register count, hence its occupancy, is set by its widest instantiation)
+// Round 5 (second form; the first -- one WAVEFRONT per row, four rows per workgroup, shuffles
+// instead of block reductions -- measured 254 us against this kernel's 224 at n = 8192,
+// profiles/r07c: dropped): the same one-workgroup-per-row walk with (a) no second stream for a
+// candidate that is the row itself (the diagonal entry <A_i, A_i>: half of all candidates),
+// (b) U steps of the row, of y1 and of every candidate requested before the first is used.
 template <int CNT, int U>
-__device__ __forceinline__ void free_row_wave_dots(const double* __restrict__ x,
-                                                   const double* const* __restrict__ xj,
-                                                   const bool* self,
-                                                   const double* __restrict__ y1, int n, int lane,
-                                                   double* rs_out, double* acc_out) {
+__device__ __forceinline__ void free_row_dots2(const double* __restrict__ x,
+                                               const double* const* __restrict__ xj,
+                                               const bool* self, const double* __restrict__ y1,
+                                               int n, double* rs_out, double* acc_out) {
   double rs = 0.0;
   double acc[CNT > 0 ? CNT : 1];
 #pragma unroll
   for (int c = 0; c < CNT; ++c) acc[c] = 0.0;
-  for (int k0 = 2 * lane; k0 < n; k0 += 128 * U) {
+  for (int k0 = 2 * threadIdx.x; k0 < n; k0 += 512 * U) {
     double2 a[U], yy[U], b[U][CNT > 0 ? CNT : 1];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = k0 + 128 * u;
-      const bool in = k < n;  // (rows are padded to ld, a multiple of 16 doubles: a pair that
-                              //  starts inside the row's storage stays inside it)
+      const int k = k0 + 512 * u;
+      const bool in = k < n;  // (rows are padded to ld, a multiple of 16 doubles)
       a[u] = in ? *reinterpret_cast<const double2*>(x + k) : make_double2(0.0, 0.0);
       yy[u] = in ? *reinterpret_cast<const double2*>(y1 + k) : make_double2(0.0, 0.0);
 #pragma unroll
@@ -819,8 +812,8 @@ __device__ __forceinline__ void free_row_wave_dots(const double* __restrict__ x,
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = k0 + 128 * u;
-      if (k + 1 >= n) {  // (the last pair of an odd row; also every pair past the end: zeros)
+      const int k = k0 + 512 * u;
+      if (k + 1 >= n) {
         a[u].y = 0.0;
         yy[u].y = 0.0;
 #pragma unroll
@@ -836,18 +829,17 @@ __device__ __forceinline__ void free_row_wave_dots(const double* __restrict__ x,
       }
     }
   }
-  *rs_out = fr_wave_sum(rs);
+  *rs_out = rs;
 #pragma unroll
-  for (int c = 0; c < CNT; ++c) acc_out[c] = fr_wave_sum(acc[c]);
+  for (int c = 0; c < CNT; ++c) acc_out[c] = acc[c];
 }
 
-__device__ __forceinline__ void free_row_stats_wave_body(
+__device__ __forceinline__ void free_row_stats_body2(
     const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
     const int* __restrict__ count, const int* __restrict__ cand, int cap,
     double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
-  const int lane = threadIdx.x & 63;
-  const int row = 4 * (int)blockIdx.x + (int)(threadIdx.x >> 6);
-  if (row >= n) return;  // (wave-uniform; no barrier below)
+  __shared__ double sm[4];
+  const int row = blockIdx.x;
   const int total = count[row];
   const int cnt = total < cap ? total : cap;
   const double* x = A + (size_t)row * ld;
@@ -863,19 +855,24 @@ __device__ __forceinline__ void free_row_stats_wave_body(
 #pragma unroll
   for (int c = 0; c < kFreeCapMax; ++c) acc[c] = 0.0;
   double rs = 0.0;
-  switch (cnt) {  // (uniform over the wavefront; 1 and 2 are nearly every row)
-    case 0: free_row_wave_dots<0, 4>(x, xj, self, y1, n, lane, &rs, acc); break;
-    case 1: free_row_wave_dots<1, 4>(x, xj, self, y1, n, lane, &rs, acc); break;
-    case 2: free_row_wave_dots<2, 4>(x, xj, self, y1, n, lane, &rs, acc); break;
-    case 3: free_row_wave_dots<3, 2>(x, xj, self, y1, n, lane, &rs, acc); break;
-    case 4: free_row_wave_dots<4, 2>(x, xj, self, y1, n, lane, &rs, acc); break;
-    default: free_row_wave_dots<kFreeCapMax, 1>(x, xj, self, y1, n, lane, &rs, acc); break;
+  switch (cnt) {  // (uniform over the workgroup; 1 and 2 are nearly every row)
+    case 0: free_row_dots2<0, 4>(x, xj, self, y1, n, &rs, acc); break;
+    case 1: free_row_dots2<1, 4>(x, xj, self, y1, n, &rs, acc); break;
+    case 2: free_row_dots2<2, 4>(x, xj, self, y1, n, &rs, acc); break;
+    case 3: free_row_dots2<3, 2>(x, xj, self, y1, n, &rs, acc); break;
+    case 4: free_row_dots2<4, 2>(x, xj, self, y1, n, &rs, acc); break;
+    default: free_row_dots2<kFreeCapMax, 1>(x, xj, self, y1, n, &rs, acc); break;
   }
-  if (lane == 0) {
-    double best = -INFINITY;
+  rs = fr_block_sum(rs, sm);
+  double best = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < kFreeCapMax; ++c)
-      if (c < cnt) best = fmax(best, acc[c]);
+  for (int c = 0; c < kFreeCapMax; ++c) {
+    if (c < cnt) {  // (block-uniform)
+      const double d = fr_block_sum(acc[c], sm);
+      best = fmax(best, d);
+    }
+  }
+  if (threadIdx.x == 0) {
     rowmax[row] = best;
     rowsum[row] = rs;
     atomicAdd(&ovf[65], cnt);
@@ -890,13 +887,13 @@ __global__ __launch_bounds__(256) void k_free_row_stats(
     const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
     const int* __restrict__ count, const int* __restrict__ cand, int cap,
     double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
-  free_row_stats_wave_body(A, n, ld, y1, count, cand, cap, rowmax, rowsum, ovf);
+  free_row_stats_body2(A, n, ld, y1, count, cand, cap, rowmax, rowsum, ovf);
 }
 __global__ __launch_bounds__(256) void k_free_row_stats_g(const GroupOf<FreeItem> g, int cap) {
   const FreeItem& a = g.s[blockIdx.y];
-  if (4 * (int)blockIdx.x >= a.n) return;
-  free_row_stats_wave_body(a.A, a.n, a.ld, a.y1, a.words + a.n, a.cand, cap, a.rowmax, a.rowsum,
-                           a.words + 2 * (size_t)a.n);
+  if ((int)blockIdx.x >= a.n) return;
+  free_row_stats_body2(a.A, a.n, a.ld, a.y1, a.words + a.n, a.cand, cap, a.rowmax, a.rowsum,
+                       a.words + 2 * (size_t)a.n);
 }
 
 // ---------------------------------------------------------------- rows evaluated in full
@@ -1044,8 +1041,8 @@ void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const 
     hipLaunchKernelGGL(k_free_row_stats_wg, dim3(n), dim3(256), 0, s, A, n, ld, y1, count, cand,
                        kFreeCapMax, rowmax, rowsum, ovf);
   else
-    hipLaunchKernelGGL(k_free_row_stats, dim3((n + 3) / 4), dim3(256), 0, s, A, n, ld, y1, count,
-                       cand, kFreeCapMax, rowmax, rowsum, ovf);
+    hipLaunchKernelGGL(k_free_row_stats, dim3(n), dim3(256), 0, s, A, n, ld, y1, count, cand,
+                       kFreeCapMax, rowmax, rowsum, ovf);
 }
 
 // ---- the same steps for a group of matrices (FreeItem per member, n = 0: idle)
@@ -1082,8 +1079,7 @@ void launch_free_scan_stats_group(hipStream_t s, const FreeItem* items, int coun
   const int nt = (nmax + kI8Tile - 1) / kI8Tile;
   hipLaunchKernelGGL(k_t32_candidates_g, dim3(nt * (nt + 1) / 2, count), dim3(256), 0, s, g,
                      kFreeCapMax);
-  hipLaunchKernelGGL(k_free_row_stats_g, dim3((nmax + 3) / 4, count), dim3(256), 0, s, g,
-                     kFreeCapMax);
+  hipLaunchKernelGGL(k_free_row_stats_g, dim3(nmax, count), dim3(256), 0, s, g, kFreeCapMax);
 }
 
 void launch_free_gather_rows(hipStream_t s, const double* A, int n, int ld, const int* rows,

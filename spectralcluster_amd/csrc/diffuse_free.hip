@@ -693,103 +693,16 @@ __global__ __launch_bounds__(256) void k_t32_candidates_g(const GroupOf<FreeItem
 // ovf[0] = rows with more candidates than `cap`, ovf[1 + e] their indices (first 64),
 // ovf[65] = candidates evaluated in total, ovf[66] = largest candidate count of a row.
 constexpr int kFreeCapMax = 8;
-// CNT candidates of this row (a compile-time count: the loads of a k-step -- the row, y1 and
-// the candidate rows, two steps per trip -- are all in flight together instead of sitting
-// behind one branch each)
-template <int CNT>
-__device__ __forceinline__ void free_row_dots(const double* __restrict__ x,
-                                              const double* const* __restrict__ xj,
-                                              const double* __restrict__ y1, int n, double* rs_out,
-                                              double* acc_out) {
-  double rs = 0.0;
-  double acc[CNT > 0 ? CNT : 1];
-#pragma unroll
-  for (int c = 0; c < CNT; ++c) acc[c] = 0.0;
-#pragma unroll 2
-  for (int k = 2 * threadIdx.x; k < n; k += 512) {
-    double2 a = *reinterpret_cast<const double2*>(x + k);
-    double2 yy = *reinterpret_cast<const double2*>(y1 + k);
-    double2 b[CNT > 0 ? CNT : 1];
-#pragma unroll
-    for (int c = 0; c < CNT; ++c) b[c] = *reinterpret_cast<const double2*>(xj[c] + k);
-    if (k + 1 >= n) {
-      a.y = 0.0;
-      yy.y = 0.0;
-#pragma unroll
-      for (int c = 0; c < CNT; ++c) b[c].y = 0.0;
-    }
-    rs = __builtin_fma(a.x, yy.x, rs);
-    rs = __builtin_fma(a.y, yy.y, rs);
-#pragma unroll
-    for (int c = 0; c < CNT; ++c) {
-      acc[c] = __builtin_fma(a.x, b[c].x, acc[c]);
-      acc[c] = __builtin_fma(a.y, b[c].y, acc[c]);
-    }
-  }
-  *rs_out = rs;
-#pragma unroll
-  for (int c = 0; c < CNT; ++c) acc_out[c] = acc[c];
-}
-
-__device__ __forceinline__ void free_row_stats_body(
-    const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
-    const int* __restrict__ count, const int* __restrict__ cand, int cap,
-    double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
-  __shared__ double sm[4];
-  const int row = blockIdx.x;
-  const int total = count[row];
-  const int cnt = total < cap ? total : cap;
-  const double* x = A + (size_t)row * ld;
-  const double* xj[kFreeCapMax];
-#pragma unroll
-  for (int c = 0; c < kFreeCapMax; ++c)
-    xj[c] = A + (size_t)(c < cnt ? cand[(size_t)row * cap + c] : row) * ld;
-  double acc[kFreeCapMax];
-#pragma unroll
-  for (int c = 0; c < kFreeCapMax; ++c) acc[c] = 0.0;
-  double rs = 0.0;
-  switch (cnt) {  // (uniform over the workgroup; 1 and 2 are nearly every row)
-    case 0: free_row_dots<0>(x, xj, y1, n, &rs, acc); break;
-    case 1: free_row_dots<1>(x, xj, y1, n, &rs, acc); break;
-    case 2: free_row_dots<2>(x, xj, y1, n, &rs, acc); break;
-    case 3: free_row_dots<3>(x, xj, y1, n, &rs, acc); break;
-    case 4: free_row_dots<4>(x, xj, y1, n, &rs, acc); break;
-    default: free_row_dots<kFreeCapMax>(x, xj, y1, n, &rs, acc); break;  // (spare slots: the row itself)
-  }
-  rs = fr_block_sum(rs, sm);
-  double best = -INFINITY;
-#pragma unroll
-  for (int c = 0; c < kFreeCapMax; ++c) {
-    if (c < cnt) {  // (block-uniform)
-      const double d = fr_block_sum(acc[c], sm);
-      best = fmax(best, d);
-    }
-  }
-  if (threadIdx.x == 0) {
-    rowmax[row] = best;
-    rowsum[row] = rs;
-    atomicAdd(&ovf[65], cnt);
-    atomicMax(&ovf[66], total);
-    if (total > cap) {
-      const int e = atomicAdd(&ovf[0], 1);
-      if (e < 64) ovf[1 + e] = row;
-    }
-  }
-}
-__global__ __launch_bounds__(256) void k_free_row_stats_wg(
-    const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
-    const int* __restrict__ count, const int* __restrict__ cand, int cap,
-    double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
-  free_row_stats_body(A, n, ld, y1, count, cand, cap, rowmax, rowsum, ovf);
-}
-
-// Round 5 (second form; the first -- one WAVEFRONT per row, four rows per workgroup, shuffles
-// instead of block reductions -- measured 254 us against this kernel's 224 at n = 8192,
-// profiles/r07c: dropped): the same one-workgroup-per-row walk with (a) no second stream for a
-// candidate that is the row itself (the diagonal entry <A_i, A_i>: half of all candidates),
-// (b) U steps of the row, of y1 and of every candidate requested before the first is used.
+// One workgroup per row; CNT candidates of this row (a compile-time count: the loads of U steps
+// -- the row, y1 and the candidate rows -- are all in flight together instead of sitting behind
+// one branch each).  A candidate that is the row itself (the diagonal entry <A_i, A_i>: half of
+// all candidates) costs no second stream.  220-224 us at n = 8192 = 2.5 TB/s of HBM traffic
+// (546 MB per launch, PMC) -- and it stays there whatever the form: round 5 measured the walk
+// with 2 and with 4 steps in flight, with and without the second stream for self-candidates,
+// and one WAVEFRONT per row with four rows per workgroup and shuffles instead of block
+// reductions (254 us): profiles/r07c_*, r07d_*.
 template <int CNT, int U>
-__device__ __forceinline__ void free_row_dots2(const double* __restrict__ x,
+__device__ __forceinline__ void free_row_dots(const double* __restrict__ x,
                                                const double* const* __restrict__ xj,
                                                const bool* self, const double* __restrict__ y1,
                                                int n, double* rs_out, double* acc_out) {
@@ -834,7 +747,7 @@ __device__ __forceinline__ void free_row_dots2(const double* __restrict__ x,
   for (int c = 0; c < CNT; ++c) acc_out[c] = acc[c];
 }
 
-__device__ __forceinline__ void free_row_stats_body2(
+__device__ __forceinline__ void free_row_stats_body(
     const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
     const int* __restrict__ count, const int* __restrict__ cand, int cap,
     double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
@@ -856,12 +769,12 @@ __device__ __forceinline__ void free_row_stats_body2(
   for (int c = 0; c < kFreeCapMax; ++c) acc[c] = 0.0;
   double rs = 0.0;
   switch (cnt) {  // (uniform over the workgroup; 1 and 2 are nearly every row)
-    case 0: free_row_dots2<0, 4>(x, xj, self, y1, n, &rs, acc); break;
-    case 1: free_row_dots2<1, 4>(x, xj, self, y1, n, &rs, acc); break;
-    case 2: free_row_dots2<2, 4>(x, xj, self, y1, n, &rs, acc); break;
-    case 3: free_row_dots2<3, 2>(x, xj, self, y1, n, &rs, acc); break;
-    case 4: free_row_dots2<4, 2>(x, xj, self, y1, n, &rs, acc); break;
-    default: free_row_dots2<kFreeCapMax, 1>(x, xj, self, y1, n, &rs, acc); break;
+    case 0: free_row_dots<0, 4>(x, xj, self, y1, n, &rs, acc); break;
+    case 1: free_row_dots<1, 4>(x, xj, self, y1, n, &rs, acc); break;
+    case 2: free_row_dots<2, 4>(x, xj, self, y1, n, &rs, acc); break;
+    case 3: free_row_dots<3, 2>(x, xj, self, y1, n, &rs, acc); break;
+    case 4: free_row_dots<4, 2>(x, xj, self, y1, n, &rs, acc); break;
+    default: free_row_dots<kFreeCapMax, 1>(x, xj, self, y1, n, &rs, acc); break;
   }
   rs = fr_block_sum(rs, sm);
   double best = -INFINITY;
@@ -887,12 +800,12 @@ __global__ __launch_bounds__(256) void k_free_row_stats(
     const double* __restrict__ A, int n, int ld, const double* __restrict__ y1,
     const int* __restrict__ count, const int* __restrict__ cand, int cap,
     double* __restrict__ rowmax, double* __restrict__ rowsum, int* __restrict__ ovf) {
-  free_row_stats_body2(A, n, ld, y1, count, cand, cap, rowmax, rowsum, ovf);
+  free_row_stats_body(A, n, ld, y1, count, cand, cap, rowmax, rowsum, ovf);
 }
 __global__ __launch_bounds__(256) void k_free_row_stats_g(const GroupOf<FreeItem> g, int cap) {
   const FreeItem& a = g.s[blockIdx.y];
   if ((int)blockIdx.x >= a.n) return;
-  free_row_stats_body2(a.A, a.n, a.ld, a.y1, a.words + a.n, a.cand, cap, a.rowmax, a.rowsum,
+  free_row_stats_body(a.A, a.n, a.ld, a.y1, a.words + a.n, a.cand, cap, a.rowmax, a.rowsum,
                        a.words + 2 * (size_t)a.n);
 }
 
@@ -1034,15 +947,8 @@ void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigne
 void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const double* y1,
                            const int* count, const int* cand, double* rowmax, double* rowsum,
                            int* ovf) {
-  // (SC_FREE_STATS_WG=1: the one-workgroup-per-row form of round 4, kept for the A/B in
-  //  tests/probes/passes_probe.py)
-  static const bool wg_form = getenv("SC_FREE_STATS_WG") != nullptr;
-  if (wg_form)
-    hipLaunchKernelGGL(k_free_row_stats_wg, dim3(n), dim3(256), 0, s, A, n, ld, y1, count, cand,
-                       kFreeCapMax, rowmax, rowsum, ovf);
-  else
-    hipLaunchKernelGGL(k_free_row_stats, dim3(n), dim3(256), 0, s, A, n, ld, y1, count, cand,
-                       kFreeCapMax, rowmax, rowsum, ovf);
+  hipLaunchKernelGGL(k_free_row_stats, dim3(n), dim3(256), 0, s, A, n, ld, y1, count, cand,
+                     kFreeCapMax, rowmax, rowsum, ovf);
 }
 
 // ---- the same steps for a group of matrices (FreeItem per member, n = 0: idle)

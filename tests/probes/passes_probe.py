@@ -14,7 +14,7 @@ import spectral_oracle as so  # noqa: E402
 import spectralcluster_amd as sca  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("SC_EIG_NO_CAP", "SC_FREE_STATS_WG")
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("SC_DIFFUSE", "SC_EIG_TRACE")
                if k in os.environ) or "default"
 rng = np.random.default_rng(512)
 ns = rng.integers(300, 3001, 512)
@@ -43,9 +43,10 @@ for _ in range(20):
   c8.predict(x)
 dt = (time.perf_counter() - t0) / 20
 d = c8.last_diag
-print("[%s] predict8192: %.3f ms/call (python loop), passes %d, stage_ms affinity %.3f total %.3f" % (
-    tag, 1e3 * dt, d.eig_matvec_passes, d.stage_ms[0], d.stage_ms[6]),
-      flush=True)
+print("[%s] predict8192: %.3f ms/call (python loop), passes %d, stage_ms affinity %.3f diffuse %.3f "
+      "eig %.3f kmeans %.3f total %.3f free_stats %.3f" % (
+          tag, 1e3 * dt, d.eig_matvec_passes, d.stage_ms[0], d.stage_ms[2], d.stage_ms[4], d.stage_ms[5],
+          d.stage_ms[6], d.stage_ms[list(sca._lib.STAGE_NAMES).index("free_stats")]), flush=True)
 
 x4 = so.blobs(4096, 256, 8, seed=4096)
 tuner = sca.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95, init_search_step=0.025,

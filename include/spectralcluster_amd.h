@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 5
+#define SC_ABI_VERSION 6
 #define SC_MAX_OPS 16
 #define SC_MAX_BLUR_RADIUS 32
 #define SC_MAX_EIG 128 /* max eigenvalues reported in sc_diag */

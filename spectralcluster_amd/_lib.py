@@ -48,7 +48,7 @@ class EigenSolverNotConverged(RuntimeError):
   """The block-Lanczos eigensolver did not reach its tolerance."""
 
 
-SC_ABI_VERSION = 5
+SC_ABI_VERSION = 6
 
 
 class ScConfig(ctypes.Structure):

@@ -1,5 +1,5 @@
 // Matrix-free Diffuse (reference refinement.py:229-245 Diffuse + RowWiseNormalize, and
-// laplacian.py:41-58 on top of them) -- DESIGN.md section 3.11.
+// laplacian.py:41-58 on top of them) -- DESIGN.md section 3.6.
 //
 // For a sequence whose Diffuse is followed only by RowWiseNormalize (+ a Laplacian) the eigen
 // stage never reads an ENTRY of S = A A^T.  It needs

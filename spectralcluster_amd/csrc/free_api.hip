@@ -1,4 +1,4 @@
-// Host side of the matrix-free Diffuse (kernels: diffuse_free.hip; DESIGN.md 3.11): when the
+// Host side of the matrix-free Diffuse (kernels: diffuse_free.hip; DESIGN.md 3.6): when the
 // route is taken, the statistics pipeline, the exact evaluation of rows the candidate search
 // cannot prune, and the two-pass operator the eigensolver applies instead of reading S.
 #include "handle.h"

@@ -415,7 +415,7 @@ __device__ __forceinline__ void gemm_nt_body(const double* __restrict__ A,
   // one global counter, then other XCDs' tiles.  Which workgroup computes which item does
   // not change any result.  (Round 2 also tried shifting the two workgroups of a CU against
   // each other by a split unit, and a K-window throttle that kept an XCD's tiles in one L2
-  // window: both measured slower; the code is gone.)
+  // window: both measured slower, DESIGN_HISTORY.md section 3.3; the code is gone.)
   int item_blk = (int)blockIdx.x;
   if constexpr (GROUPED) {
     // XCD-aware order (workgroup ids go round-robin over the 8 XCDs, each with its own L2):
@@ -1038,7 +1038,7 @@ static void launch_variant(hipStream_t s, const double* A, int lda, const double
     // SC_GEMM_CLOCK=1 (diagnostic): every launch also records, per whole tile, the
     // shader-clock cycles (s_memtime) and the constant-rate wall ticks (s_memrealtime)
     // between kernel entry and the end of the K loop, synchronises and prints the effective
-    // shader clock -- the GEMM is power-managed, see DESIGN.md section 3.3.  Any other value is
+    // shader clock -- the GEMM is power-managed, see DESIGN_HISTORY.md section 3.3.  Any other value is
     // a file that also receives "workgroup cycles ticks start_tick ..." per tile
     // (tools/gemm_tile_timeline.py reads it).  Off: one pointer compare per workgroup.
     static double* dbg = nullptr;

@@ -133,7 +133,7 @@ struct sc_handle_s {
   int krnd_k = -1, krnd_trials = -1;
   int kfirst_n = -1, kfirst = 0;  // first k-means++ centre of the last n (RandomState(0) draw)
   bool eig_skip_fused = false;  // next sym_topk: go straight to the host-driven chain
-  // ---- matrix-free Diffuse (free_api.hip; DESIGN.md 3.11)
+  // ---- matrix-free Diffuse (free_api.hip; DESIGN.md 3.6)
   int diffuse_mode = -1;   // sc_set_diffuse_mode: 0 auto, 1 explicit fp64 product, 2 matrix-free
                            // wherever the sequence allows it; -1: the environment's default
   DevBuf fq, ft32, fy1, fR, fscal, fwords, fcand, fY, fsplit, fypart, frpart;  // digits, T (fp32 tiles), A 1, sum|q|,

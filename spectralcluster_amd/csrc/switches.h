@@ -5,7 +5,7 @@
 //                    the same goldens: tests/test_gpu_alternate_paths.py runs every one.
 // Each is read once per process.  (Round 2's experiment switches -- K-window throttle,
 // staggered CU partners, bank priorities, a third bank, row caps -- are gone with the code
-// they guarded; their measurements are in DESIGN.md and profiles/r02_*.)
+// they guarded; their measurements are in DESIGN_HISTORY.md and profiles/r02_*.)
 #ifndef SPECTRALCLUSTER_AMD_SWITCHES_H_
 #define SPECTRALCLUSTER_AMD_SWITCHES_H_
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Parity experiment behind DESIGN.md section 3.3 "matrix-free Diffuse" (CPU only, uses the
+"""Parity experiment behind DESIGN_HISTORY.md section 3.3 "matrix-free Diffuse" (CPU only, uses the
 oracle): for a refinement sequence that ENDS in Diffuse (no RowWiseNormalize after it), the
 eigen-stage never needs S = A A^T itself -- only S.V = A (A^T V) and rowsum(S) = A (A^T 1) --
 so the n^3 product can be skipped.  This script checks that claim against the explicit

@@ -1,4 +1,4 @@
-"""GPU: the matrix-free Diffuse (csrc/diffuse_free.hip, free_api.hip; DESIGN.md 3.11).
+"""GPU: the matrix-free Diffuse (csrc/diffuse_free.hip, free_api.hip; DESIGN.md 3.6).
 
 For a sequence whose Diffuse (reference refinement.py:229-234) is followed only by
 RowWiseNormalize (:240-245) and the Laplacian (laplacian.py:41-58) the device never forms

@@ -14,7 +14,7 @@ import spectral_oracle as so  # noqa: E402
 import spectralcluster_amd as sca  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("SC_DIFFUSE", "SC_EIG_TRACE")
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("SC_HOST_RR_FULL", "SC_DIFFUSE")
                if k in os.environ) or "default"
 rng = np.random.default_rng(512)
 ns = rng.integers(300, 3001, 512)
@@ -64,3 +64,33 @@ for _ in range(3):
 dt = (time.perf_counter() - t0) / 3
 print("[%s] autotune16 predict: %.2f ms, passes per value %s" % (
     tag, 1e3 * dt, [int(dg.eig_matvec_passes) for dg in c4.last_sweep_diags]), flush=True)
+
+# ---- the workloads whose time is host Rayleigh-Ritz + chain latency (SC_HOST_RR_FULL A/B)
+xh = np.random.default_rng(8192).standard_normal((8192, 256))
+for _ in range(2):
+  c8.predict(xh)
+t0 = time.perf_counter()
+for _ in range(5):
+  c8.predict(xh)
+dt = (time.perf_counter() - t0) / 5
+d = c8.last_diag
+print("[%s] hard8192: %.2f ms/call, passes %d, eig %.2f ms, basis %d cycles %d" % (
+    tag, 1e3 * dt, d.eig_matvec_passes, d.stage_ms[4], d.eig_basis, d.eig_cycles), flush=True)
+
+opts = sca.RefinementOptions(
+    thresholding_soft_multiplier=0.01, thresholding_type=sca.ThresholdType.Percentile,
+    thresholding_with_binarization=True, thresholding_preserve_diagonal=True,
+    symmetrize_type=sca.SymmetrizeType.Average,
+    refinement_sequence=[sca.RefinementName.RowWiseThreshold, sca.RefinementName.Symmetrize])
+ct = sca.SpectralClusterer(min_clusters=2, max_clusters=20,
+                           autotune=sca.AutoTune(p_percentile_min=0.55, p_percentile_max=0.95,
+                                                 init_search_step=0.025, search_level=1),
+                           laplacian_type=sca.LaplacianType.GraphCut, refinement_options=opts,
+                           row_wise_renorm=True)
+ct.predict(x4)
+t0 = time.perf_counter()
+for _ in range(3):
+  ct.predict(x4)
+dt = (time.perf_counter() - t0) / 3
+print("[%s] autotune16_ttd predict: %.2f ms, passes per value %s" % (
+    tag, 1e3 * dt, [int(dg.eig_matvec_passes) for dg in ct.last_sweep_diags]), flush=True)

@@ -9,7 +9,7 @@ O=gpurun_out/$TAG
 mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest exit $?" >> $O/pytest.log
 tail -3 $O/pytest.log
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 1800 python bench.py > $O/bench.json 2> $O/bench.err
 cut -c1-400 $O/bench.json
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o run -- python $GRAFT_REPO_ROOT/bench.py --no-extras --no-concurrent --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/rocprof.err)
 DB=$(ls $O/prof/*/*.db $O/prof/*.db 2>/dev/null | head -1)
@@ -25,5 +25,7 @@ python tools/pmc_summary.py $(dirname $(find $O/pmc_fetch -name '*counter_collec
 DB=$(ls $O/prof5/*/*.db $O/prof5/*.db 2>/dev/null | head -1)
 python tools/rocprof_summary.py $DB > $O/grouped_kernel_stats.txt
 head -14 $O/grouped_kernel_stats.txt
+timeout 300 python tests/probes/gen_dense_time.py > $O/gen_dense_time.txt 2>&1
+cat $O/gen_dense_time.txt
 rm -rf $O/prof $O/prof5 $O/pmc_fetch $O/pmc_write
 du -sh $O

@@ -286,8 +286,47 @@ extern "C" int sc_host_tridiag_eigvectors(const double* d, const double* e, int 
 // reflectors (O(m^2) each).
 
 // a (m x m symmetric, FULL storage, row-major lda; destroyed) -> d, e (e[i] couples i, i+1),
-// tau; reflector i: v(i, i+1) = 1, v(i, i+2 ..).  Both triangles are kept up to date so that
-// every inner loop walks a contiguous row (the compiler vectorises them).
+// tau; reflector i: v(i, i+1) = 1, v(i, i+2 ..).
+// Round 5: ONE pass over the trailing block per step.  The rank-2 update of step i
+// (A22 -= v w^T + w v^T) and the matrix-vector product of step i + 1 (p' = tau' A22' v') touch
+// the same rows: row c0 is updated first (it IS the next step's x, so v' and tau' follow), then
+// every other row is updated and dotted with v' while it is in registers.  The dot products
+// keep four independent partial sums (the compiler does not reassociate a floating-point
+// reduction, so a single accumulator stays scalar).  (madd is a plain a * b + c, not an explicit
+// fma: `target_clones` splits "avx2,fma" into an avx2 clone WITHOUT fma and an fma clone and the
+// resolver prefers avx2 -- a __builtin_fma in it is a libm call, 6x slower than the code this
+// replaced.)  Only the part of a row right of the next diagonal is kept up
+// to date (what is left of it is never read again).
+namespace {
+inline double madd(double a, double b, double c) { return a * b + c; }
+// LAPACK dlarfg on x[0 .. len): v[0] = 1, v[1 ..] = x[1 ..] / (alpha - beta); returns tau, *beta
+__attribute__((target_clones("avx2,fma", "default")))
+double make_reflector(const double* x, int len, double* v, double* beta_out) {
+  const double alpha = x[0];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = 1;
+  for (; k + 3 < len; k += 4) {
+    s0 = madd(x[k], x[k], s0);
+    s1 = madd(x[k + 1], x[k + 1], s1);
+    s2 = madd(x[k + 2], x[k + 2], s2);
+    s3 = madd(x[k + 3], x[k + 3], s3);
+  }
+  for (; k < len; ++k) s0 = madd(x[k], x[k], s0);
+  const double xnorm2 = (s0 + s1) + (s2 + s3);
+  if (!(xnorm2 > 0.0)) {
+    for (int q = 0; q < len; ++q) v[q] = 0.0;
+    *beta_out = alpha;
+    return 0.0;
+  }
+  const double beta = -std::copysign(std::sqrt(alpha * alpha + xnorm2), alpha);
+  const double scale = 1.0 / (alpha - beta);
+  v[0] = 1.0;
+  for (int q = 1; q < len; ++q) v[q] = x[q] * scale;
+  *beta_out = beta;
+  return (beta - alpha) / beta;
+}
+}  // namespace
+
 __attribute__((target_clones("avx2,fma", "default")))
 static void host_tridiagonalize(HostTridiag* w) {
   const int m = w->m, lda = w->lda;
@@ -297,45 +336,99 @@ static void host_tridiagonalize(HostTridiag* w) {
   w->d.assign(m, 0.0);
   w->e.assign(std::max(m, 1), 0.0);
   w->tau.assign(std::max(m, 1), 0.0);
-  std::vector<double> pbuf(m);
+  if (m == 0) return;
+  std::vector<double> pbuf(m), pnext(m), wbuf(m);
   double* p = pbuf.data();
+  double* pn = pnext.data();
+  double* ww = wbuf.data();
+  // step 0: reflector of row 0 and p = tau A22 v by a plain product
+  double tau = 0.0, beta = 0.0;
+  if (m > 1) {
+    const int len = m - 1;
+    double* v = vv + 1;
+    tau = make_reflector(a + 1, len, v, &beta);
+    for (int r = 0; r < len; ++r) {
+      const double* row = a + (size_t)(1 + r) * lda + 1;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int c = 0;
+      for (; c + 3 < len; c += 4) {
+        s0 = madd(row[c], v[c], s0);
+        s1 = madd(row[c + 1], v[c + 1], s1);
+        s2 = madd(row[c + 2], v[c + 2], s2);
+        s3 = madd(row[c + 3], v[c + 3], s3);
+      }
+      for (; c < len; ++c) s0 = madd(row[c], v[c], s0);
+      p[r] = tau * ((s0 + s1) + (s2 + s3));
+    }
+  }
   for (int i = 0; i + 1 < m; ++i) {
     const int c0 = i + 1, len = m - c0;
-    const double* x = a + (size_t)i * lda + c0;  // row i right of the diagonal (= column i below)
-    double* v = vv + (size_t)i * lda + c0;
-    const double alpha = x[0];
-    double xnorm2 = 0.0;
-    for (int k = 1; k < len; ++k) xnorm2 += x[k] * x[k];
-    double tau = 0.0, beta = alpha;
-    if (xnorm2 > 0.0) {
-      beta = -std::copysign(std::sqrt(alpha * alpha + xnorm2), alpha);
-      tau = (beta - alpha) / beta;
-      const double scale = 1.0 / (alpha - beta);
-      v[0] = 1.0;
-      for (int k = 1; k < len; ++k) v[k] = x[k] * scale;
-    }
+    const double* v = vv + (size_t)i * lda + c0;  // reflector i (len entries, v[0] = 1 or all 0)
     w->e[i] = beta;
     w->tau[i] = tau;
     w->d[i] = a[(size_t)i * lda + i];
-    if (tau == 0.0) continue;
-    // p = tau A22 v ; w = p - (tau/2)(p^T v) v ; A22 -= v w^T + w v^T
-    double dot = 0.0;
-    for (int r = 0; r < len; ++r) {
-      const double* row = a + (size_t)(c0 + r) * lda + c0;
-      double acc = 0.0;
-      for (int c = 0; c < len; ++c) acc += row[c] * v[c];
-      p[r] = tau * acc;
-      dot += p[r] * v[r];
+    if (len == 1) {  // last step: a 1 x 1 trailing block, H = I - tau (scalar)
+      if (tau != 0.0) {  // A22 <- (1 - tau)^2 A22: with the w form below
+        const double dot = p[0] * v[0];
+        const double w0 = p[0] - 0.5 * tau * dot * v[0];
+        a[(size_t)c0 * lda + c0] -= 2.0 * v[0] * w0;
+      }
+      break;
     }
-    const double half = 0.5 * tau * dot;
-    for (int r = 0; r < len; ++r) p[r] -= half * v[r];
-    for (int r = 0; r < len; ++r) {
-      double* row = a + (size_t)(c0 + r) * lda + c0;
-      const double vr = v[r], pr = p[r];
-      for (int c = 0; c < len; ++c) row[c] -= vr * p[c] + pr * v[c];
+    // w = p - (tau / 2)(p^T v) v
+    if (tau != 0.0) {
+      double dot = 0.0;
+      for (int r = 0; r < len; ++r) dot = madd(p[r], v[r], dot);
+      const double half = 0.5 * tau * dot;
+      for (int r = 0; r < len; ++r) ww[r] = madd(-half, v[r], p[r]);
+    } else {
+      for (int r = 0; r < len; ++r) ww[r] = 0.0;
     }
+    // row c0 first: it carries the next step's x
+    double* row0 = a + (size_t)c0 * lda + c0;
+    if (tau != 0.0) {
+      const double v0 = v[0], w0 = ww[0];
+      for (int c = 0; c < len; ++c)
+        row0[c] = madd(-v0, ww[c], madd(-w0, v[c], row0[c]));
+    }
+    double* vn = vv + (size_t)c0 * lda + (c0 + 1);  // reflector i + 1 (len - 1 entries)
+    double beta_n = 0.0;
+    const double tau_n = make_reflector(row0 + 1, len - 1, vn, &beta_n);
+    // the other rows: update (columns >= 1 of the block) + product with the next reflector
+    const int ln = len - 1;
+    for (int r = 1; r < len; ++r) {
+      double* row = a + (size_t)(c0 + r) * lda + (c0 + 1);
+      const double vr = tau != 0.0 ? v[r] : 0.0, wr = ww[r];
+      const double* vc = v + 1;
+      const double* wc = ww + 1;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int c = 0;
+      for (; c + 3 < ln; c += 4) {
+        const double t0 = madd(-vr, wc[c], madd(-wr, vc[c], row[c]));
+        const double t1 = madd(-vr, wc[c + 1], madd(-wr, vc[c + 1], row[c + 1]));
+        const double t2 = madd(-vr, wc[c + 2], madd(-wr, vc[c + 2], row[c + 2]));
+        const double t3 = madd(-vr, wc[c + 3], madd(-wr, vc[c + 3], row[c + 3]));
+        row[c] = t0;
+        row[c + 1] = t1;
+        row[c + 2] = t2;
+        row[c + 3] = t3;
+        s0 = madd(t0, vn[c], s0);
+        s1 = madd(t1, vn[c + 1], s1);
+        s2 = madd(t2, vn[c + 2], s2);
+        s3 = madd(t3, vn[c + 3], s3);
+      }
+      for (; c < ln; ++c) {
+        const double t = madd(-vr, wc[c], madd(-wr, vc[c], row[c]));
+        row[c] = t;
+        s0 = madd(t, vn[c], s0);
+      }
+      pn[r - 1] = tau_n * ((s0 + s1) + (s2 + s3));
+    }
+    std::swap(p, pn);
+    tau = tau_n;
+    beta = beta_n;
   }
-  if (m > 0) w->d[m - 1] = a[(size_t)(m - 1) * lda + (m - 1)];
+  w->d[m - 1] = a[(size_t)(m - 1) * lda + (m - 1)];
 }
 
 // eigenvalues of the tridiagonal (d, e) by implicit QL (tql1); ascending on return.
@@ -404,24 +497,35 @@ bool host_partial_values(const double* T, int ld, int m, HostTridiag* w) {
 }
 
 // Step 2: eigenvectors of the leading `need` eigenvalues into Y (row-major ldy: column q).
+// The reflectors are applied to all `need` vectors at once, in place in Y's rows: a reflector's
+// v is read once for all of them and the loops run over contiguous row segments of Y.
+__attribute__((target_clones("avx2,fma", "default")))
 bool host_partial_vectors(const HostTridiag& w, int need, double* Y, int ldy) {
   const int m = w.m, lda = w.lda;
   std::vector<double> z((size_t)m * need);
   if (!host_tridiag_eigvectors(w.d.data(), w.e.data(), m, w.theta.data(), need, z.data(),
                                (size_t)m))
     return false;
-  for (int q = 0; q < need; ++q) {
-    double* x = z.data() + (size_t)q * m;
-    for (int i = m - 2; i >= 0; --i) {  // x <- H_i x, last reflector first
-      const double tau = w.tau[i];
-      if (tau == 0.0) continue;
-      const double* v = w.v.data() + (size_t)i * lda;
-      double dot = 0.0;
-      for (int k = i + 1; k < m; ++k) dot += v[k] * x[k];
-      dot *= tau;
-      for (int k = i + 1; k < m; ++k) x[k] -= dot * v[k];
+  for (int r = 0; r < m; ++r)
+    for (int q = 0; q < need; ++q) Y[(size_t)r * ldy + q] = z[(size_t)q * m + r];
+  std::vector<double> dots(need);
+  double* dt = dots.data();
+  for (int i = m - 2; i >= 0; --i) {  // Y <- H_i Y, last reflector first
+    const double tau = w.tau[i];
+    if (tau == 0.0) continue;
+    const double* v = w.v.data() + (size_t)i * lda;
+    for (int q = 0; q < need; ++q) dt[q] = 0.0;
+    for (int k = i + 1; k < m; ++k) {
+      const double vk = v[k];
+      const double* yr = Y + (size_t)k * ldy;
+      for (int q = 0; q < need; ++q) dt[q] = madd(vk, yr[q], dt[q]);
     }
-    for (int r = 0; r < m; ++r) Y[(size_t)r * ldy + q] = x[r];
+    for (int q = 0; q < need; ++q) dt[q] *= tau;
+    for (int k = i + 1; k < m; ++k) {
+      const double vk = v[k];
+      double* yr = Y + (size_t)k * ldy;
+      for (int q = 0; q < need; ++q) yr[q] = madd(-vk, dt[q], yr[q]);
+    }
   }
   return true;
 }

@@ -14,7 +14,7 @@ import spectral_oracle as so  # noqa: E402
 import spectralcluster_amd as sca  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("SC_HOST_RR_FULL", "SC_DIFFUSE")
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("SC_DIFFUSE", "SC_EIG_TRACE")
                if k in os.environ) or "default"
 rng = np.random.default_rng(512)
 ns = rng.integers(300, 3001, 512)

@@ -609,7 +609,8 @@ def test_host_hessenberg_eigenvalues_vs_numpy():
   for n in (3, 4, 17, 65, 200, 421):
     cases.append(("randn", rng.standard_normal((n, n))))
   x = so.blobs(300, 24, 5, seed=9)
-  a = so.row_wise_threshold(so.affinity(x), p_percentile=0.9)
+  a = so.row_wise_threshold(so.affinity(x), p_percentile=0.9,
+                             threshold_type=so.THRESHOLD_PERCENTILE)
   cases.append(("thresholded affinity", a))
   cases.append(("graph-cut laplacian", so.laplacian(a, so.LAPLACIAN_GRAPH_CUT)))
   cases.append(("random-walk laplacian", so.laplacian(a, so.LAPLACIAN_RANDOM_WALK)))
@@ -643,7 +644,8 @@ def test_host_hessenberg_eigenvectors_are_eigenvectors_of_the_original_matrix():
   conjugate pairs."""
   rng = np.random.default_rng(71)
   x = so.blobs(260, 24, 6, seed=4)
-  a = so.row_wise_threshold(so.affinity(x), p_percentile=0.9)
+  a = so.row_wise_threshold(so.affinity(x), p_percentile=0.9,
+                             threshold_type=so.THRESHOLD_PERCENTILE)
   lap = so.laplacian(a, so.LAPLACIAN_GRAPH_CUT)
   blk = np.zeros((120, 120))
   for b in range(4):

@@ -4,6 +4,9 @@
 #include "host_eig.h"
 
 #include <algorithm>
+#include <thread>
+#include <mutex>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 
@@ -1000,6 +1003,127 @@ bool host_hessenberg_eigenvalues(const HostHessenberg& w, double* wr, double* wi
 // eigenvalues (wr, wi), column-major into vre / vim (column q at + q * ldv); *max_resid: the
 // largest ||H y - lambda y||_2 / (||H||_max ||y||_2) seen.  A conjugate partner that follows its
 // pair directly is the conjugate vector.  false: an iterate failed to grow.
+// One solve is O(n^2) (LU of a Hessenberg matrix + a few substitutions + the back-transform) and
+// the solves are independent except inside a cluster of equal real eigenvalues, whose iterates are
+// kept independent of each other: the eigenvalues are dealt to up to 16 host threads in groups (a
+// real cluster, a conjugate pair, or a single eigenvalue), each thread with its own n x n work
+// matrix; real eigenvalues are iterated in real arithmetic.
+namespace {
+inline double mag1(double z) { return std::fabs(z); }
+inline double mag1(const cplx& z) { return abs1(z); }
+inline double sq(double z) { return z * z; }
+inline double sq(const cplx& z) { return std::norm(z); }
+inline double cj(double z) { return z; }
+inline cplx cj(const cplx& z) { return std::conj(z); }
+
+// y <- an eigenvector of H for the (already separated) shift lam; prev: earlier vectors of the
+// same cluster (real shifts only).  U: n x n scratch.  Returns the relative residual, < 0: failed.
+template <typename T>
+double hessenberg_inverse_iteration(const HostHessenberg& w, T lam, double eps3,
+                                    const std::vector<const std::vector<T>*>& prev,
+                                    std::vector<T>* U_store, std::vector<T>* y_out) {
+  const int n = w.n;
+  const double hnorm = std::max(w.norm, 1e-300);
+  std::vector<T>& U = *U_store;
+  U.resize((size_t)n * n);
+  std::vector<T> mult(n), y(n);
+  std::vector<char> swapped(n);
+  // ---- LU of H - lambda I with row interchanges: column k eliminates H(k + 1, k)
+  for (int i = 0; i < n; ++i) {
+    const double* hr = w.H.data() + (size_t)i * n;
+    T* ur = U.data() + (size_t)i * n;
+    for (int j = 0; j < n; ++j) ur[j] = hr[j];
+    ur[i] -= lam;
+  }
+  for (int k = 0; k + 1 < n; ++k) {
+    T* rk = U.data() + (size_t)k * n;
+    T* rn = rk + n;
+    if (mag1(rk[k]) < mag1(rn[k])) {
+      for (int j = k; j < n; ++j) std::swap(rk[j], rn[j]);
+      swapped[k] = 1;
+    } else {
+      swapped[k] = 0;
+    }
+    if (mag1(rk[k]) == 0.0) rk[k] = eps3;
+    const T f = rn[k] / rk[k];
+    mult[k] = f;
+    if (f != T(0.0))
+      for (int j = k + 1; j < n; ++j) rn[j] -= f * rk[j];
+    rn[k] = 0.0;
+  }
+  for (int i = 0; i < n; ++i)
+    if (mag1(U[(size_t)i * n + i]) < eps3) U[(size_t)i * n + i] = eps3;  // (dlaein)
+  // ---- inverse iteration
+  const double rootn = std::sqrt((double)n);
+  for (int i = 0; i < n; ++i) y[i] = 1.0 / rootn;
+  double res = -1.0;
+  for (int iter = 0; iter < 6; ++iter) {
+    if (iter > 0) {  // forward: P and L (the first solve takes its start vector as L^-1 P b)
+      for (int k = 0; k + 1 < n; ++k) {
+        if (swapped[k]) std::swap(y[k], y[k + 1]);
+        y[k + 1] -= mult[k] * y[k];
+      }
+    }
+    for (int i = n - 1; i >= 0; --i) {  // U x = y
+      const T* ur = U.data() + (size_t)i * n;
+      T s = y[i];
+      for (int j = i + 1; j < n; ++j) s -= ur[j] * y[j];
+      y[i] = s / ur[i];
+    }
+    // a cluster of (numerically) equal real eigenvalues: stay independent of its earlier
+    // vectors (any basis of the invariant subspace will do; np.linalg.eig returns one)
+    for (const std::vector<T>* pv : prev) {
+      T dot = 0.0;
+      double nn = 0.0;
+      for (int r = 0; r < n; ++r) {
+        dot += cj((*pv)[r]) * y[r];
+        nn += sq((*pv)[r]);
+      }
+      if (nn > 0.0)
+        for (int r = 0; r < n; ++r) y[r] -= (dot / nn) * (*pv)[r];
+    }
+    double big = 0.0, n2 = 0.0;
+    for (int r = 0; r < n; ++r) big = std::max(big, mag1(y[r]));
+    if (!(big > 0.0) || !std::isfinite(big)) return -1.0;
+    for (int r = 0; r < n; ++r) {
+      y[r] /= big;
+      n2 += sq(y[r]);
+    }
+    const double inv = 1.0 / std::sqrt(n2);
+    for (int r = 0; r < n; ++r) y[r] *= inv;
+    // converged when the residual is at rounding level (one solve with the shift at an
+    // eigenvalue already multiplies a generic start vector by ~1 / eps3; two are the rule)
+    double res2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double* hr = w.H.data() + (size_t)i * n;
+      T s = -lam * y[i];
+      for (int j = std::max(0, i - 1); j < n; ++j) s += hr[j] * y[j];
+      res2 += sq(s);
+    }
+    res = std::sqrt(res2) / hnorm;
+    if (iter >= 1 && res <= 1e-12 * rootn) break;
+  }
+  *y_out = y;
+  return res;
+}
+
+// t <- Q t = H_0 H_1 ... H_{n-3} t (the reflectors of the reduction, last first)
+template <typename T>
+void hessenberg_back_transform(const HostHessenberg& w, std::vector<T>* t_io) {
+  const int n = w.n;
+  std::vector<T>& t = *t_io;
+  for (int k = n - 3; k >= 0; --k) {
+    const double tk = w.tau[k];
+    if (tk == 0.0) continue;
+    const double* v = w.V.data() + (size_t)k * n;
+    T dot = 0.0;
+    for (int r = k + 1; r < n; ++r) dot += v[r] * t[r];
+    dot *= tk;
+    for (int r = k + 1; r < n; ++r) t[r] -= dot * v[r];
+  }
+}
+}  // namespace
+
 bool host_hessenberg_vectors(const HostHessenberg& w, const double* wr, const double* wi, int count,
                              double* vre, double* vim, size_t ldv, double* max_resid) {
   const int n = w.n;
@@ -1008,9 +1132,6 @@ bool host_hessenberg_vectors(const HostHessenberg& w, const double* wr, const do
   const double ulp = 2.220446049250313e-16;
   const double hnorm = std::max(w.norm, 1e-300);
   const double eps3 = hnorm * ulp;
-  std::vector<cplx> U((size_t)n * n), y(n), t(n);
-  std::vector<cplx> mult(n);
-  std::vector<char> swapped(n);
   std::vector<cplx> lam(count);
   for (int q = 0; q < count; ++q) lam[q] = cplx(wr[q], wi[q]);
   // dhsein: an eigenvalue closer than eps3 to one already used is moved by eps3
@@ -1026,122 +1147,93 @@ bool host_hessenberg_vectors(const HostHessenberg& w, const double* wr, const do
         }
     }
   }
+  // ---- groups: a conjugate pair | a chain of real eigenvalues closer than cluster_tol | one
   const double cluster_tol = 1e-10 * hnorm;  // real eigenvalues this close: one invariant subspace
-  std::vector<std::vector<cplx>> done;       // eigenvectors of H so far (for the cluster step)
-  done.reserve(count);
+  std::vector<std::vector<int>> groups;
+  int last_real_group = -1, last_real_q = -1;
   for (int q = 0; q < count; ++q) {
-    // the conjugate of the pair just computed
-    if (q > 0 && wi[q] != 0.0 && wi[q] == -wi[q - 1] && wr[q] == wr[q - 1]) {
-      for (int r = 0; r < n; ++r) {
-        vre[(size_t)q * ldv + r] = vre[(size_t)(q - 1) * ldv + r];
-        vim[(size_t)q * ldv + r] = -vim[(size_t)(q - 1) * ldv + r];
+    if (wi[q] != 0.0) {
+      if (q > 0 && wi[q] == -wi[q - 1] && wr[q] == wr[q - 1] && !groups.empty() &&
+          groups.back().back() == q - 1 && groups.back().size() == 1) {
+        groups.back().push_back(q);  // the conjugate of the eigenvalue just before it
+      } else {
+        groups.push_back({q});
       }
-      std::vector<cplx> c(done.back());
-      for (cplx& z : c) z = std::conj(z);
-      done.push_back(std::move(c));
       continue;
     }
-    // ---- LU of H - lambda I with row interchanges: column k eliminates H(k + 1, k)
-    for (int i = 0; i < n; ++i) {
-      const double* hr = w.H.data() + (size_t)i * n;
-      cplx* ur = U.data() + (size_t)i * n;
-      for (int j = 0; j < n; ++j) ur[j] = hr[j];
-      ur[i] -= lam[q];
+    if (last_real_q >= 0 && std::fabs(wr[q] - wr[last_real_q]) <= cluster_tol) {
+      groups[last_real_group].push_back(q);
+    } else {
+      groups.push_back({q});
+      last_real_group = (int)groups.size() - 1;
     }
-    for (int k = 0; k + 1 < n; ++k) {
-      cplx* rk = U.data() + (size_t)k * n;
-      cplx* rn = rk + n;
-      if (abs1(rk[k]) < abs1(rn[k])) {
-        for (int j = k; j < n; ++j) std::swap(rk[j], rn[j]);
-        swapped[k] = 1;
-      } else {
-        swapped[k] = 0;
-      }
-      if (abs1(rk[k]) == 0.0) rk[k] = eps3;
-      const cplx f = rn[k] / rk[k];
-      mult[k] = f;
-      if (f != cplx(0.0)) {
-        for (int j = k + 1; j < n; ++j) rn[j] -= f * rk[j];
-      }
-      rn[k] = 0.0;
-    }
-    if (abs1(U[(size_t)(n - 1) * n + n - 1]) == 0.0) U[(size_t)(n - 1) * n + n - 1] = eps3;
-    for (int i = 0; i < n; ++i)
-      if (abs1(U[(size_t)i * n + i]) < eps3) U[(size_t)i * n + i] = eps3;  // (dlaein)
-    // ---- inverse iteration
-    const double rootn = std::sqrt((double)n);
-    for (int i = 0; i < n; ++i) y[i] = 1.0 / rootn;
-    for (int iter = 0; iter < 6; ++iter) {
-      if (iter > 0) {  // forward: P and L (the first solve takes its start vector as L^-1 P b)
-        for (int k = 0; k + 1 < n; ++k) {
-          if (swapped[k]) std::swap(y[k], y[k + 1]);
-          y[k + 1] -= mult[k] * y[k];
-        }
-      }
-      for (int i = n - 1; i >= 0; --i) {  // U x = y
-        const cplx* ur = U.data() + (size_t)i * n;
-        cplx s = y[i];
-        for (int j = i + 1; j < n; ++j) s -= ur[j] * y[j];
-        y[i] = s / ur[i];
-      }
-      // a cluster of (numerically) equal real eigenvalues: stay independent of its earlier
-      // vectors (any basis of the invariant subspace will do; np.linalg.eig returns one)
-      if (wi[q] == 0.0) {
-        for (int p = 0; p < q; ++p) {
-          if (wi[p] != 0.0 || std::fabs(wr[p] - wr[q]) > cluster_tol) continue;
-          cplx dot = 0.0;
-          double nn = 0.0;
-          for (int r = 0; r < n; ++r) {
-            dot += std::conj(done[p][r]) * y[r];
-            nn += std::norm(done[p][r]);
-          }
-          if (nn > 0.0)
-            for (int r = 0; r < n; ++r) y[r] -= (dot / nn) * done[p][r];
-        }
-      }
-      double big = 0.0, n2 = 0.0;
-      for (int r = 0; r < n; ++r) big = std::max(big, abs1(y[r]));
-      if (!(big > 0.0) || !std::isfinite(big)) return false;
-      for (int r = 0; r < n; ++r) {
-        y[r] /= big;
-        n2 += std::norm(y[r]);
-      }
-      const double inv = 1.0 / std::sqrt(n2);
-      for (int r = 0; r < n; ++r) y[r] *= inv;
-      // converged when the residual is at rounding level (one solve with the shift at an
-      // eigenvalue already multiplies a generic start vector by ~1 / eps3; two are the rule)
-      double res2 = 0.0;
-      for (int i = 0; i < n; ++i) {
-        const double* hr = w.H.data() + (size_t)i * n;
-        cplx s = -lam[q] * y[i];
-        for (int j = std::max(0, i - 1); j < n; ++j) s += hr[j] * y[j];
-        res2 += std::norm(s);
-      }
-      const double res = std::sqrt(res2) / hnorm;
-      if (iter >= 1 && res <= 1e-12 * rootn) {
-        *max_resid = std::max(*max_resid, res);
-        break;
-      }
-      if (iter == 5) *max_resid = std::max(*max_resid, res);
-    }
-    done.emplace_back(y);
-    // ---- x = Q y = H_0 H_1 ... H_{n-3} y
-    t = y;
-    for (int k = n - 3; k >= 0; --k) {
-      const double tk = w.tau[k];
-      if (tk == 0.0) continue;
-      const double* v = w.V.data() + (size_t)k * n;
-      cplx dot = 0.0;
-      for (int r = k + 1; r < n; ++r) dot += v[r] * t[r];
-      dot *= tk;
-      for (int r = k + 1; r < n; ++r) t[r] -= dot * v[r];
-    }
-    for (int r = 0; r < n; ++r) {
-      vre[(size_t)q * ldv + r] = t[r].real();
-      vim[(size_t)q * ldv + r] = t[r].imag();
-    }
+    last_real_q = q;
   }
-  return true;
+  std::atomic<int> next{0};
+  std::atomic<bool> failed{false};
+  std::mutex res_mutex;
+  double worst = 0.0;
+  auto worker = [&]() {
+    std::vector<double> Ur;
+    std::vector<cplx> Uc;
+    for (;;) {
+      const int g = next.fetch_add(1);
+      if (g >= (int)groups.size() || failed.load()) return;
+      const std::vector<int>& grp = groups[g];
+      double local_worst = 0.0;
+      if (wi[grp[0]] != 0.0) {  // complex: the vector, and its conjugate for the partner
+        std::vector<cplx> y;
+        const double res = hessenberg_inverse_iteration<cplx>(w, lam[grp[0]], eps3, {}, &Uc, &y);
+        if (res < 0.0) {
+          failed.store(true);
+          return;
+        }
+        local_worst = res;
+        hessenberg_back_transform(w, &y);
+        for (size_t e = 0; e < grp.size(); ++e) {
+          const int q = grp[e];
+          const double sgn = e == 0 ? 1.0 : -1.0;
+          for (int r = 0; r < n; ++r) {
+            vre[(size_t)q * ldv + r] = y[r].real();
+            vim[(size_t)q * ldv + r] = sgn * y[r].imag();
+          }
+        }
+      } else {  // real eigenvalue(s): real arithmetic, the cluster's members one after the other
+        std::vector<std::vector<double>> ys(grp.size());
+        for (size_t e = 0; e < grp.size(); ++e) {
+          const int q = grp[e];
+          std::vector<const std::vector<double>*> prev;
+          for (size_t f = 0; f < e; ++f) prev.push_back(&ys[f]);
+          const double res =
+              hessenberg_inverse_iteration<double>(w, lam[q].real(), eps3, prev, &Ur, &ys[e]);
+          if (res < 0.0) {
+            failed.store(true);
+            return;
+          }
+          local_worst = std::max(local_worst, res);
+          std::vector<double> t(ys[e]);
+          hessenberg_back_transform(w, &t);
+          for (int r = 0; r < n; ++r) {
+            vre[(size_t)q * ldv + r] = t[r];
+            vim[(size_t)q * ldv + r] = 0.0;
+          }
+        }
+      }
+      std::lock_guard<std::mutex> lock(res_mutex);
+      worst = std::max(worst, local_worst);
+    }
+  };
+  const unsigned hw = std::thread::hardware_concurrency();
+  // (n^2 work-matrix entries per thread: 16 threads at n = 16384 are 34-69 GB -- fewer there)
+  int threads = (int)std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, groups.size(),
+                                      std::max<size_t>(1, ((size_t)4 << 30) / ((size_t)n * n * 16))});
+  if ((size_t)n * n < 65536) threads = 1;  // (small problems: a thread costs more than it saves)
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+  worker();
+  for (std::thread& t : pool) t.join();
+  *max_resid = worst;
+  return !failed.load();
 }
 
 // host-only exports (CPU tests): `packed` (n, n) row-major in the device reduction's storage

@@ -1480,6 +1480,12 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
     // test switch (tests/test_gpu_alternate_paths.py): straight to the landing pad
     if (sw::eig_force_dense())
       return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 4);
+    // a small problem: the dense route costs 20-60 ms up to n = 512 and returns np.linalg.eig's
+    // whole spectrum to rounding level -- block Arnoldi is faster there, but its decision-aware
+    // stop (below) leaves the consumed values that cannot move the decision at 1e-3.  Parity
+    // first where it is this cheap; fixed-count stage requests keep the Krylov solver.
+    if (rq.fixed_count == 0 && n <= sw::gen_dense_max_n())
+      return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 8);
     // max_clusters=None with a Laplacian reads every eigenvalue (utils.py:100-115): dense route
     if (rq.fixed_count == 0 && rq.max_clusters == 0 && !rq.descend)
       return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 6);

@@ -83,6 +83,15 @@ inline int diffuse_free_min_n_group() {
       getenv("SC_DIFFUSE_FREE_MIN_N") ? atoi(getenv("SC_DIFFUSE_FREE_MIN_N")) : 1536;
   return v;
 }
+// SC_GEN_DENSE_MAX_N=<n> (default 512): eigengap requests on the general (non-symmetrisable) path
+// up to this size take the dense Hessenberg route straight away (every eigenvalue to rounding
+// level, 20-60 ms) instead of block Arnoldi (faster, but its decision-aware stop holds the values
+// that cannot move the eigengap decision to 1e-3 only); 64 puts block Arnoldi back on everything
+// above the one-wavefront solver
+inline int gen_dense_max_n() {
+  static const int v = getenv("SC_GEN_DENSE_MAX_N") ? atoi(getenv("SC_GEN_DENSE_MAX_N")) : 512;
+  return v;
+}
 // SC_SWEEP_ONE_BY_ONE=1: an AutoTune level as separate sc_eig_ncluster calls (what a level
 // falls back to when member arenas do not fit or a value leaves the grouped path)
 inline bool sweep_one_by_one() {

@@ -21,6 +21,8 @@ they are the repair / large-problem routes of the default ones:
                         default takes the explicit product
   SC_DIFFUSE=explicit   the fp64 Diffuse product on every golden, n = 2048 included, where the
                         default is matrix-free
+  SC_GEN_DENSE_MAX_N=64 block Arnoldi (narrow and wide) on the general-path goldens of n = 300 /
+                        400, where the default since round 5 is the dense Hessenberg route
 
 Each runs in a fresh interpreter (the switches are read once per process) over reference
 goldens of both Laplacian branches."""
@@ -123,6 +125,33 @@ if os.environ.get("SC_EIG_FORCE_DENSE") and not os.environ.get("SC_DIFFUSE"):
   assert dg.n_clusters_raw == int(g["n_clusters_raw"])
   assert abs(dg.max_delta - float(g["max_delta"])) <= 1e-6 * float(g["max_delta"])
   assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+if os.environ.get("SC_GEN_DENSE_MAX_N"):
+  g = np.load(os.path.join(ROOT, "tests", "golden", "general_wide_n400.npz"))
+  n, d, k, seed, lap, maxc = (int(v) for v in g["params"])
+  c = sca.SpectralClusterer(
+      min_clusters=int(g["min_clusters"]), max_clusters=maxc,
+      refinement_options=sca.RefinementOptions(
+          thresholding_type=sca.ThresholdType.Percentile, p_percentile=float(g["p_percentile"]),
+          refinement_sequence=[sca.RefinementName.RowWiseThreshold]),
+      laplacian_type=sca.LaplacianType.GraphCut, row_wise_renorm=True)
+  labels = c.predict(so.blobs(n, d, k, seed))
+  dg = c.last_diag
+  assert dg.eig_path == 4, dg.eig_path  # wide block Arnoldi
+  assert dg.n_clusters_raw == int(g["n_clusters_raw"])
+  assert abs(dg.max_delta - float(g["max_delta"])) <= 1e-6 * float(g["max_delta"])
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
+  g = np.load(os.path.join(ROOT, "tests", "golden", "general_n300.npz"))
+  x = so.blobs(int(g["n"]), int(g["d"]), int(g["k"]), int(g["seed"]))
+  tuner = sca.AutoTune(p_percentile_min=0.60, p_percentile_max=0.95, init_search_step=0.05,
+                       search_level=1)
+  c = sca.SpectralClusterer(
+      min_clusters=2, max_clusters=6, autotune=tuner, laplacian_type=sca.LaplacianType.GraphCut,
+      row_wise_renorm=True, refinement_options=sca.RefinementOptions(
+          thresholding_type=sca.ThresholdType.Percentile,
+          refinement_sequence=[sca.RefinementName.RowWiseThreshold]))
+  labels = c.predict(x)
+  assert c.last_diag.eig_path == 4  # narrow block Arnoldi
+  assert so.adjusted_rand_index(labels, g["labels"]) == 1.0
 if os.environ.get("SC_KMEANS_SINGLE"):
   # every member of a grouped batch is handed back after its front (the lockstep k-means chain
   # is switched off): the large ones took the matrix-free Diffuse and must be resumed on the
@@ -147,6 +176,7 @@ print("ALTERNATE_PATH_OK")
 @pytest.mark.parametrize("switch", ["SC_EIG_HOST_CHAIN", "SC_EIG_DEVICE_RR", "SC_KMEANS_SINGLE",
                                     "SC_MATVEC_SYM_MIN_N", "SC_SWEEP_ONE_BY_ONE",
                                     "SC_EIG_FORCE_DENSE", "SC_DIFFUSE=free", "SC_DIFFUSE=explicit",
+                                    "SC_GEN_DENSE_MAX_N=64",
                                     "SC_DIFFUSE=free+SC_EIG_HOST_CHAIN",
                                     "SC_DIFFUSE=free+SC_EIG_FORCE_DENSE",
                                     "SC_DIFFUSE=free+SC_MATVEC_SYM_MIN_N"])

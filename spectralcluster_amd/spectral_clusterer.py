@@ -8,8 +8,10 @@ device too, and refinement sequences whose result is n
 diagonally similar to a symmetric matrix take the general eigen path (8f-N2);
 `max_spectral_size` pre-clusters on the device (cosine complete-linkage AHC) and
 `fallback_options` (too-few-embeddings fallback, single-cluster test for min_clusters=1) run
-there too (8f-N4).  `custom_dist`: cosine, euclidean, sqeuclidean, cityblock, chebyshev;
-other scipy metrics and callables are out of the device scope.  Those raise `UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
+there too (8f-N4).  `custom_dist`: cosine, euclidean (minkowski), sqeuclidean, cityblock,
+chebyshev, correlation, braycurtis, canberra and scipy's aliases of them; metrics that need more
+than the two vectors and callables are out of the device scope.  Those raise
+`UnsupportedOnDeviceError`; nothing silently falls back to the CPU.
 """
 
 from __future__ import annotations
@@ -214,9 +216,10 @@ class SpectralClusterer:
 
     Returns (eigenvectors, n_clusters, max_delta_norm).  For n <= 128 the
     eigenvector matrix is (n, n) like the reference's; above that it has only the
-    columns the eigengap search can select (max_clusters + 1, at most 64; with
-    max_clusters=None and a Laplacian -- where every eigenvalue is read, from the dense
-    tridiagonalisation path -- the max(n_clusters, min_clusters) columns predict() uses).
+    columns the eigengap search can select (max_clusters + 1, at most 64 from a Krylov solve;
+    on the dense routes -- max_clusters=None with a Laplacian, where every eigenvalue is read,
+    more than 64 selected clusters, the general path up to n = 512 -- the
+    max(n_clusters, min_clusters) columns predict() uses).
     """
     a = np.ascontiguousarray(affinity, dtype=np.float64)
     if a.ndim != 2 or a.shape[0] != a.shape[1]:

@@ -869,6 +869,10 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
         m = keep;
       }
     }
+    // (block steps enqueued ahead of a check that ended the solve were not part of it: the
+    //  reported pass count is what the result was computed from.  They wrote Vs, W and basis
+    //  columns beyond m only -- every path that goes on from here rebuilds those.)
+    if (ahead > 0) passes -= ahead;
     if (vectors_from_dense) {
       dc.max_resid = 0.0;
       if (diag) diag->eig_path = SC_EIG_PATH_DENSE_FULL;

@@ -217,7 +217,9 @@ typedef struct sc_diag {
                                     eigenvalue of multiplicity > 8: the dense path counts it);
                                     on the general path (eig_path 7) also 6: every eigenvalue
                                     is read (max_clusters=None with a Laplacian), 8: n <= 512,
-                                    where the dense route is the default */
+                                    where the dense route is the default, 9: ascending
+                                    NormalizedDiff reads np.max(eigenvalues), the far end of
+                                    the spectrum (utils.py:110,123) */
   float stage_ms[SC_MAX_STAGES]; /* hipEvent time per SC_STAGE_* slot */
   int32_t diffuse_path;          /* SC_DIFFUSE_PATH_* */
   int32_t free_candidates;       /* matrix-free Diffuse: exact dot products evaluated (n + few) */

@@ -1054,55 +1054,75 @@ double hessenberg_inverse_iteration(const HostHessenberg& w, T lam, double eps3,
   for (int i = 0; i < n; ++i)
     if (mag1(U[(size_t)i * n + i]) < eps3) U[(size_t)i * n + i] = eps3;  // (dlaein)
   // ---- inverse iteration
+  // Gate: an iterate is only accepted with a residual at 1e-8 sqrt(n) ||H|| or below.
+  // One that is still above it after six solves gets a different start vector (dlaein's: flat,
+  // with one entry pushed the other way); the last attempt of a cluster member gives up the
+  // independence from the earlier members -- of a DEFECTIVE eigenvalue there is only one
+  // eigenvector, and LAPACK returns it twice as well.  No attempt left: < 0, the caller reports
+  // SC_ERR_NOT_CONVERGED instead of handing an unconverged vector to k-means.
   const double rootn = std::sqrt((double)n);
-  for (int i = 0; i < n; ++i) y[i] = 1.0 / rootn;
+  const double gate = 1e-8 * rootn;
+  const int attempts = prev.empty() ? 3 : 4;
   double res = -1.0;
-  for (int iter = 0; iter < 6; ++iter) {
-    if (iter > 0) {  // forward: P and L (the first solve takes its start vector as L^-1 P b)
-      for (int k = 0; k + 1 < n; ++k) {
-        if (swapped[k]) std::swap(y[k], y[k + 1]);
-        y[k + 1] -= mult[k] * y[k];
+  for (int attempt = 0; attempt < attempts; ++attempt) {
+    const bool project = attempt < 3;
+    for (int i = 0; i < n; ++i) y[i] = 1.0 / rootn;
+    if (attempt > 0 && attempt < 3 && n - attempt >= 0) y[n - attempt] -= rootn / (rootn + 1.0);
+    res = -1.0;
+    for (int iter = 0; iter < 6; ++iter) {
+      if (iter > 0) {  // forward: P and L (the first solve takes its start vector as L^-1 P b)
+        for (int k = 0; k + 1 < n; ++k) {
+          if (swapped[k]) std::swap(y[k], y[k + 1]);
+          y[k + 1] -= mult[k] * y[k];
+        }
       }
-    }
-    for (int i = n - 1; i >= 0; --i) {  // U x = y
-      const T* ur = U.data() + (size_t)i * n;
-      T s = y[i];
-      for (int j = i + 1; j < n; ++j) s -= ur[j] * y[j];
-      y[i] = s / ur[i];
-    }
-    // a cluster of (numerically) equal real eigenvalues: stay independent of its earlier
-    // vectors (any basis of the invariant subspace will do; np.linalg.eig returns one)
-    for (const std::vector<T>* pv : prev) {
-      T dot = 0.0;
-      double nn = 0.0;
+      for (int i = n - 1; i >= 0; --i) {  // U x = y
+        const T* ur = U.data() + (size_t)i * n;
+        T s = y[i];
+        for (int j = i + 1; j < n; ++j) s -= ur[j] * y[j];
+        y[i] = s / ur[i];
+      }
+      // a cluster of (numerically) equal real eigenvalues: stay independent of its earlier
+      // vectors (any basis of the invariant subspace will do; np.linalg.eig returns one)
+      if (project) {
+        for (const std::vector<T>* pv : prev) {
+          T dot = 0.0;
+          double nn = 0.0;
+          for (int r = 0; r < n; ++r) {
+            dot += cj((*pv)[r]) * y[r];
+            nn += sq((*pv)[r]);
+          }
+          if (nn > 0.0)
+            for (int r = 0; r < n; ++r) y[r] -= (dot / nn) * (*pv)[r];
+        }
+      }
+      double big = 0.0, n2 = 0.0;
+      for (int r = 0; r < n; ++r) big = std::max(big, mag1(y[r]));
+      if (!(big > 0.0) || !std::isfinite(big)) {  // this start vector leads nowhere
+        res = -1.0;
+        break;
+      }
       for (int r = 0; r < n; ++r) {
-        dot += cj((*pv)[r]) * y[r];
-        nn += sq((*pv)[r]);
+        y[r] /= big;
+        n2 += sq(y[r]);
       }
-      if (nn > 0.0)
-        for (int r = 0; r < n; ++r) y[r] -= (dot / nn) * (*pv)[r];
+      const double inv = 1.0 / std::sqrt(n2);
+      for (int r = 0; r < n; ++r) y[r] *= inv;
+      // converged when the residual is at rounding level (one solve with the shift at an
+      // eigenvalue already multiplies a generic start vector by ~1 / eps3; two are the rule)
+      double res2 = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double* hr = w.H.data() + (size_t)i * n;
+        T s = -lam * y[i];
+        for (int j = std::max(0, i - 1); j < n; ++j) s += hr[j] * y[j];
+        res2 += sq(s);
+      }
+      res = std::sqrt(res2) / hnorm;
+      if (iter >= 1 && res <= 1e-12 * rootn) break;
     }
-    double big = 0.0, n2 = 0.0;
-    for (int r = 0; r < n; ++r) big = std::max(big, mag1(y[r]));
-    if (!(big > 0.0) || !std::isfinite(big)) return -1.0;
-    for (int r = 0; r < n; ++r) {
-      y[r] /= big;
-      n2 += sq(y[r]);
-    }
-    const double inv = 1.0 / std::sqrt(n2);
-    for (int r = 0; r < n; ++r) y[r] *= inv;
-    // converged when the residual is at rounding level (one solve with the shift at an
-    // eigenvalue already multiplies a generic start vector by ~1 / eps3; two are the rule)
-    double res2 = 0.0;
-    for (int i = 0; i < n; ++i) {
-      const double* hr = w.H.data() + (size_t)i * n;
-      T s = -lam * y[i];
-      for (int j = std::max(0, i - 1); j < n; ++j) s += hr[j] * y[j];
-      res2 += sq(s);
-    }
-    res = std::sqrt(res2) / hnorm;
-    if (iter >= 1 && res <= 1e-12 * rootn) break;
+    if (res >= 0.0 && res <= gate) break;
   }
+  if (!(res >= 0.0 && res <= gate)) return -1.0;
   *y_out = y;
   return res;
 }

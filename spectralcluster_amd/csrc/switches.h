@@ -92,6 +92,12 @@ inline int gen_dense_max_n() {
   static const int v = getenv("SC_GEN_DENSE_MAX_N") ? atoi(getenv("SC_GEN_DENSE_MAX_N")) : 512;
   return v;
 }
+// SC_GEN_LOOSE_BULK=1: rounds 3-5's stop rule of the general path (consumed eigenvalues that
+// cannot move the eigengap decision held to 1e-3 instead of value_tol) -- A/B measurements only
+inline bool gen_loose_bulk() {
+  static const bool v = getenv("SC_GEN_LOOSE_BULK") != nullptr;
+  return v;
+}
 // SC_SWEEP_ONE_BY_ONE=1: an AutoTune level as separate sc_eig_ncluster calls (what a level
 // falls back to when member arenas do not fit or a value leaves the grouped path)
 inline bool sweep_one_by_one() {

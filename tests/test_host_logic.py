@@ -672,6 +672,27 @@ def test_host_hessenberg_eigenvectors_are_eigenvectors_of_the_original_matrix():
         assert np.array_equal(v[:, i + 1], np.conj(v[:, i])), name
 
 
+def test_host_hessenberg_vectors_residual_gate_on_a_defective_eigenvalue():
+  """inverse iteration accepted whatever six solves left.  A DEFECTIVE eigenvalue
+  (exact Jordan block in an already-triangular matrix: the QR iteration returns 2.0 twice) has ONE
+  eigenvector; the second member of its cluster, kept orthogonal to the first, is rounding noise.
+  The gate must reject that iterate and fall back to what LAPACK returns (the eigenvector again):
+  every returned column has a residual at rounding level."""
+  m = np.zeros((40, 40))
+  m[0, 0] = m[1, 1] = 2.0
+  m[0, 1] = 1.0
+  m[2:, 2:] = np.triu(np.random.default_rng(5).uniform(-1.0, 1.0, (38, 38)))
+  m[0:2, 2:] = 0.3
+  rc, w, _, _ = _host_hessenberg_eig(m, [])
+  assert rc == 0
+  pick = np.argsort(-w.real, kind="stable")[:4]
+  assert np.all(w[pick[:2]] == 2.0)
+  rc, _, v, res = _host_hessenberg_eig(m, pick)
+  assert rc == 0 and res < 1e-8 * np.sqrt(40)
+  r = np.linalg.norm(m @ v - v * w[pick][None, :], axis=0) / np.linalg.norm(v, axis=0)
+  assert r.max() < 1e-7 * np.abs(m).max() * 40, r
+
+
 def test_cost_model_matches_its_calibration_record():
   """multigpu.cost_model against the measured per-utterance times it was fitted on
   (profiles/r06g_cost_fit.txt, written by tests/probes/cost_model_fit.py on the GPU box):

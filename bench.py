@@ -582,21 +582,23 @@ def kernel_roofline(stage_ms, passes):
   if stage_ms.get("free_product", 0.0) > 0:
     # matrix-free Diffuse: the digit product runs on the int8 matrix cores
     us = 1e3 * stage_ms["free_product"]
-    ops = 4.0 * tri * ((n + 63) // 64 * 64)
+    tiles_run = stage_ms.get("_tiles_run") or nt * (nt + 1) // 2
+    ops = 4.0 * tiles_run * 2.0 * GEMM_TILE * GEMM_TILE * ((n + 63) // 64 * 64)
     tops = ops / (us * 1e-6) / 1e12
     rows.append({"kernel": "k_gemm_i8_sym (digit product of the matrix-free Diffuse)",
                  "bound": "mfma", "us": us, "flops": ops, "achieved": tops,
                  "peak": PEAK_I8_MFMA_TOPS, "unit": "TFLOP/s", "frac": tops / PEAK_I8_MFMA_TOPS,
                  "note": "int8 multiply-adds counted as 2 ops; 4 digit products (hh, hl, lh, ll) "
-                         "of the upper-triangle tiles"})
+                         "of the %d upper-triangle tiles (of %d) on the skip list; includes "
+                         "k_free_tile_flags and k_i8_tail_finish" % (tiles_run, nt * (nt + 1) // 2)})
     t32 = nt * (nt + 1) // 2 * GEMM_TILE * GEMM_TILE * 4.0
     nblk = (n + 63) // 64
     hbm("k_free_partials_reduce (row partials of the quantiser fused into threshold+symmetrise)",
         "free_quantize", n * nblk * 12.0 + n * 16.0,
         "the digits are written by k_threshold_symmetrize_digits; what is left is the sum of "
         "its per-block partials: n * n/64 * 12 B read")
-    hbm("k_t32_candidates", "free_scan", t32,
-        "1 read of the fp32 upper-triangle tiles of T (row maxima come from the product's epilogue)")
+    hbm("k_t32_candidates", "free_scan", t32 * tiles_run / (nt * (nt + 1) // 2),
+        "1 read of the fp32 tiles of T that were computed (row maxima come from the product's epilogue)")
     hbm("k_free_row_stats (exact rowmax / rowsum of S)", "free_stats", 2.2 * mat,
         "row i and its ~1.2 candidate rows: ~2.2 n^2 * 8 B")
   else:
@@ -783,18 +785,48 @@ def main():
     xdiffuse_s = explicit_ms["diffuse"] * 1e-3
     xachieved = flops / xdiffuse_s / 1e12 if xdiffuse_s > 0 else 0.0
     if free:
-      # dominant kernel of the call as it runs: the int8 digit product (4 products of the
-      # upper-triangle tiles, K rounded up to the 64-wide stage)
-      ops = 4.0 * nt * (nt + 1) // 2 * 2.0 * GEMM_TILE * GEMM_TILE * ((N_SAMPLES + 63) // 64 * 64)
+      # Round 6: the digit product walks a skip list (sc_diag.free_tiles_run of the upper
+      # triangle's tiles; the others are proven free of row maxima and candidates).  Its
+      # algorithmic work is that of the tiles that HAVE to be computed: 4 digit products x
+      # tiles_run x 2 * 128^2 * K, K rounded up to the 64-wide stage.
+      tiles_total = nt * (nt + 1) // 2
+      tiles_run = int(diag.free_tiles_run) or tiles_total
+      per_tile = 4.0 * 2.0 * GEMM_TILE * GEMM_TILE * ((N_SAMPLES + 63) // 64 * 64)
+      ops = per_tile * tiles_run
       prod_s = stage_ms["free_product"] * 1e-3
       achieved = ops / prod_s / 1e12
-      roof = {"bound": "mfma", "kernel": "k_gemm_i8_sym (exact int8-digit product of the "
-                                         "matrix-free Diffuse)",
-              "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TFLOP/s",
-              "frac": achieved / PEAK_I8_MFMA_TOPS, "traffic": None,
-              "ops_note": "int8 multiply-add = 2 ops; peak = dense int8 MFMA (2x the 2.5 PF bf16 "
-                          "rate, MI355X_MICROARCH.md); 4 digit products hh, hl, lh, ll",
-              "flops_per_launch": ops, "avg_launch_ms": stage_ms["free_product"]}
+      i8 = {"bound": "mfma", "kernel": "k_free_tile_flags + k_gemm_i8_sym + k_i8_tail_finish "
+                                       "(exact int8-digit product of the matrix-free Diffuse "
+                                       "over its skip list)",
+            "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_I8_MFMA_TOPS, "traffic": None,
+            "tiles_run": tiles_run, "tiles_total": tiles_total,
+            "ops_note": "int8 multiply-add = 2 ops; peak = dense int8 MFMA (2x the 2.5 PF bf16 "
+                        "rate, MI355X_MICROARCH.md); 4 digit products hh, hl, lh, ll of the "
+                        "tiles that ran",
+            "flops_per_launch": ops, "avg_launch_ms": stage_ms["free_product"],
+            "all_tiles_equivalent_tops": per_tile * tiles_total / prod_s / 1e12}
+      # ... which leaves the affinity GEMM (fp64 MFMA, K = d) as the longest kernel of the call
+      aff_s = stage_ms.get("affinity_gemm", 0.0) * 1e-3
+      aff_flops = tiles_total * 2.0 * GEMM_TILE * GEMM_TILE * N_FEATURES
+      aff = {"bound": "mfma", "kernel": "k_gemm_nt<EpiAffinity,SYM> (cosine affinity, fp64 "
+                                        "MFMA, upper-triangle tiles, crop value in the epilogue)",
+             "achieved": aff_flops / aff_s / 1e12 if aff_s > 0 else 0.0,
+             "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+             "flops_per_launch": aff_flops, "avg_launch_ms": stage_ms.get("affinity_gemm", 0.0),
+             "note": "K = %d is %d K-tiles: prologue / epilogue bound; its write floor is "
+                     "n^2 * 8 B / 8 TB/s = %.0f us" % (N_FEATURES, N_FEATURES // 16,
+                                                      N_SAMPLES * N_SAMPLES * 8.0 / 8e12 * 1e6)}
+      aff["frac"] = aff["achieved"] / PEAK_F64_MFMA_TFLOPS
+      if aff_s > prod_s:
+        roof = aff
+        roof["dominant_by"] = ("longest kernel of the call in the timed region (hipEvents): "
+                               "%.0f us against %.0f us of the digit product" %
+                               (1e6 * aff_s, 1e6 * prod_s))
+        roof["i8_product"] = i8
+      else:
+        roof = i8
+        roof["affinity_gemm"] = aff
     else:
       diffuse_s = stage_ms["diffuse"] * 1e-3
       achieved = flops / diffuse_s / 1e12 if diffuse_s > 0 else 0.0
@@ -802,6 +834,7 @@ def main():
               "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
               "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None,
               "flops_per_launch": flops, "avg_launch_ms": stage_ms["diffuse"]}
+    fine_ms["_tiles_run"] = int(diag.free_tiles_run) if free else 0
     roof["kernels"] = kernel_roofline(fine_ms, passes_per_call)
     roof["fp64_diffuse_route"] = {
         "kernel": "k_gemm_nt<EpiNone,SYM> (Diffuse), sc_config.diffuse_mode = 1",
@@ -822,8 +855,11 @@ def main():
     mat = nn * 8.0
     x_floor = ((nn * (N_SAMPLES + N_FEATURES)) / (PEAK_F64_MFMA_TFLOPS * 1e12) +
                ((7.0 + passes_per_call) * mat + N_SAMPLES * N_FEATURES * 8.0) / (PEAK_HBM_TBS * 1e12))
+    # (round 6: the int8 term counts the tiles the skip list left -- the work that has to be done)
+    i8_share = (float(diag.free_tiles_run) / (nt * (nt + 1) // 2)
+                if free and diag.free_tiles_run > 0 else 1.0)
     f_floor = (nn * N_FEATURES / (PEAK_F64_MFMA_TFLOPS * 1e12) +
-               4.0 * nn * N_SAMPLES / (PEAK_I8_MFMA_TOPS * 1e12) +
+               i8_share * 4.0 * nn * N_SAMPLES / (PEAK_I8_MFMA_TOPS * 1e12) +
                (5.0 * mat + nn * 2.0 + 2 * nn * 2.0 + mat + 2.0 * passes_per_call * 0.5 * mat +
                 N_SAMPLES * N_FEATURES * 8.0) / (PEAK_HBM_TBS * 1e12))
     whole = {"measured_ms": 1e3 * elapsed / k,
@@ -832,6 +868,7 @@ def main():
              "route": "matrix-free Diffuse" if free else "explicit fp64 Diffuse",
              "explicit_route_floor_ms": 1e3 * x_floor,
              "matrix_free_route_floor_ms": 1e3 * f_floor,
+             "int8_share_of_tiles": i8_share,
              "measured_over_explicit_route_floor": (elapsed / k) / x_floor,
              "note": "floors: MFMA time of the flops/ops at peak + algorithmic HBM bytes at "
                      "8 TB/s, stages data-dependent so they add; H2D of X inside measured_ms"}
@@ -905,12 +942,25 @@ def main():
       import hashlib
       src = os.path.join(ROOT, "spectralcluster_amd", "csrc", "diffuse_free.hip")
       now = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+      tgt = out["roofline"].get("i8_product", out["roofline"])
+      tgt["traffic"] = t["hbm_bytes_per_launch"]
+      tgt["traffic_source"] = t["source"]
+      tgt["algorithmic_bytes_per_launch"] = t["algorithmic_bytes_per_launch"]
+      tgt["traffic_measured_on"] = {
+          "commit": t.get("commit"), "diffuse_free_sha16": t.get("diffuse_free_sha16"),
+          "kernel_source_unchanged_since": t.get("diffuse_free_sha16") == now}
+    apath = os.path.join(ROOT, "profiles", "pmc_traffic_affinity.json")
+    if free and "i8_product" in out["roofline"] and os.path.exists(apath):
+      t = json.load(open(apath))  # HBM bytes per affinity-GEMM launch (separate --pmc run)
+      import hashlib
+      src = os.path.join(ROOT, "spectralcluster_amd", "csrc", "gemm_f64.hip")
+      now = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
       out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
       out["roofline"]["traffic_source"] = t["source"]
       out["roofline"]["algorithmic_bytes_per_launch"] = t["algorithmic_bytes_per_launch"]
       out["roofline"]["traffic_measured_on"] = {
-          "commit": t.get("commit"), "diffuse_free_sha16": t.get("diffuse_free_sha16"),
-          "kernel_source_unchanged_since": t.get("diffuse_free_sha16") == now}
+          "commit": t.get("commit"), "gemm_f64_sha16": t.get("gemm_f64_sha16"),
+          "kernel_source_unchanged_since": t.get("gemm_f64_sha16") == now}
     out.update(extras)
     if args.workload != "predict8192":
       leg = extras[args.workload]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 6
+#define SC_ABI_VERSION 7
 #define SC_MAX_OPS 16
 #define SC_MAX_BLUR_RADIUS 32
 #define SC_MAX_EIG 128 /* max eigenvalues reported in sc_diag */
@@ -224,7 +224,10 @@ typedef struct sc_diag {
   int32_t diffuse_path;          /* SC_DIFFUSE_PATH_* */
   int32_t free_candidates;       /* matrix-free Diffuse: exact dot products evaluated (n + few) */
   int32_t free_overflow_rows;    /* ... rows evaluated in full (more candidates than the cap) */
-  int32_t reserved_diag;
+  int32_t free_tiles_run;        /* ... 128 x 128 tiles of the digit product that were computed:
+                                    the others -- of ceil(n/128) (ceil(n/128) + 1) / 2 -- were
+                                    excluded by the segment-norm bound (0: not reported, the
+                                    grouped routes) */
 } sc_diag;
 
 /* ---- library / device ---------------------------------------------------- */
@@ -256,6 +259,12 @@ int sc_set_profiling(sc_handle h, int level);
  * Both routes return the same rowmax / rowsum to summation order; sc_diag.diffuse_path says
  * which one ran. */
 int sc_set_diffuse_mode(sc_handle h, int mode);
+/* Tile skip list of the matrix-free route's digit product (ABI 7): 1 (default) = tiles that a
+ * Cauchy-Schwarz bound on 64-column digit-segment norms proves free of row maxima and candidates
+ * are not computed (exact for any input: rowmax / rowsum / candidate sets are those of the full
+ * product); 0 = every tile (A/B measurements, parity tests); -1 = the process default
+ * (environment SC_FREE_NO_PRUNE).  sc_diag.free_tiles_run reports what ran. */
+int sc_set_free_prune(sc_handle h, int on);
 
 /* fills cfg with the reference defaults (refinement.py:76-100,
  * spectral_clusterer.py:29-46): no ops, sigma 1 weights, p .95, mult .01 ... */
@@ -412,8 +421,9 @@ int sc_stage_constraint(sc_handle h, const sc_config* cfg, const double* affinit
 /* rowmax / rowsum of Diffuse(a) = a a^T (refinement.py:232-234) for a SYMMETRIC (n, n) input --
  * what RowWiseNormalize (refinement.py:240-245) and the Laplacian degree (laplacian.py:41) read
  * of it -- by either route: mode 1 the explicit fp64 product, mode 2 the matrix-free search
- * (n <= 65536).  info (4 ints, may be NULL): candidates evaluated exactly, rows over the
- * candidate cap (evaluated in full), largest candidate count of a row, 1 if S was formed after all. */
+ * (n <= 65536).  info (6 ints since ABI 7, may be NULL): candidates evaluated exactly, rows over
+ * the candidate cap (evaluated in full), largest candidate count of a row, 1 if S was formed after
+ * all, tiles of the digit product computed, tiles in its upper triangle. */
 int sc_stage_diffuse_rowstats(sc_handle h, const double* a, int n, int mode, double* rowmax,
                               double* rowsum, int32_t* info);
 /* laplacian.compute_laplacian (laplacian.py:24-60) */

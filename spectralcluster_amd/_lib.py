@@ -48,7 +48,7 @@ class EigenSolverNotConverged(RuntimeError):
   """The block-Lanczos eigensolver did not reach its tolerance."""
 
 
-SC_ABI_VERSION = 6
+SC_ABI_VERSION = 7
 
 
 class ScConfig(ctypes.Structure):
@@ -108,7 +108,7 @@ class ScDiag(ctypes.Structure):
       ("diffuse_path", ctypes.c_int32),
       ("free_candidates", ctypes.c_int32),
       ("free_overflow_rows", ctypes.c_int32),
-      ("reserved_diag", ctypes.c_int32),
+      ("free_tiles_run", ctypes.c_int32),
   ]
 
   def eigenvalue_array(self) -> np.ndarray:
@@ -139,6 +139,7 @@ PROTOTYPES = {
     "sc_synchronize": (ctypes.c_int, [_handle_t]),
     "sc_set_profiling": (ctypes.c_int, [_handle_t, ctypes.c_int]),
     "sc_set_diffuse_mode": (ctypes.c_int, [_handle_t, ctypes.c_int]),
+    "sc_set_free_prune": (ctypes.c_int, [_handle_t, ctypes.c_int]),
     "sc_stage_diffuse_rowstats": (ctypes.c_int, [_handle_t, _c_double_p, ctypes.c_int,
                                                  ctypes.c_int, _c_double_p, _c_double_p,
                                                  ctypes.POINTER(ctypes.c_int32)]),

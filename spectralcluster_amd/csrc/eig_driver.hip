@@ -918,6 +918,7 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
       diag->diffuse_path = h->free_on ? SC_DIFFUSE_PATH_FREE : SC_DIFFUSE_PATH_FREE_THEN_EXPLICIT;
       diag->free_candidates = h->free_checked ? h->h_free[65] : 0;
       diag->free_overflow_rows = h->free_checked ? h->h_free[0] : 0;
+      diag->free_tiles_run = h->free_checked ? h->h_free[67] : 0;
     }
   }
   *out_dc = dc;

@@ -14,6 +14,15 @@ extern "C" int sc_set_diffuse_mode(sc_handle h, int mode) {
   return SC_OK;
 }
 
+extern "C" int sc_set_free_prune(sc_handle h, int on) {
+  if (!h || on < -1 || on > 1) return SC_ERR_INVALID;
+  h->free_prune = on;
+  return SC_OK;
+}
+static bool free_prune_on(sc_handle h) {
+  return h->free_prune >= 0 ? h->free_prune != 0 : !sw::free_no_prune();
+}
+
 bool free_diffuse_wanted(sc_handle h, const sc_config* cfg, int n, const EigRequest& rq,
                          bool in_group) {
   // the call's own choice, else the handle's, else the process default
@@ -42,18 +51,29 @@ int ensure_free(sc_handle h, int n) {
   SC_TRY(grow(h, h->fwords, ((size_t)2 * n + kOvfWords) * sizeof(int)));
   SC_TRY(grow(h, h->fcand, (size_t)n * free_candidate_cap() * sizeof(int)));
   SC_TRY(grow(h, h->fY, (size_t)n * kEigBlock * sizeof(double)));
+  SC_TRY(grow(h, h->fq2part, free_q2part_bytes(n)));
+  SC_TRY(grow(h, h->fmx64, free_mx64_bytes(n)));
+  SC_TRY(grow(h, h->ftau64, free_tau64_bytes(n)));
+  SC_TRY(grow(h, h->fplan, free_plan_bytes(n)));
   if (!h->h_free)
     SC_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_free), kOvfWords * sizeof(int)));
   return SC_OK;
 }
 
-// the integer product of the handle's digits (split-K tail on the handle's workspace)
+static FreeSegs free_segs(sc_handle h) {
+  return FreeSegs{ptr<double>(h->fq2part), ptr<double>(h->fmx64), ptr<float>(h->ftau64)};
+}
+
+// the integer product of the handle's digits over the tiles of its skip list (the pass that wrote
+// the digits left mx64 / tau64; split-K tail on the handle's workspace)
 int free_product(sc_handle h, hipStream_t s, int n) {
   // (the workspace of the split-K tail belongs to handles that launch a product of their own:
   //  the members of a sweep share one grouped launch and never need it)
-  if (free_i8_split_bytes(n) > 0) SC_TRY(grow(h, h->fsplit, free_i8_split_bytes(n)));
+  SC_TRY(grow(h, h->fsplit, free_i8_split_bytes_plan()));
+  launch_free_tile_flags(s, ptr<double>(h->fmx64), ptr<float>(h->ftau64), n, ptr<int>(h->fplan),
+                         free_prune_on(h));
   launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32),
-                     ptr<unsigned>(h->fwords), ptr<int>(h->fsplit));
+                     ptr<unsigned>(h->fwords), ptr<int>(h->fsplit), ptr<int>(h->fplan));
   return SC_OK;
 }
 
@@ -67,15 +87,17 @@ int free_stats_begin(sc_handle h, hipStream_t s, const double* A, int ld, int n,
   SC_HIP(h, hipMemsetAsync(h->fwords.p, 0, ((size_t)2 * n + kOvfWords) * sizeof(int), s));
   if (!have_amax) launch_free_absmax(s, A, n, ld, ptr<double>(h->fscal));
   launch_free_quantize(s, A, n, ld, ptr<signed char>(h->fq), ptr<double>(h->fscal),
-                       ptr<double>(h->fy1), ptr<double>(h->fR));
+                       ptr<double>(h->fy1), ptr<double>(h->fR), ptr<double>(h->fq2part));
+  launch_free_seg_reduce(s, ptr<double>(h->fR), n, free_segs(h));
   return SC_OK;
 }
-int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool timed) {
+int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool timed,
+                   const int* plan) {
   unsigned* M = ptr<unsigned>(h->fwords);
   int* count = ptr<int>(h->fwords) + n;
   int* ovf = ptr<int>(h->fwords) + 2 * (size_t)n;
   launch_t32_candidates(s, ptr<float>(h->ft32), n, M, ptr<double>(h->fR), ptr<double>(h->fscal),
-                        count, ptr<int>(h->fcand));
+                        count, ptr<int>(h->fcand), plan);
   if (timed) ev_rec(h, &h->free_ev[3]);
   launch_free_row_stats(s, A, n, ld, ptr<double>(h->fy1), count, ptr<int>(h->fcand),
                         ptr<double>(h->rowmax), ptr<double>(h->rowsum), ovf);
@@ -141,13 +163,14 @@ int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_am
   ev_rec(h, &h->free_ev[0]);
   if (digits_ready)
     launch_free_partials_reduce(s, ptr<double>(h->fypart), ptr<int>(h->frpart), n,
-                                ptr<double>(h->fy1), ptr<double>(h->fR), ptr<double>(h->fscal));
+                                ptr<double>(h->fy1), ptr<double>(h->fR), ptr<double>(h->fscal),
+                                free_segs(h));
   else
     SC_TRY(free_stats_begin(h, s, A, ld, n, have_amax));
   ev_rec(h, &h->free_ev[1]);
   SC_TRY(free_product(h, s, n));
   ev_rec(h, &h->free_ev[2]);
-  return free_stats_end(h, s, A, ld, n, true);
+  return free_stats_end(h, s, A, ld, n, true, ptr<int>(h->fplan));
 }
 
 // plain product W = A Vs by the solver's own block matvec (c = 1, p = 0)
@@ -223,7 +246,7 @@ extern "C" int sc_stage_diffuse_rowstats(sc_handle h, const double* a, int n, in
   hipStream_t s = h->stream;
   double* A = ptr<double>(h->B2);
   SC_TRY(h2d_matrix(h, a, n, n, A, ld));
-  int inf[4] = {0, 0, 0, 0};
+  int inf[6] = {0, 0, 0, 0, 0, 0};
   auto explicit_stats = [&]() -> int {
     GemmRowStats rs{1, ptr<double>(h->statp), ptr<double>(h->statp) + (size_t)n * gemm_tile_dim(n),
                     ptr<double>(h->rowmax), ptr<double>(h->rowsum)};
@@ -240,6 +263,8 @@ extern "C" int sc_stage_diffuse_rowstats(sc_handle h, const double* a, int n, in
     inf[0] = h->h_free[65];
     inf[1] = h->h_free[0];
     inf[2] = h->h_free[66];
+    inf[4] = h->h_free[67];
+    inf[5] = gemm_tile_dim(n) * (gemm_tile_dim(n) + 1) / 2;
     if (too_many) {
       inf[3] = 1;
       SC_TRY(explicit_stats());

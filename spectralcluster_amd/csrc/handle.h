@@ -138,6 +138,10 @@ struct sc_handle_s {
                            // wherever the sequence allows it; -1: the environment's default
   DevBuf fq, ft32, fy1, fR, fscal, fwords, fcand, fY, fsplit, fypart, frpart;  // digits, T (fp32 tiles), A 1, sum|q|,
                            // scalars, M | count | ovf words, candidate lists, A Vs
+  int free_prune = -1;     // sc_set_free_prune: 1 skip list on, 0 every tile, -1 environment
+  DevBuf fq2part, fmx64, ftau64, fplan;  // tile skip list of the digit product (diffuse_free.hip):
+                           // squared segment norms per (block, row), their maxima per 64-row
+                           // group, the groups' thresholds, surviving tiles per tile row
   int* h_free = nullptr;   // pinned copy of the ovf words (80)
   bool free_on = false;    // the operator of the current solve is c .* A (A (c .* v)) + p .* v
   bool free_checked = false;  // ... and its overflow rows have been dealt with
@@ -350,7 +354,8 @@ int ensure_free(sc_handle h, int n);
 // exact statistics + the overflow words on their way to h->h_free
 int free_product(sc_handle h, hipStream_t s, int n);
 int free_stats_begin(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool have_amax);
-int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool timed);
+int free_stats_end(sc_handle h, hipStream_t s, const double* A, int ld, int n, bool timed,
+                   const int* plan = nullptr);
 // after the stream has drained: rows with more candidates than the cap are evaluated in full.
 // *changed: rowmax was rewritten (the scaling vectors must be rebuilt); *too_many: more such
 // rows than the exact route takes (the caller forms S explicitly).

@@ -338,10 +338,15 @@ struct TsDigits {
                        // a finite value had to be clamped after all (diffuse_free.hip)
   double* ypart;       // [block * 64 nblk + row] sum of a  (a tile's 64 partials are contiguous:
   int* rpart;          // [block * 64 nblk + row] sum of |q|   whole lines leave the L2)
+  double* q2part;      // [block * 64 nblk + row] sum of q^2 (an exact integer < 2^37): the squared
+                       // norm of the row's digit segment, for the tile skip list (diffuse_free.hip)
+  double* mx64;        // [row group * nblk + block] the largest segment norm of a tile's 64 rows
+                       // (rounded up): exactly one workgroup holds the 64 values, a plain store
 };
-__device__ __forceinline__ void ts_digits(const TsDigits& dg, double sigma, int row, int blk,
+__device__ __forceinline__ double ts_digits(const TsDigits& dg, double sigma, int row, int blk,
                                           int c0, double v0, double v1, bool lane0 /* the half-wave's LAST lane */) {
   int qv[2];
+  double q2 = 0.0;
   const double e[2] = {v0, v1};
   signed char hb[2], lb[2];
 #pragma unroll
@@ -353,6 +358,7 @@ __device__ __forceinline__ void ts_digits(const TsDigits& dg, double sigma, int 
     const int h = (q + 128) >> 8;
     const int l = q - (h << 8);
     qv[w] = q < 0 ? -q : q;
+    q2 += qd * qd;  // (integers below 2^31: every partial sum is exact)
     hb[w] = (signed char)h;
     lb[w] = (signed char)l;
   }
@@ -362,10 +368,21 @@ __device__ __forceinline__ void ts_digits(const TsDigits& dg, double sigma, int 
   // the 32 lanes of a half-wave hold the row's 64 columns: their sums land in its last lane
   const double ys = half_sum_to_last(v0 + v1);
   const int rs = half_sum_to_last(qv[0] + qv[1]);
+  const double q2s = half_sum_to_last(q2);
   if (lane0) {
     dg.ypart[(size_t)blk * (kTsTile * dg.nblk) + row] = ys;
     dg.rpart[(size_t)blk * (kTsTile * dg.nblk) + row] = rs;
+    dg.q2part[(size_t)blk * (kTsTile * dg.nblk) + row] = q2s;
   }
+  return q2s;  // (valid in the half-wave's last lane)
+}
+__device__ __forceinline__ void ts_store_mx(const TsDigits& dg, const double* sm, int group,
+                                            int blk) {
+  double m = sm[0];
+#pragma unroll
+  for (int u = 1; u < 8; ++u) m = fmax(m, sm[u]);
+  // sqrt rounds to nearest: one ulp up makes it an upper bound of the segment norm
+  dg.mx64[(size_t)group * dg.nblk + blk] = sqrt(m) * (1.0 + 0x1p-52);
 }
 template <bool DIGITS>
 __device__ __forceinline__ void threshold_symmetrize_body(
@@ -379,6 +396,8 @@ __device__ __forceinline__ void threshold_symmetrize_body(
   // first (round 3's 32 x 32 form had two 8-byte loads in flight per thread and 256-byte row
   // segments: 4.7 TB/s).
   __shared__ double tT[kTsTile][kTsTile + 1];
+  __shared__ double smax[2][8];
+  double q2m = 0.0;
   // tile pair of this workgroup: row ti of the upper triangle starts at
   // off(ti) = ti * ntiles - ti (ti - 1) / 2.  Closed form + one correction step (a counting
   // loop here was 5.6e7 scalar instructions per launch at n = 8192: up to 256 trips per wave)
@@ -455,10 +474,20 @@ __device__ __forceinline__ void threshold_symmetrize_body(
     else if (gi < n && gj < n)
       out[(size_t)gi * ld + gj] = a[q].x;
     // (entries outside the matrix are zero here: thr() returned 0 for them and sym(0, 0) = 0)
-    if (DIGITS) ts_digits(dg, sigma, gi, tj, c0, a[q].x, a[q].y, tx == 31);
+    if (DIGITS) q2m = fmax(q2m, ts_digits(dg, sigma, gi, tj, c0, a[q].x, a[q].y, tx == 31));
   }
-  if (diag_tile) return;
+  // the tile's largest squared segment norm: 8 half-waves x 8 rows each
+  if (DIGITS && tx == 31) smax[0][ty] = q2m;
+  if (diag_tile) {
+    if (DIGITS) {
+      __syncthreads();
+      if (threadIdx.x == 0) ts_store_mx(dg, smax[0], ti, tj);
+    }
+    return;
+  }
   __syncthreads();  // everybody has read B^T
+  if (DIGITS && threadIdx.x == 0) ts_store_mx(dg, smax[0], ti, tj);
+  q2m = 0.0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int r = ty + 8 * q;
@@ -475,7 +504,12 @@ __device__ __forceinline__ void threshold_symmetrize_body(
       *reinterpret_cast<double2*>(out + (size_t)gi * ld + gj) = o;
     else if (gi < n && gj < n)
       out[(size_t)gi * ld + gj] = o.x;
-    if (DIGITS) ts_digits(dg, sigma, gi, ti, c0, o.x, o.y, tx == 31);
+    if (DIGITS) q2m = fmax(q2m, ts_digits(dg, sigma, gi, ti, c0, o.x, o.y, tx == 31));
+  }
+  if (DIGITS) {
+    if (tx == 31) smax[1][ty] = q2m;
+    __syncthreads();
+    if (threadIdx.x == 0) ts_store_mx(dg, smax[1], tj, ti);
   }
 }
 __global__ __launch_bounds__(256) void k_threshold_symmetrize(
@@ -496,23 +530,38 @@ __global__ __launch_bounds__(256) void k_threshold_symmetrize_digits(
 // workgroup takes 64 rows; thread (row, quarter) adds a quarter of the row's blocks in order,
 // the quarters are folded in order, and the workgroup sends ONE candidate for the maximum (a
 // wave per row and a look at the word each cost 40 us of same-address traffic for 8 us of work).
+// With `segs` (the tile skip list of the digit product, sc_internal.h FreeSegs): the group's
+// smallest diagonal-only candidate threshold from the rows' exact T_ii (the segment maxima mx64
+// were stored by the threshold pass itself).
 __global__ __launch_bounds__(256) void k_free_partials_reduce(
     const double* __restrict__ ypart, const int* __restrict__ rpart, int n, int nblk,
-    double* __restrict__ y1, double* __restrict__ R, unsigned long long* __restrict__ rmax_bits) {
+    double* __restrict__ y1, double* __restrict__ R, unsigned long long* __restrict__ rmax_bits,
+    const FreeSegs segs) {
   __shared__ double sy[4][64];
+  __shared__ double sq[4][64];
   __shared__ long long sr[4][64];
   const int r = threadIdx.x & 63, qd = threadIdx.x >> 6;
   const int row = blockIdx.x * 64 + r;
   const size_t rows = (size_t)kTsTile * nblk;
   const int b0 = (int)((long long)nblk * qd / 4), b1 = (int)((long long)nblk * (qd + 1) / 4);
-  double ys = 0.0;
+  double ys = 0.0, q2s = 0.0;
   long long rs = 0;
+  if (segs.q2part == nullptr) {
 #pragma unroll 8
-  for (int b = b0; b < b1; ++b) {
-    ys += ypart[(size_t)b * rows + row];
-    rs += rpart[(size_t)b * rows + row];
+    for (int b = b0; b < b1; ++b) {
+      ys += ypart[(size_t)b * rows + row];
+      rs += rpart[(size_t)b * rows + row];
+    }
+  } else {
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) {
+      ys += ypart[(size_t)b * rows + row];
+      rs += rpart[(size_t)b * rows + row];
+      q2s += row < n ? segs.q2part[(size_t)b * rows + row] : 0.0;  // (integers: exact)
+    }
   }
   sy[qd][r] = ys;
+  sq[qd][r] = q2s;
   sr[qd][r] = rs;
   __syncthreads();
   if (qd == 0) {
@@ -531,6 +580,15 @@ __global__ __launch_bounds__(256) void k_free_partials_reduce(
       const unsigned long long cur =
           __hip_atomic_load(rmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (bits > cur) atomicMax(rmax_bits, bits);
+    }
+    if (segs.q2part != nullptr) {
+      // T_ii = ||q_i||^2 exactly (< 2^46); (float) of it is what the product's epilogue stores
+      // for the diagonal entry, and the row's maximum M_i is at least that
+      const double tii = ((sq[0][r] + sq[1][r]) + sq[2][r]) + sq[3][r];
+      float t = row < n ? free_threshold((float)tii, rd, 32639.0 * (double)n, n) : INFINITY;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t = fminf(t, __shfl_xor(t, o));
+      if (r == 0) segs.tau64[blockIdx.x] = t;
     }
   }
 }
@@ -824,22 +882,23 @@ void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, i
 void launch_threshold_symmetrize_digits(hipStream_t s, const double* in, double* out, int n, int ld,
                                         const double* cut, double mult, int binarize, int symtype,
                                         int preserve_diag, signed char* Q, double* scal,
-                                        double* ypart, int* rpart) {
+                                        double* ypart, int* rpart, double* q2part,
+                                        double* mx64) {
   const int t = (n + kTsTile - 1) / kTsTile;
   const size_t pitch = (size_t)2 * t * kTsTile;
   // rows [64 t, round_up(n, 128)) belong to no tile: zero digits
   const int rows_padded = (n + 127) / 128 * 128;
   if (rows_padded > t * kTsTile)
     hipMemsetAsync(Q + (size_t)t * kTsTile * pitch, 0, (size_t)(rows_padded - t * kTsTile) * pitch, s);
-  const TsDigits dg{Q, pitch, t, scal, ypart, rpart};
+  const TsDigits dg{Q, pitch, t, scal, ypart, rpart, q2part, mx64};
   hipLaunchKernelGGL(k_threshold_symmetrize_digits, dim3(t * (t + 1) / 2), dim3(256), 0, s, in,
                      out, n, ld, cut, mult, binarize, symtype, t, preserve_diag, dg);
 }
 void launch_free_partials_reduce(hipStream_t s, const double* ypart, const int* rpart, int n,
-                                 double* y1, double* R, double* scal) {
+                                 double* y1, double* R, double* scal, const FreeSegs& segs) {
   const int nblk = (n + kTsTile - 1) / kTsTile;
   hipLaunchKernelGGL(k_free_partials_reduce, dim3(nblk), dim3(256), 0, s, ypart, rpart, n,
-                     nblk, y1, R, reinterpret_cast<unsigned long long*>(scal) + 2);
+                     nblk, y1, R, reinterpret_cast<unsigned long long*>(scal) + 2, segs);
 }
 void launch_row_normalize(hipStream_t s, const double* in, double* out, int n,
                           int ld) {

@@ -125,9 +125,11 @@ void launch_threshold_symmetrize(hipStream_t s, const double* in, double* out, i
 void launch_threshold_symmetrize_digits(hipStream_t s, const double* in, double* out, int n, int ld,
                                         const double* cut, double mult, int binarize, int symtype,
                                         int preserve_diag, signed char* Q, double* scal,
-                                        double* ypart, int* rpart);
+                                        double* ypart, int* rpart, double* q2part,
+                                        double* mx64);
+struct FreeSegs;  // (below, with the matrix-free Diffuse)
 void launch_free_partials_reduce(hipStream_t s, const double* ypart, const int* rpart, int n,
-                                 double* y1, double* R, double* scal);
+                                 double* y1, double* R, double* scal, const FreeSegs& segs);
 void launch_row_threshold(hipStream_t s, const double* in, double* out, int n,
                           int ld, double p, double mult, int binarize,
                           int preserve_diag);
@@ -381,6 +383,28 @@ void launch_scaling_general(hipStream_t s, const double* deg, int n, int laplaci
 // integer MFMA product of them, row maxima + candidates within a proven slack, exact fp64 dot
 // products for the candidates.  scal: 4 doubles ([0] max|a| bits, [2] max R bits; zeroed by
 // the caller); M / count: n words each, zeroed; ovf: 80 words, zeroed; cand: n x cap.
+// The candidate threshold of a row whose maximum of T is m (diffuse_free.hip's header: twice the
+// bound on |sigma^2 S - T| with R_j replaced by its maximum, plus the fp32 rounding of the two
+// stored values that are compared -- 2^-24 relative each, doubled for safety).  Monotone in m,
+// decreasing in Rmax; rounded DOWN to fp32 (the comparison is made in fp32).
+__device__ __forceinline__ float free_threshold(float m, double Ri, double Rmax, int n) {
+  const double e = 0.5000001 * (Ri + Rmax) + 0.26 * (double)n;
+  const double thr = (double)m - 2.0 * e - 2.4e-7 * fabs((double)m);
+  float t = (float)thr;
+  if ((double)t > thr) t = nextafterf(t, -INFINITY);
+  return t;
+}
+// Tile skip list of the digit product (diffuse_free.hip, "tile pruning"): what the pass that
+// produces the digits leaves per 64-row group g and 64-column block b
+//   mx64[g * nblk + b] = max over the group's rows of ||q_i[block b]||_2      (0 for rows >= n)
+//   tau64[g]           = min over the group's rows < n of the candidate threshold the row would
+//                        have if its maximum of T were only its diagonal entry T_ii = ||q_i||^2
+//                        and R_max the trivial bound 32639 n  (+inf for a group without rows)
+struct FreeSegs {
+  const double* q2part;  // [block * 64 nblk + row]: sum of q^2 over the block (exact integers)
+  double* mx64;
+  float* tau64;
+};
 int free_rows_padded(int n);
 int free_k_padded(int n);
 size_t free_q_bytes(int n);
@@ -391,12 +415,24 @@ void launch_free_absmax(hipStream_t s, const double* A, int n, int ld, double* s
 // from the threshold stage's cut vector (cut_i = rowmax(B)_i * p): no pass over the matrix
 void launch_free_amax_from_cut(hipStream_t s, const double* cut, int n, double p,
                                double floor_value, double* scal);
+// (q2part: [block][row] squared digit-segment norms for the tile skip list, or nullptr)
 void launch_free_quantize(hipStream_t s, const double* A, int n, int ld, signed char* Q,
-                          double* scal, double* y1, double* R);
+                          double* scal, double* y1, double* R, double* q2part = nullptr);
+// tile skip list of the product (diffuse_free.hip "tile skip list"): mx64 / tau64 from the pass
+// that wrote the digits (FreeSegs), then plan = per tile row the surviving tile columns
+size_t free_q2part_bytes(int n);
+size_t free_mx64_bytes(int n);
+size_t free_tau64_bytes(int n);
+size_t free_plan_bytes(int n);
+size_t free_i8_split_bytes_plan();
+void launch_free_seg_reduce(hipStream_t s, const double* R, int n, const FreeSegs& segs);
+void launch_free_tile_flags(hipStream_t s, const double* mx64, const float* tau64, int n,
+                            int* plan, bool prune);
 // (split_ws: workspace of free_i8_split_bytes(n) for the split-K tail; nullptr = every tile
-//  by one workgroup)
+//  by one workgroup.  plan: walk the skip list instead of `tilemap` -- split_ws must then hold
+//  free_i8_split_bytes_plan())
 void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* tilemap,
-                        float* T32, unsigned* M, int* split_ws);
+                        float* T32, unsigned* M, int* split_ws, const int* plan = nullptr);
 // one member of a grouped run of the pipeline (AutoTune sweep, large members of a batch group)
 struct FreeItem {
   const double* A;   // the symmetric matrix, row pitch ld
@@ -423,7 +459,8 @@ void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float*
                               unsigned* const* M, int count, const int* ns,
                               const int2* const* tilemaps);
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,
-                           const double* R, const double* scal, int* count, int* cand);
+                           const double* R, const double* scal, int* count, int* cand,
+                           const int* plan = nullptr);
 void launch_free_row_stats(hipStream_t s, const double* A, int n, int ld, const double* y1,
                            const int* count, const int* cand, double* rowmax, double* rowsum,
                            int* ovf);

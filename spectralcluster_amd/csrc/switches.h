@@ -92,6 +92,12 @@ inline int gen_dense_max_n() {
   static const int v = getenv("SC_GEN_DENSE_MAX_N") ? atoi(getenv("SC_GEN_DENSE_MAX_N")) : 512;
   return v;
 }
+// SC_FREE_NO_PRUNE=1: the digit product of the matrix-free Diffuse computes every tile (the
+// skip list keeps them all): what an unstructured input gets anyway
+inline bool free_no_prune() {
+  static const bool v = getenv("SC_FREE_NO_PRUNE") != nullptr;
+  return v;
+}
 // SC_GEN_LOOSE_BULK=1: rounds 3-5's stop rule of the general path (consumed eigenvalues that
 // cannot move the eigengap decision held to 1e-3 instead of value_tol) -- A/B measurements only
 inline bool gen_loose_bulk() {

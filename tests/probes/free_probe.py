@@ -12,7 +12,7 @@ def rowstats(a, mode):
   a = np.ascontiguousarray(a, dtype=np.float64)
   n = a.shape[0]
   rmax, rsum = np.empty(n), np.empty(n)
-  info = (ctypes.c_int32 * 4)()
+  info = (ctypes.c_int32 * 6)()
   h.check(h.lib.sc_stage_diffuse_rowstats(h.raw, _lib.as_double_p(a), n, mode,
                                           _lib.as_double_p(rmax), _lib.as_double_p(rsum), info))
   return rmax, rsum, list(info)

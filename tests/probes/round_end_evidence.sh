@@ -19,6 +19,10 @@ head -14 $O/kernel_stats.txt
 (cd /tmp && timeout 400 rocprofv3 --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/$O/pmc_write -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extras --no-concurrent --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/$O/pmc_write.err)
 python tools/make_pmc_traffic.py $O/pmc_fetch $O/pmc_write "$TAG" > $O/pmc_traffic_diffuse.json
 cat $O/pmc_traffic_diffuse.json
+TILES=$(python -c "import json;d=json.load(open('$O/bench_under_rocprof.json'));r=d['roofline'];print(r.get('i8_product',r).get('tiles_run',2080))")
+python tools/make_pmc_traffic.py $O/pmc_fetch $O/pmc_write "$TAG" i8 $TILES > $O/pmc_traffic_i8.json
+python tools/make_pmc_traffic.py $O/pmc_fetch $O/pmc_write "$TAG" affinity > $O/pmc_traffic_affinity.json
+cat $O/pmc_traffic_i8.json $O/pmc_traffic_affinity.json
 python tools/pmc_summary.py $(dirname $(find $O/pmc_fetch -name '*counter_collection.csv' | head -1)) $(dirname $(find $O/pmc_write -name '*counter_collection.csv' | head -1)) > $O/pmc.txt
 # the grouped batch alone under the kernel trace (timeline of config 5)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof5 -o run -- python $GRAFT_REPO_ROOT/tests/probes/group_only.py 16 > $GRAFT_REPO_ROOT/$O/group_only.log 2>&1)

@@ -34,14 +34,23 @@ LAP = {0: None, 2: sca.LaplacianType.Unnormalized, 3: sca.LaplacianType.RandomWa
 EXPLICIT, FREE = 1, 2
 
 
-def rowstats(a, mode):
+def rowstats(a, mode, prune=None):
+  """info: candidates evaluated, rows over the cap, largest candidate count, S formed after all,
+  tiles of the digit product computed, tiles in its upper triangle.  prune: the tile skip list
+  on (1) / off (0) for this call; None = the default (on)."""
   h = _lib.default_handle()
   a = np.ascontiguousarray(a, dtype=np.float64)
   n = a.shape[0]
   rmax, rsum = np.empty(n), np.empty(n)
-  info = (ctypes.c_int32 * 4)()
-  h.check(h.lib.sc_stage_diffuse_rowstats(h.raw, _lib.as_double_p(a), n, mode,
-                                          _lib.as_double_p(rmax), _lib.as_double_p(rsum), info))
+  info = (ctypes.c_int32 * 6)()
+  if prune is not None:
+    h.check(h.lib.sc_set_free_prune(h.raw, int(prune)))
+  try:
+    h.check(h.lib.sc_stage_diffuse_rowstats(h.raw, _lib.as_double_p(a), n, mode,
+                                            _lib.as_double_p(rmax), _lib.as_double_p(rsum), info))
+  finally:
+    if prune is not None:
+      h.check(h.lib.sc_set_free_prune(h.raw, -1))
   return rmax, rsum, list(info)
 
 
@@ -135,6 +144,75 @@ def test_rowstats_wide_dynamic_range():
   check_rowstats(a, "range", expect_formed=False)
 
 
+# ------------------------------------------------------------------- tile skip list
+def check_skip_list(a, name, expect_pruned):
+  """The skip list must change NOTHING: rowmax / rowsum bit for bit, the candidate counts, the
+  overflow record -- against the same search over every tile -- and rowmax against NumPy."""
+  on = rowstats(a, FREE, prune=1)
+  off = rowstats(a, FREE, prune=0)
+  assert np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1]), name
+  assert on[2][:4] == off[2][:4], (name, on[2], off[2])
+  total = off[2][5]
+  assert off[2][4] == total == on[2][5], (name, off[2])
+  assert on[2][4] <= total
+  if expect_pruned is True:
+    assert on[2][4] < total, (name, on[2])
+  elif expect_pruned is False:
+    assert on[2][4] == total, (name, on[2])
+  s = a @ a.T
+  want = s.max(axis=1)
+  tol = 1e-13 * np.maximum(np.abs(want), 1e-3 * np.abs(s).max())
+  assert np.all(np.abs(on[0] - want) <= tol), name
+  return on[2]
+
+
+@pytest.mark.parametrize("n,d,k", [(1153, 48, 4), (2048, 128, 4), (3007, 64, 3), (4100, 64, 8)])
+def test_skip_list_on_refined_affinities(n, d, k):
+  """Blob-like input (clusters contiguous in the sample order, like speaker turns): most
+  off-diagonal tiles hold nothing but entries far below their rows' diagonal -- skipped."""
+  a = refined_before_diffuse(so.blobs(n, d, k, seed=n))
+  info = check_skip_list(a, "blobs%d" % n, expect_pruned=True if n >= 2048 else None)
+  if n >= 4096:
+    assert info[4] < 0.5 * info[5], info
+
+
+def test_skip_list_keeps_every_tile_of_unstructured_input():
+  rng = np.random.default_rng(11)
+  for n in (640, 1500):
+    b = rng.random((n, n))
+    check_skip_list(0.5 * (b + b.T), "uniform%d" % n, expect_pruned=False)
+  # the same blobs in a random sample order: the block structure is gone from the tiles
+  n = 2048
+  x = so.blobs(n, 64, 4, seed=8)[rng.permutation(n)]
+  check_skip_list(refined_before_diffuse(x), "shuffled", expect_pruned=None)
+
+
+def test_skip_list_keeps_the_tile_of_a_distant_tie():
+  """Duplicated samples 1500 rows apart: a row's product with its partner's row is (nearly) its
+  own diagonal entry -- the partner's far-away tile holds a candidate and must stay: the candidate
+  sets are the same with and without the list (check_skip_list), and larger than one per row."""
+  n = 2304
+  x = so.blobs(n, 64, 4, seed=12)
+  for i in (5, 300, 700):
+    x[i + 1500] = x[i]
+  a = refined_before_diffuse(x)
+  info = check_skip_list(a, "distant ties", expect_pruned=None)
+  assert info[0] > n       # (candidates beyond the rows' own diagonal entries)
+
+
+def test_skip_list_with_rows_tiny_against_the_rest_and_a_zero_row():
+  """Rows whose diagonal-only threshold is negative (tiny rows: their slack exceeds their own
+  T_ii) keep every tile of their tile row; a zero row keeps everything too."""
+  n = 1792
+  a = refined_before_diffuse(so.blobs(n, 64, 4, seed=13))
+  scale = np.ones(n)
+  scale[[7, 900, 1791]] = 1e-4
+  a = a * scale[:, None] * scale[None, :]
+  a[1000, :] = 0.0
+  a[:, 1000] = 0.0
+  check_skip_list(a, "tiny rows", expect_pruned=None)
+
+
 # ------------------------------------------------------------------- end to end
 def icassp_options():
   return sca.RefinementOptions(
@@ -204,6 +282,42 @@ def test_routes_agree_at_ragged_sizes(n, lap):
   scale = np.abs(wx).max()
   assert np.max(np.abs(wf - wx)) < 2e-6 * scale
   assert so.adjusted_rand_index(out[FREE][0], out[EXPLICIT][0]) == 1.0
+
+
+@pytest.mark.parametrize("lap", [0, 4])
+def test_matrix_free_route_vs_oracle_at_a_ragged_size(lap):
+  """the matrix-free route (skip list on) at a size that ends inside a tile,
+  against the ORACLE (np.linalg.eig on the reference's own matrix), not against the other route:
+  labels, cluster count, maximum gap, every consumed eigenvalue; and the skip list off gives the
+  same eigenvalues bit for bit."""
+  n, maxc = 2239, 12
+  x = so.blobs(n, 48, 5, seed=n + lap)
+  dump = {}
+  want = so.predict(x, so.icassp2018_config(laplacian_type=lap, max_clusters=maxc), dump)
+  got = {}
+  for prune in (1, 0):
+    c = sca.SpectralClusterer(min_clusters=2, max_clusters=maxc,
+                              refinement_options=icassp_options(), laplacian_type=LAP[lap])
+    c.diffuse_mode = FREE
+    h = c._handle()
+    h.check(h.lib.sc_set_free_prune(h.raw, prune))
+    try:
+      labels = c.predict(x)
+    finally:
+      h.check(h.lib.sc_set_free_prune(h.raw, -1))
+    dg = c.last_diag
+    assert dg.diffuse_path == _lib.DIFFUSE_PATH_FREE
+    total = -(-n // 128) * (-(-n // 128) + 1) // 2
+    assert (dg.free_tiles_run < total) if prune else (dg.free_tiles_run == total)
+    assert dg.n_clusters == dump["n_clusters"]
+    np.testing.assert_allclose(dg.max_delta, dump["max_delta"], rtol=1e-6)
+    assert so.adjusted_rand_index(labels, want) == 1.0
+    w = c.consumed_eigenvalues()
+    idx = so.consumed_eigen_indices(n, maxc, lap == 0, dump["eigenvalues"] if lap == 0 else None,
+                                    1e-2 if lap == 0 else None)
+    assert rel_err(w[idx], dump["eigenvalues"][idx]) < 1e-6
+    got[prune] = w
+  assert np.array_equal(got[0], got[1])
 
 
 @pytest.mark.parametrize("binarize,preserve,sym", [(True, False, "Max"), (False, True, "Average"),

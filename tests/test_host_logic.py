@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
   for name in sorted(declared):
     assert hasattr(lib, name), name
   assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-  assert lib.sc_abi_version() == _lib.SC_ABI_VERSION == 6
+  assert lib.sc_abi_version() == _lib.SC_ABI_VERSION == 7
 
 
 def test_graft_entry_build_runs():

@@ -32,13 +32,21 @@ def per_dispatch(d, counter):
 fetch = per_dispatch(sys.argv[1], "FETCH_SIZE")
 write = per_dispatch(sys.argv[2], "WRITE_SIZE")
 label = sys.argv[3] if len(sys.argv) > 3 else ""
-# which kernel: "diffuse" (the fp64 product, default) or "i8" (the digit product of the
+# which kernel: "diffuse" (the fp64 product, default), "affinity" or "i8" (the digit product of the
 # matrix-free Diffuse: reads n^2 * 2 B of digits, writes the fp32 upper-triangle tiles)
 which = sys.argv[4] if len(sys.argv) > 4 else "diffuse"
 n = 8192
-if which == "i8":
+if which == "affinity":
+  # the cosine-affinity GEMM: reads the normalised embeddings (n d * 8 B), writes n^2 * 8 B
+  main, red = "sc::k_gemm_nt<1, true>", "sc::k_gemm_reduce<1, true>"
+  algorithmic = n * n * 8 + n * 256 * 8
+  what = "k_gemm_nt<EpiAffinity,SYM> (+ split-K reduce)"
+elif which == "i8":
   main, red = "sc::k_gemm_i8_sym<0>", "-"
-  algorithmic = n * n * 2 + (n // 128) * (n // 128 + 1) // 2 * 128 * 128 * 4
+  # (with the skip list: the digits of the tile rows that have a surviving tile -- all of them,
+  #  every diagonal tile survives -- and the fp32 tiles that ran; tiles_run from argv[5])
+  tiles_run = int(sys.argv[5]) if len(sys.argv) > 5 else (n // 128) * (n // 128 + 1) // 2
+  algorithmic = n * n * 2 + tiles_run * 128 * 128 * 4
   what = "k_gemm_i8_sym"
 else:
   main, red = "sc::k_gemm_nt<0, true>", "sc::k_gemm_reduce<0, true>"

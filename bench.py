@@ -634,7 +634,9 @@ def kernel_roofline(stage_ms, passes):
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--gpus", type=int, default=None,
+                  help="ranks (one per GPU of this node).  Under a launcher (WORLD_SIZE set) it "
+                       "must equal the world size; without one, N > 1 starts the N ranks itself")
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--workload", default="predict8192",
@@ -647,13 +649,30 @@ def main():
                   help="skip the batch512 / autotune16 legs")
   args = ap.parse_args()
 
+  from spectralcluster_amd import multigpu
+  if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+    # `python bench.py --gpus N` with no launcher around it: this process becomes the launcher
+    # (one rank per GPU, same arguments), rank 0 prints the JSON line on our stdout
+    sys.exit(multigpu.launch_local_ranks(
+        [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if args.gpus is not None and args.gpus != world:
+    sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+  if os.environ.get("SC_BENCH_LAUNCH_ECHO"):
+    # launch check without a GPU (tests/test_distributed_cpu.py): the ranks meet over the TCP
+    # rendezvous the real run starts with, and rank 0 prints what a run would report about it
+    sock = multigpu.SocketComm.from_env(rank, world) if world > 1 else multigpu.LocalComm()
+    seen = [int(b.decode()) for b in sock.allgather_bytes(str(rank).encode())]
+    sock.barrier()
+    if rank == 0:
+      print(json.dumps({"n_gpus": world, "ranks_seen": seen, "launch": "echo"}), flush=True)
+    sock.close()
+    return
 
   import spectralcluster_amd as sca
   from spectralcluster_amd import _lib
-  from spectralcluster_amd import multigpu
 
   # (one rank per GPU; on a box with fewer GPUs than ranks -- a 1-GPU test box -- ranks share)
   handle = _lib.default_handle(local_rank % max(1, _lib.device_count()))

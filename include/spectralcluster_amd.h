@@ -226,8 +226,7 @@ typedef struct sc_diag {
   int32_t free_overflow_rows;    /* ... rows evaluated in full (more candidates than the cap) */
   int32_t free_tiles_run;        /* ... 128 x 128 tiles of the digit product that were computed:
                                     the others -- of ceil(n/128) (ceil(n/128) + 1) / 2 -- were
-                                    excluded by the segment-norm bound (0: not reported, the
-                                    grouped routes) */
+                                    excluded by the segment-norm bound */
 } sc_diag;
 
 /* ---- library / device ---------------------------------------------------- */

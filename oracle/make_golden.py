@@ -3,7 +3,7 @@
 Run in the build container only (needs /root/reference, which does not exist
 on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --constraints | --general | --size-reduction | --fallback | --autotune4096 | --autotune4096-ttd | --batch512 | --dense | --hard]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [--large | --float32 | --constraints | --general | --size-reduction | --fallback | --autotune4096 | --autotune4096-ttd | --batch512 | --dense | --hard]
 
 `--autotune4096` and `--batch512` pin BASELINE.json configs 4 and 5 at their
 full sizes (about 6 and 20 minutes of CPU).
@@ -85,11 +85,15 @@ def staged_run(x, sigma, p, lap, min_clusters, max_clusters):
   return out
 
 
-def e2e_run(n, d, k, seed, lap, max_clusters, p=0.95):
+def e2e_run(n, d, k, seed, lap, max_clusters, p=0.95, dtype=None):
   """One whole reference predict(); eigenvalues / eigengap results are
   captured by wrapping the reference's own utils functions (called through
-  the module attribute at spectral_clusterer.py:146-167)."""
+  the module attribute at spectral_clusterer.py:146-167).  dtype: the embeddings are cast to
+  it first (float32: the reference then computes the affinity, the refinement and
+  np.linalg.eig in single precision, utils.py:32-39, :59)."""
   x = so.blobs(n, d, k, seed)
+  if dtype is not None:
+    x = x.astype(dtype)
   clusterer = ref_sc.SpectralClusterer(
       min_clusters=2, max_clusters=max_clusters,
       refinement_options=icassp_options(1, p), laplacian_type=LAP[lap])
@@ -124,6 +128,18 @@ def e2e_run(n, d, k, seed, lap, max_clusters, p=0.95):
               n_clusters_raw=np.int64(seen["k"]),
               max_delta=np.float64(seen["delta"]),
               labels=labels, ref_seconds=np.float64(secs))
+
+
+def float32_goldens():
+  """what the REFERENCE returns for float32 embeddings (it stays in float32 end
+  to end; the device promotes to float64).  Stored with the dtype the reference returned, so the
+  GPU test measures the promotion's deviation instead of asserting it away."""
+  for c in ((200, 32, 4, 200, 4, 7), (1000, 64, 5, 1000, 4, 20), (1000, 64, 5, 1000, 0, 7),
+            (2048, 128, 4, 2048, 4, 20)):
+    r = e2e_run(*c, dtype=np.float32)
+    r["eigenvalue_dtype"] = np.array(str(r["consumed_eigenvalues"].dtype))
+    save("e2e_f32_n%d_lap%d_max%d.npz" % (c[0], c[4], c[5]), **r)
+    print("   eigenvalues come back as", r["consumed_eigenvalues"].dtype, flush=True)
 
 
 def save(name, **arrays):
@@ -650,6 +666,9 @@ def main():
   large = "--large" in sys.argv
   if "--many-clusters" in sys.argv:  # only section 15
     many_cluster_goldens()
+    return
+  if "--float32" in sys.argv:  # only section 18
+    float32_goldens()
     return
   if "--general-wide" in sys.argv:  # only section 16
     general_wide_golden()

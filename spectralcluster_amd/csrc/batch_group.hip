@@ -296,13 +296,15 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
         float* ts[kGroupMax];
         unsigned* ms[kGroupMax];
         const int2* tms[kGroupMax];
+        const int* pls[kGroupMax];
         for (int q = 0; q < nf; ++q) {
           qs[q] = ptr<signed char>(fh[q]->fq);
           ts[q] = ptr<float>(fh[q]->ft32);
           ms[q] = ptr<unsigned>(fh[q]->fwords);
           tms[q] = fh[q]->tilemap_cur;
+          pls[q] = fitems[q].plan;
         }
-        launch_gemm_i8_sym_group(s, qs, ts, ms, nf, nn, tms);
+        launch_gemm_i8_sym_group(s, qs, ts, ms, nf, nn, tms, pls);
       }
       SC_TRY(free_group_end(fh, fitems, nf, s));
     }
@@ -406,6 +408,7 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
       if (m.free_op) {
         dg->diffuse_path = SC_DIFFUSE_PATH_FREE;
         dg->free_candidates = h->h_free[65];
+        dg->free_tiles_run = h->h_free[67];
       } else if (m.front.folded_rownorm) {  // (the grouped front: the explicit product)
         dg->diffuse_path = SC_DIFFUSE_PATH_EXPLICIT;
       }
@@ -980,8 +983,13 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       {
         int nn[kGroupMax];
         const int2* tms[kGroupMax];
-        for (int z = 0; z < cnt; ++z) { nn[z] = n; tms[z] = em[0].h->tilemap_cur; }
-        launch_gemm_i8_sym_group(s, qs, ts, ms, cnt, nn, tms);
+        const int* pls[kGroupMax];
+        for (int z = 0; z < cnt; ++z) {
+          nn[z] = n;
+          tms[z] = em[0].h->tilemap_cur;
+          pls[z] = amax_from_cut ? fitems[z].plan : nullptr;
+        }
+        launch_gemm_i8_sym_group(s, qs, ts, ms, cnt, nn, tms, pls);
       }
       if (amax_from_cut) {
         SC_TRY(free_group_end(fh, fitems, cnt, s));
@@ -1029,7 +1037,10 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       dg->eig_max_residual = em[z].dc.max_resid;
       dg->diffuse_path = !icassp ? SC_DIFFUSE_PATH_NONE
                                  : (free_route ? SC_DIFFUSE_PATH_FREE : SC_DIFFUSE_PATH_EXPLICIT);
-      if (free_route) dg->free_candidates = em[z].h->h_free[65];
+      if (free_route) {
+        dg->free_candidates = em[z].h->h_free[65];
+        dg->free_tiles_run = em[z].h->h_free[67];
+      }
     }
   }
   SC_HIP(h, hipStreamSynchronize(s));

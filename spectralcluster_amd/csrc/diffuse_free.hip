@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_free_quantize_g(const GroupOf<FreeItem>
   if (a.n <= 0 || (int)blockIdx.x >= (a.n + 127) / 128 * 128) return;  // rows padded to a product tile
   const int Kp = (a.n + 63) / 64 * 64;
   free_quantize_body<0>(a.A, a.n, a.ld, a.Q, (size_t)2 * Kp, Kp, a.scal, a.y1, a.R,
-                        reinterpret_cast<unsigned long long*>(a.scal) + 2, nullptr);
+                        reinterpret_cast<unsigned long long*>(a.scal) + 2, a.q2part);
 }
 
 // ---------------------------------------------------------------- tile skip list
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256) void k_free_quantize_g(const GroupOf<FreeItem>
 // n = 8192, 8 speakers: 2080 -> ~345.  Unstructured input keeps every tile and pays one launch.
 
 // (non-fused quantiser only; the fused threshold pass has this inside k_free_partials_reduce)
-__global__ __launch_bounds__(256) void k_free_seg_reduce(const double* __restrict__ R, int n,
-                                                         int nblk, const FreeSegs segs) {
+__device__ __forceinline__ void free_seg_reduce_body(const double* __restrict__ R, int n,
+                                                     int nblk, const FreeSegs segs) {
   __shared__ double sq[4][64];
   const int r = threadIdx.x & 63, qd = threadIdx.x >> 6;
   const int row = blockIdx.x * 64 + r;
@@ -374,6 +374,18 @@ __global__ __launch_bounds__(256) void k_free_seg_reduce(const double* __restric
     for (int o = 32; o > 0; o >>= 1) t = fminf(t, __shfl_xor(t, o));
     if (r == 0) segs.tau64[blockIdx.x] = t;
   }
+}
+__global__ __launch_bounds__(256) void k_free_seg_reduce(const double* __restrict__ R, int n,
+                                                         int nblk, const FreeSegs segs) {
+  free_seg_reduce_body(R, n, nblk, segs);
+}
+// segment maxima + tile flags of every member of a group: workgroups [0, nblk) of a member do
+// the former ... (two launches: the flags read what ALL of a member's segment workgroups wrote)
+__global__ __launch_bounds__(256) void k_free_seg_reduce_g(const GroupOf<FreeItem> g) {
+  const FreeItem& a = g.s[blockIdx.y];
+  const int nblk = (a.n + 63) / 64;
+  if (a.n <= 0 || a.plan == nullptr || (int)blockIdx.x >= nblk) return;
+  free_seg_reduce_body(a.R, a.n, nblk, FreeSegs{a.q2part, a.mx64, a.tau64});
 }
 
 // One workgroup per tile row I: plan[I] = number of surviving tiles (I, J >= I), their columns in
@@ -420,6 +432,12 @@ __device__ __forceinline__ void free_tile_flags_body(const double* __restrict__ 
     }
     if (lane == 0) plan[I] = total;
   }
+}
+__global__ __launch_bounds__(256) void k_free_tile_flags_g(const GroupOf<FreeItem> g, int prune) {
+  const FreeItem& a = g.s[blockIdx.y];
+  const int nt = (a.n + 127) / 128;  // (kI8Tile, declared with the product below)
+  if (a.n <= 0 || a.plan == nullptr || (int)blockIdx.x >= nt) return;
+  free_tile_flags_body(a.mx64, a.tau64, nt, (a.n + 63) / 64, a.plan, prune);
 }
 __global__ __launch_bounds__(256) void k_free_tile_flags(const double* __restrict__ mx64,
                                                          const float* __restrict__ tau64, int nt,
@@ -494,8 +512,8 @@ __device__ __forceinline__ void gemm_i8_sym_body(
     plan_scan(sp.plan, nt, pref);
     __syncthreads();
     const int count = pref[nt - 1];
-    int r, f;
-    i8_split_plan(count, sp.cus, nstages, &r, &f);
+    int r = 0, f = 1;
+    if (sp.cus > 0) i8_split_plan(count, sp.cus, nstages, &r, &f);  // (0: a member of a group)
     sp.full_tiles = count - r;
     sp.parts = f;
     if (tile >= sp.full_tiles + r * f) return;  // (the grid is sized for the worst case)
@@ -510,7 +528,7 @@ __device__ __forceinline__ void gemm_i8_sym_body(
     part = tb % sp.parts;
     nstages /= sp.parts;
     kb = part * nstages;
-  } else if (sp.plan != nullptr) {
+  } else if (sp.plan != nullptr && sp.cus > 0) {
     // XCD x (workgroup ids go round-robin over the 8 XCDs) walks a contiguous run of the
     // row-major list: its workgroups share the digit panel of a tile row through their L2
     const int chunk = sp.full_tiles >> 3, rem = sp.full_tiles & 7, x = tile & 7;
@@ -734,14 +752,17 @@ struct I8GroupItem {
   unsigned* M;
   const int2* tilemap;
   int n;
+  const int* plan;  // the member's skip list, or nullptr
 };
 __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym_g(const GroupOf<I8GroupItem> g) {
   const I8GroupItem& a = g.s[blockIdx.y];
   const int nt = (a.n + kI8Tile - 1) / kI8Tile;
   if (a.n <= 0 || (int)blockIdx.x >= nt * (nt + 1) / 2) return;
   const int Kp = (a.n + 63) / 64 * 64;
-  gemm_i8_sym_body<0>(a.Q, (size_t)2 * Kp, Kp / 64, a.tilemap, 0, a.T32, nt, a.n, a.M, nullptr,
-                      I8Split{0, 1, nullptr});
+  I8Split sp{0, 1, nullptr};
+  sp.plan = a.plan;
+  sp.cus = 0;
+  gemm_i8_sym_body<0>(a.Q, (size_t)2 * Kp, Kp / 64, a.tilemap, 0, a.T32, nt, a.n, a.M, nullptr, sp);
 }
 
 // The tail tiles' epilogue: thread t of workgroup (tt, cq) owns what thread t of the product's
@@ -898,7 +919,7 @@ __global__ __launch_bounds__(256) void k_t32_candidates_g(const GroupOf<FreeItem
   if (a.n <= 0 || (int)blockIdx.x >= nt * (nt + 1) / 2) return;
   t32_candidates_body(a.T32, nt, a.n, reinterpret_cast<const unsigned*>(a.words), a.R,
                       reinterpret_cast<const unsigned long long*>(a.scal) + 2, cap, a.words + a.n,
-                      a.cand, nullptr);
+                      a.cand, a.plan);
 }
 
 
@@ -1172,14 +1193,14 @@ void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* 
 
 void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
                               unsigned* const* M, int count, const int* ns,
-                              const int2* const* tilemaps) {
+                              const int2* const* tilemaps, const int* const* plans) {
   const int lds = kI8Buffers * kI8StageBytes;
   SC_OPT_IN_LDS(k_gemm_i8_sym_g, lds);
   GroupOf<I8GroupItem> g;
   memset(&g, 0, sizeof(g));
   int tiles = 0;
   for (int z = 0; z < count; ++z) {
-    g.s[z] = I8GroupItem{Q[z], T32[z], M[z], tilemaps[z], ns[z]};
+    g.s[z] = I8GroupItem{Q[z], T32[z], M[z], tilemaps[z], ns[z], plans ? plans[z] : nullptr};
     const int nt = (ns[z] + kI8Tile - 1) / kI8Tile;
     tiles = std::max(tiles, nt * (nt + 1) / 2);
   }
@@ -1229,6 +1250,14 @@ void launch_free_quantize_group(hipStream_t s, const FreeItem* items, int count)
   SC_OPT_IN_LDS(k_free_quantize_g, 2 * 65536);
   hipLaunchKernelGGL(k_free_quantize_g, dim3(free_rows_padded(nmax), count), dim3(256),
                      (size_t)2 * free_k_padded(nmax), s, g);
+}
+void launch_free_tile_flags_group(hipStream_t s, const FreeItem* items, int count, bool prune) {
+  int nmax;
+  const GroupOf<FreeItem> g = free_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_free_seg_reduce_g, dim3(free_k_padded(nmax) / 64, count), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(k_free_tile_flags_g, dim3((nmax + kI8Tile - 1) / kI8Tile, count), dim3(256), 0,
+                     s, g, prune ? 1 : 0);
 }
 void launch_free_scan_stats_group(hipStream_t s, const FreeItem* items, int count) {
   int nmax;

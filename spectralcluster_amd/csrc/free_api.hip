@@ -124,9 +124,15 @@ int free_group_begin(sc_handle* hs, const double* const* A, const double* const*
                         ptr<int>(h->fwords), ptr<double>(h->fscal), ptr<double>(h->fy1),
                         ptr<double>(h->fR), ptr<int>(h->fcand), ptr<double>(h->rowmax),
                         ptr<double>(h->rowsum), cuts[z], ps[z]};
+    items[z].q2part = ptr<double>(h->fq2part);
+    items[z].mx64 = ptr<double>(h->fmx64);
+    items[z].tau64 = ptr<float>(h->ftau64);
+    items[z].plan = ptr<int>(h->fplan);
   }
   launch_free_begin_group(s, items, count, floor_value);
   launch_free_quantize_group(s, items, count);
+  // the members' skip lists (the caller hands items[z].plan to the grouped product)
+  launch_free_tile_flags_group(s, items, count, free_prune_on(hs[0]));
   return SC_OK;
 }
 int free_group_end(sc_handle* hs, const FreeItem* items, int count, hipStream_t s) {

@@ -448,6 +448,11 @@ struct FreeItem {
   double* rowsum;
   const double* cut; // RowMax cut vector (max|a| = max cut / p) and its p
   double p;
+  // tile skip list of the member's digit product (nullptr: every tile)
+  double* q2part = nullptr;
+  double* mx64 = nullptr;
+  float* tau64 = nullptr;
+  int* plan = nullptr;
 };
 void launch_free_begin_group(hipStream_t s, const FreeItem* items, int count, double floor_value);
 void launch_free_quantize_group(hipStream_t s, const FreeItem* items, int count);
@@ -455,9 +460,11 @@ void launch_free_scan_stats_group(hipStream_t s, const FreeItem* items, int coun
 void free_i8_split_plan(int n, int* tail_tiles, int* parts);
 size_t free_i8_split_bytes(int n);
 // the same product for `count` (<= kGroupMax) problems of one size in ONE launch
+// (plans: per member its skip list, or nullptr -- the array or an entry -- for every tile)
 void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
                               unsigned* const* M, int count, const int* ns,
-                              const int2* const* tilemaps);
+                              const int2* const* tilemaps, const int* const* plans = nullptr);
+void launch_free_tile_flags_group(hipStream_t s, const FreeItem* items, int count, bool prune);
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,
                            const double* R, const double* scal, int* count, int* cand,
                            const int* plan = nullptr);

@@ -401,6 +401,49 @@ class RcclComm(Comm):
 _DTYPES = [np.float64, np.int64, np.int32, np.int8, np.uint8]
 
 
+def launch_local_ranks(argv: typing.Sequence[str], nproc: int,
+                       timeout_s: typing.Optional[float] = None) -> int:
+  """One process per GPU of THIS node without an external launcher: starts `nproc` copies of
+  `argv` with what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would export
+  (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT)
+  and waits for them.  Rank 0 keeps this process's stdout (its ONE JSON line); the other ranks'
+  stdout goes to stderr.  The ranks share this process as parent, which is what names their
+  rendezvous file (`_id_file`).  Returns the largest exit code (124 on timeout: every rank still
+  running is killed -- by PID, they are ours)."""
+  import subprocess
+  import sys
+  if nproc < 1:
+    raise ValueError("nproc must be >= 1")
+  probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+  probe.bind(("127.0.0.1", 0))
+  port = probe.getsockname()[1]
+  probe.close()
+  procs = []
+  for rank in range(nproc):
+    env = dict(os.environ)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(nproc),
+                "LOCAL_WORLD_SIZE": str(nproc), "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(port)})
+    # (the host driver only supports dmabuf IPC: RCCL needs this on the GPU boxes of this pool)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs.append(subprocess.Popen(list(argv), env=env,
+                                  stdout=None if rank == 0 else sys.stderr))
+  deadline = None if timeout_s is None else time.monotonic() + timeout_s
+  worst = 0
+  for p in procs:
+    try:
+      rc = p.wait(None if deadline is None else max(0.0, deadline - time.monotonic()))
+    except subprocess.TimeoutExpired:
+      for q in procs:
+        if q.poll() is None:
+          q.kill()
+      for q in procs:
+        q.wait()
+      return 124
+    worst = max(worst, rc if rc >= 0 else 128 - rc)
+  return worst
+
+
 def broadcast_array(comm: Comm, arr: typing.Optional[np.ndarray], root: int = 0) -> np.ndarray:
   """Broadcast an ndarray from `root` (a 72-byte header -- ndim, dtype, shape -- then the
   data).  Used for embeddings (n*d*8 bytes) and packed configs."""

@@ -228,3 +228,52 @@ def test_rendezvous_file_rejects_stale_and_planted_files(tmp_path, monkeypatch):
   assert got["uid"] == uid
   assert not path.is_symlink() and target.read_bytes()[16:] == bytes(128)
   assert (path.stat().st_mode & 0o777) == 0o600
+
+
+def _bench(args, extra_env, timeout=180):
+  import subprocess
+  env = dict(os.environ)
+  for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+    env.pop(name, None)
+  env.update(extra_env)
+  return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
+                        capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+  """`python bench.py --gpus N` with no launcher around it starts the N
+  ranks itself (multigpu.launch_local_ranks: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+  torch.distributed.run exports them); rank 0's ONE JSON line arrives on the command's stdout.
+  SC_BENCH_LAUNCH_ECHO stops the ranks after the TCP rendezvous the real run starts with."""
+  import json
+  for n in (2, 3):
+    res = _bench(["--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                 {"SC_BENCH_LAUNCH_ECHO": "1"})
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["ranks_seen"] == list(range(n))
+
+
+def test_bench_refuses_a_world_that_is_not_its_gpus_argument():
+  """Under a launcher WORLD_SIZE decides how many ranks exist; `--gpus` must say the same
+  (round 5's bench.py parsed --gpus and never read it)."""
+  res = _bench(["--gpus", "8"], {"SC_BENCH_LAUNCH_ECHO": "1", "WORLD_SIZE": "1", "RANK": "0"})
+  assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr
+  res = _bench([], {"SC_BENCH_LAUNCH_ECHO": "1", "WORLD_SIZE": "1", "RANK": "0"})
+  assert res.returncode == 0 and '"n_gpus": 1' in res.stdout
+
+
+def test_launch_local_ranks_reports_the_worst_exit_code_and_times_out(tmp_path):
+  sys.path.insert(0, ROOT)
+  from spectralcluster_amd import multigpu
+  script = tmp_path / "rank.py"
+  script.write_text("import os, sys, time\n"
+                    "r = int(os.environ['RANK'])\n"
+                    "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r)\n"
+                    "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                    "if len(sys.argv) > 1: time.sleep(60)\n"
+                    "sys.exit(5 if r == 2 else 0)\n")
+  assert multigpu.launch_local_ranks([sys.executable, str(script)], 3) == 5
+  assert multigpu.launch_local_ranks([sys.executable, str(script), "hang"], 3, timeout_s=1.0) == 124

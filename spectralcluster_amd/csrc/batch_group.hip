@@ -760,8 +760,10 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     for (int l = 1; l < lanes; ++l)
       if (rcs[l] != SC_OK) return fail(h, rcs[l], leads[l]->err.c_str());
   }
-  for (int i : single)
-    SC_TRY(sc_predict(h, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr));
+  // (members outside the grouped path's range -- n >= 4096 above all: their uploads ride under
+  //  the previous member's pipeline, api.hip predict_sequence)
+  if (!single.empty())
+    SC_TRY(predict_sequence(h, single.data(), (int)single.size(), xs, ns, d, cfg, labels, diags));
   return SC_OK;
 }
 

@@ -49,6 +49,8 @@ struct sc_handle_s {
   int n_vec = 0;          // eigenvector columns resident in E
   // matrices
   DevBuf X, Xn, A0, B1, B2;
+  DevBuf Xalt;                       // second embeddings buffer: the NEXT call's upload lands here
+  hipStream_t copy_stream = nullptr; // ... on this stream (predict_sequence, api.hip)
   // n-vectors
   DevBuf rowmax, rowsum, cvec, pvec, tvec, deg, dvec, cut, rmpart, splitk, tilemap;
   DevBuf cropval, statp;  // fused GEMM row statistics: result + per-tile partials
@@ -220,6 +222,11 @@ int ensure_matrices(sc_handle h, int n, int d, bool affinity_copy = true);
 
 // (ti, tj) order of the symmetric GEMM tiles for problems of n rows (cached per handle)
 int ensure_tilemap(sc_handle h, int n);
+// `count` independent calls (indices idx[0..count) into xs / ns / labels / diags; idx == nullptr:
+// 0..count-1) one after the other on handle h, each call's upload under its predecessor's pipeline
+int predict_sequence(sc_handle h, const int* idx, int count, const double* const* xs,
+                     const int* ns, int d, const sc_config* cfg, int64_t* const* labels,
+                     sc_diag* diags);
 
 int ensure_eig(sc_handle h, int n);
 

@@ -92,6 +92,12 @@ inline int gen_dense_max_n() {
   static const int v = getenv("SC_GEN_DENSE_MAX_N") ? atoi(getenv("SC_GEN_DENSE_MAX_N")) : 512;
   return v;
 }
+// SC_NO_PREFETCH=1: the calls of a batch upload their embeddings themselves, one after the
+// other (what a sequence of sc_predict calls does) instead of under their predecessor's pipeline
+inline bool no_prefetch() {
+  static const bool v = getenv("SC_NO_PREFETCH") != nullptr;
+  return v;
+}
 // SC_FREE_NO_PRUNE=1: the digit product of the matrix-free Diffuse computes every tile (the
 // skip list keeps them all): what an unstructured input gets anyway
 inline bool free_no_prune() {

@@ -293,6 +293,32 @@ def test_batch_matches_single_calls():
     assert np.array_equal(lab, clusterer.predict(u))
 
 
+def test_batch_with_prefetched_uploads_vs_reference_golden():
+  """A plain batch (streams=1, no groups) uploads call i + 1's embeddings under call i's
+  pipeline (api.hip predict_sequence: helper thread, copy stream, two embeddings buffers).  Same
+  kernels, same arguments: members against the reference golden of their seed, bit-equal to a
+  single predict(), in either position of the double buffer, and after a differently sized one."""
+  g = golden("e2e_n1000_lap4_max20.npz")
+  n, d, k, seed, lap, maxc = [int(v) for v in g["params"]]
+  x = so.blobs(n, d, k, seed)
+  other = so.blobs(1500, d, 4, seed=7)
+  third = so.blobs(2100, d, 6, seed=8)
+  clusterer = sca.SpectralClusterer(min_clusters=2, max_clusters=maxc,
+                                    refinement_options=icassp_options(1, 0.95),
+                                    laplacian_type=LAP[lap])
+  singles = [clusterer.predict(u) for u in (x, other, third)]
+  w_single = clusterer.consumed_eigenvalues()
+  batch = clusterer.predict_batch([x, other, x, third, x, third], streams=1)
+  for got, want in zip(batch, (singles[0], singles[1], singles[0], singles[2], singles[0],
+                               singles[2])):
+    assert np.array_equal(got, want)
+  assert np.array_equal(clusterer.consumed_eigenvalues(), w_single)  # (the last member: third)
+  for i in (0, 2, 4):
+    assert so.adjusted_rand_index(batch[i], g["labels"]) == 1.0
+  # ... and a following single call is not disturbed by whichever buffer the batch left resident
+  assert np.array_equal(clusterer.predict(other), singles[1])
+
+
 # --- error behaviour (reference spectral_clusterer.py:222-227 etc.) ---------------------------
 def test_error_behaviour():
   clusterer = sca.configs.icassp2018_clusterer

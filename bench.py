@@ -142,9 +142,10 @@ def cpu_baseline_legs(gpu_clusterer, full_size=True):
 
   port_s, port_reps, port_labels = timed(lambda: so.predict(x, cfg), 20.0, 3)
   # the CPU number beside the headline on the SAME configuration and the same box:
-  # the oracle port once at n = 8192 (np.linalg.eig of an 8192 x 8192 matrix: minutes).  Skipped
-  # (and said so) when the n = 2048 sample predicts more than 15 minutes, or with
-  # --cpu-baseline-sample-only.
+  # the oracle port once at n = 8192 (np.linalg.eig of an 8192 x 8192 matrix: ~200 s on the GPU
+  # box's 64 cores).  Skipped (and said so) when the n = 2048 sample predicts more than 15 minutes
+  # -- its n^3 extrapolation divided by the 2.5 it has overstated by on every box so far -- or
+  # with --cpu-baseline-sample-only.
   full = None
   if full_size:
     est = port_s * (N_SAMPLES / float(n_s)) ** 3

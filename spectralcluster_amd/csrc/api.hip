@@ -249,7 +249,7 @@ extern "C" int sc_destroy(sc_handle h) {
                     &h->td_d,  &h->td_e,  &h->td_theta, &h->td_work, &h->td_tau, &h->td_panel, &h->mvsym,
                     &h->kXc,   &h->kxsq,  &h->kclosest, &h->kcand, &h->kenorm, &h->krnd,
                     &h->kcent, &h->klab32, &h->klab64, &h->kinfo, &h->kchain, &h->gkrnd, &h->gpack, &h->gypack, &h->ginfo, &h->glabels,
-                    &h->kbig, &h->kbigw, &h->fq, &h->ft32, &h->fy1, &h->fR, &h->fscal, &h->fwords, &h->fcand, &h->fY, &h->fsplit, &h->fypart, &h->frpart, &h->fq2part, &h->fmx64, &h->ftau64, &h->fplan, &h->Xalt};
+                    &h->kbig, &h->kbigw, &h->fq, &h->ft32, &h->fy1, &h->fR, &h->fscal, &h->fwords, &h->fcand, &h->fY, &h->fsplit, &h->fypart, &h->frpart, &h->fq2part, &h->fmx64, &h->ftau64, &h->fplan, &h->Xalt, &h->gneg};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 48; ++i) hipEventDestroy(h->ev[i]);

@@ -571,8 +571,8 @@ int independent_streams(sc_handle h, std::vector<hipStream_t> have, hipStream_t*
 // members each) on the lead's streams and member arenas.
 int run_group_lane(sc_handle h, const double* const* xs, const int* ns, int d,
                    const sc_config* cfg, int64_t* const* labels, sc_diag* diags,
-                   const std::vector<int>& grouped, int width, const std::vector<int>& mine,
-                   const EigRequest& rq) {
+                   const std::vector<int>& grouped, const std::vector<int>& gstart, int width,
+                   const std::vector<int>& mine, const EigRequest& rq) {
   if (mine.empty()) return SC_OK;
   // (the lead's lockstep chains run on its dedicated stream for the duration of the batch)
   struct StreamSwap {
@@ -592,10 +592,9 @@ int run_group_lane(sc_handle h, const double* const* xs, const int* ns, int d,
   // third one put two more GEMMs next to the chains and cost 9 % on config 5: the chains'
   // short kernels wait longer for a free CU.)
   constexpr int banks = kGroupBanks;
-  auto group_count = [&](int j) {
-    return (int)std::min<size_t>(width, grouped.size() - (size_t)mine[j] * width);
-  };
-  auto group_members = [&](int j) { return grouped.data() + (size_t)mine[j] * width; };
+  // (group g of the size-sorted list = [gstart[g], gstart[g + 1]); `width` = the largest group)
+  auto group_count = [&](int j) { return gstart[mine[j] + 1] - gstart[mine[j]]; };
+  auto group_members = [&](int j) { return grouped.data() + gstart[mine[j]]; };
   // arenas once, for the largest member each will see
   for (int b = 0; b < std::min(banks, ngroups); ++b)
     for (int z = 0; z < width; ++z) {
@@ -665,8 +664,49 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
   if (!grouped.empty()) {
     // similar sizes together: a group's launches are sized by its largest member
     std::stable_sort(grouped.begin(), grouped.end(), [&](int a, int b) { return ns[a] > ns[b]; });
-    const int width = std::min(group, (int)grouped.size());
-    const int ngroups = ((int)grouped.size() + width - 1) / width;
+    // Groups: round 6 -- of equal COST, not equal count.  A group's chains advance in lockstep at
+    // the pace of its slowest member and its launches are sized by its largest one; sixteen
+    // utterances of n ~ 3000 are 6 ms of work, sixteen of n ~ 400 one.  With equal counts the
+    // lane that drew the first group finished long after the others (the 64-utterance share of
+    // an 8-GPU run: lanes at 7.4 and 4.2 ms by the cost model).  Now the size-sorted list is cut
+    // where the running cost passes total / G (at most `group` members), G a multiple of the lane
+    // count with at least two groups per lane (a lane overlaps the front of its next group with
+    // the chains of the current one), and the groups go to the lanes longest-first, each to the
+    // least loaded lane.  SC_GROUP_EQUAL_COUNT=1: round 5's slicing (A/B, profiles/r27).
+    auto unit_cost = [&](int i) { const double n = ns[i]; return 60.0 + 3.5e-5 * n * n; };
+    std::vector<int> gstart;
+    int width = std::min(group, (int)grouped.size());
+    const bool equal_count = sw::group_equal_count();
+    const int min_groups = ((int)grouped.size() + width - 1) / width;
+    const int lanes_wanted = std::max(
+        1, std::min(kGroupLanes, grouped_front_covers(cfg) ? min_groups / kGroupBanks : 1));
+    if (equal_count || min_groups < 2) {
+      for (int at = 0; at < (int)grouped.size(); at += width) gstart.push_back(at);
+    } else {
+      double total = 0.0;
+      for (int i : grouped) total += unit_cost(i);
+      const int per_lane = std::max(kGroupBanks, (min_groups + lanes_wanted - 1) / lanes_wanted);
+      const int target_groups = lanes_wanted * per_lane;
+      const double share = total / target_groups;
+      double run = 0.0;
+      int start = 0;
+      for (int at = 0; at < (int)grouped.size(); ++at) {
+        const double c = unit_cost(grouped[at]);
+        // close the group before this member if it is full, or if adding the member moves the
+        // running cost further from the share than leaving it out
+        if (at > start && (at - start >= width || (run + c - share > share - run))) {
+          gstart.push_back(start);
+          start = at;
+          run = 0.0;
+        }
+        run += c;
+      }
+      gstart.push_back(start);
+    }
+    const int ngroups = (int)gstart.size();
+    gstart.push_back((int)grouped.size());
+    width = 0;
+    for (int g = 0; g < ngroups; ++g) width = std::max(width, gstart[g + 1] - gstart[g]);
     // Lanes: the groups of the size-sorted list are dealt round-robin to kGroupLanes leads (the
     // caller's handle and kGroupLanes - 1 more, each with its own streams, member arenas, staging
     // and host workers), and every lead but the first is driven by its own host thread.  The
@@ -680,7 +720,24 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
     const int lanes =
         std::max(1, std::min(kGroupLanes, grouped_front_covers(cfg) ? ngroups / kGroupBanks : 1));
     std::vector<int> lane_groups[kGroupLanes];
-    for (int g = 0; g < ngroups; ++g) lane_groups[g % lanes].push_back(g);
+    if (equal_count) {
+      for (int g = 0; g < ngroups; ++g) lane_groups[g % lanes].push_back(g);
+    } else {  // longest group first, each to the least loaded lane (ties: the lower lane)
+      std::vector<double> gcost(ngroups, 0.0);
+      for (int g = 0; g < ngroups; ++g)
+        for (int at = gstart[g]; at < gstart[g + 1]; ++at) gcost[g] += unit_cost(grouped[at]);
+      std::vector<int> order(ngroups);
+      for (int g = 0; g < ngroups; ++g) order[g] = g;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gcost[a] > gcost[b]; });
+      double load[kGroupLanes] = {0.0};
+      for (int g : order) {
+        int best = 0;
+        for (int l = 1; l < lanes; ++l)
+          if (load[l] < load[best]) best = l;
+        lane_groups[best].push_back(g);
+        load[best] += gcost[g];
+      }
+    }
     sc_handle leads[kGroupLanes] = {h};
     for (int l = 1; l < lanes; ++l) {
       while ((int)h->glanes.size() < l) {
@@ -727,7 +784,7 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
           rcs[l] = fail(leads[l], SC_ERR_HIP, "hipSetDevice failed on a lane");
           return;
         }
-        rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, width,
+        rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, gstart, width,
                                 lane_groups[l], rq);
       };
       try {
@@ -736,10 +793,11 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
         inline_lane[l] = true;
       }
     }
-    rcs[0] = run_group_lane(h, xs, ns, d, cfg, labels, diags, grouped, width, lane_groups[0], rq);
+    rcs[0] = run_group_lane(h, xs, ns, d, cfg, labels, diags, grouped, gstart, width,
+                            lane_groups[0], rq);
     for (int l = 1; l < lanes; ++l)
       if (inline_lane[l])
-        rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, width,
+        rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, gstart, width,
                                 lane_groups[l], rq);
     for (auto& t : side) t.join();
     {  // member arenas that hold a large share of the device do not outlive the batch (the

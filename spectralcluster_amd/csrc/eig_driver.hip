@@ -24,8 +24,11 @@
 // multiplicity > 8 in front of the decisive gap.)
 // The Kato-Temple bound is a HEURISTIC tightening: its gap delta comes from Ritz values and
 // residual estimates, not from the spectrum, and the factor 2 below is empirical.  What is
-// PROVEN about an accepted value is the plain residual bound, which analyze() caps at the
-// parity bar: |lambda - theta| <= resid <= 1e-5 |theta| whatever Kato-Temple says.
+// PROVEN about an accepted value of a SYMMETRIC operator is the plain residual bound, which
+// analyze() caps at max(value_tol, 1e-5) |theta|: |lambda - theta| <= resid <= 1e-5 |theta| for
+// every consumed value whenever value_tol <= 1e-5 (the default is 1e-6), whatever Kato-Temple
+// says.  (General path: every consumed value is held to value_tol by its residual since round 6;
+// there the residual bounds the error only up to the eigenvalue's condition number.)
 static double value_error_bound(const double* theta, const double* resid, int m, int i,
                                 bool symmetric) {
   const double r = resid[i];
@@ -87,7 +90,8 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
   } else {
     // np.max(eigenvalues) is taken over the WHOLE spectrum (utils.py:110,123): the
     // first value when descending, the far end of the Ritz spectrum when ascending.
-    const double wmax = rq.descend ? w[0] : w[m - 1];
+    // (general path, ascending NormalizedDiff: the far end from its own solve, gen_topk)
+    const double wmax = rq.have_far ? rq.far_value : (rq.descend ? w[0] : w[m - 1]);
     eigengap_core(w.data(), kw, rq.max_clusters, rq.use_stop ? rq.stop_eigenvalue : 0.0,
                   rq.eigengap_type, rq.descend, wmax, &dc.n_clusters_raw, &dc.max_delta);
     dc.kvec = std::max(dc.n_clusters_raw, rq.min_clusters);
@@ -140,7 +144,7 @@ static EigDecision analyze(const EigRequest& rq, const double* theta, const doub
     // factor for the departure from normality)
     auto err = [&](int i) { return 10.0 * resid[i]; };
     const double eps = 1e-10;
-    const double wmax = rq.descend ? w[0] : w[m - 1];
+    const double wmax = rq.have_far ? rq.far_value : (rq.descend ? w[0] : w[m - 1]);
     auto gap_bounds = [&](int lo_i, int hi_i, double* lower, double* upper) {
       // Ratio: w[hi_i] / (w[lo_i] + eps); NormalizedDiff: (w[hi_i] - w[lo_i]) / wmax,
       // where hi_i is the numerator index
@@ -1430,8 +1434,9 @@ static int gen_dense_large(sc_handle h, const double* M, int ld, int n, int lapl
 }
 
 int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
-                    const EigRequest& rq, sc_diag* diag, EigDecision* out_dc,
+                    const EigRequest& rq_in, sc_diag* diag, EigDecision* out_dc,
                     std::vector<double>* out_w, double* scratch) {
+  EigRequest rq = rq_in;
   hipStream_t s = h->stream;
   SC_TRY(ensure_eig(h, n));
   SC_TRY(ensure_gen(h, n));
@@ -1449,8 +1454,9 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
   EigDecision dc;
   int m = 0, passes = 0, cycles = 0;
   const bool is_lap = laplacian_type >= SC_LAPLACIAN_UNNORMALIZED;
-  const bool far_end = !rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF &&
-                       rq.fixed_count == 0;
+  bool far_end = !rq.descend && rq.eigengap_type == SC_EIGENGAP_NORMALIZED_DIFF &&
+                 rq.fixed_count == 0;
+  int far_passes = 0, far_cycles = 0;
 
   auto fetch_ritz = [&](int count) -> int {
     SC_HIP(h, hipMemcpyAsync(th, theta_d, count * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1503,10 +1509,46 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
     // end of the Laplacian's spectrum, the edge of a dense bulk where a Krylov space converges
     // like 1 / degree^2 -- 1e-4 .. 4e-3 on the far-end Ritz value of a 64-vector basis
     // (profiles/r18_general_strict_probe.txt), and max_delta inherits that error.  It is a
-    // consumed eigenvalue like the others: the dense route has it to rounding level.  (Beyond
-    // the dense route's size limit the Krylov solver keeps the request, far end as it comes.)
-    if (far_end && n <= kGenDenseLimit && !sw::gen_loose_bulk())
-      return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 9);
+    // consumed eigenvalue like the others.
+    // So it gets a solve of its own first: ONE eigenvalue, the one of largest real part of the
+    // operator with its sign turned (+L), to value_tol by its residual; the main solve below then
+    // divides by that value instead of its own far-end Ritz value.  Tens of block passes where the
+    // dense route is seconds at n = 2000.  Only a far-end solve that spends its restart budget
+    // sends the request to the dense route (eig_fallback 9).
+    if (far_end && !sw::gen_loose_bulk()) {
+      EigRequest fr = rq;
+      fr.fixed_count = 1;
+      fr.descend = 1;
+      fr.negate = !rq.negate;
+      fr.no_dense = 1;
+      fr.decision_aware = 0;
+      // (a residual bounds the error of an eigenvalue of a non-normal matrix only up to the
+      //  eigenvalue's condition number: 7.8e-6 was seen at a residual of 1e-6,
+      //  profiles/r25_general_far_end_probe.txt -- one decade of margin costs ~1/6 more passes)
+      fr.value_tol = 0.1 * rq.value_tol;
+      fr.vector_tol = fr.value_tol;  // (the vector is not used)
+      fr.max_cycles = std::max(rq.max_cycles, 60);
+      EigDecision fdc;
+      std::vector<double> fw;
+      sc_diag fdiag;
+      memset(&fdiag, 0, sizeof(fdiag));
+      const int rc_far = gen_topk(h, M, ld, n, laplacian_type, fr, &fdiag, &fdc, &fw, scratch);
+      if (rc_far == SC_OK && !fw.empty()) {
+        rq.have_far = 1;
+        rq.far_value = fw[0];
+        far_end = false;
+        far_passes = fdiag.eig_matvec_passes;
+        far_cycles = fdiag.eig_cycles;
+        if (sw::eig_trace())
+          fprintf(stderr, "[sc] general eigen path: far end %.12g in %d passes, %d cycles\n",
+                  fw[0], far_passes, far_cycles);
+      } else if (rc_far == SC_ERR_NOT_CONVERGED && n <= kGenDenseLimit) {
+        return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 9);
+      } else if (rc_far != SC_OK && rc_far != SC_ERR_NOT_CONVERGED) {
+        return rc_far;
+      }
+      // (beyond the dense route's size limit: the far end as the main solve's basis has it)
+    }
     // Narrow form: basis <= 64, projected problems solved by the one-wavefront device kernel,
     // up to 32 Ritz pairs.  WIDE form (a request for more -- max_clusters up to 63,
     // min_clusters up to 64 -- or a descending request whose stop_eigenvalue turns out to lie
@@ -1530,6 +1572,13 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
     const double* cl = ptr<double>(h->cvec);
     const double* cr = ptr<double>(h->crvec);
     const double* pv = ptr<double>(h->pvec);
+    if (rq.negate) {  // -Op x = (-p) .* x + (-cl) .* (M (cr .* x))
+      const size_t stride = round_up(n, 16);
+      SC_TRY(grow(h, h->gneg, 2 * stride * sizeof(double)));
+      launch_negate2(s, cl, pv, n, ptr<double>(h->gneg), stride);
+      cl = ptr<double>(h->gneg);
+      pv = ptr<double>(h->gneg) + stride;
+    }
     double* Q = ptr<double>(h->Q);
     double* OpQ = ptr<double>(h->Q2);
     double* W = ptr<double>(h->W);
@@ -1650,8 +1699,11 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
       }
       if (m + kEigBlock > cap) {
         // ---- explicit restart from the wanted Ritz vectors
-        if (++cycles > rq.max_cycles)  // restart budget spent: the landing pad
+        if (++cycles > rq.max_cycles) {  // restart budget spent: the landing pad
+          if (rq.no_dense)
+            return fail(h, SC_ERR_NOT_CONVERGED, "far-end eigenvalue: restart budget spent");
           return gen_dense_large(h, M, ld, n, laplacian_type, rq, diag, out_dc, out_w, scratch, 1);
+        }
         // (thick restart: the new basis is [wanted Ritz vectors | residual block], after
         // which the Arnoldi recurrence continues from the residual block)
         const int kStash = wide ? 112 : 48;  // Vre columns [kStash, kStash + 8): the residual block
@@ -1723,10 +1775,10 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
     for (int i = 0; i < dc.kw; ++i) (*out_w)[i] = rq.descend ? th[i] : -th[i];
   }
   if (diag) {
-    diag->eig_matvec_passes = passes;
+    diag->eig_matvec_passes = passes + far_passes;  // (the far-end solve's count too)
     diag->eig_block = kEigBlock;
     diag->eig_basis = m;
-    diag->eig_cycles = cycles;
+    diag->eig_cycles = cycles + far_cycles;
     diag->eig_max_residual = dc.max_resid;
   }
   *out_dc = dc;

@@ -566,6 +566,17 @@ void launch_gen_gather(hipStream_t s, const double* Vre, const double* Vim, int 
   hipLaunchKernelGGL(k_gen_gather, dim3((n * kEigBlock + 255) / 256), dim3(256), 0, s, Vre,
                      Vim, ldv, n, src, seed, W);
 }
+__global__ void k_negate2(const double* __restrict__ a, const double* __restrict__ b, int n,
+                          double* __restrict__ out, size_t stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = -a[i];
+  out[stride + i] = -b[i];
+}
+void launch_negate2(hipStream_t s, const double* a, const double* b, int n, double* out,
+                    size_t stride) {
+  hipLaunchKernelGGL(k_negate2, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, out, stride);
+}
 void launch_scaling_general(hipStream_t s, const double* deg, int n, int laplacian_type,
                             double* cl, double* cr, double* p) {
   hipLaunchKernelGGL(k_scaling_general, dim3((n + 255) / 256), dim3(256), 0, s, deg, n,

@@ -78,7 +78,7 @@ struct sc_handle_s {
   std::vector<double> last_w;    // eigenvalues the last eig call consumed (reference order)
   // general (non-symmetric) eigen path: right scaling, Im(theta), complex Ritz vectors
   // (column-major), residual partials, restart codes, dense Laplacian scratch
-  DevBuf crvec, thetai, Vre, Vim, gpart, gsrc, genL;
+  DevBuf crvec, thetai, Vre, Vim, gpart, gsrc, genL, gneg;
   const double* vs_scale = nullptr;  // Vs = vs_scale .* V in orthonormalize (default cvec)
   DevBuf ahc_size, ahc_chain, ahc_Z, ahc_lab, ahc_cent;  // size reduction (AHC) scratch
   DevBuf fb_part, fb_small, fb_x, fb_cent, fb_int;      // fallback decisions scratch
@@ -272,6 +272,14 @@ struct EigRequest {
   // the others must be accurate enough that, with their residual intervals, no other gap
   // can reach the maximum and no comparison with stop_eigenvalue can flip.
   int decision_aware = 0;
+  // General path, internal (gen_topk's far-end solve, eig_driver.hip): the operator with the
+  // opposite sign -- the eigenvalues of largest real part of +L instead of -L; give up with
+  // SC_ERR_NOT_CONVERGED instead of landing on the dense route; and, for the main solve that
+  // follows, np.max(eigenvalues) of the ascending NormalizedDiff rule as that solve found it.
+  int negate = 0;
+  int no_dense = 0;
+  int have_far = 0;
+  double far_value = 0.0;
 };
 
 struct EigDecision {

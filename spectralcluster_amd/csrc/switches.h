@@ -92,6 +92,13 @@ inline int gen_dense_max_n() {
   static const int v = getenv("SC_GEN_DENSE_MAX_N") ? atoi(getenv("SC_GEN_DENSE_MAX_N")) : 512;
   return v;
 }
+// SC_GROUP_EQUAL_COUNT=1: the grouped batch cuts its size-sorted list into groups of equal
+// COUNT dealt round-robin to the lanes (rounds 2-5) instead of groups of equal cost dealt
+// longest-first (A/B measurements)
+inline bool group_equal_count() {
+  static const bool v = getenv("SC_GROUP_EQUAL_COUNT") != nullptr;
+  return v;
+}
 // SC_NO_PREFETCH=1: the calls of a batch upload their embeddings themselves, one after the
 // other (what a sequence of sc_predict calls does) instead of under their predecessor's pipeline
 inline bool no_prefetch() {

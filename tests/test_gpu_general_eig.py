@@ -214,17 +214,24 @@ def test_block_arnoldi_every_consumed_eigenvalue_vs_oracle(n, lap, gap):
   descend = lap in (0, 1)
   assert diag.symmetry_state == 3
   # ascending NormalizedDiff reads np.max(eigenvalues), the far end of the spectrum
-  # (utils.py:110,123): no Krylov space has that to 1e-5 -- dense route (eig_fallback 9);
-  # everything else here is block Arnoldi
+  # (utils.py:110,123): the main solve's Krylov space has that to 1e-3 at best, so it gets a
+  # block Arnoldi solve of its own (the operator with its sign turned, one eigenvalue, to its
+  # residual); only a far-end solve that spends its budget goes to the dense route (fallback 9)
   far_end = (not descend) and gap == "NormalizedDiff"
-  assert diag.eig_path == (7 if far_end else 4), (diag.eig_path, diag.eig_fallback)
+  assert diag.eig_path == 4 or (far_end and diag.eig_path == 7 and diag.eig_fallback == 9), (
+      diag.eig_path, diag.eig_fallback)
   assert diag.n_clusters_raw == k_ref
   w = clusterer.consumed_eigenvalues()   # (the dense route reports all n, far end included)
   idx = so.consumed_eigen_indices(n, maxc, descend, ref if descend else None,
                                   1e-2 if descend else None, gap_code)
-  assert (n - 1 in idx) == far_end and idx.max() < w.size
+  assert (n - 1 in idx) == far_end
   for i in idx:
+    if i >= w.size:   # block Arnoldi: the far end is held through max_delta = gap / far end below
+      assert far_end and i == n - 1 and diag.eig_path == 4
+      continue
     assert abs(w[i] - ref[i]) <= 1e-5 * max(abs(ref[i]), 1e-12), (i, w[i], ref[i])
+  # (max_delta = (w[k] - w[k - 1]) / np.max(w): with both gap eigenvalues on the bar above, 1e-5
+  #  on it is 1e-5 on the far end)
   np.testing.assert_allclose(diag.max_delta, delta_ref, rtol=1e-5)
   if gap == "Ratio":   # (labels of the oracle's predict(), which ran with the Ratio rule)
     assert so.adjusted_rand_index(got, want) == 1.0

@@ -356,6 +356,10 @@ int finish_group(sc_handle lead, const int* ns, const sc_config* cfg, int64_t* c
   {  // staging for the labels of this group (every member could end up in it)
     size_t need = 0;
     for (int z = 0; z < count; ++z) need += (size_t)ns[mb[z].index];
+    // (never less than a full group of the largest utterances the grouped path takes -- 512 KB:
+    //  a staging buffer that follows the batch's composition is a hipHostFree + hipHostMalloc,
+    //  milliseconds, whenever a group's total grows)
+    need = std::max(need, (size_t)kGroupMax * 4096);
     SC_TRY(grow(lead, lead->ginfo, (size_t)kGroupMax * 16 * sizeof(int)));
     SC_TRY(grow(lead, lead->glabels, need * sizeof(int64_t)));
     if (!lead->h_ginfo)
@@ -572,7 +576,7 @@ int independent_streams(sc_handle h, std::vector<hipStream_t> have, hipStream_t*
 int run_group_lane(sc_handle h, const double* const* xs, const int* ns, int d,
                    const sc_config* cfg, int64_t* const* labels, sc_diag* diags,
                    const std::vector<int>& grouped, const std::vector<int>& gstart, int width,
-                   const std::vector<int>& mine, const EigRequest& rq) {
+                   const std::vector<int>& mine, const EigRequest& rq, int group_limit) {
   if (mine.empty()) return SC_OK;
   // (the lead's lockstep chains run on its dedicated stream for the duration of the batch)
   struct StreamSwap {
@@ -595,16 +599,26 @@ int run_group_lane(sc_handle h, const double* const* xs, const int* ns, int d,
   // (group g of the size-sorted list = [gstart[g], gstart[g + 1]); `width` = the largest group)
   auto group_count = [&](int j) { return gstart[mine[j] + 1] - gstart[mine[j]]; };
   auto group_members = [&](int j) { return grouped.data() + gstart[mine[j]]; };
-  // arenas once, for the largest member each will see
+  // arenas once.  Groups of equal cost put a member of any size at any position z (five
+  // utterances of n ~ 3000 in one batch's first group, seven of n ~ 2800 in the next batch's), so
+  // every position of a bank that is used at all is reserved for the largest member of the
+  // lane: an arena that has to grow is a hipFree + hipMalloc in the middle of a batch (the 8-GPU
+  // shares of config 5 ran 3x slower on arenas sized position by position).
+  // (the largest grouped member of the BATCH, not of this lane's groups: which lane draws the
+  //  large groups changes from batch to batch too)
+  const int lane_largest = ns[grouped[0]];
+  // (all `group_limit` positions of a bank in use, whatever this batch's largest group: the next
+  //  batch -- or the next rank's share -- cuts its list elsewhere, and a position that does not
+  //  exist yet is an sc_create: streams, events, pinned buffers, milliseconds)
   for (int b = 0; b < std::min(banks, ngroups); ++b)
-    for (int z = 0; z < width; ++z) {
-      int largest = 0;
-      for (int j = b; j < ngroups; j += banks)
-        if (z < group_count(j)) largest = std::max(largest, ns[group_members(j)[z]]);
-      if (largest == 0) continue;
+    for (int z = 0; z < std::max(width, group_limit); ++z) {
+      const int largest = lane_largest;
       sc_handle hz = nullptr;
-      SC_TRY(group_slot(h, b * width + z, &hz));
-      const int rc = sc_reserve(hz, largest, d);
+      SC_TRY(group_slot(h, b * kGroupMax + z, &hz));  // (a stride that does not move with the batch)
+      int rc = sc_reserve(hz, largest, d);
+      // (... and the buffers of the matrix-free Diffuse, which a member arena otherwise grows the
+      //  first time a member of n >= 1536 lands in it)
+      if (rc == SC_OK && free_diffuse_wanted(hz, cfg, largest, rq, true)) rc = ensure_free(hz, largest);
       if (rc != SC_OK) return fail(h, rc, hz->err);
       hz->have_constraint = false;
     }
@@ -624,10 +638,10 @@ int run_group_lane(sc_handle h, const double* const* xs, const int* ns, int d,
     //  are sorted, the last member of the group is its smallest)
     if (covers && blur_group_front_supported(ns[idx[cnt - 1]], cfg->blur_radius)) {
       front_bank[b] = b;
-      return enqueue_front_grouped(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b], b);
+      return enqueue_front_grouped(h, xs, ns, d, cfg, diags, idx, cnt, b * kGroupMax, mbs[b], b);
     }
     front_bank[b] = -1;
-    return enqueue_front(h, xs, ns, d, cfg, diags, idx, cnt, b * width, mbs[b]);
+    return enqueue_front(h, xs, ns, d, cfg, diags, idx, cnt, b * kGroupMax, mbs[b]);
   };
   for (int j = 0; j < std::min(banks - 1, ngroups); ++j) SC_TRY(front(j));
   for (int j = 0; j < ngroups; ++j) {
@@ -785,7 +799,7 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
           return;
         }
         rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, gstart, width,
-                                lane_groups[l], rq);
+                                lane_groups[l], rq, equal_count ? 0 : group);
       };
       try {
         side.emplace_back(body);
@@ -794,11 +808,11 @@ extern "C" int sc_predict_batch_grouped(sc_handle h, const double* const* xs, co
       }
     }
     rcs[0] = run_group_lane(h, xs, ns, d, cfg, labels, diags, grouped, gstart, width,
-                            lane_groups[0], rq);
+                            lane_groups[0], rq, equal_count ? 0 : group);
     for (int l = 1; l < lanes; ++l)
       if (inline_lane[l])
         rcs[l] = run_group_lane(leads[l], xs, ns, d, cfg, labels, diags, grouped, gstart, width,
-                                lane_groups[l], rq);
+                                lane_groups[l], rq, equal_count ? 0 : group);
     for (auto& t : side) t.join();
     {  // member arenas that hold a large share of the device do not outlive the batch (the
        // lanes keep up to 3 x 2 x 16 of them warm otherwise: 21 GB after config 5)

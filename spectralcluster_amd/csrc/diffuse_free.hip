@@ -83,6 +83,7 @@ __device__ __forceinline__ void atomic_max_if_larger(unsigned long long* word, u
 }
 
 constexpr int kFreeOvfWords = 80;  // (free_api.hip's kOvfWords: the overflow record behind M and count)
+constexpr int kPlanTotalWord = 68;  // ovf[68]: length of the tile skip list (k_free_tile_flags adds it up)
 
 // order-preserving map float -> unsigned (for atomicMax on values of either sign)
 __device__ __forceinline__ unsigned ordered_bits(float f) {
@@ -390,21 +391,24 @@ __global__ __launch_bounds__(256) void k_free_seg_reduce_g(const GroupOf<FreeIte
 
 // One workgroup per tile row I: plan[I] = number of surviving tiles (I, J >= I), their columns in
 // ascending order at plan[nt + I * nt ...].  ng = 64-row groups that exist (= nblk).
+// (16 waves: tile row 0 of n = 8192 has 64 bounds of 128 terms to form, each a dependent chain of
+//  loads from L2 -- with 4 waves the launch took 15 us)
+constexpr int kFlagThreads = 1024;
 __device__ __forceinline__ void free_tile_flags_body(const double* __restrict__ mx64,
                                                      const float* __restrict__ tau64, int nt,
                                                      int nblk, int* __restrict__ plan,
-                                                     int prune) {
+                                                     int prune, int* __restrict__ total_out) {
   __shared__ double mI[1024];       // n <= 65536: nblk <= 1024
   __shared__ unsigned char keep[512];
   const int I = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int ng = nblk;
   const bool i1 = 2 * I + 1 < ng;
-  for (int b = threadIdx.x; b < nblk; b += 256)
+  for (int b = threadIdx.x; b < nblk; b += kFlagThreads)
     mI[b] = fmax(mx64[(size_t)(2 * I) * nblk + b], i1 ? mx64[(size_t)(2 * I + 1) * nblk + b] : 0.0);
   const float tauI = fminf(tau64[2 * I], i1 ? tau64[2 * I + 1] : INFINITY);
   __syncthreads();
-  for (int J = I + w; J < nt; J += 4) {
+  for (int J = I + w; J < nt; J += kFlagThreads / 64) {
     const bool j1 = 2 * J + 1 < ng;
     const double* mj0 = mx64 + (size_t)(2 * J) * nblk;
     const double* mj1 = mx64 + (size_t)(2 * J + 1) * nblk;
@@ -430,20 +434,26 @@ __device__ __forceinline__ void free_tile_flags_body(const double* __restrict__ 
       if (k) plan[nt + I * nt + total + __popcll(mask & ((1ull << lane) - 1ull))] = I + e;
       total += __popcll(mask);
     }
-    if (lane == 0) plan[I] = total;
+    if (lane == 0) {
+      plan[I] = total;
+      // the list's length, for workgroups that only need to know whether they are beyond it
+      // (zeroed with the handle's words before this launch)
+      atomicAdd(total_out, total);
+    }
   }
 }
-__global__ __launch_bounds__(256) void k_free_tile_flags_g(const GroupOf<FreeItem> g, int prune) {
+__global__ __launch_bounds__(kFlagThreads) void k_free_tile_flags_g(const GroupOf<FreeItem> g, int prune) {
   const FreeItem& a = g.s[blockIdx.y];
   const int nt = (a.n + 127) / 128;  // (kI8Tile, declared with the product below)
   if (a.n <= 0 || a.plan == nullptr || (int)blockIdx.x >= nt) return;
-  free_tile_flags_body(a.mx64, a.tau64, nt, (a.n + 63) / 64, a.plan, prune);
+  free_tile_flags_body(a.mx64, a.tau64, nt, (a.n + 63) / 64, a.plan, prune,
+                       a.words + 2 * (size_t)a.n + kPlanTotalWord);
 }
-__global__ __launch_bounds__(256) void k_free_tile_flags(const double* __restrict__ mx64,
+__global__ __launch_bounds__(kFlagThreads) void k_free_tile_flags(const double* __restrict__ mx64,
                                                          const float* __restrict__ tau64, int nt,
                                                          int nblk, int* __restrict__ plan,
-                                                         int prune) {
-  free_tile_flags_body(mx64, tau64, nt, nblk, plan, prune);
+                                                         int prune, int* __restrict__ total_out) {
+  free_tile_flags_body(mx64, tau64, nt, nblk, plan, prune, total_out);
 }
 
 // ---------------------------------------------------------------- T = Q Q^T, integer MFMA
@@ -490,6 +500,7 @@ struct I8Split {
   // `cus` compute units) -- the host never learns the count before it launches
   const int* plan = nullptr;
   int cus = 256;
+  const int* total = nullptr;  // the list's length (so that surplus workgroups leave at once)
 };
 
 // PROBE (tests/probes/i8_gemm_probe.hip only; the library instantiates 0): 1 = no DMA inside
@@ -508,15 +519,14 @@ __device__ __forceinline__ void gemm_i8_sym_body(
   int I, J;
   if (sp.plan != nullptr) {
     // ---- device-built list: its length decides the split, the list the tile
-    int* pref = reinterpret_cast<int*>(lds);
-    plan_scan(sp.plan, nt, pref);
-    __syncthreads();
-    const int count = pref[nt - 1];
+    const int count = *sp.total;
     int r = 0, f = 1;
     if (sp.cus > 0) i8_split_plan(count, sp.cus, nstages, &r, &f);  // (0: a member of a group)
     sp.full_tiles = count - r;
     sp.parts = f;
     if (tile >= sp.full_tiles + r * f) return;  // (the grid is sized for the worst case)
+    plan_scan(sp.plan, nt, reinterpret_cast<int*>(lds));
+    __syncthreads();
   }
   // the tail of the tile list (what would be a last, nearly empty round of workgroups) is cut
   // along K: `parts` workgroups per tile, each with nstages / parts stages
@@ -753,6 +763,7 @@ struct I8GroupItem {
   const int2* tilemap;
   int n;
   const int* plan;  // the member's skip list, or nullptr
+  const int* total; // ... and its length
 };
 __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym_g(const GroupOf<I8GroupItem> g) {
   const I8GroupItem& a = g.s[blockIdx.y];
@@ -762,6 +773,7 @@ __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym_g(const GroupOf<I8Gr
   I8Split sp{0, 1, nullptr};
   sp.plan = a.plan;
   sp.cus = 0;
+  sp.total = a.total;
   gemm_i8_sym_body<0>(a.Q, (size_t)2 * Kp, Kp / 64, a.tilemap, 0, a.T32, nt, a.n, a.M, nullptr, sp);
 }
 
@@ -772,17 +784,17 @@ __global__ __launch_bounds__(kI8Threads) void k_gemm_i8_sym_g(const GroupOf<I8Gr
 __global__ __launch_bounds__(kI8Threads) void k_i8_tail_finish(
     const int* __restrict__ wsp, int parts, int full_tiles, const int2* __restrict__ tilemap,
     float* __restrict__ T32, int nt, int n, unsigned* __restrict__ M,
-    const int* __restrict__ plan, int cus, int nstages) {
+    const int* __restrict__ plan, int cus, int nstages, const int* __restrict__ total) {
   const int tt = blockIdx.x, cq = blockIdx.y, cb = cq >> 2, q = cq & 3;
   int I, J;
   if (plan != nullptr) {  // (the product's own arithmetic: length of the list -> split)
     __shared__ int pref[512];
-    plan_scan(plan, nt, pref);
-    __syncthreads();
-    const int count = pref[nt - 1];
+    const int count = *total;
     int r;
     i8_split_plan(count, cus, nstages, &r, &parts);
     if (parts < 2 || tt >= r) return;
+    plan_scan(plan, nt, pref);
+    __syncthreads();
     full_tiles = count - r;
     plan_lookup(plan, nt, pref, full_tiles + tt, &I, &J);
   } else {
@@ -849,11 +861,11 @@ __device__ __forceinline__ void t32_candidates_body(
   size_t slot = blockIdx.x;
   if (plan != nullptr) {  // only the tiles the product computed (k_free_tile_flags)
     __shared__ int pref[512];
-    plan_scan(plan, nt, pref);
-    __syncthreads();
-    const int tiles_run = pref[nt - 1];
+    const int tiles_run = count[n + kPlanTotalWord];
     if (blockIdx.x == 0 && threadIdx.x == 0) count[n + 67] = tiles_run;  // (ovf[67], for sc_diag)
     if ((int)blockIdx.x >= tiles_run) return;
+    plan_scan(plan, nt, pref);
+    __syncthreads();
     plan_lookup(plan, nt, pref, blockIdx.x, &I, &J);
     slot = tile_to_slot(I, J, nt);
   } else {
@@ -1110,10 +1122,11 @@ void launch_free_seg_reduce(hipStream_t s, const double* R, int n, const FreeSeg
   hipLaunchKernelGGL(k_free_seg_reduce, dim3(nblk), dim3(256), 0, s, R, n, nblk, segs);
 }
 void launch_free_tile_flags(hipStream_t s, const double* mx64, const float* tau64, int n,
-                            int* plan, bool prune) {
+                            int* plan, bool prune, int* words) {
   const int nt = (n + kI8Tile - 1) / kI8Tile;
-  hipLaunchKernelGGL(k_free_tile_flags, dim3(nt), dim3(256), 0, s, mx64, tau64, nt,
-                     free_k_padded(n) / 64, plan, prune ? 1 : 0);
+  hipLaunchKernelGGL(k_free_tile_flags, dim3(nt), dim3(kFlagThreads), 0, s, mx64, tau64, nt,
+                     free_k_padded(n) / 64, plan, prune ? 1 : 0,
+                     words + 2 * (size_t)n + kPlanTotalWord);
 }
 
 // The tail of the product: `tiles` tiles on `cus` compute units leave tiles % cus tiles for a
@@ -1170,12 +1183,13 @@ void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* 
     I8Split sp{0, 1, split_ws};
     sp.plan = plan;
     sp.cus = cus;
+    sp.total = reinterpret_cast<const int*>(M) + 2 * (size_t)n + kPlanTotalWord;
     SC_OPT_IN_LDS(k_gemm_i8_sym<0>, lds);
     hipLaunchKernelGGL(k_gemm_i8_sym<0>, dim3(tiles + cus), dim3(kI8Threads), lds, s, Q,
                        (size_t)2 * Kp, Kp / 64, tilemap, 0, T32, nt, n, M,
                        static_cast<unsigned long long*>(nullptr), sp);
     hipLaunchKernelGGL(k_i8_tail_finish, dim3(cus / 2, 8), dim3(kI8Threads), 0, s, split_ws, 1, 0,
-                       tilemap, T32, nt, n, M, plan, cus, Kp / 64);
+                       tilemap, T32, nt, n, M, plan, cus, Kp / 64, sp.total);
     return;
   }
   int r = 0, f = 1;
@@ -1188,7 +1202,8 @@ void launch_gemm_i8_sym(hipStream_t s, const signed char* Q, int n, const int2* 
                      static_cast<unsigned long long*>(nullptr), I8Split{full, f, split_ws});
   if (f > 1)
     hipLaunchKernelGGL(k_i8_tail_finish, dim3(r, 8), dim3(kI8Threads), 0, s, split_ws, f, full,
-                       tilemap, T32, nt, n, M, static_cast<const int*>(nullptr), 0, 0);
+                       tilemap, T32, nt, n, M, static_cast<const int*>(nullptr), 0, 0,
+                       static_cast<const int*>(nullptr));
 }
 
 void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
@@ -1200,7 +1215,9 @@ void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float*
   memset(&g, 0, sizeof(g));
   int tiles = 0;
   for (int z = 0; z < count; ++z) {
-    g.s[z] = I8GroupItem{Q[z], T32[z], M[z], tilemaps[z], ns[z], plans ? plans[z] : nullptr};
+    // (M = the member's words: M | count | ovf)
+    g.s[z] = I8GroupItem{Q[z], T32[z], M[z], tilemaps[z], ns[z], plans ? plans[z] : nullptr,
+                         reinterpret_cast<const int*>(M[z]) + 2 * (size_t)ns[z] + kPlanTotalWord};
     const int nt = (ns[z] + kI8Tile - 1) / kI8Tile;
     tiles = std::max(tiles, nt * (nt + 1) / 2);
   }
@@ -1256,8 +1273,8 @@ void launch_free_tile_flags_group(hipStream_t s, const FreeItem* items, int coun
   const GroupOf<FreeItem> g = free_pack(items, count, &nmax);
   if (nmax == 0) return;
   hipLaunchKernelGGL(k_free_seg_reduce_g, dim3(free_k_padded(nmax) / 64, count), dim3(256), 0, s, g);
-  hipLaunchKernelGGL(k_free_tile_flags_g, dim3((nmax + kI8Tile - 1) / kI8Tile, count), dim3(256), 0,
-                     s, g, prune ? 1 : 0);
+  hipLaunchKernelGGL(k_free_tile_flags_g, dim3((nmax + kI8Tile - 1) / kI8Tile, count),
+                     dim3(kFlagThreads), 0, s, g, prune ? 1 : 0);
 }
 void launch_free_scan_stats_group(hipStream_t s, const FreeItem* items, int count) {
   int nmax;

@@ -4,7 +4,8 @@
 #include "handle.h"
 
 namespace {
-constexpr int kOvfWords = 80;   // [0] rows over the cap, [1..64] their ids, [65] candidates, [66] max
+constexpr int kOvfWords = 80;   // [0] rows over the cap, [1..64] their ids, [65] candidates, [66] max,
+                                // [67] tiles of the digit product that ran, [68] length of its skip list
 constexpr int kOvfRowsMax = 64;
 }  // namespace
 
@@ -71,7 +72,7 @@ int free_product(sc_handle h, hipStream_t s, int n) {
   //  the members of a sweep share one grouped launch and never need it)
   SC_TRY(grow(h, h->fsplit, free_i8_split_bytes_plan()));
   launch_free_tile_flags(s, ptr<double>(h->fmx64), ptr<float>(h->ftau64), n, ptr<int>(h->fplan),
-                         free_prune_on(h));
+                         free_prune_on(h), ptr<int>(h->fwords));
   launch_gemm_i8_sym(s, ptr<signed char>(h->fq), n, h->tilemap_cur, ptr<float>(h->ft32),
                      ptr<unsigned>(h->fwords), ptr<int>(h->fsplit), ptr<int>(h->fplan));
   return SC_OK;

@@ -429,8 +429,9 @@ size_t free_tau64_bytes(int n);
 size_t free_plan_bytes(int n);
 size_t free_i8_split_bytes_plan();
 void launch_free_seg_reduce(hipStream_t s, const double* R, int n, const FreeSegs& segs);
+// (words: the handle's M | count | ovf words, zeroed for this call: ovf[68] receives the length)
 void launch_free_tile_flags(hipStream_t s, const double* mx64, const float* tau64, int n,
-                            int* plan, bool prune);
+                            int* plan, bool prune, int* words);
 // (split_ws: workspace of free_i8_split_bytes(n) for the split-K tail; nullptr = every tile
 //  by one workgroup.  plan: walk the skip list instead of `tilemap` -- split_ws must then hold
 //  free_i8_split_bytes_plan())

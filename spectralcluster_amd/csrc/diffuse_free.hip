@@ -1036,11 +1036,37 @@ __device__ __forceinline__ void free_row_stats_body(
   if (threadIdx.x == 0) {
     rowmax[row] = best;
     rowsum[row] = rs;
-    atomicAdd(&ovf[65], cnt);
-    atomicMax(&ovf[66], total);
     if (total > cap) {
       const int e = atomicAdd(&ovf[0], 1);
       if (e < 64) ovf[1 + e] = row;
+    }
+  }
+  // ovf[65] / ovf[66] (candidates evaluated, largest count): the counts are final when this
+  // launch starts, so ONE workgroup adds them up.  (Every row used to send an atomicAdd and an
+  // atomicMax to those two words: 16384 same-address atomics were 77 us of this kernel's 228 at
+  // n = 8192, profiles/r28.)
+  if (row == 0) {
+    int sum = 0, big = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int t = count[i];
+      sum += t < cap ? t : cap;
+      big = t > big ? t : big;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sum += __shfl_xor(sum, o);
+      const int other = __shfl_xor(big, o);
+      big = other > big ? other : big;
+    }
+    __shared__ int ssum[4], sbig[4];
+    if ((threadIdx.x & 63) == 0) {
+      ssum[threadIdx.x >> 6] = sum;
+      sbig[threadIdx.x >> 6] = big;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      ovf[65] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+      ovf[66] = max(max(sbig[0], sbig[1]), max(sbig[2], sbig[3]));
     }
   }
 }

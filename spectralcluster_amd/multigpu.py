@@ -31,12 +31,13 @@ import numpy as np
 def cost_model(n: int) -> float:
   """Cost of one utterance of n samples inside a grouped batch (predict_batch(group=16), the
   execution the partition schedules), in microseconds on one MI355X.  Calibrated on measured
-  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r06g_cost_fit.txt: 55 us
-  at n=300, 77 at 650, 121 at 1200, 163 at 1535, 177 at 1536, 238 at 2000, 407 at 3000;
-  non-negative least squares on the relative error, 1 % per branch): a fixed per-utterance
-  share of the group's launch chains and the O(n^2) passes -- the cubic term of the fp64
-  Diffuse product no longer shows below n=1536, and from there on members take the
-  matrix-free route (round 4), hence two branches.
+  grouped times at d=256 (tests/probes/cost_model_fit.py, profiles/r30_cost_fit.txt -- round 6's
+  tree: 55 us at n=300, 79 at 650, 122 at 1200, 168 at 1535, 143 at 1536, 197 at 2000, 386 at
+  3000; non-negative least squares on the relative error): a fixed per-utterance share of the
+  group's launch chains and the O(n^2) passes.  From n = 1536 on members take the matrix-free
+  Diffuse, whose digit product now runs over a skip list: what it costs depends on how the
+  utterance's speakers fall into tiles, not on n alone -- the upper branch fits its record to 8 %
+  (the branches below to 1.5 %), where round 5's, with every tile computed, fitted to 1 %.
   (Round 3's single cubic, calibrated on the explicit route, was 2x too high everywhere and
   had no kink: the 8 shares of config 5 came out 10-14 % apart.  Round 2's n^3 + 64 n^2 put a
   factor 900 between n=300 and n=3000 where the measured factor is 7.)"""
@@ -44,8 +45,8 @@ def cost_model(n: int) -> float:
   if n < 512.0:
     return 50.0 + 6.5e-5 * n * n
   if n < 1536.0:
-    return 58.3 + 4.429e-5 * n * n
-  return 97.3 + 3.437e-5 * n * n
+    return 65.38 + 2.665e-5 * n * n + 1.06e-8 * n * n * n
+  return 66.5 + 3.529e-5 * n * n
 
 
 def lpt_assignment(sizes: typing.Sequence[int], world: int) -> typing.List[typing.List[int]]:

@@ -1354,6 +1354,25 @@ static int gen_dense_large(sc_handle h, const double* M, int ld, int n, int lapl
     SC_HIP(h, hipMemcpyAsync(scratch, M, (size_t)n * ld * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
   const double t_begin = sw::eig_trace() ? now_us() : 0.0;
+  // a badly scaled matrix (max|a| beyond 2^+-400) is brought to [1, 2) by a power of two first:
+  // the reflectors square their columns (hessenberg.hip); the eigenvalues get the factor back
+  double eig_scale = 1.0;
+  {
+    SC_TRY(grow(h, h->fscal, 4 * sizeof(double)));
+    SC_HIP(h, hipMemsetAsync(h->fscal.p, 0, sizeof(double), s));
+    launch_free_absmax(s, scratch, n, ld, ptr<double>(h->fscal));
+    double amax = 0.0;
+    SC_HIP(h, hipMemcpyAsync(&amax, h->fscal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    SC_HIP(h, hipStreamSynchronize(s));
+    int e = 0;
+    if (amax > 0.0 && std::isfinite(amax)) {
+      std::frexp(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
+      if (e > 400 || e < -400) {
+        eig_scale = std::ldexp(1.0, e - 1);  // amax / eig_scale in [1, 2)
+        launch_scale_matrix(s, scratch, ld, n, std::ldexp(1.0, 1 - e));
+      }
+    }
+  }
   SC_HIP(h, hipMemsetAsync(h->td_tau.p, 0, (size_t)n * sizeof(double), s));
   launch_hessenberg(s, scratch, ld, n, ptr<double>(h->td_tau), ptr<double>(h->td_work));
   SC_TRY(check_last(h, "Hessenberg reduction launch"));
@@ -1376,6 +1395,8 @@ static int gen_dense_large(sc_handle h, const double* M, int ld, int n, int lapl
   if (!host_hessenberg_eigenvalues(hw, wr.data(), wi.data()))
     return fail(h, SC_ERR_NOT_CONVERGED, "QR iteration on the Hessenberg form failed");
   const double t_values = sw::eig_trace() ? now_us() : 0.0;
+  // (hw, wr, wi stay in the scaled units for the inverse iteration below; theta -- what the
+  //  eigengap reads and the caller gets -- is in the matrix's own)
   // np.linalg.eig + .real + argsort (utils.py:59-67): by real part, descending for the
   // affinity itself, ascending for a Laplacian (= descending in -L, the convention of `theta`)
   const double sign = is_lap ? -1.0 : 1.0;
@@ -1384,7 +1405,7 @@ static int gen_dense_large(sc_handle h, const double* M, int ld, int n, int lapl
   std::stable_sort(order.begin(), order.end(),
                    [&](int a, int b) { return sign * wr[a] > sign * wr[b]; });
   std::vector<double> theta(n), zeros(n, 0.0);
-  for (int i = 0; i < n; ++i) theta[i] = sign * wr[order[i]];
+  for (int i = 0; i < n; ++i) theta[i] = sign * wr[order[i]] * eig_scale;
   EigDecision dc = analyze(rq, theta.data(), zeros.data(), n, n, true, false);
   if (!dc.enough) return fail(h, SC_ERR_UNSUPPORTED, "eigen request cannot be satisfied");
   const int cols = std::max(1, std::min(n, dc.kvec));
@@ -1415,7 +1436,7 @@ static int gen_dense_large(sc_handle h, const double* M, int ld, int n, int lapl
   h->n_vec = cols;
   dc.kw = n;
   dc.converged = true;
-  dc.max_resid = max_resid * std::max(hw.norm, 1e-300);
+  dc.max_resid = max_resid * std::max(hw.norm, 1e-300) * eig_scale;
   if (out_w) {  // the whole spectrum, in the reference's order
     out_w->resize(n);
     for (int i = 0; i < n; ++i) (*out_w)[i] = rq.descend ? theta[i] : -theta[i];

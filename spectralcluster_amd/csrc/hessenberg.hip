@@ -135,4 +135,17 @@ void launch_hessenberg(hipStream_t s, double* B, int ld, int n, double* tau, dou
   }
 }
 
+// A <- f * A (f a power of two: exact).  The reduction forms x^T x of its columns without
+// dlarfg's safmin rescaling: entries around 1e-160 underflow to a skipped reflector, around 1e155
+// overflow.  gen_dense_large brings a badly scaled matrix to max|a| in [1, 2) first
+// and gives the eigenvalues their factor back; a matrix within 2^+-400 of 1 is left alone.
+__global__ void k_scale_matrix(double* __restrict__ A, int ld, int n, double f) {
+  const int row = blockIdx.x;
+  double* x = A + (size_t)row * ld;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) x[j] *= f;
+}
+void launch_scale_matrix(hipStream_t s, double* A, int ld, int n, double f) {
+  hipLaunchKernelGGL(k_scale_matrix, dim3(n), dim3(256), 0, s, A, ld, n, f);
+}
+
 }  // namespace sc

@@ -375,6 +375,7 @@ void launch_gen_phase(hipStream_t s, double* Vre, double* Vim, int ldv, int n, i
 void launch_hessenberg(hipStream_t s, double* B, int ld, int n, double* tau, double* vwork);
 void launch_gen_gather(hipStream_t s, const double* Vre, const double* Vim, int ldv, int n,
                        const int* src, uint64_t seed, double* W);
+void launch_scale_matrix(hipStream_t s, double* A, int ld, int n, double f);
 // out[0 .. n) = -a, out[stride .. stride + n) = -b  (the operator of gen_topk with its sign turned)
 void launch_negate2(hipStream_t s, const double* a, const double* b, int n, double* out,
                     size_t stride);

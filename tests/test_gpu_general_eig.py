@@ -83,6 +83,23 @@ def test_dense_general_near_defective_laplacians(n, d, k, seed):
       np.testing.assert_allclose(w, wr, rtol=0, atol=1e-6 * np.abs(wr).max())
 
 
+@pytest.mark.parametrize("scale", [1e-170, 1e160])
+def test_dense_hessenberg_route_on_a_badly_scaled_matrix(scale):
+  """the reflectors of the device reduction square their columns without dlarfg's
+  safmin rescaling -- entries around 1e-160 underflowed to skipped reflectors, around 1e155
+  overflowed.  The route now brings such a matrix to max|a| in [1, 2) by a power of two (exact)
+  and gives the eigenvalues the factor back: same relative accuracy as at scale 1."""
+  rng = np.random.default_rng(31)
+  n, count = 150, 100          # (more than 64 pairs of a general matrix: eig_path 7)
+  m = rng.random((n, n))
+  m[0, 1] += 0.5
+  ref = np.sort(np.linalg.eigvals(m).real)[::-1][:count]
+  w, v = sca.utils.compute_sorted_eigenvectors(m * scale, descend=True, count=count)
+  np.testing.assert_allclose(w / scale, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+  r = np.linalg.norm((m * scale) @ v[:, :1] - v[:, :1] * w[0]) / (np.abs(w[0]) * np.linalg.norm(v[:, 0]))
+  assert r < 1e-10          # the Perron vector: real, simple
+
+
 def thresholded(n, d, k, seed, p=0.9):
   x = so.blobs(n, d, k, seed=seed)
   return so.row_wise_threshold(so.affinity(x), p, 0.01, so.THRESHOLD_PERCENTILE), x

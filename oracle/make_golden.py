@@ -377,6 +377,18 @@ def kmeans_metric_goldens():
   save("kmeans_metrics.npz", **km)
 
 
+def kmeans_bigk_golden():
+  """4c. ADVICE r5: the correlation metric with MORE than 128 clusters -- scipy centres every
+  row by `mean(axis=1)`, and numpy's mean of a row longer than 128 splits it pairwise
+  (loops_utils.h pairwise_sum); the other goldens stop at k = 12."""
+  r2 = np.random.default_rng(15)
+  n, k = 900, 150
+  cent = r2.standard_normal((k, k))
+  e = cent[r2.integers(0, k, n)] * 0.6 + 0.35 * r2.standard_normal((n, k))
+  save("kmeans_correlation_k150.npz", e=e,
+       labels=ref_kmeans.run_kmeans(e, k, "correlation", 300))
+
+
 class _Spy:
   """Captures what the reference's own eigen / eigengap calls return (they are
   looked up through the module attribute at spectral_clusterer.py:146-167)."""
@@ -666,6 +678,9 @@ def main():
   large = "--large" in sys.argv
   if "--many-clusters" in sys.argv:  # only section 15
     many_cluster_goldens()
+    return
+  if "--kmeans-bigk" in sys.argv:  # only section 4c
+    kmeans_bigk_golden()
     return
   if "--float32" in sys.argv:  # only section 18
     float32_goldens()

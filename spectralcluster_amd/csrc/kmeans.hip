@@ -364,24 +364,67 @@ __global__ __launch_bounds__(KT) void k_kmeans(
   // scipy's `correlation` is its cosine distance on row-centred operands (scipy 1.15
   // spatial/distance.py _correlation_cdist_wrap: X - X.mean(axis=1, keepdims=True)): the row mean
   // in numpy's summation order for short rows, then the cosine code on the differences
-  auto row_mean = [&](auto at) -> double {
+  // (numpy's pairwise_sum, numpy/core/src/umath/loops_utils.h: fewer than 8 elements one by one;
+  //  up to PW_BLOCKSIZE = 128 eight running sums folded as a tree, then the tail; longer rows --
+  //  more than 128 clusters -- split at n / 2 rounded down to a multiple of 8 and the halves'
+  //  sums added, recursively: an explicit stack here, depth <= log2(k / 128) + 1)
+  auto leaf_sum = [&](auto at, int lo, int cnt) -> double {
     double s;
-    if (k < 8) {
+    if (cnt < 8) {
       s = 0.0;
-      for (int j = 0; j < k; ++j) s += at(j);
+      for (int j = 0; j < cnt; ++j) s += at(lo + j);
     } else {
       double a8[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) a8[q] = at(q);
+      for (int q = 0; q < 8; ++q) a8[q] = at(lo + q);
       int j = 8;
-      for (; j < k - (k % 8); j += 8) {
+      for (; j < cnt - (cnt % 8); j += 8) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a8[q] += at(j + q);
+        for (int q = 0; q < 8; ++q) a8[q] += at(lo + j + q);
       }
       s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
-      for (; j < k; ++j) s += at(j);
+      for (; j < cnt; ++j) s += at(lo + j);
     }
-    return s / (double)k;
+    return s;
+  };
+  auto row_mean = [&](auto at) -> double {
+    if (k <= 128) return leaf_sum(at, 0, k) / (double)k;
+    int lo[24], cnt[24], stage[24];
+    double left[24];
+    int sp = 0;
+    lo[0] = 0;
+    cnt[0] = k;
+    stage[0] = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+      if (stage[sp] == 0) {
+        if (cnt[sp] <= 128) {
+          ret = leaf_sum(at, lo[sp], cnt[sp]);
+          --sp;
+          continue;
+        }
+        int half = cnt[sp] / 2;
+        half -= half % 8;
+        stage[sp] = 1;
+        lo[sp + 1] = lo[sp];
+        cnt[sp + 1] = half;
+        stage[sp + 1] = 0;
+        ++sp;
+      } else if (stage[sp] == 1) {
+        left[sp] = ret;
+        int half = cnt[sp] / 2;
+        half -= half % 8;
+        stage[sp] = 2;
+        lo[sp + 1] = lo[sp] + half;
+        cnt[sp + 1] = cnt[sp] - half;
+        stage[sp + 1] = 0;
+        ++sp;
+      } else {
+        ret = left[sp] + ret;
+        --sp;
+      }
+    }
+    return ret / (double)k;
   };
   for (;; ++it) {
     for (int t = tid; t < k; t += KT) {

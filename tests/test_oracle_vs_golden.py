@@ -325,6 +325,9 @@ def test_kmeans_other_metrics_vs_reference():
                    "braycurtis", "canberra", "minkowski"):
       got = so.run_kmeans_metric(g["e_" + tag], k, 300, metric)
       assert np.array_equal(got, g["labels_%s_%s" % (tag, metric)])
+  # more than 128 clusters (numpy's pairwise row mean inside scipy's correlation)
+  gk = golden("kmeans_correlation_k150.npz")
+  assert np.array_equal(so.run_kmeans_metric(gk["e"], 150, 300, "correlation"), gk["labels"])
   # cosine through the generic function equals the bit-exact restatement
   e = g["e_a"]
   assert np.array_equal(so.run_kmeans_metric(e, 4, 300, "cosine"), so.run_kmeans(e, 4, 300))

@@ -648,8 +648,10 @@ def kernel_roofline(stage_ms, passes):
         "its per-block partials: n * n/64 * 12 B read")
     hbm("k_t32_candidates", "free_scan", t32 * tiles_run / (nt * (nt + 1) // 2),
         "1 read of the fp32 tiles of T that were computed (row maxima come from the product's epilogue)")
-    hbm("k_free_row_stats (exact rowmax / rowsum of S)", "free_stats", 2.2 * mat,
-        "row i and its ~1.2 candidate rows: ~2.2 n^2 * 8 B")
+    hbm("k_free_row_stats (exact rowmax / rowsum of S)", "free_stats", 1.0 * mat,
+        "one read of A: a row's candidates are itself or rows of its own cluster, read a moment "
+        "earlier by their own workgroups (PMC: 546 MB from HBM per launch at n = 8192 = 1.02 n^2 "
+        "* 8 B); y1 = A 1 comes from L2")
   else:
     mfma("k_gemm_nt<EpiNone,SYM> (Diffuse)", "diffuse", tri * n, "upper-triangle tiles")
   mfma("k_gemm_nt<EpiAffinity,SYM> (affinity)", "affinity_gemm", tri * d,

@@ -911,6 +911,8 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   }
   ev_rec(h, &e_after_refine);
   // ---- scaling vectors (RowWiseNormalize fold + Laplacian)
+  bool flags_by_kernel = false;
+  h->chain_flags_clean = false;
   if (resume) {
     SC_TRY(ensure_eig(h, n));  // (scaling vectors and the finite-ness flag are resident)
   } else if (!symmetric) {
@@ -923,21 +925,27 @@ int eig_ncluster_impl(sc_handle h, const sc_config* cfg, sc_diag* diag, FrontRes
   } else {
     if (!have_row_stats)
       launch_row_stats(s, cur, n, ld, ptr<double>(h->rowmax), ptr<double>(h->rowsum));
+    // (the kernel's first thread also sets up the solver's flag words: see rowops.hip)
+    SC_TRY(ensure_eig(h, n));
     launch_scaling_vectors(s, ptr<double>(h->rowmax), ptr<double>(h->rowsum), n,
                            cfg->laplacian_type, folded_rownorm ? 1 : 0, ptr<double>(h->cvec),
-                           ptr<double>(h->pvec), ptr<double>(h->tvec));
+                           ptr<double>(h->pvec), ptr<double>(h->tvec), ptr<int>(h->flags),
+                           h->affinity_from_embeddings ? ptr<int>(h->symflag) : nullptr);
+    flags_by_kernel = true;
+    h->chain_flags_clean = true;
   }
   // a NaN / inf anywhere in the refined matrix (zero embedding rows, an all-zero refined row
   // under RowWiseNormalize, ...) reaches its row sums, hence c / p: np.linalg.eig raises on
   // such input; the flag is read with the solver's first host sync
   SC_TRY(ensure_eig(h, n));
-  if (h->affinity_from_embeddings)  // a zero embedding row: its NaNs may have been dropped
+  if (flags_by_kernel) {
+  } else if (h->affinity_from_embeddings)  // a zero embedding row: its NaNs may have been dropped
     SC_HIP(h, hipMemcpyAsync(ptr<int>(h->flags) + 12, ptr<int>(h->symflag) + 1, sizeof(int),
                              hipMemcpyDeviceToDevice, s));
   else
     SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 12, 0, sizeof(int), s));
   launch_check_finite(s, ptr<double>(h->cvec), ptr<double>(h->pvec), n, ptr<int>(h->flags) + 12);
-  if (front_only)  // the lockstep group solve starts from clean chain flags
+  if (front_only && !flags_by_kernel)  // the lockstep group solve starts from clean chain flags
     SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
   SC_TRY(check_last(h, "scaling launch"));
   if (sw::eig_trace() > 2 && symmetric) {

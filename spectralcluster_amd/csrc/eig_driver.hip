@@ -489,6 +489,10 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
   const double* S = S_in;
   double* scratch = scratch_in;
   const bool free_at_entry = h->free_on;
+  // (set by eig_ncluster_impl when its scaling kernel has just cleared flags[13..15]; consumed
+  //  here whatever route this solve takes, so that it never outlives the call it was set for)
+  bool chain_flags_clean = h->chain_flags_clean;
+  h->chain_flags_clean = false;
   // S = A A^T after all (a dense route reads entries; or the exact-row route gave up): the fp64
   // MFMA product into the scratch matrix, A's buffer becomes the scratch
   auto free_materialize = [&](bool with_stats) -> int {
@@ -629,7 +633,10 @@ int sym_topk(sc_handle h, const double* S_in, int ld, int n, const EigRequest& r
     if (done) {
     } else if (fused) {
       // fused chain (k_lz_step): no host synchronisation until the first Rayleigh-Ritz
-      SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
+      // (the first start of a call: the scaling kernel has just cleared them, api.hip)
+      if (!chain_flags_clean)
+        SC_HIP(h, hipMemsetAsync(ptr<int>(h->flags) + 13, 0, 3 * sizeof(int), s));
+      chain_flags_clean = false;
       const EigWorkspace ws = eig_workspace(h);
       chain = LzChain();
       chain.three_pass = three_pass;

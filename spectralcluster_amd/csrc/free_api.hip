@@ -156,9 +156,16 @@ int free_fused_prepare(sc_handle h, hipStream_t s, int n, const double* cut, dou
   const size_t rows64 = (size_t)round_up(n, 64), nblk = rows64 / 64;
   SC_TRY(grow(h, h->fypart, rows64 * nblk * sizeof(double)));
   SC_TRY(grow(h, h->frpart, rows64 * nblk * sizeof(int)));
-  SC_HIP(h, hipMemsetAsync(h->fscal.p, 0, 4 * sizeof(double), s));
-  SC_HIP(h, hipMemsetAsync(h->fwords.p, 0, ((size_t)2 * n + kOvfWords) * sizeof(int), s));
-  launch_free_amax_from_cut(s, cut, n, p, floor_value, ptr<double>(h->fscal));
+  // max|a| from the cut vector, the other scalars and the words (M | count | ovf) cleared: ONE
+  // launch -- the group form with one member -- where rounds 4-5 had two fills and a reduction,
+  // each a dependent operation of ~4 us on the stream
+  FreeItem item{};
+  item.n = n;
+  item.words = ptr<int>(h->fwords);
+  item.scal = ptr<double>(h->fscal);
+  item.cut = cut;
+  item.p = p;
+  launch_free_begin_group(s, &item, 1, floor_value);
   return SC_OK;
 }
 

@@ -49,6 +49,8 @@ struct sc_handle_s {
   int n_vec = 0;          // eigenvector columns resident in E
   // matrices
   DevBuf X, Xn, A0, B1, B2;
+  bool chain_flags_clean = false;    // flags[13..15] were cleared by the scaling kernel: the first
+                                     // start of sym_topk skips its fill
   DevBuf Xalt;                       // second embeddings buffer: the NEXT call's upload lands here
   hipStream_t copy_stream = nullptr; // ... on this stream (predict_sequence, api.hip)
   // n-vectors

@@ -735,11 +735,23 @@ __device__ __forceinline__ void scaling_vectors_body(const double* __restrict__ 
   p[i] = pv;
   t[i] = tv;
 }
+// flags (may be nullptr): thread 0 also prepares the solver's flag words -- flags[12] (non-finite
+// input) starts from the zero-embedding-row word of the affinity stage (symflag[1], left as it is:
+// it describes the resident affinity, which later calls may solve again; nullptr: from 0) and the
+// chain words flags[13..15] from 0.  Rounds 1-5 did this with a device-to-device copy and a
+// fill: ~10-15 us each on the stream.
 __global__ void k_scaling_vectors(const double* __restrict__ rowmax,
                                   const double* __restrict__ rowsum, int n,
                                   int lap, int rownorm, double* __restrict__ c,
-                                  double* __restrict__ p, double* __restrict__ t) {
+                                  double* __restrict__ p, double* __restrict__ t,
+                                  int* __restrict__ flags, int* __restrict__ symflag) {
   scaling_vectors_body(rowmax, rowsum, n, lap, rownorm, c, p, t);
+  if (flags != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    flags[12] = symflag != nullptr ? symflag[1] : 0;
+    flags[13] = 0;
+    flags[14] = 0;
+    flags[15] = 0;
+  }
 }
 // scaling vectors + the finite-ness word of every member (flags[12] = a NaN embedding row or
 // a non-finite scaling entry: what the single-call path gets from its copy + k_check_finite)
@@ -912,9 +924,10 @@ void launch_row_stats(hipStream_t s, const double* in, int n, int ld,
 }
 void launch_scaling_vectors(hipStream_t s, const double* rowmax,
                             const double* rowsum, int n, int laplacian_type,
-                            int row_normalized, double* c, double* p, double* t) {
+                            int row_normalized, double* c, double* p, double* t, int* flags,
+                            int* symflag) {
   hipLaunchKernelGGL(k_scaling_vectors, dim3((n + 255) / 256), dim3(256), 0, s,
-                     rowmax, rowsum, n, laplacian_type, row_normalized, c, p, t);
+                     rowmax, rowsum, n, laplacian_type, row_normalized, c, p, t, flags, symflag);
 }
 // ---- grouped launches of the stages between the two GEMMs of a batch group
 static GroupOf<FrontItem> front_pack(const FrontItem* items, int count, int* nmax) {

@@ -152,7 +152,8 @@ void launch_row_stats(hipStream_t s, const double* in, int n, int ld,
 // c/p/t vectors of the symmetric operator  Op = diag(p) + diag(c) S diag(c)
 void launch_scaling_vectors(hipStream_t s, const double* rowmax,
                             const double* rowsum, int n, int laplacian_type,
-                            int row_normalized, double* c, double* p, double* t);
+                            int row_normalized, double* c, double* p, double* t,
+                            int* flags = nullptr, int* symflag = nullptr);
 void launch_laplacian(hipStream_t s, const double* in, double* out, int n, int ld,
                       int laplacian_type, double* deg_ws);
 // *flag = 1 if a or b holds a NaN / inf

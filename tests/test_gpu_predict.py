@@ -342,6 +342,29 @@ def test_batch_with_prefetched_uploads_vs_reference_golden():
   assert np.array_equal(clusterer.predict(other), singles[1])
 
 
+def test_batch_with_prefetched_uploads_reports_a_bad_member_and_recovers():
+  """A member that the reference would reject (a zero embedding row: `np.linalg.eig` raises "Array
+  must not contain infs or NaNs") in the middle of a prefetched sequence: the batch raises what the
+  single call raises, the helper thread is gone, and the handle serves the next calls correctly
+  (the resident buffer is whichever of the two the failed call used)."""
+  d = 64
+  good = so.blobs(1300, d, 4, seed=21)
+  bad = so.blobs(1400, d, 4, seed=22)
+  bad[700] = 0.0
+  clusterer = sca.SpectralClusterer(min_clusters=2, max_clusters=7,
+                                    refinement_options=icassp_options(1, 0.95),
+                                    laplacian_type=LAP[4])
+  want = clusterer.predict(good)
+  with pytest.raises(ValueError, match="infs or NaNs"):
+    clusterer.predict(bad)
+  for _ in range(2):
+    with pytest.raises(ValueError, match="infs or NaNs"):
+      clusterer.predict_batch([good, good, bad, good, good], streams=1)
+    assert np.array_equal(clusterer.predict(good), want)
+    batch = clusterer.predict_batch([good, good, good], streams=1)
+    assert all(np.array_equal(b, want) for b in batch)
+
+
 # --- error behaviour (reference spectral_clusterer.py:222-227 etc.) ---------------------------
 def test_error_behaviour():
   clusterer = sca.configs.icassp2018_clusterer

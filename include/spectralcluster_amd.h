@@ -481,6 +481,14 @@ int sc_host_tridiag_eigvectors(const double* d, const double* e, int n, const do
  * substitution.  Host-only; exported so it can be pinned against numpy without a GPU. */
 int sc_host_general_eig(const double* a, int m, int nvec, double* values_re, double* values_im,
                         double* vectors_re, double* vectors_im);
+/* The same contract in real arithmetic -- Householder Hessenberg reduction, double-shift QR for
+ * the values, inverse iteration + back-transform for the nvec leading vectors: what the
+ * Rayleigh-Ritz checks of block Arnoldi (every basis size, general eigen path; replaces
+ * np.linalg.eig of utils.py:59 on the projected problem) call since round 6; the function above is
+ * its fallback when an inverse iteration does not converge.  Host-only; exported so it can be
+ * pinned against numpy without a GPU. */
+int sc_host_general_eig_fast(const double* a, int m, int nvec, double* values_re,
+                             double* values_im, double* vectors_re, double* vectors_im);
 /* The host half of the dense general eigensolver for n > 64 (SC_EIG_PATH_DENSE_HESSENBERG;
  * replaces np.linalg.eig, utils.py:59, where more eigenvalues of a non-symmetric matrix are read
  * than a Krylov basis holds).  `packed` (n, n) row-major: an upper Hessenberg matrix on and

@@ -226,6 +226,8 @@ PROTOTYPES = {
                                                   _c_double_p, ctypes.c_int, _c_double_p]),
     "sc_host_general_eig": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p,
                                            _c_double_p, _c_double_p, _c_double_p]),
+    "sc_host_general_eig_fast": (ctypes.c_int, [_c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                           _c_double_p, _c_double_p, _c_double_p]),
     "sc_host_hessenberg_eig": (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_int32), _c_double_p,
                                               _c_double_p, _c_double_p, _c_double_p, _c_double_p]),

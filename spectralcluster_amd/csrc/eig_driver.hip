@@ -1660,12 +1660,17 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
           launch_copy_block(s, ptr<double>(h->Hbuf), kEigBlock, ptr<double>(h->T) + jb, kLdq,
                             m, kEigBlock);
         }
-        if (!wide) {
+        if (!wide && sw::gen_device_rr()) {
           launch_gen_eig(s, ptr<double>(h->T), kLdq, m, 1.0, m, theta_d, thetai_d, Yre, Yim, kLdq,
                          info_d);
         } else {
-          // projected problem of order up to 128: T comes to the host, its eigenpairs go back
-          // to where k_gen_eig leaves them
+          // The projected problem (order <= 64 narrow, <= 128 wide) is solved on the HOST: T comes
+          // over, its eigenpairs go back to where k_gen_eig leaves them.  Round 6: in the narrow
+          // form too -- the one-wavefront device kernel takes 4.0 ms at m = 64 and was 77 % of the
+          // GPU time of a general-path call (profiles/r35_gen_kernel_stats.txt); real double-shift
+          // QR + inverse iteration for the vectors a restart keeps take 0.3-0.9 ms
+          // (host_general_eig_fast; the complex Schur form is its fallback).  SC_GEN_DEVICE_RR=1:
+          // the device kernel (narrow form).
           SC_HIP(h, hipMemcpy2DAsync(h->h_rr, (size_t)m * sizeof(double), h->T.p,
                                      (size_t)kLdq * sizeof(double), (size_t)m * sizeof(double), m,
                                      hipMemcpyDeviceToHost, s));
@@ -1673,7 +1678,12 @@ int gen_topk(sc_handle h, const double* M, int ld, int n, int laplacian_type,
           hy.assign(2 * (size_t)m * m, 0.0);
           for (size_t e = 0; e < (size_t)m * m; ++e)
             if (!std::isfinite(h->h_rr[e])) return fail(h, SC_ERR_NON_FINITE, kNonFiniteMessage);
-          if (!host_general_eig(h->h_rr, m, m, m, th, thi, hy.data(), hy.data() + (size_t)m * m, m))
+          // (vectors: the pairs whose residual is evaluated and a restart materialises; all of
+          //  them while the far end -- Ritz pair m - 1 -- is tracked)
+          const int nvec = far_end ? m : std::min(m, wide ? 104 : 40);
+          if (!host_general_eig_fast(h->h_rr, m, m, nvec, th, thi, hy.data(),
+                                     hy.data() + (size_t)m * m, m) &&
+              !host_general_eig(h->h_rr, m, m, m, th, thi, hy.data(), hy.data() + (size_t)m * m, m))
             return fail(h, SC_ERR_NOT_CONVERGED, "QR iteration of the projected eigenproblem failed");
           SC_HIP(h, hipMemcpyAsync(theta_d, th, m * sizeof(double), hipMemcpyHostToDevice, s));
           SC_HIP(h, hipMemcpyAsync(thetai_d, thi, m * sizeof(double), hipMemcpyHostToDevice, s));

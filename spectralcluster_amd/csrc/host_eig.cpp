@@ -1256,6 +1256,120 @@ bool host_hessenberg_vectors(const HostHessenberg& w, const double* wr, const do
   return !failed.load();
 }
 
+// The projected (Rayleigh-Ritz) problems of block Arnoldi, order m <= 128, by the dense route's
+// own pieces instead of the complex Schur form above: Householder reduction to Hessenberg form
+// (dgehd2, in the storage host_hessenberg_unpack produces), every eigenvalue by the real
+// double-shift QR iteration (host_hessenberg_eigenvalues), and only the `nvec` leading
+// eigenvectors -- by inverse iteration on the Hessenberg form + back-transform
+// (host_hessenberg_vectors).  Same contract as host_general_eig: eigenvalues sorted by real part,
+// descending; vectors of unit 2-norm in Y[:, q] (row-major, ldy).  The complex QR with
+// accumulated Schur vectors is ~25 m^3 complex operations (4.3 ms at m = 64, 42 ms at m = 128 on a
+// host core -- what made the one-wavefront device kernel, 4 ms, worth having); this is ~10 m^3
+// real ones + O(nvec m^2): 0.3 / 2 ms.  false: QR or inverse iteration did not converge.
+bool host_general_eig_fast(const double* a, int lda, int m, int nvec, double* wr, double* wi,
+                           double* yre, double* yim, int ldy) {
+  if (m <= 0) return true;
+  HostHessenberg hw;
+  hw.n = m;
+  hw.H.assign((size_t)m * m, 0.0);
+  hw.V.assign((size_t)m * m, 0.0);
+  hw.tau.assign(std::max(0, m - 2), 0.0);
+  std::vector<double>& H = hw.H;
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) {
+      const double v = a[(size_t)i * lda + j];
+      if (!std::isfinite(v)) return false;
+      H[(size_t)i * m + j] = v;
+    }
+  // ---- dgehd2: H <- (I - tau v v^T) H (I - tau v v^T), v = (0 .. 0, 1, v_{k+2} ..)
+  std::vector<double> v(m), w(m);
+  for (int k = 0; k + 2 < m; ++k) {
+    double xnorm2 = 0.0, scale = 0.0;
+    for (int i = k + 2; i < m; ++i) scale = std::max(scale, std::fabs(H[(size_t)i * m + k]));
+    if (scale == 0.0) continue;  // tau = 0: nothing to annihilate
+    for (int i = k + 2; i < m; ++i) {
+      const double t = H[(size_t)i * m + k] / scale;
+      xnorm2 += t * t;
+    }
+    const double xnorm = scale * std::sqrt(xnorm2);
+    const double alpha = H[(size_t)(k + 1) * m + k];
+    const double beta = -std::copysign(std::hypot(alpha, xnorm), alpha);
+    const double tau = (beta - alpha) / beta;
+    const double inv = 1.0 / (alpha - beta);
+    v[k + 1] = 1.0;
+    for (int i = k + 2; i < m; ++i) v[i] = H[(size_t)i * m + k] * inv;
+    // right: H[:, k+1:] -= tau (H[:, k+1:] v) v^T
+    for (int i = 0; i < m; ++i) {
+      double dot = 0.0;
+      const double* row = H.data() + (size_t)i * m;
+      for (int j = k + 1; j < m; ++j) dot += row[j] * v[j];
+      w[i] = tau * dot;
+    }
+    for (int i = 0; i < m; ++i) {
+      double* row = H.data() + (size_t)i * m;
+      const double wi_ = w[i];
+      for (int j = k + 1; j < m; ++j) row[j] -= wi_ * v[j];
+    }
+    // left: H[k+1:, :] -= tau v (v^T H[k+1:, :])   (column k becomes (beta, 0 ..) by construction)
+    for (int j = k + 1; j < m; ++j) w[j] = 0.0;
+    for (int i = k + 1; i < m; ++i) {
+      const double* row = H.data() + (size_t)i * m;
+      const double vi = v[i];
+      for (int j = k + 1; j < m; ++j) w[j] += vi * row[j];
+    }
+    for (int i = k + 1; i < m; ++i) {
+      double* row = H.data() + (size_t)i * m;
+      const double tv = tau * v[i];
+      for (int j = k + 1; j < m; ++j) row[j] -= tv * w[j];
+    }
+    H[(size_t)(k + 1) * m + k] = beta;
+    for (int i = k + 2; i < m; ++i) H[(size_t)i * m + k] = 0.0;
+    hw.tau[k] = tau;
+    double* vk = hw.V.data() + (size_t)k * m;
+    for (int i = k + 1; i < m; ++i) vk[i] = v[i];
+  }
+  for (int k = 0; k + 2 < m; ++k) hw.V[(size_t)k * m + k + 1] = 1.0;
+  hw.norm = 0.0;
+  for (size_t e = 0; e < (size_t)m * m; ++e) hw.norm = std::max(hw.norm, std::fabs(H[e]));
+  std::vector<double> er(m), ei(m);
+  if (!host_hessenberg_eigenvalues(hw, er.data(), ei.data())) return false;
+  std::vector<int> order(m);
+  for (int i = 0; i < m; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return er[p] > er[q]; });
+  for (int i = 0; i < m; ++i) {
+    wr[i] = er[order[i]];
+    wi[i] = ei[order[i]];
+  }
+  nvec = std::min(nvec, m);
+  if (nvec <= 0) return true;
+  std::vector<double> vre((size_t)m * nvec, 0.0), vim((size_t)m * nvec, 0.0);
+  double resid = 0.0;
+  if (!host_hessenberg_vectors(hw, wr, wi, nvec, vre.data(), vim.data(), (size_t)m, &resid))
+    return false;
+  for (int q = 0; q < nvec; ++q) {
+    double n2 = 0.0;
+    for (int r = 0; r < m; ++r)
+      n2 += vre[(size_t)q * m + r] * vre[(size_t)q * m + r] + vim[(size_t)q * m + r] * vim[(size_t)q * m + r];
+    const double inv = n2 > 0.0 ? 1.0 / std::sqrt(n2) : 0.0;
+    for (int r = 0; r < m; ++r) {
+      yre[(size_t)r * ldy + q] = vre[(size_t)q * m + r] * inv;
+      yim[(size_t)r * ldy + q] = vim[(size_t)q * m + r] * inv;
+    }
+  }
+  return true;
+}
+
+extern "C" int sc_host_general_eig_fast(const double* a, int m, int nvec, double* values_re,
+                                        double* values_im, double* vectors_re,
+                                        double* vectors_im) {
+  if (!a || m <= 0 || nvec < 0 || nvec > m || !values_re || !values_im ||
+      (nvec > 0 && (!vectors_re || !vectors_im)))
+    return SC_ERR_INVALID;
+  return host_general_eig_fast(a, m, m, nvec, values_re, values_im, vectors_re, vectors_im, nvec)
+             ? SC_OK
+             : SC_ERR_NOT_CONVERGED;
+}
+
 // host-only exports (CPU tests): `packed` (n, n) row-major in the device reduction's storage
 // (Hessenberg matrix on and above the subdiagonal, reflectors below it), tau (n - 2).
 extern "C" int sc_host_hessenberg_eig(const double* packed, const double* tau, int n, int count,

@@ -33,6 +33,13 @@ bool host_partial_vectors(const HostTridiag& w, int need, double* Y, int ldy);
 bool host_general_eig(const double* a, int lda, int m, int nvec, double* wr, double* wi,
                       double* yre, double* yim, int ldy);
 
+// The same contract by real arithmetic: Householder Hessenberg reduction + double-shift QR for the
+// values + inverse iteration for the nvec leading vectors (the dense route's pieces below): what
+// block Arnoldi's Rayleigh-Ritz checks call since round 6 (0.3 ms at m = 64 where the complex
+// Schur form takes 4.3 and the one-wavefront device kernel 4.0).
+bool host_general_eig_fast(const double* a, int lda, int m, int nvec, double* wr, double* wi,
+                           double* yre, double* yim, int ldy);
+
 // ---- dense general eigenproblem of order n > 64: what follows the device's Hessenberg reduction
 struct HostHessenberg {
   int n = 0;

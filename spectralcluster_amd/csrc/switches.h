@@ -92,6 +92,12 @@ inline int gen_dense_max_n() {
   static const int v = getenv("SC_GEN_DENSE_MAX_N") ? atoi(getenv("SC_GEN_DENSE_MAX_N")) : 512;
   return v;
 }
+// SC_GEN_DEVICE_RR=1: the Rayleigh-Ritz problems of the narrow block Arnoldi (order <= 64) on the
+// one-wavefront device kernel k_gen_eig (rounds 2-5) instead of the host
+inline bool gen_device_rr() {
+  static const bool v = getenv("SC_GEN_DEVICE_RR") != nullptr;
+  return v;
+}
 // SC_GROUP_EQUAL_COUNT=1: the grouped batch cuts its size-sorted list into groups of equal
 // COUNT dealt round-robin to the lanes (rounds 2-5) instead of groups of equal cost dealt
 // longest-first (A/B measurements)

@@ -21,6 +21,9 @@ they are the repair / large-problem routes of the default ones:
                         default takes the explicit product
   SC_DIFFUSE=explicit   the fp64 Diffuse product on every golden, n = 2048 included, where the
                         default is matrix-free
+  SC_GEN_DEVICE_RR / SC_GEN_LOOSE_BULK (with SC_GEN_DENSE_MAX_N=64), SC_FREE_NO_PRUNE, SC_NO_PREFETCH,
+  SC_GROUP_EQUAL_COUNT: round 6's switches -- the Rayleigh-Ritz kernel, stop rule, product,
+  uploads and group formation of round 5
   SC_GEN_DENSE_MAX_N=64 block Arnoldi (narrow and wide) on the general-path goldens of n = 300 /
                         400, where the default since round 5 is the dense Hessenberg route
 
@@ -169,6 +172,16 @@ if os.environ.get("SC_KMEANS_SINGLE"):
     assert np.array_equal(got[i], want), i
     if u.shape[0] >= 1536:
       assert bd[i].diffuse_path in (_lib.DIFFUSE_PATH_FREE, _lib.DIFFUSE_PATH_FREE_THEN_EXPLICIT)
+if os.environ.get("SC_NO_PREFETCH") or os.environ.get("SC_GROUP_EQUAL_COUNT"):
+  # batches with the round-5 behaviours (every call uploads for itself; groups of equal count):
+  # members against single calls, a plain sequence and a grouped batch
+  utts = [so.blobs(m, 64, 4, seed=m) for m in (1300, 640, 1500, 380, 1700, 900, 2100, 450)]
+  c = sca.SpectralClusterer(min_clusters=2, max_clusters=12, refinement_options=opts,
+                            laplacian_type=sca.LaplacianType.GraphCut)
+  singles = [c.predict(u) for u in utts]
+  for got in (c.predict_batch(utts, streams=1), c.predict_batch(utts, group=4)):
+    for a, b in zip(got, singles):
+      assert so.adjusted_rand_index(a, b) == 1.0
 print("ALTERNATE_PATH_OK")
 """
 
@@ -177,6 +190,10 @@ print("ALTERNATE_PATH_OK")
                                     "SC_MATVEC_SYM_MIN_N", "SC_SWEEP_ONE_BY_ONE",
                                     "SC_EIG_FORCE_DENSE", "SC_DIFFUSE=free", "SC_DIFFUSE=explicit",
                                     "SC_GEN_DENSE_MAX_N=64",
+                                    "SC_GEN_DENSE_MAX_N=64+SC_GEN_DEVICE_RR",
+                                    "SC_GEN_DENSE_MAX_N=64+SC_GEN_LOOSE_BULK",
+                                    "SC_FREE_NO_PRUNE", "SC_DIFFUSE=free+SC_FREE_NO_PRUNE",
+                                    "SC_NO_PREFETCH", "SC_GROUP_EQUAL_COUNT",
                                     "SC_DIFFUSE=free+SC_EIG_HOST_CHAIN",
                                     "SC_DIFFUSE=free+SC_EIG_FORCE_DENSE",
                                     "SC_DIFFUSE=free+SC_MATVEC_SYM_MIN_N"])

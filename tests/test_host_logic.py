@@ -533,10 +533,14 @@ def test_host_partial_symmetric_eig_vs_numpy():
     assert np.abs(v.T @ v - np.eye(need)).max() < 1e-12 * m
 
 
-def test_host_general_eig_vs_numpy():
-  """The Rayleigh-Ritz solve of the WIDE block Arnoldi (general eigen path, projected
-  problems of order up to 128): eigenvalues sorted by real part, unit-norm eigenvectors."""
+@pytest.mark.parametrize("entry", ["sc_host_general_eig", "sc_host_general_eig_fast"])
+def test_host_general_eig_vs_numpy(entry):
+  """The Rayleigh-Ritz solves of block Arnoldi (general eigen path, projected problems of order
+  up to 128): eigenvalues sorted by real part, unit-norm eigenvectors.  `_fast` (round 6, what
+  the checks call: Hessenberg + real double-shift QR + inverse iteration for the leading vectors)
+  and the complex-Schur solver that is its fallback, both against numpy."""
   lib = _lib.load()
+  solve = getattr(lib, entry)
   rng = np.random.default_rng(11)
   for m, nvec in ((1, 1), (2, 2), (7, 7), (24, 10), (64, 64), (100, 50), (128, 128)):
     for kind in ("random", "nearly symmetric", "block Hessenberg"):
@@ -548,9 +552,8 @@ def test_host_general_eig_vs_numpy():
       a = np.ascontiguousarray(a)
       wr, wi = np.empty(m), np.empty(m)
       vr, vi = np.empty((m, nvec)), np.empty((m, nvec))
-      assert lib.sc_host_general_eig(_lib.as_double_p(a), m, nvec, _lib.as_double_p(wr),
-                                     _lib.as_double_p(wi), _lib.as_double_p(vr),
-                                     _lib.as_double_p(vi)) == 0
+      assert solve(_lib.as_double_p(a), m, nvec, _lib.as_double_p(wr), _lib.as_double_p(wi),
+                   _lib.as_double_p(vr), _lib.as_double_p(vi)) == 0
       assert np.all(np.diff(wr) <= 0.0)  # sorted by real part, descending
       w = wr + 1j * wi
       ref = np.linalg.eigvals(a)

@@ -1299,7 +1299,7 @@ int predict_sequence(sc_handle h, const int* idx, int count, const double* const
   int finished = 0;   // calls [0, finished) are done with their buffer
   bool stop = false;
   hipError_t upload_err = hipSuccess;
-  std::thread helper([&]() {
+  auto upload_loop = [&]() {
     hipSetDevice(h->device);
     for (int k = 0; k < count; ++k) {
       {
@@ -1322,7 +1322,17 @@ int predict_sequence(sc_handle h, const int* idx, int count, const double* const
       uploaded = k + 1;
       cv.notify_all();
     }
-  });
+  };
+  std::thread helper;
+  try {
+    helper = std::thread(upload_loop);
+  } catch (...) {  // (no thread to be had: every call uploads for itself)
+    for (int k = 0; k < count; ++k) {
+      const int i = at(k);
+      SC_TRY(sc_predict(h, xs[i], ns[i], d, cfg, labels[i], diags ? diags + i : nullptr));
+    }
+    return SC_OK;
+  }
   int rc = SC_OK;
   for (int k = 0; k < count && rc == SC_OK; ++k) {
     const int i = at(k);

@@ -216,9 +216,29 @@ __device__ __forceinline__ void row_percentile_cut_body(
     __syncthreads();
     const unsigned long long prefix = s_prefix, mask = s_mask;
     const int shift = 8 * pass;
-    for (int j = tid; j < n; j += 256) {
-      const unsigned long long k = key_at(j);
-      if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> shift) & 255)], 1);
+    // Histogram with wave-aggregated atomics: affinities live in [0, 1], so in the first passes
+    // (sign, exponent, leading mantissa bits) nearly every key of the row falls into one or two
+    // bins and 4096-8192 LDS atomics on the same address serialise (the 16-member Turn-to-Diarize
+    // sweep at n = 4096 spent 2.9 ms in this kernel, profiles/r37).  Lanes that share the wave
+    // leader's bin send ONE atomicAdd of their count; after three such rounds whatever is left
+    // (scattered keys: the late passes) goes one by one.
+    for (int j0 = 0; j0 < n; j0 += 256) {  // (wave-uniform trip count)
+      const int j = j0 + tid;
+      const unsigned long long k = j < n ? key_at(j) : 0ull;
+      const bool active = j < n && (k & mask) == prefix;
+      const int bin = (int)((k >> shift) & 255);
+      unsigned long long todo = __ballot(active);
+      for (int round = 0; todo != 0ull; ++round) {
+        if (round == 3) {
+          if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1);
+          break;
+        }
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b0 = __shfl(bin, leader);
+        const unsigned long long same = __ballot(active && bin == b0) & todo;
+        if (lane == leader) atomicAdd(&hist[b0], (int)__popcll(same));
+        todo &= ~same;
+      }
     }
     __syncthreads();
     if (wave == 0) {  // bins 4*lane .. 4*lane+3: scan, find the bin holding the rank

@@ -346,10 +346,29 @@ class RcclComm(Comm):
     ready = sock.allgather_bytes((b"\0" if pre else b"\1") + pre.encode()[:200])
     comm = None
     if head[:1] == b"\1" and all(r[:1] == b"\1" for r in ready):
-      try:
-        comm = cls(handle, rank, size, head[1:])
-      except Exception as exc:  # pylint: disable=broad-except
-        why = "rank %d: %s" % (rank, exc)
+      # ncclCommInitRank cannot be cancelled: it runs on a daemon thread, and a rank that does
+      # not get its communicator within SC_COMM_INIT_TIMEOUT seconds (default 90: a first
+      # communicator of 8 ranks takes a few seconds) reports that instead of hanging the job --
+      # the ranks then agree on the TCP communicator below.  (No N > 1 RCCL communicator has
+      # ever been brought up in this project's test pool: the watchdog is for the day one is.)
+      import threading
+      box = {}
+
+      def bring_up():
+        try:
+          box["comm"] = cls(handle, rank, size, head[1:])
+        except Exception as exc:  # pylint: disable=broad-except
+          box["why"] = "rank %d: %s" % (rank, exc)
+
+      worker = threading.Thread(target=bring_up, daemon=True)
+      worker.start()
+      limit = float(os.environ.get("SC_COMM_INIT_TIMEOUT", "90"))
+      worker.join(limit)
+      if worker.is_alive():
+        why = "rank %d: ncclCommInitRank did not return within %g s" % (rank, limit)
+      else:
+        comm = box.get("comm")
+        why = box.get("why", why)
     elif pre:
       why = pre
     reports = sock.allgather_bytes((b"\1" if comm is not None else b"\0") + why.encode()[:200])

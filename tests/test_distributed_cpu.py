@@ -192,6 +192,57 @@ def test_tcp_fallback_when_rccl_cannot_come_up(tmp_path):
   assert all(os.path.exists("%s.%d" % (out, r)) for r in range(3))
 
 
+def _hung_init_worker(rank, world, path, out):
+  sys.path.insert(0, ROOT)
+  os.environ.update({"SC_COMM_ID_FILE": path, "WORLD_SIZE": str(world), "RANK": str(rank),
+                     "MASTER_ADDR": "127.0.0.1", "SC_COMM_INIT_TIMEOUT": "1.5"})
+  import time
+  from spectralcluster_amd import multigpu
+
+  class Lib:  # a library whose preflight passes ...
+    @staticmethod
+    def sc_comm_available():
+      return 1
+
+    @staticmethod
+    def sc_synchronize(raw):
+      return 0
+
+  class Handle:
+    lib, raw = Lib(), None
+
+  def hang(self, handle, rank, size, unique_id):  # ... and whose ncclCommInitRank never returns
+    time.sleep(3600)
+
+  multigpu.RcclComm.__init__ = hang
+  multigpu.RcclComm.new_unique_id = staticmethod(lambda: bytes(128))
+  t0 = time.monotonic()
+  comm = multigpu.RcclComm.from_env(Handle(), timeout_s=60.0)
+  assert isinstance(comm, multigpu.SocketComm) and "did not return within" in comm.note
+  assert time.monotonic() - t0 < 30.0
+  assert comm.allgather_bytes(bytes([rank])) == [bytes([r]) for r in range(world)]
+  comm.close()
+  with open("%s.%d" % (out, rank), "w") as f:
+    f.write("ok")
+  os._exit(0)  # (the hung daemon thread must not keep the process)
+
+
+def test_tcp_fallback_when_rccl_init_hangs(tmp_path):
+  """A communicator bring-up that never returns (ncclCommInitRank cannot be cancelled) must not
+  hang the job: after SC_COMM_INIT_TIMEOUT every rank reports it and the TCP communicator
+  carries the collectives."""
+  import multiprocessing as mp
+  ctx = mp.get_context("spawn")
+  path, out = str(tmp_path / "id"), str(tmp_path / "done")
+  procs = [ctx.Process(target=_hung_init_worker, args=(r, 2, path, out)) for r in (1, 0)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(120)
+    assert p.exitcode == 0
+  assert all(os.path.exists("%s.%d" % (out, r)) for r in range(2))
+
+
 def test_rendezvous_file_rejects_stale_and_planted_files(tmp_path, monkeypatch):
   """the id file of a crashed earlier launch (old timestamp), a truncated blob and
   a pre-planted symlink must not be taken for this launch's rendezvous blob."""

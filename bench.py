@@ -410,7 +410,7 @@ def batch512_leg(sca, multigpu, comm, fence, group=16, streams=8, project=True):
         lambda share: clusterer.predict_batch([mine[i] for i in share], group=group),
         elapsed, fence,
         "each rank's LPT share of the 512 utterances as its own predict_batch(group=%d) on "
-        "this one GPU (median of 3 passes per share, like the whole job's time): arenas warm (a "
+        "this one GPU (median over 3 interleaved rounds per share, like the whole job's time): arenas warm (a "
         "long-lived server process), pageable H2D of the share and the group pipeline's "
         "fill/drain inside; the all-gather of < 1 MB of labels is not" % group)
   return out
@@ -422,22 +422,25 @@ def project_shares(partition, run_share, t_whole, fence, note):
   `sum_share_s` > `t_whole` is the fixed per-rank cost that strong scaling does not divide."""
   rows = {}
   for world in (2, 4, 8):
-    secs = []
-    for share in partition(world):
-      if not share:
-        secs.append(0.0)
-        continue
-      # (median of three passes per share -- like `t_whole`, which is the median of three passes
-      #  of the whole job: a single pass of a 12 ms share carries host-thread scheduling noise
-      #  of a millisecond or more now and then, and the maximum over 8 shares collects it)
-      trials = []
-      for _ in range(3):
+    # Three ROUNDS over all shares, the median per share (like `t_whole`, the median of three
+    # passes of the whole job).  Interleaved, not three passes of one share back to back: a
+    # transient of some tens of milliseconds on the box (host scheduling, clocks) then meets
+    # different shares in different rounds instead of all three trials of one -- a single pass
+    # of a 12 ms share, or three in a row, put one share at 14-19 ms in about every second run,
+    # and the maximum over 8 shares collects it.
+    shares = partition(world)
+    trials = [[] for _ in shares]
+    for _ in range(3):
+      for idx, share in enumerate(shares):
+        if not share:
+          trials[idx].append(0.0)
+          continue
         fence()
         t0 = time.perf_counter()
         run_share(share)
         fence()
-        trials.append(time.perf_counter() - t0)
-      secs.append(float(np.median(trials)))
+        trials[idx].append(time.perf_counter() - t0)
+    secs = [float(np.median(t)) for t in trials]
     rows[str(world)] = {"max_share_s": max(secs), "sum_share_s": sum(secs),
                         "share_ms": [round(1e3 * v, 2) for v in secs],
                         "imbalance": max(secs) / (sum(secs) / world),

@@ -263,34 +263,51 @@ int enqueue_front_grouped(sc_handle lead, const double* const* xs, const int* ns
   launch_front_begin_group(s, fi, count, true);
   launch_gemm_nt_group(s, aff, count, kEpiAffinity, 2);
   launch_gaussian_blur_group(s, fi, count, cfg->blur_radius, ptr<double>(lead->blurw));
-  launch_threshold_symmetrize_group(s, fi, count, cfg->p_percentile, cfg->soft_multiplier,
-                                    cfg->binarize, cfg->symmetrize_type, cfg->preserve_diagonal);
+  // rowmax / rowsum of S = A A^T without forming it, for the members that take that route (the
+  // cut vector bounds max|a|: the grouped front is the ICASSP2018 sequence on a cosine affinity):
+  // begin, scan and statistics are one launch each for all of them, the digit products one
+  // launch with a member per blockIdx.y; round 6: their digits come out of the threshold pass
+  sc_handle fh[kGroupMax];
+  const double* mats[kGroupMax];
+  const double* cuts[kGroupMax];
+  double ps[kGroupMax];
+  int nn[kGroupMax], ll[kGroupMax], nf = 0, fz[kGroupMax];
+  FreeItem fitems[kGroupMax];
+  for (int z = 0; z < count; ++z) {
+    if (!mb[z].free_op) continue;
+    sc_handle h = mb[z].h;
+    fh[nf] = h;
+    fz[nf] = z;
+    mats[nf] = fi[z].B2;
+    cuts[nf] = ptr<double>(h->cut);
+    ps[nf] = cfg->p_percentile;
+    nn[nf] = h->n;
+    ll[nf] = h->ldn;
+    ++nf;
+  }
+  const double amax_floor = (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0;
+  const bool fused_digits = nf > 0 && !sw::group_quantize_pass();
+  if (fused_digits) {
+    // (the cuts first -- max|a| comes from them --, then the begin step, then the pass itself)
+    launch_cut_from_partials_group(s, fi, count, cfg->p_percentile);
+    TsDigits packed[kGroupMax], digits[kGroupMax];
+    memset(digits, 0, sizeof(digits));
+    SC_TRY(free_group_prepare(fh, mats, cuts, ps, nf, ll, nn, s, amax_floor, fitems, packed));
+    for (int q = 0; q < nf; ++q) digits[fz[q]] = packed[q];
+    launch_threshold_symmetrize_group(s, fi, count, cfg->p_percentile, cfg->soft_multiplier,
+                                      cfg->binarize, cfg->symmetrize_type, cfg->preserve_diagonal,
+                                      true, digits);
+  } else {
+    launch_threshold_symmetrize_group(s, fi, count, cfg->p_percentile, cfg->soft_multiplier,
+                                      cfg->binarize, cfg->symmetrize_type, cfg->preserve_diagonal);
+  }
   launch_gemm_nt_group(s, dif, count, kEpiNone, 1);
   {
-    // rowmax / rowsum of S = A A^T without forming it, for the members that take that route
-    // (the cut vector bounds max|a|: the grouped front is the ICASSP2018 sequence on a cosine
-    // affinity): begin, quantiser, scan and statistics are one launch each for all of them,
-    // the digit products one per member (their sizes differ)
-    sc_handle fh[kGroupMax];
-    const double* mats[kGroupMax];
-    const double* cuts[kGroupMax];
-    double ps[kGroupMax];
-    int nn[kGroupMax], ll[kGroupMax], nf = 0;
-    FreeItem fitems[kGroupMax];
-    for (int z = 0; z < count; ++z) {
-      if (!mb[z].free_op) continue;
-      sc_handle h = mb[z].h;
-      fh[nf] = h;
-      mats[nf] = fi[z].B2;
-      cuts[nf] = ptr<double>(h->cut);
-      ps[nf] = cfg->p_percentile;
-      nn[nf] = h->n;
-      ll[nf] = h->ldn;
-      ++nf;
-    }
     if (nf > 0) {
-      SC_TRY(free_group_begin(fh, mats, cuts, ps, nf, ll, nn, s,
-                              (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0, fitems));
+      if (fused_digits)
+        SC_TRY(free_group_digits(fh, fitems, nf, s));
+      else
+        SC_TRY(free_group_begin(fh, mats, cuts, ps, nf, ll, nn, s, amax_floor, fitems));
       {  // the digit products of all of them: one launch (blockIdx.y = member)
         const signed char* qs[kGroupMax];
         float* ts[kGroupMax];
@@ -1016,9 +1033,35 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
                                cfg->preserve_diagonal);
       }
     }
-    launch_threshold_symmetrize_group(s, fi, cnt, cfg->p_percentile, cfg->soft_multiplier,
-                                      cfg->binarize, cfg->symmetrize_type,
-                                      cfg->preserve_diagonal, own_cuts);
+    // (round 6: with max|a| known from the cuts the threshold pass writes the members' digits
+    //  itself -- free_group_prepare / free_group_digits, free_api.hip)
+    FreeItem fitems[kGroupMax];
+    const bool fused_digits = icassp && free_route && amax_from_cut && !sw::group_quantize_pass();
+    if (fused_digits) {
+      sc_handle fh0[kGroupMax];
+      const double* mats[kGroupMax];
+      const double* cuts[kGroupMax];
+      int nn[kGroupMax], ll[kGroupMax];
+      for (int z = 0; z < cnt; ++z) {
+        fh0[z] = em[z].h;
+        mats[z] = em[z].S;
+        cuts[z] = ptr<double>(em[z].h->cut);
+        nn[z] = n;
+        ll[z] = ld;
+      }
+      if (!own_cuts) launch_cut_from_partials_group(s, fi, cnt, cfg->p_percentile);
+      TsDigits digits[kGroupMax];
+      SC_TRY(free_group_prepare(fh0, mats, cuts, p_values + base, cnt, ll, nn, s,
+                                (cfg->binarize || cfg->preserve_diagonal) ? 1.0 : 0.0, fitems,
+                                digits));
+      launch_threshold_symmetrize_group(s, fi, cnt, cfg->p_percentile, cfg->soft_multiplier,
+                                        cfg->binarize, cfg->symmetrize_type,
+                                        cfg->preserve_diagonal, true, digits);
+    } else {
+      launch_threshold_symmetrize_group(s, fi, cnt, cfg->p_percentile, cfg->soft_multiplier,
+                                        cfg->binarize, cfg->symmetrize_type,
+                                        cfg->preserve_diagonal, own_cuts);
+    }
     if (!icassp) {
       // no Diffuse: the row sums of the symmetrised matrix are the degrees
       launch_row_stats_group(s, fi, cnt);
@@ -1028,10 +1071,11 @@ extern "C" int sc_eig_ncluster_sweep(sc_handle h, const sc_config* cfg, const do
       const signed char* qs[kGroupMax];
       float* ts[kGroupMax];
       unsigned* ms[kGroupMax];
-      FreeItem fitems[kGroupMax];
       sc_handle fh[kGroupMax];
       for (int z = 0; z < cnt; ++z) fh[z] = em[z].h;
-      if (amax_from_cut) {
+      if (fused_digits) {
+        SC_TRY(free_group_digits(fh, fitems, cnt, s));
+      } else if (amax_from_cut) {
         // begin, quantiser, scan and statistics of all members: one launch each
         const double* mats[kGroupMax];
         const double* cuts[kGroupMax];

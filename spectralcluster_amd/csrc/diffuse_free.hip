@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void k_free_amax_from_cut(const double* __rest
 // group; blockIdx.y = member): workgroup 0 of a member turns its cut vector into max|a| and
 // clears the other scalars, the others clear its words (row maxima, candidate counts, overflow
 // record) -- one launch where every member had two fills and a reduction of its own.
-__global__ __launch_bounds__(256) void k_free_begin_g(const GroupOf<FreeItem> g, double floor_value) {
+__global__ __launch_bounds__(256) void k_free_begin_g(const GroupOf<FreeItem> g, double floor_value,
+                                                      int pad_rows) {
   const FreeItem& a = g.s[blockIdx.y];
   if (a.n <= 0) return;
   if (blockIdx.x == 0) {
@@ -224,12 +225,27 @@ __global__ __launch_bounds__(256) void k_free_begin_g(const GroupOf<FreeItem> g,
     return;
   }
   const int nwords = 2 * a.n + kFreeOvfWords;
-  const int e = ((int)blockIdx.x - 1) * 1024 + 4 * threadIdx.x;
-  if (e + 3 < nwords) {
-    *reinterpret_cast<int4*>(a.words + e) = make_int4(0, 0, 0, 0);
-  } else {
-    for (int u = e; u < nwords && u < e + 4; ++u) a.words[u] = 0;
+  const int wblocks = (nwords + 1023) / 1024;
+  if ((int)blockIdx.x <= wblocks) {
+    const int e = ((int)blockIdx.x - 1) * 1024 + 4 * threadIdx.x;
+    if (e + 3 < nwords) {
+      *reinterpret_cast<int4*>(a.words + e) = make_int4(0, 0, 0, 0);
+    } else {
+      for (int u = e; u < nwords && u < e + 4; ++u) a.words[u] = 0;
+    }
+    return;
   }
+  // (workgroups beyond the words, launched only when the threshold pass writes the digits: the
+  //  digit rows [64 ceil(n / 64), 128 ceil(n / 128)) belong to none of its tiles -- zero)
+  if (!pad_rows || a.Q == nullptr) return;
+  const int t64 = (a.n + 63) / 64 * 64, t128 = (a.n + 127) / 128 * 128;
+  if (t128 == t64) return;
+  const size_t pitch = (size_t)2 * t64;  // bytes per digit row
+  const size_t total16 = (size_t)(t128 - t64) * pitch / 16;
+  int4* dst = reinterpret_cast<int4*>(a.Q + (size_t)t64 * pitch);
+  const size_t stride = (size_t)(gridDim.x - 1 - wblocks) * 256;
+  for (size_t u = (size_t)((int)blockIdx.x - 1 - wblocks) * 256 + threadIdx.x; u < total16; u += stride)
+    dst[u] = make_int4(0, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------- quantiser
@@ -1278,13 +1294,15 @@ static GroupOf<FreeItem> free_pack(const FreeItem* items, int count, int* nmax) 
   }
   return g;
 }
-void launch_free_begin_group(hipStream_t s, const FreeItem* items, int count, double floor_value) {
+void launch_free_begin_group(hipStream_t s, const FreeItem* items, int count, double floor_value,
+                             bool pad_rows) {
   int nmax;
   const GroupOf<FreeItem> g = free_pack(items, count, &nmax);
   if (nmax == 0) return;
   const int nwords = 2 * nmax + kFreeOvfWords;
-  hipLaunchKernelGGL(k_free_begin_g, dim3(1 + (nwords + 1023) / 1024, count), dim3(256), 0, s, g,
-                     floor_value);
+  // (pad_rows: 32 more workgroups per member clear the digit rows no threshold tile writes)
+  hipLaunchKernelGGL(k_free_begin_g, dim3(1 + (nwords + 1023) / 1024 + (pad_rows ? 32 : 0), count),
+                     dim3(256), 0, s, g, floor_value, pad_rows ? 1 : 0);
 }
 void launch_free_quantize_group(hipStream_t s, const FreeItem* items, int count) {
   int nmax;
@@ -1294,11 +1312,13 @@ void launch_free_quantize_group(hipStream_t s, const FreeItem* items, int count)
   hipLaunchKernelGGL(k_free_quantize_g, dim3(free_rows_padded(nmax), count), dim3(256),
                      (size_t)2 * free_k_padded(nmax), s, g);
 }
-void launch_free_tile_flags_group(hipStream_t s, const FreeItem* items, int count, bool prune) {
+void launch_free_tile_flags_group(hipStream_t s, const FreeItem* items, int count, bool prune,
+                                  bool seg_reduce) {
   int nmax;
   const GroupOf<FreeItem> g = free_pack(items, count, &nmax);
   if (nmax == 0) return;
-  hipLaunchKernelGGL(k_free_seg_reduce_g, dim3(free_k_padded(nmax) / 64, count), dim3(256), 0, s, g);
+  if (seg_reduce)
+    hipLaunchKernelGGL(k_free_seg_reduce_g, dim3(free_k_padded(nmax) / 64, count), dim3(256), 0, s, g);
   hipLaunchKernelGGL(k_free_tile_flags_g, dim3((nmax + kI8Tile - 1) / kI8Tile, count),
                      dim3(kFlagThreads), 0, s, g, prune ? 1 : 0);
 }

@@ -133,9 +133,52 @@ int free_group_begin(sc_handle* hs, const double* const* A, const double* const*
   launch_free_begin_group(s, items, count, floor_value);
   launch_free_quantize_group(s, items, count);
   // the members' skip lists (the caller hands items[z].plan to the grouped product)
-  launch_free_tile_flags_group(s, items, count, free_prune_on(hs[0]));
+  launch_free_tile_flags_group(s, items, count, free_prune_on(hs[0]), true);
   return SC_OK;
 }
+// Round 6: the grouped threshold + symmetrise pass writes the members' digits itself (what the
+// single call has done since round 4) -- the quantiser's extra read of every member's matrix goes
+// (k_free_quantize_g: 0.57 ms of a 16-value sweep at n = 4096, 3.3 % of config 5's GPU time).
+//   free_group_prepare   BEFORE the threshold pass, once the cut vectors are there: buffers, max|a|
+//                        from the cuts, words cleared, the digit rows no tile writes cleared; fills
+//                        items[] and digits[] (what launch_threshold_symmetrize_group takes)
+//   free_group_digits    AFTER it: y1 / R / max R / the skip-list thresholds from the row partials,
+//                        then the members' skip lists
+// then the grouped product and free_group_end as before.  SC_GROUP_QUANTIZE_PASS=1: rounds 4-5's
+// separate quantiser (free_group_begin).
+int free_group_prepare(sc_handle* hs, const double* const* A, const double* const* cuts,
+                       const double* ps, int count, const int* lds, const int* ns, hipStream_t s,
+                       double floor_value, FreeItem* items, TsDigits* digits) {
+  for (int z = 0; z < count; ++z) {
+    sc_handle h = hs[z];
+    const int n = ns[z], ld = lds[z];
+    SC_TRY(ensure_free(h, n));
+    const size_t rows64 = (size_t)round_up(n, 64), nblk = rows64 / 64;
+    SC_TRY(grow(h, h->fypart, rows64 * nblk * sizeof(double)));
+    SC_TRY(grow(h, h->frpart, rows64 * nblk * sizeof(int)));
+    items[z] = FreeItem{A[z], n, ld, ptr<signed char>(h->fq), ptr<float>(h->ft32),
+                        ptr<int>(h->fwords), ptr<double>(h->fscal), ptr<double>(h->fy1),
+                        ptr<double>(h->fR), ptr<int>(h->fcand), ptr<double>(h->rowmax),
+                        ptr<double>(h->rowsum), cuts[z], ps[z]};
+    items[z].q2part = ptr<double>(h->fq2part);
+    items[z].mx64 = ptr<double>(h->fmx64);
+    items[z].tau64 = ptr<float>(h->ftau64);
+    items[z].plan = ptr<int>(h->fplan);
+    items[z].ypart = ptr<double>(h->fypart);
+    items[z].rpart = ptr<int>(h->frpart);
+    digits[z] = TsDigits{ptr<signed char>(h->fq), (size_t)2 * rows64, (int)nblk,
+                         ptr<double>(h->fscal), ptr<double>(h->fypart), ptr<int>(h->frpart),
+                         ptr<double>(h->fq2part), ptr<double>(h->fmx64)};
+  }
+  launch_free_begin_group(s, items, count, floor_value, true);
+  return SC_OK;
+}
+int free_group_digits(sc_handle* hs, const FreeItem* items, int count, hipStream_t s) {
+  launch_free_partials_reduce_group(s, items, count);
+  launch_free_tile_flags_group(s, items, count, free_prune_on(hs[0]), false);
+  return SC_OK;
+}
+
 int free_group_end(sc_handle* hs, const FreeItem* items, int count, hipStream_t s) {
   launch_free_scan_stats_group(s, items, count);
   SC_TRY(check_last(hs[0], "matrix-free diffuse launch"));

@@ -361,6 +361,11 @@ int free_group_begin(sc_handle* hs, const double* const* A, const double* const*
                      const double* ps, int count, const int* lds, const int* ns, hipStream_t s,
                      double floor_value, struct FreeItem* items);
 int free_group_end(sc_handle* hs, const struct FreeItem* items, int count, hipStream_t s);
+// (the grouped threshold pass writes the digits: free_api.hip)
+int free_group_prepare(sc_handle* hs, const double* const* A, const double* const* cuts,
+                       const double* ps, int count, const int* lds, const int* ns, hipStream_t s,
+                       double floor_value, struct FreeItem* items, struct TsDigits* digits);
+int free_group_digits(sc_handle* hs, const struct FreeItem* items, int count, hipStream_t s);
 int free_fused_prepare(sc_handle h, hipStream_t s, int n, const double* cut, double p,
                        double floor_value);
 int free_diffuse_stats(sc_handle h, const double* A, int ld, int n, bool have_amax = false,

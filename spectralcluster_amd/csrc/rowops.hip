@@ -346,23 +346,7 @@ __global__ __launch_bounds__(kRowThreads) void k_row_threshold_cut(
 // coalesced): 1 read + 1 write of n^2 for the two ops together.
 constexpr int kTsTile = 64;  // tile edge of the threshold + symmetrise pass
 // DIGITS: the pass also leaves what the quantiser of the matrix-free Diffuse (diffuse_free.hip,
-// k_free_quantize) would compute from its result in a pass of its own -- the two 8-bit digits of
-// q = rint(sigma a) in the product's layout (a 64 x 64 tile is exactly one 128-byte line per row:
-// 64 high digits, 64 low digits) and, per row and 64-column block, the partial sums of a and of
-// |q| (k_free_partials_reduce adds them in block order).  Saves one read of the matrix.
-struct TsDigits {
-  signed char* Q;      // digits, row pitch `pitch` bytes
-  size_t pitch;
-  int nblk;            // 64-column blocks per row
-  double* scal;        // [0] = max |a| (known from the cut vector before this pass); [3] set when
-                       // a finite value had to be clamped after all (diffuse_free.hip)
-  double* ypart;       // [block * 64 nblk + row] sum of a  (a tile's 64 partials are contiguous:
-  int* rpart;          // [block * 64 nblk + row] sum of |q|   whole lines leave the L2)
-  double* q2part;      // [block * 64 nblk + row] sum of q^2 (an exact integer < 2^37): the squared
-                       // norm of the row's digit segment, for the tile skip list (diffuse_free.hip)
-  double* mx64;        // [row group * nblk + block] the largest segment norm of a tile's 64 rows
-                       // (rounded up): exactly one workgroup holds the 64 values, a plain store
-};
+// k_free_quantize) would compute from its result in a pass of its own: TsDigits, sc_internal.h.
 __device__ __forceinline__ double ts_digits(const TsDigits& dg, double sigma, int row, int blk,
                                           int c0, double v0, double v1, bool lane0 /* the half-wave's LAST lane */) {
   int qv[2];
@@ -418,6 +402,8 @@ __device__ __forceinline__ void threshold_symmetrize_body(
   __shared__ double tT[kTsTile][kTsTile + 1];
   __shared__ double smax[2][8];
   double q2m = 0.0;
+  // (grouped launches carry members with and without digits: a workgroup-uniform branch)
+  const bool digits = DIGITS && dg.Q != nullptr;
   // tile pair of this workgroup: row ti of the upper triangle starts at
   // off(ti) = ti * ntiles - ti (ti - 1) / 2.  Closed form + one correction step (a counting
   // loop here was 5.6e7 scalar instructions per launch at n = 8192: up to 256 trips per wave)
@@ -477,7 +463,7 @@ __device__ __forceinline__ void threshold_symmetrize_body(
   }
   __syncthreads();
   double sigma = 0.0;
-  if (DIGITS) {
+  if (digits) {
     const double amax = dg.scal[0];
     sigma = (amax > 0.0 && isfinite(amax)) ? 32639.0 / amax : 0.0;
   }
@@ -494,19 +480,19 @@ __device__ __forceinline__ void threshold_symmetrize_body(
     else if (gi < n && gj < n)
       out[(size_t)gi * ld + gj] = a[q].x;
     // (entries outside the matrix are zero here: thr() returned 0 for them and sym(0, 0) = 0)
-    if (DIGITS) q2m = fmax(q2m, ts_digits(dg, sigma, gi, tj, c0, a[q].x, a[q].y, tx == 31));
+    if (digits) q2m = fmax(q2m, ts_digits(dg, sigma, gi, tj, c0, a[q].x, a[q].y, tx == 31));
   }
   // the tile's largest squared segment norm: 8 half-waves x 8 rows each
-  if (DIGITS && tx == 31) smax[0][ty] = q2m;
+  if (digits && tx == 31) smax[0][ty] = q2m;
   if (diag_tile) {
-    if (DIGITS) {
+    if (digits) {
       __syncthreads();
       if (threadIdx.x == 0) ts_store_mx(dg, smax[0], ti, tj);
     }
     return;
   }
   __syncthreads();  // everybody has read B^T
-  if (DIGITS && threadIdx.x == 0) ts_store_mx(dg, smax[0], ti, tj);
+  if (digits && threadIdx.x == 0) ts_store_mx(dg, smax[0], ti, tj);
   q2m = 0.0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -524,9 +510,9 @@ __device__ __forceinline__ void threshold_symmetrize_body(
       *reinterpret_cast<double2*>(out + (size_t)gi * ld + gj) = o;
     else if (gi < n && gj < n)
       out[(size_t)gi * ld + gj] = o.x;
-    if (DIGITS) q2m = fmax(q2m, ts_digits(dg, sigma, gi, ti, c0, o.x, o.y, tx == 31));
+    if (digits) q2m = fmax(q2m, ts_digits(dg, sigma, gi, ti, c0, o.x, o.y, tx == 31));
   }
-  if (DIGITS) {
+  if (digits) {
     if (tx == 31) smax[1][ty] = q2m;
     __syncthreads();
     if (threadIdx.x == 0) ts_store_mx(dg, smax[1], tj, ti);
@@ -553,7 +539,7 @@ __global__ __launch_bounds__(256) void k_threshold_symmetrize_digits(
 // With `segs` (the tile skip list of the digit product, sc_internal.h FreeSegs): the group's
 // smallest diagonal-only candidate threshold from the rows' exact T_ii (the segment maxima mx64
 // were stored by the threshold pass itself).
-__global__ __launch_bounds__(256) void k_free_partials_reduce(
+__device__ __forceinline__ void free_partials_reduce_body(
     const double* __restrict__ ypart, const int* __restrict__ rpart, int n, int nblk,
     double* __restrict__ y1, double* __restrict__ R, unsigned long long* __restrict__ rmax_bits,
     const FreeSegs segs) {
@@ -612,6 +598,20 @@ __global__ __launch_bounds__(256) void k_free_partials_reduce(
     }
   }
 }
+__global__ __launch_bounds__(256) void k_free_partials_reduce(
+    const double* __restrict__ ypart, const int* __restrict__ rpart, int n, int nblk,
+    double* __restrict__ y1, double* __restrict__ R, unsigned long long* __restrict__ rmax_bits,
+    const FreeSegs segs) {
+  free_partials_reduce_body(ypart, rpart, n, nblk, y1, R, rmax_bits, segs);
+}
+__global__ __launch_bounds__(256) void k_free_partials_reduce_g(const GroupOf<FreeItem> g) {
+  const FreeItem& a = g.s[blockIdx.y];
+  const int nblk = (a.n + kTsTile - 1) / kTsTile;
+  if (a.n <= 0 || a.ypart == nullptr || (int)blockIdx.x >= nblk) return;
+  free_partials_reduce_body(a.ypart, a.rpart, a.n, nblk, a.y1, a.R,
+                            reinterpret_cast<unsigned long long*>(a.scal) + 2,
+                            FreeSegs{a.q2part, nullptr, a.tau64});
+}
 __global__ __launch_bounds__(256) void k_threshold_symmetrize_g(const GroupOf<FrontItem> g,
                                                                 double mult, int binarize,
                                                                 int symtype, int preserve_diag) {
@@ -620,6 +620,16 @@ __global__ __launch_bounds__(256) void k_threshold_symmetrize_g(const GroupOf<Fr
   if ((int)blockIdx.x >= t * (t + 1) / 2) return;
   threshold_symmetrize_body<false>(a.B1, a.B2, a.n, a.ldn, a.cut, mult, binarize, symtype, t,
                                    preserve_diag, TsDigits{});
+}
+// ... with the digits of the members that take the matrix-free Diffuse (dg.s[member].Q != nullptr)
+__global__ __launch_bounds__(256) void k_threshold_symmetrize_digits_g(
+    const GroupOf<FrontItem> g, const GroupOf<TsDigits> dg, double mult, int binarize, int symtype,
+    int preserve_diag) {
+  const FrontItem& a = g.s[blockIdx.y];
+  const int t = (a.n + kTsTile - 1) / kTsTile;
+  if ((int)blockIdx.x >= t * (t + 1) / 2) return;
+  threshold_symmetrize_body<true>(a.B1, a.B2, a.n, a.ldn, a.cut, mult, binarize, symtype, t,
+                                  preserve_diag, dg.s[blockIdx.y]);
 }
 
 // ---- R3: RowWiseThreshold, RowMax (refinement.py:182-210) --------------------
@@ -990,7 +1000,7 @@ void launch_row_stats_group(hipStream_t s, const FrontItem* items, int count) {
 }
 void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,
                                        double p, double mult, int binarize, int symtype,
-                                       int preserve_diag, bool cut_ready) {
+                                       int preserve_diag, bool cut_ready, const TsDigits* digits) {
   int nmax;
   const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
   if (nmax == 0) return;
@@ -999,8 +1009,34 @@ void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, in
   if (!cut_ready)
     hipLaunchKernelGGL(k_cut_from_partials_g, dim3((nmax + 3) / 4, count), dim3(256), 0, s, g, p);
   const int t = (nmax + kTsTile - 1) / kTsTile;
+  if (digits != nullptr) {
+    GroupOf<TsDigits> dg;
+    memset(&dg, 0, sizeof(dg));
+    for (int z = 0; z < count; ++z) dg.s[z] = digits[z];
+    hipLaunchKernelGGL(k_threshold_symmetrize_digits_g, dim3(t * (t + 1) / 2, count), dim3(256), 0,
+                       s, g, dg, mult, binarize, symtype, preserve_diag);
+    return;
+  }
   hipLaunchKernelGGL(k_threshold_symmetrize_g, dim3(t * (t + 1) / 2, count), dim3(256), 0, s, g,
                      mult, binarize, symtype, preserve_diag);
+}
+void launch_cut_from_partials_group(hipStream_t s, const FrontItem* items, int count, double p) {
+  int nmax;
+  const GroupOf<FrontItem> g = front_pack(items, count, &nmax);
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_cut_from_partials_g, dim3((nmax + 3) / 4, count), dim3(256), 0, s, g, p);
+}
+void launch_free_partials_reduce_group(hipStream_t s, const FreeItem* items, int count) {
+  GroupOf<FreeItem> g;
+  memset(&g, 0, sizeof(g));
+  int nmax = 0;
+  for (int z = 0; z < count; ++z) {
+    g.s[z] = items[z];
+    nmax = std::max(nmax, items[z].n);
+  }
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_free_partials_reduce_g, dim3((nmax + kTsTile - 1) / kTsTile, count),
+                     dim3(256), 0, s, g);
 }
 void launch_scaling_vectors_group(hipStream_t s, const FrontItem* items, int count,
                                   int laplacian_type, int row_normalized) {

@@ -284,9 +284,31 @@ bool blur_group_front_supported(int n_min, int radius);
 int blur_stream_columns(int n, int radius);
 void launch_gaussian_blur_group(hipStream_t s, const FrontItem* items, int count, int radius,
                                 const double* weights_dev);
+// What the threshold + symmetrise pass leaves for the matrix-free Diffuse when it writes the digits
+// itself (rowops.hip threshold_symmetrize_body<true>; Q == nullptr: this matrix gets none): the
+// two 8-bit digits of q = rint(sigma a) in the product's layout (a 64 x 64 tile is one 128-byte
+// line per row: 64 high digits, 64 low digits) and, per row and 64-column block, the partial
+// sums of a, of |q| and of q^2 (k_free_partials_reduce adds them in block order), and per
+// 64 x 64 tile its largest segment norm.  Saves one read of the matrix.
+struct TsDigits {
+  signed char* Q;      // digits, row pitch `pitch` bytes
+  size_t pitch;
+  int nblk;            // 64-column blocks per row
+  double* scal;        // [0] = max |a| (known from the cut vector before this pass); [3] set when
+                       // a finite value had to be clamped after all (diffuse_free.hip)
+  double* ypart;       // [block * 64 nblk + row] sum of a  (a tile's 64 partials are contiguous:
+  int* rpart;          // [block * 64 nblk + row] sum of |q|   whole lines leave the L2)
+  double* q2part;      // [block * 64 nblk + row] sum of q^2 (an exact integer < 2^37): the squared
+                       // norm of the row's digit segment, for the tile skip list (diffuse_free.hip)
+  double* mx64;        // [row group * nblk + block] the largest segment norm of a tile's 64 rows
+                       // (rounded up): exactly one workgroup holds the 64 values, a plain store
+};
+// (digits: per member what the pass writes besides the matrix, or nullptr -- no member gets any)
 void launch_threshold_symmetrize_group(hipStream_t s, const FrontItem* items, int count,
                                        double p, double mult, int binarize, int symtype,
-                                       int preserve_diag, bool cut_ready = false);
+                                       int preserve_diag, bool cut_ready = false,
+                                       const TsDigits* digits = nullptr);
+void launch_cut_from_partials_group(hipStream_t s, const FrontItem* items, int count, double p);
 void launch_scaling_vectors_group(hipStream_t s, const FrontItem* items, int count,
                                   int laplacian_type, int row_normalized);
 struct GatherItem {  // T == nullptr: idle
@@ -459,8 +481,19 @@ struct FreeItem {
   double* mx64 = nullptr;
   float* tau64 = nullptr;
   int* plan = nullptr;
+  // row partials when the grouped threshold pass wrote the member's digits (TsDigits)
+  double* ypart = nullptr;
+  int* rpart = nullptr;
 };
-void launch_free_begin_group(hipStream_t s, const FreeItem* items, int count, double floor_value);
+// y1, R, max R and the skip list's thresholds of every member from the partials of a grouped
+// threshold pass that wrote the digits (the group form of launch_free_partials_reduce)
+void launch_free_partials_reduce_group(hipStream_t s, const FreeItem* items, int count);
+// (seg_reduce: the members' digits came from the quantiser, whose segment maxima are not formed
+//  by the pass itself)
+void launch_free_tile_flags_group(hipStream_t s, const FreeItem* items, int count, bool prune,
+                                  bool seg_reduce);
+void launch_free_begin_group(hipStream_t s, const FreeItem* items, int count, double floor_value,
+                             bool pad_rows = false);
 void launch_free_quantize_group(hipStream_t s, const FreeItem* items, int count);
 void launch_free_scan_stats_group(hipStream_t s, const FreeItem* items, int count);
 void free_i8_split_plan(int n, int* tail_tiles, int* parts);
@@ -470,7 +503,6 @@ size_t free_i8_split_bytes(int n);
 void launch_gemm_i8_sym_group(hipStream_t s, const signed char* const* Q, float* const* T32,
                               unsigned* const* M, int count, const int* ns,
                               const int2* const* tilemaps, const int* const* plans = nullptr);
-void launch_free_tile_flags_group(hipStream_t s, const FreeItem* items, int count, bool prune);
 void launch_t32_candidates(hipStream_t s, const float* T32, int n, const unsigned* M,
                            const double* R, const double* scal, int* count, int* cand,
                            const int* plan = nullptr);

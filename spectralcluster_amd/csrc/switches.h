@@ -92,6 +92,12 @@ inline int gen_dense_max_n() {
   static const int v = getenv("SC_GEN_DENSE_MAX_N") ? atoi(getenv("SC_GEN_DENSE_MAX_N")) : 512;
   return v;
 }
+// SC_GROUP_QUANTIZE_PASS=1: the matrix-free members of a grouped front / sweep get their digits from
+// a quantiser pass of their own (rounds 4-5) instead of from the grouped threshold pass
+inline bool group_quantize_pass() {
+  static const bool v = getenv("SC_GROUP_QUANTIZE_PASS") != nullptr;
+  return v;
+}
 // SC_GEN_DEVICE_RR=1: the Rayleigh-Ritz problems of the narrow block Arnoldi (order <= 64) on the
 // one-wavefront device kernel k_gen_eig (rounds 2-5) instead of the host
 inline bool gen_device_rr() {

@@ -22,8 +22,8 @@ they are the repair / large-problem routes of the default ones:
   SC_DIFFUSE=explicit   the fp64 Diffuse product on every golden, n = 2048 included, where the
                         default is matrix-free
   SC_GEN_DEVICE_RR / SC_GEN_LOOSE_BULK (with SC_GEN_DENSE_MAX_N=64), SC_FREE_NO_PRUNE, SC_NO_PREFETCH,
-  SC_GROUP_EQUAL_COUNT: round 6's switches -- the Rayleigh-Ritz kernel, stop rule, product,
-  uploads and group formation of round 5
+  SC_GROUP_EQUAL_COUNT, SC_GROUP_QUANTIZE_PASS: round 6's switches -- the Rayleigh-Ritz kernel,
+  stop rule, product, uploads, group formation and grouped quantiser of round 5
   SC_GEN_DENSE_MAX_N=64 block Arnoldi (narrow and wide) on the general-path goldens of n = 300 /
                         400, where the default since round 5 is the dense Hessenberg route
 
@@ -172,7 +172,8 @@ if os.environ.get("SC_KMEANS_SINGLE"):
     assert np.array_equal(got[i], want), i
     if u.shape[0] >= 1536:
       assert bd[i].diffuse_path in (_lib.DIFFUSE_PATH_FREE, _lib.DIFFUSE_PATH_FREE_THEN_EXPLICIT)
-if os.environ.get("SC_NO_PREFETCH") or os.environ.get("SC_GROUP_EQUAL_COUNT"):
+if (os.environ.get("SC_NO_PREFETCH") or os.environ.get("SC_GROUP_EQUAL_COUNT") or
+    os.environ.get("SC_GROUP_QUANTIZE_PASS")):
   # batches with the round-5 behaviours (every call uploads for itself; groups of equal count):
   # members against single calls, a plain sequence and a grouped batch
   utts = [so.blobs(m, 64, 4, seed=m) for m in (1300, 640, 1500, 380, 1700, 900, 2100, 450)]
@@ -194,6 +195,7 @@ print("ALTERNATE_PATH_OK")
                                     "SC_GEN_DENSE_MAX_N=64+SC_GEN_LOOSE_BULK",
                                     "SC_FREE_NO_PRUNE", "SC_DIFFUSE=free+SC_FREE_NO_PRUNE",
                                     "SC_NO_PREFETCH", "SC_GROUP_EQUAL_COUNT",
+                                    "SC_GROUP_QUANTIZE_PASS",
                                     "SC_DIFFUSE=free+SC_EIG_HOST_CHAIN",
                                     "SC_DIFFUSE=free+SC_EIG_FORCE_DENSE",
                                     "SC_DIFFUSE=free+SC_MATVEC_SYM_MIN_N"])
